@@ -1,0 +1,155 @@
+/*
+ * russell_hipmf.h -- C-ABI of the MI355X-native sparse direct solver backend ("HIPMF": HIP
+ * multifrontal LU) that plugs in behind russell_sparse's solver boundary.
+ *
+ * The entry points are what russell_sparse's FFI for this path binds.  They keep the shape of the
+ * reference's existing GPU plug-in (c_code/interface_cudss.cu) and of the UMFPACK shim
+ * (c_code/interface_umfpack.c): an opaque handle, new/drop, and the three phases
+ * initialize (once) / factorize (values only, repeatable) / solve.  All sizes, indices, enums and
+ * booleans are int32_t; matrices are 0-based CSR with f64 values; host pointers are borrowed for
+ * the duration of a call and never retained (ownership rules of SURVEY.md section 8b).
+ *
+ * Reference interface each declaration replaces (paths relative to /root/reference):
+ *   solver_hipmf_new         russell_sparse/c_code/interface_cudss.cu:62-123   (solver_cudss_new)
+ *   solver_hipmf_drop        russell_sparse/c_code/interface_cudss.cu:126-171  (solver_cudss_drop)
+ *   solver_hipmf_initialize  russell_sparse/c_code/interface_cudss.cu:190-396  (solver_cudss_initialize)
+ *                            and interface_umfpack.c:82-124 (ordering, scaling arguments)
+ *   solver_hipmf_factorize   russell_sparse/c_code/interface_cudss.cu:406-501  (solver_cudss_factorize)
+ *                            and interface_umfpack.c:141-200 (rcond, determinant outputs)
+ *   solver_hipmf_solve       russell_sparse/c_code/interface_cudss.cu:510-566  (solver_cudss_solve)
+ * Rust side that calls them: russell_sparse/src/solver_cudss.rs:25-52,194-360.
+ *
+ * Status codes: 0 = success; the shared 100000..700000 codes are those of
+ * russell_sparse/c_code/constants.h:5-12 verbatim; 1 = "Matrix is singular" is the value UMFPACK
+ * returns (russell_sparse/src/solver_umfpack.rs:492); the 100..1000 block is this backend's
+ * analogue of the cuDSS block (constants.h:22-36).
+ */
+#ifndef RUSSELL_HIPMF_H
+#define RUSSELL_HIPMF_H
+
+#include <inttypes.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C_BOOL int32_t
+
+#define SUCCESSFUL_EXIT 0
+#define ERROR_NULL_POINTER 100000
+#define ERROR_MALLOC 200000
+#define ERROR_VERSION 300000
+#define ERROR_NOT_AVAILABLE 400000
+#define ERROR_NEED_INITIALIZATION 500000
+#define ERROR_NEED_FACTORIZATION 600000
+#define ERROR_ALREADY_INITIALIZED 700000
+
+#define HIPMF_WARNING_SINGULAR_MATRIX 1
+#define ERROR_HIP_MALLOC 100
+#define ERROR_HIP_MEMCPY 200
+#define ERROR_HIP_SYNCHRONIZE 300
+#define ERROR_HIP_LAUNCH 350
+#define ERROR_HIPMF_INVALID_MATRIX 600
+#define ERROR_HIPMF_SYMBOLIC 700
+#define ERROR_HIPMF_INVALID_VALUE 803
+#define ERROR_HIPMF_NO_DEVICE 1000
+
+/* ordering argument of solver_hipmf_initialize */
+#define HIPMF_ORDERING_DEFAULT 0            /* nested dissection */
+#define HIPMF_ORDERING_NESTED_DISSECTION 1
+#define HIPMF_ORDERING_NONE 2               /* natural order (Ordering::No) */
+/* scaling argument (same numbering as UMFPACK_SCALE_*) */
+#define HIPMF_SCALE_NONE 0
+#define HIPMF_SCALE_SUM 1
+#define HIPMF_SCALE_MAX 2
+
+struct InterfaceHIPMF;
+
+/* Allocates a solver bound to the calling thread's current HIP device.  Returns NULL on failure. */
+struct InterfaceHIPMF *solver_hipmf_new(void);
+
+/* Frees every host and device resource.  NULL-safe. */
+void solver_hipmf_drop(struct InterfaceHIPMF *solver);
+
+/* Phase 1 (once): ordering + symbolic analysis on the host, device allocation, structure upload.
+ * pivot_epsilon < 0 and refinement_nstep < 0 select the defaults (1e-13 relative, 2 steps).
+ * general_symmetric: the CSR holds the LOWER triangle of a symmetric matrix (Sym::YesLower).
+ * values may be NULL (they are not needed before solver_hipmf_factorize). */
+int32_t solver_hipmf_initialize(struct InterfaceHIPMF *solver,
+                                int32_t ordering,
+                                int32_t scaling,
+                                double pivot_epsilon,
+                                int32_t refinement_nstep,
+                                C_BOOL verbose,
+                                C_BOOL general_symmetric,
+                                C_BOOL positive_definite,
+                                int32_t ndim,
+                                const int32_t *row_pointers,
+                                const int32_t *col_indices,
+                                const double *values);
+
+/* Phase 2 (repeatable): numeric multifrontal LU of the same structure with new values.
+ * Returns 0, or 1 when an exactly-zero pivot was met ("Matrix is singular"). */
+int32_t solver_hipmf_factorize(struct InterfaceHIPMF *solver,
+                               int32_t *effective_ordering,
+                               int32_t *effective_scaling,
+                               int32_t *num_perturbed_pivots,
+                               double *rcond_estimate,
+                               double *determinant_coefficient,
+                               double *determinant_exponent,
+                               C_BOOL compute_determinant,
+                               C_BOOL verbose,
+                               const double *values);
+
+/* Phase 3: x = A^{-1} rhs (forward/backward level-set solves + iterative refinement). */
+int32_t solver_hipmf_solve(struct InterfaceHIPMF *solver, double *x, const double *rhs, C_BOOL verbose);
+
+/* ---- extensions that the reference's single-RHS boundary lacks ---------- */
+
+/* nrhs right-hand sides, column-major with leading dimension ld >= ndim (host pointers) */
+int32_t solver_hipmf_solve_many(struct InterfaceHIPMF *solver, double *x, const double *rhs, int32_t nrhs, int32_t ld,
+                                C_BOOL verbose);
+
+/* the same two phases with operands already resident in HBM (device pointers) */
+int32_t solver_hipmf_factorize_device(struct InterfaceHIPMF *solver, const double *d_values);
+int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *solver, double *d_x, const double *d_rhs, int32_t nrhs, int32_t ld);
+
+/* v = alpha * A * u on the device with the values of the last factorize (host pointers);
+ * the CSR SpMV of russell_sparse/src/csr_matrix.rs:709-729 */
+int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *solver, double *v, double alpha, const double *u);
+
+/* perm[new] = old: the fill-reducing permutation applied to rows and columns (ndim entries) */
+int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *solver, int32_t *perm);
+
+/* istats[16]: 0 ndim, 1 nnz(A), 2 nsuper, 3 nlevels, 4 nnz(L) strict, 5 nnz(U) incl. diag, 6 max front,
+ *             7 max pivots, 8 perturbed pivots, 9 zero pivots, 10 refinement steps, 11 factor launches,
+ *             12 solve launches, 13 pool bytes
+ * dstats[16]: 0 flops, 1 gemm flops, 2 ordering s, 3 symbolic total s, 4 assemble ms, 5 factor ms, 6 fwd ms,
+ *             7 bwd ms, 8 solve total ms, 9 last residual inf-norm; accumulated since the last reset (HIP events on
+ *             the solver's stream): 10 assemble ms, 11 factor ms, 12 #factorizations, 13 forward-solve ms,
+ *             14 backward-solve ms, 15 #triangular passes */
+int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *solver, int64_t *istats, double *dstats);
+int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
+
+/* factor export/import for the many-RHS multi-GPU path: the numeric factor is one contiguous
+ * device buffer; a peer that ran initialize on the same structure can adopt it. */
+int32_t solver_hipmf_factor_buffers(struct InterfaceHIPMF *solver, void **d_pool, int64_t *pool_bytes, void **d_lperm,
+                                    int64_t *lperm_bytes, void **d_row_scale, int64_t *row_scale_bytes);
+int32_t solver_hipmf_adopt_factor(struct InterfaceHIPMF *solver, const double *d_values);
+
+const char *solver_hipmf_last_error(struct InterfaceHIPMF *solver);
+
+/* plain device-memory helpers so that callers need no HIP binding of their own */
+void *hipmf_device_malloc(size_t bytes);
+void hipmf_device_free(void *ptr);
+int32_t hipmf_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int32_t hipmf_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int32_t hipmf_device_synchronize(void);
+int32_t hipmf_device_count(void);
+int32_t hipmf_set_device(int32_t device); /* selects the device later solver_hipmf_new() calls of this thread bind to */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+"""ctypes binding of include/russell_hipmf.h (the C-ABI of the HIP multifrontal backend).
+
+`load()` opens russell_amd/lib/librussell_hipmf.so -- the gfx950 build.  There is no CPU fallback:
+if the shared library is missing or no HIP device is visible, the product raises.
+(`load(path)` with an explicit path is used by the development-only emulator tests.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "librussell_hipmf.so")
+
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+# every symbol include/russell_hipmf.h declares
+SYMBOLS = {
+    "solver_hipmf_new": (C.c_void_p, []),
+    "solver_hipmf_drop": (None, [C.c_void_p]),
+    "solver_hipmf_initialize": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, i32p, i32p, C.c_void_p]),
+    "solver_hipmf_factorize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
+                                           C.c_int32, f64p]),
+    "solver_hipmf_solve": (C.c_int32, [C.c_void_p, f64p, f64p, C.c_int32]),
+    "solver_hipmf_solve_many": (C.c_int32, [C.c_void_p, f64p, f64p, C.c_int32, C.c_int32, C.c_int32]),
+    "solver_hipmf_factorize_device": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "solver_hipmf_solve_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "solver_hipmf_mat_vec_mul": (C.c_int32, [C.c_void_p, f64p, C.c_double, f64p]),
+    "solver_hipmf_get_permutation": (C.c_int32, [C.c_void_p, i32p]),
+    "solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
+    "solver_hipmf_reset_timers": (C.c_int32, [C.c_void_p]),
+    "solver_hipmf_factor_buffers": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "solver_hipmf_adopt_factor": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "solver_hipmf_last_error": (C.c_char_p, [C.c_void_p]),
+    "hipmf_device_malloc": (C.c_void_p, [C.c_size_t]),
+    "hipmf_device_free": (None, [C.c_void_p]),
+    "hipmf_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hipmf_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hipmf_device_synchronize": (C.c_int32, []),
+    "hipmf_device_count": (C.c_int32, []),
+    "hipmf_set_device": (C.c_int32, [C.c_int32]),
+}
+
+_cache = {}
+
+
+def load(path=None):
+    path = path or DEFAULT_LIB
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "russell_amd: %s is missing -- build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _cache[path] = lib
+    return lib

@@ -1,0 +1,135 @@
+"""Thin object wrapper over the C-ABI (include/russell_hipmf.h): one handle = one solver on one GPU.
+
+This is plumbing for tests / bench / the Python mirror of the Rust host layer (russell_amd.sparse).
+It adds no numerics of its own; every number comes out of the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+ISTAT_NAMES = ["ndim", "nnz_a", "nsuper", "nlevels", "nnz_l", "nnz_u", "max_front", "max_pivots", "n_perturbed", "n_zero_pivot",
+               "refinement_steps", "factor_launches", "solve_launches", "pool_bytes"]
+DSTAT_NAMES = ["flops", "flops_gemm", "ordering_s", "symbolic_s", "assemble_ms", "factor_ms", "fwd_ms", "bwd_ms", "solve_total_ms",
+               "residual_inf", "acc_assemble_ms", "acc_factor_ms", "acc_factor_count", "acc_fwd_ms", "acc_bwd_ms", "acc_tri_count"]
+
+
+class HipmfError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        super().__init__("%s failed with status %d %s" % (where, code, detail))
+        self.code = code
+
+
+class Hipmf:
+    def __init__(self, lib_path=None):
+        self.lib = _capi.load(lib_path)
+        self.h = self.lib.solver_hipmf_new()
+        if not self.h:
+            raise RuntimeError("solver_hipmf_new returned NULL: no HIP device visible (there is no CPU fallback)")
+        self.n = 0
+        self.nnz = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.solver_hipmf_drop(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _err(self, code, where):
+        return HipmfError(code, where, (self.lib.solver_hipmf_last_error(self.h) or b"").decode())
+
+    def initialize(self, n, row_pointers, col_indices, ordering=0, scaling=1, pivot_epsilon=-1.0, refinement_nstep=-1,
+                   verbose=False, general_symmetric=False, positive_definite=False):
+        rp = np.ascontiguousarray(row_pointers, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        self.n, self.nnz = int(n), int(rp[n])
+        return self.lib.solver_hipmf_initialize(self.h, ordering, scaling, pivot_epsilon, refinement_nstep, int(verbose),
+                                                int(general_symmetric), int(positive_definite), n, rp, ci, None)
+
+    def factorize(self, values, compute_determinant=False, verbose=False):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.size >= self.nnz
+        eo, es, npv = C.c_int32(), C.c_int32(), C.c_int32()
+        rc, dc, de = C.c_double(), C.c_double(), C.c_double()
+        code = self.lib.solver_hipmf_factorize(self.h, C.byref(eo), C.byref(es), C.byref(npv), C.byref(rc), C.byref(dc), C.byref(de),
+                                               int(compute_determinant), int(verbose), v)
+        self.effective_ordering, self.effective_scaling, self.num_perturbed = eo.value, es.value, npv.value
+        self.rcond, self.det_coefficient, self.det_exponent = rc.value, dc.value, de.value
+        return code
+
+    def solve(self, rhs, verbose=False):
+        b = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.zeros(self.n)
+        code = self.lib.solver_hipmf_solve(self.h, x, b, int(verbose))
+        if code != 0:
+            raise self._err(code, "solver_hipmf_solve")
+        return x
+
+    def solve_many(self, rhs_colmajor):
+        """rhs_colmajor: array of shape (nrhs, n) whose rows are the right-hand sides (= column-major n x nrhs)."""
+        b = np.ascontiguousarray(rhs_colmajor, dtype=np.float64)
+        nrhs = b.shape[0]
+        x = np.zeros_like(b)
+        code = self.lib.solver_hipmf_solve_many(self.h, x, b, nrhs, self.n, 0)
+        if code != 0:
+            raise self._err(code, "solver_hipmf_solve_many")
+        return x
+
+    def mat_vec_mul(self, u, alpha=1.0):
+        v = np.zeros(self.n)
+        code = self.lib.solver_hipmf_mat_vec_mul(self.h, v, alpha, np.ascontiguousarray(u, dtype=np.float64))
+        if code != 0:
+            raise self._err(code, "solver_hipmf_mat_vec_mul")
+        return v
+
+    def permutation(self):
+        p = np.zeros(self.n, np.int32)
+        code = self.lib.solver_hipmf_get_permutation(self.h, p)
+        if code != 0:
+            raise self._err(code, "solver_hipmf_get_permutation")
+        return p
+
+    def stats(self):
+        i, d = np.zeros(16, np.int64), np.zeros(16)
+        code = self.lib.solver_hipmf_get_stats(self.h, i, d)
+        if code != 0:
+            raise self._err(code, "solver_hipmf_get_stats")
+        out = {k: int(v) for k, v in zip(ISTAT_NAMES, i)}
+        out.update({k: float(v) for k, v in zip(DSTAT_NAMES, d)})
+        return out
+
+    def reset_timers(self):
+        self.lib.solver_hipmf_reset_timers(self.h)
+
+    # ---- device-resident operands (bench / multi-GPU) -------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = self.lib.hipmf_device_malloc(nbytes)
+        if not p:
+            raise MemoryError("hipmf_device_malloc(%d)" % nbytes)
+        return p
+
+    def dev_free(self, p):
+        self.lib.hipmf_device_free(p)
+
+    def h2d(self, dptr, arr):
+        a = np.ascontiguousarray(arr)
+        code = self.lib.hipmf_memcpy_h2d(dptr, a.ctypes.data_as(C.c_void_p), a.nbytes)
+        if code != 0:
+            raise self._err(code, "hipmf_memcpy_h2d")
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        code = self.lib.hipmf_memcpy_d2h(arr.ctypes.data_as(C.c_void_p), dptr, arr.nbytes)
+        if code != 0:
+            raise self._err(code, "hipmf_memcpy_d2h")
+
+    def factorize_device(self, d_values):
+        return self.lib.solver_hipmf_factorize_device(self.h, d_values)
+
+    def solve_device(self, d_x, d_rhs, nrhs=1, ld=None):
+        code = self.lib.solver_hipmf_solve_device(self.h, d_x, d_rhs, nrhs, ld or self.n)
+        if code != 0:
+            raise self._err(code, "solver_hipmf_solve_device")

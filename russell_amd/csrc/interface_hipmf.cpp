@@ -1,0 +1,206 @@
+// interface_hipmf.cpp -- the extern "C" boundary declared in include/russell_hipmf.h.
+// Behaviour follows the reference shims: NULL-safe drop, initialize exactly once
+// (ERROR_ALREADY_INITIALIZED, interface_umfpack.c:95-97), factorize needs initialize
+// (ERROR_NEED_INITIALIZATION), solve needs factorize (ERROR_NEED_FACTORIZATION), every phase is
+// blocking (stream-synchronised) on return (interface_cudss.cu:383,449,536).
+#include <hipmf_device_rt.h>
+
+#include <cstdio>
+#include <new>
+
+#include "numeric.hpp"
+// the C header #defines the same status names as macros: it must come after numeric.hpp
+#include "../../include/russell_hipmf.h"
+
+using namespace hipmf;
+
+struct InterfaceHIPMF {
+    Solver solver;
+    int32_t ordering_requested = 0;
+    int32_t effective_ordering = 0;
+};
+
+extern "C" {
+
+struct InterfaceHIPMF *solver_hipmf_new(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return nullptr;
+    return new (std::nothrow) InterfaceHIPMF();
+}
+
+void solver_hipmf_drop(struct InterfaceHIPMF *h) {
+    if (!h) return;
+    h->solver.release();
+    delete h;
+}
+
+int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
+                                int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, C_BOOL positive_definite,
+                                int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
+    (void)values;
+    (void)positive_definite; // accepted for API parity; the numeric phase is LU with static pivoting either way
+    if (!h || !row_pointers || !col_indices) return ERROR_NULL_POINTER;
+    if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
+    if (ndim < 1) return ERROR_HIPMF_INVALID_MATRIX;
+    SymbolicOptions so;
+    so.ordering = (ordering == HIPMF_ORDERING_NONE) ? ORDERING_NATURAL : ORDERING_NESTED_DISSECTION;
+    NumericOptions no;
+    no.scaling = (scaling < 0 || scaling > 2) ? HIPMF_SCALE_SUM : scaling;
+    if (pivot_epsilon >= 0.0) no.pivot_epsilon = pivot_epsilon;
+    if (refinement_nstep >= 0) no.refinement_nstep = refinement_nstep;
+    no.verbose = verbose == 1;
+    h->ordering_requested = ordering;
+    h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
+    int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, general_symmetric == 1, so, no);
+    if (verbose == 1 && code == SUCCESSFUL_EXIT) {
+        const Symbolic &S = h->solver.S;
+        printf("solver_hipmf_initialize: n=%d nnz=%lld supernodes=%d levels=%d nnz(L)=%lld nnz(U)=%lld flops=%.3e "
+               "(ordering %.3fs, total %.3fs)\n",
+               S.n, (long long)S.nnz_a, S.nsuper, S.nlevels, (long long)S.nnz_l, (long long)S.nnz_u, S.flops, S.seconds_ordering,
+               S.seconds_total);
+    }
+    return code;
+}
+
+static int32_t finish_factorize(struct InterfaceHIPMF *h, int32_t code, int32_t *effective_ordering, int32_t *effective_scaling,
+                                int32_t *num_perturbed, double *rcond, double *det_c, double *det_e, C_BOOL compute_determinant) {
+    if (effective_ordering) *effective_ordering = h->effective_ordering;
+    if (effective_scaling) *effective_scaling = h->solver.opt.scaling;
+    if (num_perturbed) *num_perturbed = h->solver.n_perturbed;
+    if (rcond) *rcond = 0.0;
+    if (det_c) *det_c = 0.0;
+    if (det_e) *det_e = 0.0;
+    if (code != SUCCESSFUL_EXIT && code != HIPMF_WARNING_SINGULAR_MATRIX) return code;
+    if (compute_determinant == 1) {
+        int32_t c2 = h->solver.determinant(det_c, det_e, rcond);
+        if (c2 != SUCCESSFUL_EXIT) return c2;
+    }
+    return code;
+}
+
+int32_t solver_hipmf_factorize(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+                               int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
+                               double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *values) {
+    if (!h || !values) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    h->solver.opt.verbose = verbose == 1;
+    int32_t code = h->solver.factorize(values, false);
+    if (verbose == 1 && h->solver.n_perturbed > 0)
+        printf("solver_hipmf_factorize: WARNING: %d pivot(s) perturbed (matrix may be (nearly) singular)\n", h->solver.n_perturbed);
+    return finish_factorize(h, code, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate,
+                            determinant_coefficient, determinant_exponent, compute_determinant);
+}
+
+int32_t solver_hipmf_factorize_device(struct InterfaceHIPMF *h, const double *d_values) {
+    if (!h || !d_values) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    return h->solver.factorize(d_values, true);
+}
+
+int32_t solver_hipmf_solve(struct InterfaceHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
+    if (!h || !x || !rhs) return ERROR_NULL_POINTER;
+    if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+    h->solver.opt.verbose = verbose == 1;
+    int32_t code = h->solver.solve(x, rhs, 1, h->solver.S.n, false);
+    if (verbose == 1 && code == SUCCESSFUL_EXIT)
+        printf("solver_hipmf_solve: Solution completed (%d refinement step(s), |r|_inf = %.3e)\n", h->solver.refinement_steps_done,
+               h->solver.last_residual_inf);
+    return code;
+}
+
+int32_t solver_hipmf_solve_many(struct InterfaceHIPMF *h, double *x, const double *rhs, int32_t nrhs, int32_t ld, C_BOOL verbose) {
+    if (!h || !x || !rhs) return ERROR_NULL_POINTER;
+    if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+    h->solver.opt.verbose = verbose == 1;
+    return h->solver.solve(x, rhs, nrhs, ld, false);
+}
+
+int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *h, double *d_x, const double *d_rhs, int32_t nrhs, int32_t ld) {
+    if (!h || !d_x || !d_rhs) return ERROR_NULL_POINTER;
+    if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+    return h->solver.solve(d_x, d_rhs, nrhs, ld, true);
+}
+
+int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *h, double *v, double alpha, const double *u) {
+    if (!h || !v || !u) return ERROR_NULL_POINTER;
+    return h->solver.spmv(v, u, alpha, false);
+}
+
+int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *h, int32_t *perm) {
+    if (!h || !perm) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    for (int32_t i = 0; i < h->solver.S.n; i++) perm[i] = h->solver.S.perm[i];
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *h, int64_t *is, double *ds) {
+    if (!h || !is || !ds) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    const Solver &s = h->solver;
+    for (int i = 0; i < 16; i++) is[i] = 0, ds[i] = 0.0;
+    is[0] = s.S.n, is[1] = s.S.nnz_a, is[2] = s.S.nsuper, is[3] = s.S.nlevels, is[4] = s.S.nnz_l, is[5] = s.S.nnz_u;
+    is[6] = s.S.max_front, is[7] = s.S.max_pivots, is[8] = s.n_perturbed, is[9] = s.n_zero_pivot;
+    is[10] = s.refinement_steps_done, is[11] = s.times.n_kernel_launches_factor, is[12] = s.times.n_kernel_launches_solve;
+    is[13] = s.pool_doubles * 8;
+    ds[0] = s.S.flops, ds[1] = s.S.flops_gemm, ds[2] = s.S.seconds_ordering, ds[3] = s.S.seconds_total;
+    ds[4] = s.times.scale_assemble_ms, ds[5] = s.times.factor_ms, ds[6] = s.times.fwd_ms, ds[7] = s.times.bwd_ms;
+    ds[8] = s.times.solve_total_ms, ds[9] = s.last_residual_inf;
+    ds[10] = s.times.acc_assemble_ms, ds[11] = s.times.acc_factor_ms, ds[12] = (double)s.times.acc_factor_count;
+    ds[13] = s.times.acc_fwd_ms, ds[14] = s.times.acc_bwd_ms, ds[15] = (double)s.times.acc_tri_count;
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t solver_hipmf_factor_buffers(struct InterfaceHIPMF *h, void **d_pool, int64_t *pool_bytes, void **d_lperm, int64_t *lperm_bytes,
+                                    void **d_row_scale, int64_t *row_scale_bytes) {
+    if (!h) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    if (d_pool) *d_pool = h->solver.d_pool;
+    if (pool_bytes) *pool_bytes = h->solver.pool_doubles * 8;
+    if (d_lperm) *d_lperm = h->solver.d_lperm;
+    if (lperm_bytes) *lperm_bytes = (int64_t)h->solver.S.n * 4;
+    if (d_row_scale) *d_row_scale = h->solver.d_rs;
+    if (row_scale_bytes) *row_scale_bytes = (int64_t)h->solver.S.n * 8;
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t solver_hipmf_adopt_factor(struct InterfaceHIPMF *h, const double *d_values) {
+    // the peer wrote pool / lperm / row-scale through the pointers of solver_hipmf_factor_buffers;
+    // the values are still needed for the refinement SpMV
+    if (!h || !d_values) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    return h->solver.adopt_factor(d_values);
+}
+
+int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *h) {
+    if (!h) return ERROR_NULL_POINTER;
+    PhaseTimes &t = h->solver.times;
+    t.acc_assemble_ms = t.acc_factor_ms = t.acc_fwd_ms = t.acc_bwd_ms = 0.0;
+    t.acc_factor_count = t.acc_tri_count = 0;
+    return SUCCESSFUL_EXIT;
+}
+
+const char *solver_hipmf_last_error(struct InterfaceHIPMF *h) { return h ? h->solver.last_error.c_str() : "null solver"; }
+
+void *hipmf_device_malloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+void hipmf_device_free(void *ptr) {
+    if (ptr) (void)hipFree(ptr);
+}
+int32_t hipmf_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_MEMCPY;
+}
+int32_t hipmf_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_MEMCPY;
+}
+int32_t hipmf_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_SYNCHRONIZE; }
+int32_t hipmf_set_device(int32_t device) { return hipSetDevice(device) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIPMF_NO_DEVICE; }
+int32_t hipmf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+} // extern "C"

@@ -1,0 +1,488 @@
+// numeric.cpp -- host driver of the HIP kernels: plan upload, numeric factorisation, solves.
+// Compiled with hipcc (-x hip) for gfx950.  The phase structure mirrors the reference's GPU
+// plug-in (/root/reference/russell_sparse/c_code/interface_cudss.cu:190-566): initialize uploads
+// the structure once, factorize re-uploads VALUES ONLY, solve moves one rhs in and one x out, and
+// every phase synchronises its stream before returning.
+#include "numeric.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace hipmf {
+
+#define HIPC(call, code)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            last_error = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            if (opt.verbose) fprintf(stderr, "hipmf: %s\n", last_error.c_str());               \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while (0)
+
+#define STREAM ((hipStream_t)stream)
+
+template <class T>
+static hipError_t dev_upload(T **dptr, const std::vector<T> &v) {
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)dptr, bytes);
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+Solver::Solver() {}
+Solver::~Solver() { release(); }
+
+void Solver::release() {
+    if (!stream && !d_pool && !d_fd) return;
+    (void)hipSetDevice(device);
+    void *ptrs[] = {d_fd,  d_ea,   d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_b,   d_x,    d_du,   d_rows, d_rel,
+                    d_child, d_lists, d_tasks, d_rp,   d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm, d_rs};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    d_fd = nullptr, d_ea = nullptr, d_info = nullptr, d_scalar = nullptr;
+    d_work = d_vals = d_xp = d_r = d_b = d_x = d_du = d_pool = d_rs = nullptr;
+    d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
+    d_amap = d_amap2 = nullptr;
+    for (auto &e : ev)
+        if (e) {
+            (void)hipEventDestroy((hipEvent_t)e);
+            e = nullptr;
+        }
+    if (stream) {
+        (void)hipStreamDestroy(STREAM);
+        stream = nullptr;
+    }
+    initialized = factorized = false;
+}
+
+int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
+                           const NumericOptions &nopt) {
+    if (initialized) return ERROR_ALREADY_INITIALIZED;
+    opt = nopt;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        last_error = "no HIP device visible";
+        return ERROR_HIPMF_NO_DEVICE;
+    }
+    HIPC(hipGetDevice(&device), ERROR_HIPMF_NO_DEVICE);
+    if (!stream) {
+        hipStream_t st;
+        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+        stream = st;
+    }
+    int rc = analyse(n, rp, ci, sym_lower, sopt, S);
+    if (rc != 0) {
+        last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
+        return rc <= -30 || rc >= -2 ? ERROR_HIPMF_INVALID_MATRIX : ERROR_HIPMF_SYMBOLIC;
+    }
+    int32_t code = upload_plan();
+    if (code != SUCCESSFUL_EXIT) {
+        release();
+        return code;
+    }
+    // matrix structure (kept for the refinement SpMV) and per-entry row/col indices
+    const int64_t nnz = S.nnz_a;
+    std::vector<int32_t> h_rp(rp, rp + n + 1), h_ci(ci, ci + nnz), h_arow((size_t)nnz);
+    for (int32_t i = 0; i < n; i++)
+        for (int32_t p = rp[i]; p < rp[i + 1]; p++) h_arow[p] = i;
+    HIPC(dev_upload(&d_rp, h_rp), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_ci, h_ci), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_arow, h_arow), ERROR_HIP_MALLOC);
+    if (sym_lower) {
+        // transpose lists: for every row i, the stored entries (r, i), r > i, mirrored into row i
+        std::vector<int32_t> tptr((size_t)n + 1, 0), tidx;
+        for (int64_t k = 0; k < nnz; k++)
+            if (h_ci[k] != h_arow[k]) tptr[h_ci[k] + 1]++;
+        for (int32_t i = 0; i < n; i++) tptr[i + 1] += tptr[i];
+        tidx.resize((size_t)tptr[n]);
+        std::vector<int32_t> w(tptr.begin(), tptr.end() - 1);
+        for (int64_t k = 0; k < nnz; k++)
+            if (h_ci[k] != h_arow[k]) tidx[w[h_ci[k]]++] = (int32_t)k;
+        HIPC(dev_upload(&d_tptr, tptr), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_tidx, tidx), ERROR_HIP_MALLOC);
+    }
+    HIPC(dev_upload(&d_perm, S.perm), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_amap, S.amap), ERROR_HIP_MALLOC);
+    if (sym_lower) HIPC(dev_upload(&d_amap2, S.amap2), ERROR_HIP_MALLOC);
+    std::vector<int64_t>().swap(S.amap);
+    std::vector<int64_t>().swap(S.amap2);
+    HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+    for (double **p : {&d_xp, &d_r, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_scalar, 4 * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+    for (auto &e : ev) {
+        hipEvent_t he;
+        HIPC(hipEventCreate(&he), ERROR_HIP_MALLOC);
+        e = he;
+    }
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    initialized = true;
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::upload_plan() {
+    const int32_t ns = S.nsuper;
+    std::vector<FrontDesc> fd((size_t)ns);
+    work_doubles = 0;
+    for (int32_t s = 0; s < ns; s++) {
+        FrontDesc &d = fd[s];
+        d.off = S.front_off[s];
+        d.rowptr = S.sn_rowptr[s];
+        d.woff = work_doubles;
+        d.p = S.npiv(s);
+        d.m = S.nrow(s);
+        d.first = S.sn_first[s];
+        d.child_begin = S.child_ptr[s];
+        d.child_end = S.child_ptr[s + 1];
+        d.parent = S.sn_parent[s];
+        work_doubles += d.p + d.m;
+    }
+    pool_doubles = S.front_off[ns];
+
+    std::vector<int32_t> lists, tasks;
+    std::vector<EaTask> ea;
+    levels.assign((size_t)S.nlevels, LevelPlan());
+    for (int32_t l = 0; l < S.nlevels; l++) {
+        LevelPlan &L = levels[l];
+        std::vector<int32_t> small, big;
+        int32_t fmax_small = 1;
+        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            int32_t s = S.level_sn[k];
+            if (S.fsize(s) <= SMALL_F) {
+                small.push_back(s);
+                fmax_small = std::max(fmax_small, S.fsize(s));
+            } else {
+                big.push_back(s);
+            }
+        }
+        std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
+        L.all_off = (int32_t)lists.size();
+        L.small_off = (int32_t)lists.size();
+        L.small_cnt = (int32_t)small.size();
+        L.small_ld = fmax_small | 1;
+        lists.insert(lists.end(), small.begin(), small.end());
+        L.big_off = (int32_t)lists.size();
+        L.big_cnt = (int32_t)big.size();
+        lists.insert(lists.end(), big.begin(), big.end());
+        L.all_cnt = L.small_cnt + L.big_cnt;
+        // tiled steps
+        int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
+        for (int32_t k0 = 0; k0 < pmax; k0 += NB) {
+            StepPlan st;
+            while (st.nactive < L.big_cnt && S.npiv(big[st.nactive]) > k0) st.nactive++;
+            st.pfx_panel = (int64_t)tasks.size();
+            int64_t acc = 0;
+            for (int32_t a = 0; a < st.nactive; a++) {
+                tasks.push_back((int32_t)acc);
+                int32_t s = big[a], f = S.fsize(s), nb = std::min(NB, S.npiv(s) - k0);
+                int32_t below = f - (k0 + nb);
+                acc += 2 * ((below + PANEL_T - 1) / PANEL_T) + (k0 + PANEL_T - 1) / PANEL_T;
+            }
+            tasks.push_back((int32_t)acc);
+            st.n_panel = (int32_t)acc;
+            st.pfx_update = (int64_t)tasks.size();
+            acc = 0;
+            for (int32_t a = 0; a < st.nactive; a++) {
+                tasks.push_back((int32_t)acc);
+                int32_t s = big[a], f = S.fsize(s), nb = std::min(NB, S.npiv(s) - k0);
+                int64_t nt = (f - (k0 + nb) + UPD_T - 1) / UPD_T;
+                acc += nt * nt;
+            }
+            tasks.push_back((int32_t)acc);
+            if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
+            st.n_update = (int32_t)acc;
+            L.steps.push_back(st);
+        }
+        // extend-add tasks
+        L.ea_off = (int32_t)ea.size();
+        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            int32_t s = S.level_sn[k];
+            bool any = false;
+            for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
+            if (!any) continue;
+            int32_t f = S.fsize(s);
+            int32_t chunk = f <= 64 ? f : 32;
+            for (int32_t c0 = 0; c0 < f; c0 += chunk) ea.push_back({s, c0, std::min(f, c0 + chunk)});
+        }
+        L.ea_cnt = (int32_t)ea.size() - L.ea_off;
+    }
+    HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_lists, lists), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_tasks, tasks), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_rel, S.rel), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_child, S.child_idx), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_pool, sizeof(double) * std::max<int64_t>(pool_doubles, 1)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_work, sizeof(double) * std::max<int64_t>(work_doubles, 1)), ERROR_HIP_MALLOC);
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::factorize(const double *values, bool on_device) {
+    if (!initialized) return ERROR_NEED_INITIALIZATION;
+    if (!values) return ERROR_NULL_POINTER;
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    const int64_t nnz = S.nnz_a;
+    HIPC(hipMemcpyAsync(d_vals, values, sizeof(double) * nnz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, STREAM),
+         ERROR_HIP_MEMCPY);
+    int32_t code = run_factor();
+    if (code != SUCCESSFUL_EXIT) return code;
+    factorized = true;
+    return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::run_factor() {
+    const int32_t n = S.n;
+    const int64_t nnz = S.nnz_a;
+    int64_t launches = 0;
+    HIPC(hipEventRecord((hipEvent_t)ev[0], STREAM), ERROR_HIP_SYNCHRONIZE);
+    hipLaunchKernelGGL(k_row_scale, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_vals, d_tptr, d_tidx, opt.scaling, d_rs);
+    HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
+    int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
+    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_rs, d_scalar);
+    HIPC(hipMemsetAsync(d_pool, 0, sizeof(double) * pool_doubles, STREAM), ERROR_HIP_MEMCPY);
+    hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_amap, d_amap2, d_rs, d_ci, d_pool);
+    launches += 3;
+    HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
+    for (const LevelPlan &L : levels) {
+        if (L.ea_cnt > 0) {
+            hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_fd, d_child, d_rel, d_pool);
+            launches++;
+        }
+        if (L.small_cnt > 0) {
+            size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
+            hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt), dim3(64), shmem, STREAM, d_lists + L.small_off, d_fd, d_pool,
+                               d_lperm, d_scalar, opt.pivot_epsilon, d_info, L.small_ld);
+            launches++;
+        }
+        int32_t k0 = 0;
+        for (const StepPlan &st : L.steps) {
+            const int32_t *blist = d_lists + L.big_off;
+            hipLaunchKernelGGL(k_diag, dim3(st.nactive), dim3(64), 0, STREAM, blist, d_fd, k0, d_pool, d_lperm, d_scalar,
+                               opt.pivot_epsilon, d_info);
+            launches++;
+            if (st.n_panel > 0) {
+                hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist,
+                                   d_fd, k0, d_pool, d_lperm);
+                launches++;
+            }
+            if (st.n_update > 0) {
+                hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist,
+                                   d_fd, k0, d_pool);
+                launches++;
+            }
+            k0 += NB;
+        }
+    }
+    HIPC(hipEventRecord((hipEvent_t)ev[2], STREAM), ERROR_HIP_SYNCHRONIZE);
+    FactorInfo hinfo;
+    HIPC(hipMemcpyAsync(&hinfo, d_info, sizeof(FactorInfo), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
+    n_perturbed = hinfo.n_perturbed;
+    n_zero_pivot = hinfo.n_zero_pivot;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, (hipEvent_t)ev[0], (hipEvent_t)ev[1]);
+    times.scale_assemble_ms = ms;
+    (void)hipEventElapsedTime(&ms, (hipEvent_t)ev[1], (hipEvent_t)ev[2]);
+    times.factor_ms = ms;
+    times.acc_assemble_ms += times.scale_assemble_ms;
+    times.acc_factor_ms += times.factor_ms;
+    times.acc_factor_count++;
+    times.n_kernel_launches_factor = launches;
+    if (opt.verbose)
+        fprintf(stderr, "hipmf: factorize: assemble %.3f ms, factor %.3f ms, %lld launches, %d pivot(s) perturbed\n",
+                times.scale_assemble_ms, times.factor_ms, (long long)launches, n_perturbed);
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::run_triangular(double *xp) {
+    int64_t launches = 0;
+    HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
+    for (const LevelPlan &L : levels) {
+        if (L.small_cnt > 0)
+            hipLaunchKernelGGL(k_fwd, dim3(L.small_cnt), dim3(64), 0, STREAM, d_lists + L.small_off, d_fd, d_pool, d_lperm, d_child,
+                               d_rel, d_work, xp);
+        if (L.big_cnt > 0)
+            hipLaunchKernelGGL(k_fwd, dim3(L.big_cnt), dim3(256), 0, STREAM, d_lists + L.big_off, d_fd, d_pool, d_lperm, d_child,
+                               d_rel, d_work, xp);
+        launches += (L.small_cnt > 0) + (L.big_cnt > 0);
+    }
+    HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
+    for (auto it = levels.rbegin(); it != levels.rend(); ++it) {
+        const LevelPlan &L = *it;
+        if (L.big_cnt > 0)
+            hipLaunchKernelGGL(k_bwd, dim3(L.big_cnt), dim3(256), 0, STREAM, d_lists + L.big_off, d_fd, d_pool, d_rows, d_work, xp);
+        if (L.small_cnt > 0)
+            hipLaunchKernelGGL(k_bwd, dim3(L.small_cnt), dim3(64), 0, STREAM, d_lists + L.small_off, d_fd, d_pool, d_rows, d_work, xp);
+        launches += (L.small_cnt > 0) + (L.big_cnt > 0);
+    }
+    HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
+    times.n_kernel_launches_solve = launches;
+    tri_pending = true;
+    return SUCCESSFUL_EXIT;
+}
+
+// reads the forward/backward event pair of the last triangular pass (call after a stream sync)
+void Solver::harvest_tri() {
+    if (!tri_pending) return;
+    tri_pending = false;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)ev[3], (hipEvent_t)ev[4]) != hipSuccess) return;
+    times.fwd_ms = ms;
+    times.acc_fwd_ms += ms;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)ev[4], (hipEvent_t)ev[5]) != hipSuccess) return;
+    times.bwd_ms = ms;
+    times.acc_bwd_ms += ms;
+    times.acc_tri_count++;
+}
+
+int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device) {
+    if (!factorized) return ERROR_NEED_FACTORIZATION;
+    if (!x || !rhs) return ERROR_NULL_POINTER;
+    if (nrhs < 1 || ldx < S.n) return ERROR_HIPMF_INVALID_VALUE;
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    const int32_t n = S.n;
+    const dim3 g((n + 255) / 256), b(256);
+    refinement_steps_done = 0;
+    HIPC(hipEventRecord((hipEvent_t)ev[6], STREAM), ERROR_HIP_SYNCHRONIZE);
+    for (int32_t j = 0; j < nrhs; j++) {
+        const double *bj;
+        double *xj;
+        if (on_device) {
+            bj = rhs + (int64_t)j * ldx;
+            xj = x + (int64_t)j * ldx;
+        } else {
+            HIPC(hipMemcpyAsync(d_b, rhs + (int64_t)j * ldx, sizeof(double) * n, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
+            bj = d_b;
+            xj = d_x;
+        }
+        hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_perm, d_rs, bj, d_xp);
+        int32_t code = run_triangular(d_xp);
+        if (code != SUCCESSFUL_EXIT) return code;
+        hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_xp, xj, 0);
+        // iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229)
+        double prev = INFINITY;
+        for (int32_t it = 0; it <= opt.refinement_nstep && opt.refinement_nstep > 0; it++) {
+            hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj, bj, d_r);
+            HIPC(hipMemsetAsync(d_scalar + 1, 0, sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
+            hipLaunchKernelGGL(k_norminf, dim3(std::min(1024, (n + 255) / 256)), b, 0, STREAM, n, d_r, d_scalar + 1);
+            double rn = 0.0;
+            HIPC(hipMemcpyAsync(&rn, d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+            HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+            harvest_tri();
+            if (it > 0 && !(rn < prev)) {
+                // the last correction did not help: take it back and stop
+                hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_du, xj, 2);
+                break;
+            }
+            last_residual_inf = rn;
+            if (rn == 0.0 || it == opt.refinement_nstep || (it > 0 && rn > 0.5 * prev)) break;
+            prev = rn;
+            hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_perm, d_rs, d_r, d_du);
+            code = run_triangular(d_du);
+            if (code != SUCCESSFUL_EXIT) return code;
+            hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_du, xj, 1);
+            if (j == 0) refinement_steps_done++;
+        }
+        if (!on_device)
+            HIPC(hipMemcpyAsync(x + (int64_t)j * ldx, d_x, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    }
+    HIPC(hipEventRecord((hipEvent_t)ev[7], STREAM), ERROR_HIP_SYNCHRONIZE);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
+    harvest_tri();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, (hipEvent_t)ev[6], (hipEvent_t)ev[7]);
+    times.solve_total_ms = ms;
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::spmv(double *y, const double *x, double alpha, bool on_device) {
+    if (!factorized) return ERROR_NEED_FACTORIZATION;
+    if (!x || !y) return ERROR_NULL_POINTER;
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    const int32_t n = S.n;
+    const double *xd = x;
+    double *yd = y;
+    if (!on_device) {
+        HIPC(hipMemcpyAsync(d_b, x, sizeof(double) * n, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
+        xd = d_b;
+        yd = d_x;
+    }
+    hipLaunchKernelGGL(k_spmv, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, alpha, xd, yd);
+    if (!on_device) HIPC(hipMemcpyAsync(y, d_x, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::adopt_factor(const double *d_values) {
+    if (!initialized) return ERROR_NEED_INITIALIZATION;
+    if (!d_values) return ERROR_NULL_POINTER;
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    HIPC(hipMemcpyAsync(d_vals, d_values, sizeof(double) * S.nnz_a, hipMemcpyDeviceToDevice, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    n_perturbed = n_zero_pivot = 0;
+    factorized = true;
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
+    if (!factorized) return ERROR_NEED_FACTORIZATION;
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    const int32_t n = S.n;
+    hipLaunchKernelGGL(k_diag_gather, dim3(S.nsuper), dim3(64), 0, STREAM, S.nsuper, d_fd, d_pool, d_du);
+    std::vector<double> du((size_t)n), rs((size_t)n);
+    std::vector<int32_t> lp((size_t)n);
+    HIPC(hipMemcpyAsync(du.data(), d_du, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpyAsync(rs.data(), d_rs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpyAsync(lp.data(), d_lperm, sizeof(int32_t) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    // det(A) = sign * prod(u_ii) / prod(rs_i): the symmetric permutation contributes sign^2 = +1,
+    // the row interchanges inside the pivot blocks contribute the parity of their cycles
+    double m = 1.0, e = 0.0, umin = INFINITY, umax = 0.0;
+    bool zero = false;
+    for (int32_t i = 0; i < n; i++) {
+        double d = du[i] / rs[i];
+        umin = std::min(umin, std::fabs(du[i]));
+        umax = std::max(umax, std::fabs(du[i]));
+        if (d == 0.0 || !std::isfinite(d)) {
+            zero = true;
+            continue;
+        }
+        m *= d;
+        while (std::fabs(m) >= 10.0) m /= 10.0, e += 1.0;
+        while (std::fabs(m) < 1.0) m *= 10.0, e -= 1.0;
+    }
+    int parity = 0;
+    std::vector<char> seen;
+    for (int32_t s = 0; s < S.nsuper; s++) {
+        int32_t first = S.sn_first[s], p = S.npiv(s);
+        seen.assign((size_t)p, 0);
+        for (int32_t i = 0; i < p; i++) {
+            if (seen[i]) continue;
+            int len = 0;
+            for (int32_t j = i; !seen[j]; j = lp[first + j]) {
+                seen[j] = 1;
+                len++;
+            }
+            if ((len & 1) == 0) parity ^= 1;
+        }
+    }
+    if (parity) m = -m;
+    if (zero || n_zero_pivot > 0) m = 0.0, e = 0.0;
+    if (mantissa) *mantissa = m;
+    if (exponent) *exponent = e;
+    if (rcond) *rcond = (umax > 0.0 && std::isfinite(umin)) ? umin / umax : 0.0;
+    return SUCCESSFUL_EXIT;
+}
+
+} // namespace hipmf

@@ -1,0 +1,117 @@
+// numeric.hpp -- device-side state and drivers of the multifrontal LU backend (factorize / solve).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "symbolic.hpp"
+
+namespace hipmf {
+
+struct FrontDesc;
+struct EaTask;
+struct FactorInfo;
+
+// status codes shared with the reference's C shims (/root/reference/russell_sparse/c_code/constants.h:5-12)
+enum : int32_t {
+    SUCCESSFUL_EXIT = 0,
+    ERROR_NULL_POINTER = 100000,
+    ERROR_MALLOC = 200000,
+    ERROR_VERSION = 300000,
+    ERROR_NOT_AVAILABLE = 400000,
+    ERROR_NEED_INITIALIZATION = 500000,
+    ERROR_NEED_FACTORIZATION = 600000,
+    ERROR_ALREADY_INITIALIZED = 700000,
+    // HIP block, analogous to the cuDSS block of constants.h:22-36
+    ERROR_HIP_MALLOC = 100,
+    ERROR_HIP_MEMCPY = 200,
+    ERROR_HIP_SYNCHRONIZE = 300,
+    ERROR_HIP_LAUNCH = 350,
+    ERROR_HIPMF_INVALID_MATRIX = 600,
+    ERROR_HIPMF_SYMBOLIC = 700,
+    ERROR_HIPMF_INVALID_VALUE = 803,
+    ERROR_HIPMF_NO_DEVICE = 1000,
+    // numerical status, same value UMFPACK uses for a singular matrix (solver_umfpack.rs:492)
+    WARNING_SINGULAR_MATRIX = 1,
+};
+
+struct NumericOptions {
+    int32_t scaling = 1;            // 0 none, 1 sum (UMFPACK_SCALE_SUM), 2 max
+    double pivot_epsilon = 1e-13;   // relative to max|scaled a_ij| (cuDSS documents 1e-13 as its f64 default)
+    int32_t refinement_nstep = 2;   // UMFPACK's default UMFPACK_IRSTEP is 2
+    bool verbose = false;
+};
+
+struct PhaseTimes {
+    double scale_assemble_ms = 0, factor_ms = 0, fwd_ms = 0, bwd_ms = 0, solve_total_ms = 0;
+    int64_t n_kernel_launches_factor = 0, n_kernel_launches_solve = 0;
+    // accumulated over calls since the last reset (HIP events on the solver's own stream)
+    double acc_factor_ms = 0, acc_assemble_ms = 0, acc_fwd_ms = 0, acc_bwd_ms = 0;
+    int64_t acc_factor_count = 0, acc_tri_count = 0;
+};
+
+struct StepPlan {
+    int32_t nactive = 0;
+    int64_t pfx_panel = 0, pfx_update = 0; // offsets into d_tasks
+    int32_t n_panel = 0, n_update = 0;
+};
+struct LevelPlan {
+    int32_t small_off = 0, small_cnt = 0, small_ld = 0; // fronts with f <= SMALL_F
+    int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
+    int32_t all_off = 0, all_cnt = 0;                   // solve lists: [small..., big...]
+    int32_t ea_off = 0, ea_cnt = 0;
+    std::vector<StepPlan> steps;
+};
+
+class Solver {
+  public:
+    Solver();
+    ~Solver();
+    int32_t initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
+                       const NumericOptions &nopt);
+    // values: nnz doubles in the CSR order given to initialize; on_device tells where they live
+    int32_t factorize(const double *values, bool on_device);
+    int32_t solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device);
+    int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
+    int32_t determinant(double *mantissa, double *exponent, double *rcond);
+    int32_t adopt_factor(const double *d_values); // factor buffers were filled by a peer (many-RHS multi-GPU path)
+    void release();
+
+    Symbolic S;
+    NumericOptions opt;
+    PhaseTimes times;
+    bool initialized = false, factorized = false;
+    int32_t n_perturbed = 0, n_zero_pivot = 0;
+    int32_t refinement_steps_done = 0;
+    double last_residual_inf = 0.0;
+    int device = 0;
+    void *stream = nullptr;
+    std::string last_error;
+
+    // exported for the many-RHS / multi-GPU paths: the factor lives in [d_pool, d_pool + pool_doubles)
+    double *d_pool = nullptr;
+    int64_t pool_doubles = 0;
+    int32_t *d_lperm = nullptr;
+    double *d_rs = nullptr;
+
+  private:
+    int32_t upload_plan();
+    int32_t run_factor();
+    int32_t run_triangular(double *d_xp); // forward + backward on a permuted, scaled vector
+    void harvest_tri();
+    bool tri_pending = false;
+    std::vector<LevelPlan> levels;
+    int64_t work_doubles = 0;
+    // device buffers
+    FrontDesc *d_fd = nullptr;
+    EaTask *d_ea = nullptr;
+    FactorInfo *d_info = nullptr;
+    unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] norm scratch
+    double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_b = nullptr, *d_x = nullptr, *d_du = nullptr;
+    int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
+    int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
+    int64_t *d_amap = nullptr, *d_amap2 = nullptr;
+    void *ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+} // namespace hipmf

@@ -1,0 +1,655 @@
+// symbolic.cpp -- ordering, elimination tree, supernodes, frontal index sets, assembly maps.
+// See symbolic.hpp for the role this plays at the reference's solver boundary.
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+
+namespace hipmf {
+namespace {
+
+using clk = std::chrono::steady_clock;
+static double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+struct Graph {
+    int32_t n = 0;
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> adj;
+};
+
+// pattern of A + A^T without the diagonal; adjacency lists ascending and duplicate-free
+static int build_graph(int32_t n, const int32_t *rp, const int32_t *ci, Graph &g) {
+    g.n = n;
+    std::vector<int64_t> cnt((size_t)n + 1, 0);
+    for (int32_t i = 0; i < n; i++) {
+        if (rp[i + 1] < rp[i]) return -1;
+        for (int32_t p = rp[i]; p < rp[i + 1]; p++) {
+            int32_t j = ci[p];
+            if (j < 0 || j >= n) return -2;
+            if (j != i) {
+                cnt[i + 1]++;
+                cnt[j + 1]++;
+            }
+        }
+    }
+    for (int32_t i = 0; i < n; i++) cnt[i + 1] += cnt[i];
+    std::vector<int32_t> raw((size_t)cnt[n]);
+    std::vector<int64_t> w(cnt.begin(), cnt.end() - 1);
+    for (int32_t i = 0; i < n; i++)
+        for (int32_t p = rp[i]; p < rp[i + 1]; p++) {
+            int32_t j = ci[p];
+            if (j != i) {
+                raw[w[i]++] = j;
+                raw[w[j]++] = i;
+            }
+        }
+    g.ptr.assign((size_t)n + 1, 0);
+    g.adj.clear();
+    g.adj.reserve(raw.size() / 2 + 16);
+    for (int32_t i = 0; i < n; i++) {
+        auto b = raw.begin() + cnt[i], e = raw.begin() + cnt[i + 1];
+        std::sort(b, e);
+        auto u = std::unique(b, e);
+        g.adj.insert(g.adj.end(), b, u);
+        g.ptr[i + 1] = (int64_t)g.adj.size();
+    }
+    return 0;
+}
+
+static void permute_graph(const Graph &g, const std::vector<int32_t> &perm, const std::vector<int32_t> &pinv, Graph &out) {
+    int32_t n = g.n;
+    out.n = n;
+    out.ptr.assign((size_t)n + 1, 0);
+    out.adj.resize(g.adj.size());
+    for (int32_t k = 0; k < n; k++) out.ptr[k + 1] = out.ptr[k] + (g.ptr[perm[k] + 1] - g.ptr[perm[k]]);
+    for (int32_t k = 0; k < n; k++) {
+        int32_t v = perm[k];
+        int64_t o = out.ptr[k];
+        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) out.adj[o++] = pinv[g.adj[p]];
+        std::sort(out.adj.begin() + out.ptr[k], out.adj.begin() + o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nested dissection by breadth-first level structures.  A region is split by the level set of a
+// BFS from a pseudo-peripheral vertex that balances the two sides with the fewest vertices; the
+// separator is numbered last.  Regions of <= 64 vertices are numbered by minimum degree on a
+// one-word-per-row bitset elimination graph.
+// ------------------------------------------------------------------------------------------------
+struct NDWork {
+    const Graph &g;
+    std::vector<int32_t> part;   // region id per vertex, -1 once numbered
+    std::vector<int32_t> verts;  // region vertex lists (segments)
+    std::vector<int32_t> queue;  // BFS queue / scratch
+    std::vector<int32_t> lev;    // BFS level
+    std::vector<int32_t> stamp;  // visit stamps
+    std::vector<int32_t> tmp;
+    std::vector<int32_t> lvl_ptr;
+    int32_t cur_stamp = 0;
+    explicit NDWork(const Graph &gr) : g(gr) {}
+};
+
+// BFS inside region `id` from `root`; fills w.queue[0..count) in visit order, w.lev, w.lvl_ptr.
+// Returns the eccentricity (number of levels - 1).
+static int32_t bfs_region(NDWork &w, int32_t root, int32_t id, int32_t &count) {
+    const Graph &g = w.g;
+    int32_t st = ++w.cur_stamp;
+    int32_t head = 0, tail = 0;
+    w.queue[tail++] = root;
+    w.stamp[root] = st;
+    w.lev[root] = 0;
+    w.lvl_ptr.clear();
+    w.lvl_ptr.push_back(0);
+    int32_t curlev = 0;
+    while (head < tail) {
+        int32_t v = w.queue[head];
+        if (w.lev[v] != curlev) {
+            curlev = w.lev[v];
+            w.lvl_ptr.push_back(head);
+        }
+        head++;
+        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
+            int32_t u = g.adj[p];
+            if (w.part[u] == id && w.stamp[u] != st) {
+                w.stamp[u] = st;
+                w.lev[u] = curlev + 1;
+                w.queue[tail++] = u;
+            }
+        }
+    }
+    w.lvl_ptr.push_back(tail);
+    count = tail;
+    return (int32_t)w.lvl_ptr.size() - 2;
+}
+
+static void leaf_min_degree(NDWork &w, int32_t begin, int32_t end, int32_t id, int32_t pos, std::vector<int32_t> &perm) {
+    const Graph &g = w.g;
+    int32_t s = end - begin;
+    uint64_t a[64];
+    int32_t ext[64];
+    for (int32_t i = 0; i < s; i++) w.lev[w.verts[begin + i]] = i; // local index
+    for (int32_t i = 0; i < s; i++) {
+        int32_t v = w.verts[begin + i];
+        a[i] = 0;
+        ext[i] = 0;
+        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
+            int32_t u = g.adj[p];
+            if (w.part[u] == id) a[i] |= (uint64_t)1 << w.lev[u];
+            else ext[i]++;
+        }
+    }
+    uint64_t alive = (s == 64) ? ~(uint64_t)0 : (((uint64_t)1 << s) - 1);
+    for (int32_t step = 0; step < s; step++) {
+        int32_t best = -1, bestdeg = 1 << 30;
+        for (int32_t i = 0; i < s; i++) {
+            if (!((alive >> i) & 1)) continue;
+            int32_t deg = __builtin_popcountll(a[i] & alive) + ext[i];
+            if (deg < bestdeg) {
+                bestdeg = deg;
+                best = i;
+            }
+        }
+        int32_t v = w.verts[begin + best];
+        perm[pos + step] = v;
+        w.part[v] = -1;
+        alive &= ~((uint64_t)1 << best);
+        uint64_t nb = a[best] & alive;
+        for (uint64_t m = nb; m; m &= m - 1) {
+            int32_t u = __builtin_ctzll(m);
+            a[u] |= nb;
+            a[u] &= ~((uint64_t)1 << u);
+            if (ext[best] > ext[u]) ext[u] = ext[best];
+        }
+    }
+}
+
+static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm) {
+    int32_t n = g.n;
+    perm.assign((size_t)n, -1);
+    NDWork w(g);
+    w.part.assign((size_t)n, 0);
+    w.verts.resize((size_t)n);
+    std::iota(w.verts.begin(), w.verts.end(), 0);
+    w.queue.resize((size_t)n);
+    w.lev.assign((size_t)n, 0);
+    w.stamp.assign((size_t)n, 0);
+    w.tmp.resize((size_t)n);
+    struct Region {
+        int32_t begin, end, pos, id;
+        bool connected;
+    };
+    std::vector<Region> stack;
+    int32_t next_id = 1;
+    stack.push_back({0, n, 0, 0, false});
+    const int32_t leaf = std::min<int32_t>(64, std::max<int32_t>(1, opt.nd_leaf));
+    std::vector<int32_t> comp_ptr;
+    while (!stack.empty()) {
+        Region R = stack.back();
+        stack.pop_back();
+        int32_t size = R.end - R.begin;
+        if (size <= 0) continue;
+        if (!R.connected) {
+            // connected components of the region (discovery order, deterministic)
+            int32_t st = ++w.cur_stamp;
+            int32_t out = 0;
+            comp_ptr.clear();
+            comp_ptr.push_back(0);
+            for (int32_t k = R.begin; k < R.end; k++) {
+                int32_t r = w.verts[k];
+                if (w.stamp[r] == st) continue;
+                int32_t head = out;
+                w.tmp[out++] = r;
+                w.stamp[r] = st;
+                while (head < out) {
+                    int32_t v = w.tmp[head++];
+                    for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
+                        int32_t u = g.adj[p];
+                        if (w.part[u] == R.id && w.stamp[u] != st) {
+                            w.stamp[u] = st;
+                            w.tmp[out++] = u;
+                        }
+                    }
+                }
+                comp_ptr.push_back(out);
+            }
+            std::copy(w.tmp.begin(), w.tmp.begin() + size, w.verts.begin() + R.begin);
+            int32_t ncomp = (int32_t)comp_ptr.size() - 1;
+            if (ncomp > 1) {
+                // independent subtrees: number them one after the other
+                for (int32_t c = ncomp - 1; c >= 0; c--) {
+                    int32_t b = R.begin + comp_ptr[c], e = R.begin + comp_ptr[c + 1];
+                    int32_t id = next_id++;
+                    for (int32_t k = b; k < e; k++) w.part[w.verts[k]] = id;
+                    stack.push_back({b, e, R.pos + comp_ptr[c], id, true});
+                }
+                continue;
+            }
+        }
+        if (size <= leaf) {
+            leaf_min_degree(w, R.begin, R.end, R.id, R.pos, perm);
+            continue;
+        }
+        // pseudo-peripheral vertex: repeat BFS from a minimum-degree vertex of the last level
+        int32_t root = w.verts[R.begin], count = 0;
+        int32_t ecc = bfs_region(w, root, R.id, count);
+        for (int32_t it = 0; it < 4; it++) {
+            int32_t lb = w.lvl_ptr[w.lvl_ptr.size() - 2], le = w.lvl_ptr.back();
+            int32_t cand = w.queue[lb];
+            int64_t cdeg = g.ptr[cand + 1] - g.ptr[cand];
+            for (int32_t k = lb + 1; k < le; k++) {
+                int32_t v = w.queue[k];
+                int64_t d = g.ptr[v + 1] - g.ptr[v];
+                if (d < cdeg || (d == cdeg && v < cand)) {
+                    cand = v;
+                    cdeg = d;
+                }
+            }
+            if (cand == root) break;
+            int32_t e2 = bfs_region(w, cand, R.id, count);
+            if (e2 > ecc) {
+                ecc = e2;
+                root = cand;
+            } else {
+                // keep the structure rooted at `cand` anyway (same eccentricity, valid structure)
+                ecc = e2;
+                root = cand;
+                break;
+            }
+        }
+        if (ecc < 2) {
+            // (nearly) a clique: cannot be dissected; number in BFS order
+            for (int32_t k = 0; k < size; k++) {
+                perm[R.pos + k] = w.queue[k];
+                w.part[w.queue[k]] = -1;
+            }
+            continue;
+        }
+        // choose the separating level
+        int32_t best = -1;
+        int64_t best_sz = 0, best_diff = 0;
+        bool best_ok = false;
+        for (int32_t l = 1; l < ecc; l++) {
+            int64_t a = w.lvl_ptr[l], s = w.lvl_ptr[l + 1] - w.lvl_ptr[l], b = size - a - s;
+            bool ok = std::min(a, b) * 20 >= (int64_t)size * 7; // both sides >= 35 %
+            int64_t diff = a > b ? a - b : b - a;
+            bool better;
+            if (best < 0) better = true;
+            else if (ok != best_ok) better = ok;
+            else if (ok) better = (s < best_sz) || (s == best_sz && diff < best_diff);
+            else better = (diff < best_diff) || (diff == best_diff && s < best_sz);
+            if (better) {
+                best = l;
+                best_sz = s;
+                best_diff = diff;
+                best_ok = ok;
+            }
+        }
+        int32_t lb = w.lvl_ptr[best], le = w.lvl_ptr[best + 1];
+        // queue layout: [0,lb) = side A, [lb,le) = separator level, [le,size) = side B.
+        // thin the separator: a vertex with no neighbour in level best+1 can join side A
+        int32_t idA = next_id++, idB = next_id++;
+        int32_t nA = 0, nS = 0;
+        // write A
+        for (int32_t k = 0; k < lb; k++) w.tmp[nA++] = w.queue[k];
+        int32_t sep_begin = size; // separator collected at the back of tmp (reverse)
+        for (int32_t k = lb; k < le; k++) {
+            int32_t v = w.queue[k];
+            bool up = false;
+            for (int64_t p = g.ptr[v]; p < g.ptr[v + 1] && !up; p++) {
+                int32_t u = g.adj[p];
+                up = (w.part[u] == R.id && w.lev[u] == best + 1);
+            }
+            if (up) {
+                w.tmp[--sep_begin] = v;
+                nS++;
+            } else {
+                w.tmp[nA++] = v;
+            }
+        }
+        int32_t nB = size - le;
+        // tmp: [0,nA) = A ; B goes to [nA, nA+nB) ; separator currently at [sep_begin,size) == [nA+nB,size)
+        for (int32_t k = 0; k < nB; k++) w.tmp[nA + k] = w.queue[le + k];
+        for (int32_t k = 0; k < nA; k++) w.part[w.tmp[k]] = idA;
+        for (int32_t k = nA; k < nA + nB; k++) w.part[w.tmp[k]] = idB;
+        // separator numbered last, in ascending BFS order
+        for (int32_t k = 0; k < nS; k++) {
+            int32_t v = w.tmp[size - 1 - k];
+            perm[R.pos + nA + nB + k] = v;
+            w.part[v] = -1;
+        }
+        std::copy(w.tmp.begin(), w.tmp.begin() + nA + nB, w.verts.begin() + R.begin);
+        stack.push_back({R.begin + nA, R.begin + nA + nB, R.pos + nA, idB, false});
+        stack.push_back({R.begin, R.begin + nA, R.pos, idA, false});
+    }
+}
+
+// elimination tree of the permuted symmetric pattern (Liu's algorithm with path compression)
+static void etree(const Graph &gp, std::vector<int32_t> &parent) {
+    int32_t n = gp.n;
+    parent.assign((size_t)n, -1);
+    std::vector<int32_t> anc((size_t)n, -1);
+    for (int32_t j = 0; j < n; j++)
+        for (int64_t p = gp.ptr[j]; p < gp.ptr[j + 1]; p++) {
+            int32_t r = gp.adj[p];
+            if (r >= j) break; // ascending lists
+            while (anc[r] != -1 && anc[r] != j) {
+                int32_t next = anc[r];
+                anc[r] = j;
+                r = next;
+            }
+            if (anc[r] == -1) {
+                anc[r] = j;
+                parent[r] = j;
+            }
+        }
+}
+
+static void postorder(const std::vector<int32_t> &parent, std::vector<int32_t> &post) {
+    int32_t n = (int32_t)parent.size();
+    std::vector<int32_t> head((size_t)n, -1), next((size_t)n, -1), stack;
+    for (int32_t j = n - 1; j >= 0; j--)
+        if (parent[j] >= 0) {
+            next[j] = head[parent[j]];
+            head[parent[j]] = j;
+        }
+    post.clear();
+    post.reserve((size_t)n);
+    for (int32_t r = 0; r < n; r++) {
+        if (parent[r] != -1) continue;
+        stack.push_back(r);
+        while (!stack.empty()) {
+            int32_t v = stack.back();
+            int32_t c = head[v];
+            if (c == -1) {
+                post.push_back(v);
+                stack.pop_back();
+            } else {
+                head[v] = next[c];
+                stack.push_back(c);
+            }
+        }
+    }
+}
+
+// column counts of the Cholesky factor of the (postordered) symmetric pattern
+// (skeleton / least-common-ancestor method of Gilbert, Ng & Peyton, 1994)
+static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, std::vector<int64_t> &cc) {
+    int32_t n = gp.n;
+    std::vector<int32_t> first((size_t)n, -1), maxfirst((size_t)n, -1), prevleaf((size_t)n, -1), anc((size_t)n);
+    std::iota(anc.begin(), anc.end(), 0);
+    cc.assign((size_t)n, 0);
+    for (int32_t k = 0; k < n; k++) {
+        int32_t j = k;
+        cc[j] = (first[j] == -1) ? 1 : 0;
+        for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
+    }
+    for (int32_t j = 0; j < n; j++) {
+        if (parent[j] != -1) cc[parent[j]]--;
+        for (int64_t p = gp.ptr[j]; p < gp.ptr[j + 1]; p++) {
+            int32_t i = gp.adj[p];
+            if (i <= j || first[j] <= maxfirst[i]) continue;
+            maxfirst[i] = first[j];
+            int32_t jprev = prevleaf[i];
+            prevleaf[i] = j;
+            cc[j]++;
+            if (jprev != -1) {
+                int32_t q = jprev;
+                while (q != anc[q]) q = anc[q];
+                for (int32_t s = jprev; s != q;) {
+                    int32_t sp = anc[s];
+                    anc[s] = q;
+                    s = sp;
+                }
+                cc[q]--;
+            }
+        }
+        if (parent[j] != -1) anc[j] = parent[j];
+    }
+    for (int32_t j = 0; j < n; j++)
+        if (parent[j] != -1) cc[parent[j]] += cc[j];
+}
+
+} // namespace
+
+int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &opt, Symbolic &S) {
+    auto t_all = clk::now();
+    if (n < 1 || !rp || !ci) return -1;
+    S = Symbolic();
+    S.n = n;
+    S.nnz_a = rp[n];
+    S.sym_lower = sym_lower;
+
+    Graph g;
+    int rc = build_graph(n, rp, ci, g);
+    if (rc != 0) return rc;
+
+    // ---- ordering --------------------------------------------------------------------------
+    auto t_ord = clk::now();
+    std::vector<int32_t> perm0((size_t)n), pinv0((size_t)n);
+    bool single_front = n <= opt.dense_n;
+    if (single_front || opt.ordering == ORDERING_NATURAL) {
+        std::iota(perm0.begin(), perm0.end(), 0);
+    } else {
+        nested_dissection(g, opt, perm0);
+    }
+    for (int32_t k = 0; k < n; k++) {
+        if (perm0[k] < 0 || perm0[k] >= n) return -10;
+        pinv0[perm0[k]] = k;
+    }
+    S.seconds_ordering = since(t_ord);
+
+    // ---- etree, postorder, final permutation -------------------------------------------------
+    Graph gp;
+    permute_graph(g, perm0, pinv0, gp);
+    std::vector<int32_t> parent0, post;
+    etree(gp, parent0);
+    postorder(parent0, post);
+    S.perm.resize((size_t)n);
+    S.pinv.resize((size_t)n);
+    for (int32_t k = 0; k < n; k++) S.perm[k] = perm0[post[k]];
+    for (int32_t k = 0; k < n; k++) S.pinv[S.perm[k]] = k;
+    std::vector<int32_t> postinv((size_t)n), parent((size_t)n);
+    for (int32_t k = 0; k < n; k++) postinv[post[k]] = k;
+    for (int32_t k = 0; k < n; k++) parent[k] = parent0[post[k]] < 0 ? -1 : postinv[parent0[post[k]]];
+    permute_graph(g, S.perm, S.pinv, gp);
+    { Graph().ptr.swap(g.ptr); std::vector<int32_t>().swap(g.adj); }
+
+    // ---- column counts and supernodes --------------------------------------------------------
+    std::vector<int64_t> cc;
+    column_counts(gp, parent, cc);
+
+    std::vector<int32_t> fs_first; // fundamental supernodes
+    if (single_front) {
+        fs_first.push_back(0);
+    } else {
+        std::vector<int32_t> nchild((size_t)n, 0);
+        for (int32_t j = 0; j < n; j++)
+            if (parent[j] >= 0) nchild[parent[j]]++;
+        fs_first.push_back(0);
+        for (int32_t j = 1; j < n; j++) {
+            bool same = parent[j - 1] == j && cc[j - 1] == cc[j] + 1 && nchild[j] == 1;
+            if (!same) fs_first.push_back(j);
+        }
+    }
+    int32_t nfs = (int32_t)fs_first.size();
+    fs_first.push_back(n);
+    std::vector<int32_t> s_first((size_t)nfs), s_last((size_t)nfs), s_ncol((size_t)nfs);
+    std::vector<int64_t> s_m((size_t)nfs), s_nz((size_t)nfs);
+    std::vector<char> alive((size_t)nfs, 1);
+    std::vector<int32_t> col2fs((size_t)n);
+    for (int32_t s = 0; s < nfs; s++) {
+        s_first[s] = fs_first[s];
+        s_last[s] = fs_first[s + 1] - 1;
+        s_ncol[s] = fs_first[s + 1] - fs_first[s];
+        s_m[s] = single_front ? 0 : cc[s_last[s]] - 1;
+        int64_t nz = 0;
+        for (int32_t j = s_first[s]; j <= s_last[s]; j++) {
+            col2fs[j] = s;
+            nz += single_front ? (int64_t)(n - j) : cc[j];
+        }
+        s_nz[s] = nz;
+    }
+    // relaxed amalgamation: a supernode may absorb the child whose columns end right before its own
+    for (int32_t s = 0; s < nfs && !single_front; s++) {
+        int32_t pj = parent[s_last[s]];
+        if (pj < 0) continue;
+        int32_t t = col2fs[pj];
+        if (s_last[s] + 1 != s_first[t]) continue;
+        int64_t nc = (int64_t)s_ncol[s] + s_ncol[t];
+        int64_t size = nc * (nc + 1) / 2 + nc * s_m[t];
+        int64_t tru = s_nz[s] + s_nz[t];
+        double z = size > 0 ? (double)(size - tru) / (double)size : 0.0;
+        bool accept;
+        if (nc <= opt.relax_ncol[0]) accept = true;
+        else if (nc <= opt.relax_ncol[1]) accept = z < opt.relax_zeros[0];
+        else if (nc <= opt.relax_ncol[2]) accept = z < opt.relax_zeros[1];
+        else accept = z < opt.relax_zeros[2];
+        if (accept) {
+            s_first[t] = s_first[s];
+            s_ncol[t] = (int32_t)nc;
+            s_nz[t] = tru;
+            alive[s] = 0;
+        }
+    }
+    S.sn_first.clear();
+    for (int32_t s = 0; s < nfs; s++)
+        if (alive[s]) S.sn_first.push_back(s_first[s]);
+    S.nsuper = (int32_t)S.sn_first.size();
+    S.sn_first.push_back(n);
+    std::sort(S.sn_first.begin(), S.sn_first.end());
+    S.sn_of.resize((size_t)n);
+    for (int32_t s = 0; s < S.nsuper; s++)
+        for (int32_t j = S.sn_first[s]; j < S.sn_first[s + 1]; j++) S.sn_of[j] = s;
+    S.sn_parent.assign((size_t)S.nsuper, -1);
+    for (int32_t s = 0; s < S.nsuper; s++) {
+        int32_t pj = parent[S.sn_first[s + 1] - 1];
+        S.sn_parent[s] = pj < 0 ? -1 : S.sn_of[pj];
+    }
+    // children lists (ascending)
+    S.child_ptr.assign((size_t)S.nsuper + 1, 0);
+    for (int32_t s = 0; s < S.nsuper; s++)
+        if (S.sn_parent[s] >= 0) S.child_ptr[S.sn_parent[s] + 1]++;
+    for (int32_t s = 0; s < S.nsuper; s++) S.child_ptr[s + 1] += S.child_ptr[s];
+    S.child_idx.resize((size_t)S.child_ptr[S.nsuper]);
+    {
+        std::vector<int32_t> w(S.child_ptr.begin(), S.child_ptr.end() - 1);
+        for (int32_t s = 0; s < S.nsuper; s++)
+            if (S.sn_parent[s] >= 0) S.child_idx[w[S.sn_parent[s]]++] = s;
+    }
+
+    // ---- row structure of every supernode ----------------------------------------------------
+    S.sn_rowptr.assign((size_t)S.nsuper + 1, 0);
+    S.sn_rows.clear();
+    {
+        std::vector<int32_t> mark((size_t)n, -1);
+        std::vector<int32_t> rows;
+        for (int32_t s = 0; s < S.nsuper; s++) {
+            int32_t last = S.sn_first[s + 1] - 1;
+            rows.clear();
+            for (int32_t j = S.sn_first[s]; j <= last; j++)
+                for (int64_t p = gp.ptr[j + 1] - 1; p >= gp.ptr[j]; p--) {
+                    int32_t i = gp.adj[p];
+                    if (i <= last) break;
+                    if (mark[i] != s) {
+                        mark[i] = s;
+                        rows.push_back(i);
+                    }
+                }
+            for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
+                int32_t ch = S.child_idx[c];
+                for (int64_t p = S.sn_rowptr[ch]; p < S.sn_rowptr[ch + 1]; p++) {
+                    int32_t i = S.sn_rows[p];
+                    if (i > last && mark[i] != s) {
+                        mark[i] = s;
+                        rows.push_back(i);
+                    }
+                }
+            }
+            std::sort(rows.begin(), rows.end());
+            S.sn_rows.insert(S.sn_rows.end(), rows.begin(), rows.end());
+            S.sn_rowptr[s + 1] = (int64_t)S.sn_rows.size();
+        }
+    }
+    // relative indices into the parent's front
+    S.rel.assign(S.sn_rows.size(), -1);
+    for (int32_t s = 0; s < S.nsuper; s++) {
+        int32_t t = S.sn_parent[s];
+        if (t < 0) {
+            if (S.nrow(s) != 0) return -20; // a root must have an empty off-diagonal structure
+            continue;
+        }
+        int32_t tf = S.sn_first[t], tl = S.sn_first[t + 1] - 1, tp = S.npiv(t);
+        int64_t q = S.sn_rowptr[t], qe = S.sn_rowptr[t + 1];
+        for (int64_t p = S.sn_rowptr[s]; p < S.sn_rowptr[s + 1]; p++) {
+            int32_t i = S.sn_rows[p];
+            if (i <= tl) {
+                if (i < tf) return -21;
+                S.rel[p] = i - tf;
+            } else {
+                while (q < qe && S.sn_rows[q] < i) q++;
+                if (q >= qe || S.sn_rows[q] != i) return -22;
+                S.rel[p] = tp + (int32_t)(q - S.sn_rowptr[t]);
+            }
+        }
+    }
+
+    // ---- levels -----------------------------------------------------------------------------
+    S.sn_level.assign((size_t)S.nsuper, 0);
+    for (int32_t s = 0; s < S.nsuper; s++) {
+        int32_t t = S.sn_parent[s];
+        if (t >= 0 && S.sn_level[t] < S.sn_level[s] + 1) S.sn_level[t] = S.sn_level[s] + 1;
+    }
+    S.nlevels = 0;
+    for (int32_t s = 0; s < S.nsuper; s++) S.nlevels = std::max(S.nlevels, S.sn_level[s] + 1);
+    S.level_ptr.assign((size_t)S.nlevels + 1, 0);
+    for (int32_t s = 0; s < S.nsuper; s++) S.level_ptr[S.sn_level[s] + 1]++;
+    for (int32_t l = 0; l < S.nlevels; l++) S.level_ptr[l + 1] += S.level_ptr[l];
+    S.level_sn.resize((size_t)S.nsuper);
+    {
+        std::vector<int32_t> w(S.level_ptr.begin(), S.level_ptr.end() - 1);
+        for (int32_t s = 0; s < S.nsuper; s++) S.level_sn[w[S.sn_level[s]]++] = s;
+    }
+
+    // ---- front pool layout and statistics ----------------------------------------------------
+    S.front_off.assign((size_t)S.nsuper + 1, 0);
+    for (int32_t s = 0; s < S.nsuper; s++) {
+        int64_t p = S.npiv(s), m = S.nrow(s), f = p + m;
+        S.front_off[s + 1] = S.front_off[s] + f * f;
+        S.nnz_l += p * (p - 1) / 2 + p * m;
+        S.nnz_u += p * (p + 1) / 2 + p * m;
+        double dp = (double)p, dm = (double)m;
+        S.flops += 2.0 / 3.0 * dp * dp * dp + 2.0 * dp * dp * dm + 2.0 * dp * dm * dm;
+        S.flops_gemm += 2.0 * dp * dm * dm;
+        S.max_front = std::max<int32_t>(S.max_front, (int32_t)f);
+        S.max_pivots = std::max<int32_t>(S.max_pivots, (int32_t)p);
+    }
+
+    // ---- assembly map: where every input entry lands ------------------------------------------
+    S.amap.assign((size_t)S.nnz_a, -1);
+    if (sym_lower) S.amap2.assign((size_t)S.nnz_a, -1);
+    auto local = [&](int32_t s, int32_t i) -> int64_t {
+        int32_t first = S.sn_first[s], last = S.sn_first[s + 1] - 1;
+        if (i <= last) return i - first;
+        const int32_t *b = S.sn_rows.data() + S.sn_rowptr[s], *e = S.sn_rows.data() + S.sn_rowptr[s + 1];
+        const int32_t *it = std::lower_bound(b, e, i);
+        if (it == e || *it != i) return -1;
+        return (int64_t)S.npiv(s) + (it - b);
+    };
+    for (int32_t r = 0; r < n; r++)
+        for (int32_t p = rp[r]; p < rp[r + 1]; p++) {
+            int32_t i = S.pinv[r], j = S.pinv[ci[p]];
+            if (sym_lower && ci[p] > r) return -30; // lower storage promised
+            int32_t s = S.sn_of[std::min(i, j)];
+            int64_t f = S.fsize(s);
+            int64_t li = local(s, i), lj = local(s, j);
+            if (li < 0 || lj < 0) return -31;
+            S.amap[p] = S.front_off[s] + li + lj * f;
+            if (sym_lower && i != j) S.amap2[p] = S.front_off[s] + lj + li * f;
+        }
+    S.seconds_total = since(t_all);
+    return 0;
+}
+
+} // namespace hipmf

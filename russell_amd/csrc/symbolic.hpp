@@ -1,0 +1,73 @@
+// symbolic.hpp -- host-side symbolic analysis for the MI355X multifrontal LU backend.
+//
+// This is the "initialize" phase of the solver boundary (the role umfpack_di_symbolic plays at
+// /root/reference/russell_sparse/c_code/interface_umfpack.c:109 and cudssExecute(ANALYSIS) plays
+// at interface_cudss.cu:361): fill-reducing ordering, elimination tree, supernode partition,
+// frontal-matrix index sets, assembly maps and the level schedule the HIP kernels run.
+// Everything here is integer graph work on the host; it is deterministic (no hashing, no
+// threads, ties broken by vertex number) so the permutation is reproducible bit for bit.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace hipmf {
+
+enum OrderingKind : int32_t {
+    ORDERING_NESTED_DISSECTION = 0, // level-structure nested dissection + minimum degree on the leaves
+    ORDERING_NATURAL = 1,           // identity (Ordering::No in the reference's enum)
+    ORDERING_MIN_DEGREE = 2,        // nested dissection with one-vertex separators disabled: leaves only (small n)
+};
+
+struct SymbolicOptions {
+    int32_t ordering = ORDERING_NESTED_DISSECTION;
+    int32_t nd_leaf = 64;         // leaf regions are ordered by bitset minimum degree (<= 64 vertices)
+    int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
+    int32_t relax_ncol[3] = {4, 16, 48};
+    double relax_zeros[3] = {0.8, 0.1, 0.05};
+};
+
+struct Symbolic {
+    int32_t n = 0;
+    int64_t nnz_a = 0;          // entries of the input CSR
+    bool sym_lower = false;     // input holds the lower triangle of a symmetric matrix
+
+    std::vector<int32_t> perm;  // perm[new] = old   (applied to rows and columns)
+    std::vector<int32_t> pinv;  // pinv[old] = new
+
+    int32_t nsuper = 0;
+    std::vector<int32_t> sn_first;   // nsuper+1: first permuted column of each supernode
+    std::vector<int32_t> sn_of;      // n: supernode of a permuted column
+    std::vector<int64_t> sn_rowptr;  // nsuper+1
+    std::vector<int32_t> sn_rows;    // off-diagonal row structure (permuted indices, ascending)
+    std::vector<int32_t> sn_parent;  // parent supernode or -1
+    std::vector<int32_t> sn_level;   // 0 = leaves
+    int32_t nlevels = 0;
+    std::vector<int32_t> level_ptr;  // nlevels+1
+    std::vector<int32_t> level_sn;   // supernodes grouped by level
+    std::vector<int32_t> child_ptr;  // nsuper+1
+    std::vector<int32_t> child_idx;  // children of each supernode, ascending
+    std::vector<int32_t> rel;        // aligned with sn_rows: position of the row in the PARENT's front
+    std::vector<int64_t> front_off;  // nsuper+1: offset (in doubles) of each f x f front in the pool
+    std::vector<int64_t> amap;       // nnz_a: pool offset every input entry is added to
+    std::vector<int64_t> amap2;      // nnz_a when sym_lower: mirrored position (-1 on the diagonal)
+
+    // statistics
+    int64_t nnz_l = 0;   // strictly lower entries of L (stored, incl. amalgamation padding)
+    int64_t nnz_u = 0;   // upper entries of U incl. diagonal
+    double flops = 0.0;  // sum over fronts of 2/3 p^3 + 2 p^2 m + 2 p m^2
+    double flops_gemm = 0.0;
+    int32_t max_front = 0;
+    int32_t max_pivots = 0;
+    double seconds_ordering = 0.0, seconds_total = 0.0;
+
+    inline int32_t npiv(int32_t s) const { return sn_first[s + 1] - sn_first[s]; }
+    inline int32_t nrow(int32_t s) const { return (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]); }
+    inline int32_t fsize(int32_t s) const { return npiv(s) + nrow(s); }
+};
+
+// Analyse the n x n matrix given as 0-based CSR (the layout solver_cudss_initialize receives,
+// interface_cudss.cu:190-203).  Returns 0 on success, a negative number on invalid input.
+int analyse(int32_t n, const int32_t *row_ptr, const int32_t *col_idx, bool sym_lower,
+            const SymbolicOptions &opt, Symbolic &out);
+
+} // namespace hipmf

@@ -1,0 +1,252 @@
+"""Parity of the HIP backend (through the C-ABI) with the CPU oracle and the reference's golden vectors.
+
+Everything here needs a real MI355X:  python -m pytest tests -m gpu
+Tolerances (fp64): small golden cases use the reference's own tolerances (1e-14 ... 1e-10, cited per case);
+oracle comparisons use |x_gpu - x_oracle|_inf <= 1e-10 * max(1, |x|_inf) unless stated; the large synthetic
+cases use the reference's accuracy metric relative_error = |A x - b|_inf / (max|a| + 1) <= 1e-10
+(russell_sparse/src/verify_lin_sys.rs:60-96; the reference's logs show 1e-11 ... 1e-15).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import BY_NAME, CASES, GOLD, read_mtx, relative_error_metric, rows_of, triplets
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_solve(n, rp, ci, v, b, sym_lower=False, **kw):
+    s = Hipmf()
+    st = s.initialize(n, rp, ci, general_symmetric=sym_lower, **kw)
+    assert st == 0, st
+    code = s.factorize(v, compute_determinant=True)
+    x = s.solve(b) if code in (0, 1) else None
+    return s, code, x
+
+
+def oracle_solve(n, rp, ci, v, b, q=None, sym_lower=False):
+    rows = rows_of(n, rp)
+    ai, aj, ax = rows, np.asarray(ci), np.asarray(v)
+    if sym_lower:
+        off = ai != aj
+        ai, aj, ax = np.concatenate([ai, aj[off]]), np.concatenate([aj, rows[off]]), np.concatenate([ax, ax[off]])
+    cp, ri, vx = O.coo_to_csc(n, n, ai, aj, ax)
+    lu = O.OracleLU(n, cp, ri, vx, q=q)
+    return lu.solve(b), lu
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in CASES if "x" in c])
+def test_reference_golden_solutions(name):
+    c = BY_NAME[name]
+    ai, aj, ax = triplets(c)
+    lower = c["sym"] == "YesLower"
+    rp, cj, vx = O.coo_to_csr(c["n"], c["n"], ai, aj, ax)  # the Rust layer hands CSR to the shim (solver_cudss.rs:223)
+    s, code, x = gpu_solve(c["n"], rp, cj, vx, np.array(c["rhs"], float), sym_lower=lower)
+    assert code == 0
+    assert np.max(np.abs(x - np.array(c["x"]))) <= c["tol"] * max(1.0, np.max(np.abs(c["x"])))
+    if "det" in c:
+        det = s.det_coefficient * 10.0 ** s.det_exponent
+        assert abs(det - c["det"]) <= 1e-13 * abs(c["det"]) * 10  # solver_umfpack.rs:600 uses 1e-13
+    # twice, as solve_works does (solver_umfpack.rs:673-675)
+    x2 = s.solve(np.array(c["rhs"], float))
+    assert np.array_equal(x, x2)
+    s.close()
+
+
+def test_singular_matrix_is_reported():
+    c = BY_NAME["singular_2x2"]
+    ai, aj, ax = triplets(c)
+    rp, cj, vx = O.coo_to_csr(2, 2, ai, aj, ax)
+    s = Hipmf()
+    assert s.initialize(2, rp, cj) == 0
+    assert s.factorize(vx) == 1  # "Error(1): Matrix is singular" (solver_umfpack.rs:492,624-630)
+    s.close()
+
+
+def test_bfwb62_golden():
+    dims, r, c, v, sym = read_mtx(os.path.join(GOLD, "mtx", "bfwb62.mtx"))
+    n = dims[0]
+    assert sym
+    rp, cj, vx = O.coo_to_csr(n, n, r, c, v)
+    xg = np.array(json.load(open(os.path.join(GOLD, "bfwb62_x.json"))))
+    s, code, x = gpu_solve(n, rp, cj, vx, np.ones(n), sym_lower=True)
+    assert code == 0
+    assert np.max(np.abs(x - xg)) <= 1e-10  # bin/solve_matrix_market.rs:217-229
+    s.close()
+
+
+def test_nonlinear_newton_iterates():
+    # russell_sparse/tests/test_nonlinear_system.rs:63-110: re-factorise the same structure 5 times
+    c = BY_NAME["nonlinear_4eq"]
+
+    def jac(u):
+        d1, d2, d3, d4 = u
+        return np.array([
+            [2.0 + 4.0 * d1 ** 3 + 3.0 * d2 * d2, 1.0 + 6.0 * d1 * d2, 0.0, -9.0 + 4.0 * d4 ** 3],
+            [1.0 + 6.0 * d1 * d2, 10.0 + 3.0 * d1 * d1 + 8.0 * d2 + 2.0 * d3, -8.0 + 2.0 * d2, 7.0],
+            [0.0, -8.0 + 2.0 * d2, 3.0 + 2.0 * d3, 2.0],
+            [-9.0 + 4.0 * d4 ** 3, 7.0, 2.0, 5.0 + 12.0 * d1 * d4 * d4]])
+
+    # the residual is not part of the fixture; Newton consistency is checked instead: with the reference's
+    # iterates u_k, the step J(u_k)^{-1} r must be reproduced by the dense solve to 1e-12 on every re-factorisation
+    rp = np.arange(0, 17, 4).astype(np.int32)
+    ci = np.tile(np.arange(4, dtype=np.int32), 4)
+    s = Hipmf()
+    assert s.initialize(4, rp, ci) == 0
+    rng = np.random.default_rng(0)
+    for u in c["iterates"]:
+        J = jac(np.array(u))
+        r = rng.standard_normal(4)
+        assert s.factorize(J.reshape(-1).copy()) == 0
+        x = s.solve(r)
+        assert np.max(np.abs(x - np.linalg.solve(J, r))) <= 1e-12 * max(1.0, np.max(np.abs(x)))
+    s.close()
+
+
+@pytest.mark.parametrize("shape", [(7, 5), (33, 31), (130, 97), (300, 200)])
+def test_poisson2d_matches_oracle(shape):
+    n, rp, ci, v = P.poisson2d(*shape)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s, code, x = gpu_solve(n, rp, ci, v, b)
+    assert code == 0
+    xo, lu = oracle_solve(n, rp, ci, v, b, q=s.permutation())
+    assert lu.status == 0
+    assert np.max(np.abs(x - xo)) <= 1e-10 * max(1.0, np.max(np.abs(xo)))
+    assert relative_error_metric(n, rp, ci, v, x, b) <= 1e-12
+    s.close()
+
+
+def test_poisson3d_matches_oracle():
+    n, rp, ci, v = P.poisson3d(18, 17, 16)
+    b = np.random.default_rng(20260927).standard_normal(n)
+    s, code, x = gpu_solve(n, rp, ci, v, b)
+    assert code == 0
+    xo, _ = oracle_solve(n, rp, ci, v, b, q=s.permutation())
+    assert np.max(np.abs(x - xo)) <= 1e-10 * max(1.0, np.max(np.abs(xo)))
+    s.close()
+
+
+def test_unsymmetric_badly_scaled_matches_oracle():
+    n, rp, ci, v = P.convection_diffusion2d(90, 70)
+    xs = np.random.default_rng(5).standard_normal(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s, code, x = gpu_solve(n, rp, ci, v, b)
+    assert code == 0
+    xo, _ = oracle_solve(n, rp, ci, v, b, q=s.permutation())
+    assert np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo)))
+    assert np.max(np.abs(x - xs)) <= 1e-9 * np.max(np.abs(xs))
+    s.close()
+
+
+def test_random_unsymmetric_weak_diagonal():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    n = 400
+    M = (sp.random(n, n, density=0.02, random_state=5, format="csr") + sp.diags(rng.standard_normal(n) * 0.1)).tocsr()
+    M.sort_indices()
+    xs = rng.standard_normal(n)
+    b = M @ xs
+    s, code, x = gpu_solve(n, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data, b)
+    assert code == 0
+    xo, _ = oracle_solve(n, M.indptr, M.indices, M.data, b)
+    assert np.max(np.abs(x - xo)) <= 1e-8 * max(1.0, np.max(np.abs(xo)))
+    s.close()
+
+
+def test_symmetric_lower_storage_equals_full_storage():
+    n, rp, ci, v = P.poisson2d(64, 50)
+    rows = rows_of(n, rp)
+    keep = ci <= rows
+    rpl = np.zeros(n + 1, np.int64)
+    np.add.at(rpl, rows[keep] + 1, 1)
+    rpl = np.cumsum(rpl).astype(np.int32)
+    b = np.random.default_rng(1).standard_normal(n)
+    s1, c1, x1 = gpu_solve(n, rp, ci, v, b)
+    s2, c2, x2 = gpu_solve(n, rpl, ci[keep], v[keep], b, sym_lower=True)
+    assert c1 == 0 and c2 == 0
+    assert np.max(np.abs(x1 - x2)) <= 1e-12 * np.max(np.abs(x1))
+    assert abs(s1.det_coefficient - s2.det_coefficient) < 1e-9 and s1.det_exponent == s2.det_exponent
+    s1.close(), s2.close()
+
+
+def test_refactorize_with_new_values_and_bit_reproducibility():
+    n, rp, ci, v = P.poisson2d(120, 110)
+    b = np.random.default_rng(2).standard_normal(n)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    x1 = s.solve(b)
+    v2 = v * (1.0 + 0.1 * np.sin(np.arange(v.size)))
+    v2[ci == rows_of(n, rp)] += 1.0
+    assert s.factorize(v2) == 0  # values only, same structure (interface_cudss.cu:406-424)
+    x2 = s.solve(b)
+    xo, _ = oracle_solve(n, rp, ci, v2, b, q=s.permutation())
+    assert np.max(np.abs(x2 - xo)) <= 1e-10 * max(1.0, np.max(np.abs(xo)))
+    assert s.factorize(v) == 0
+    x3 = s.solve(b)
+    assert np.array_equal(x1, x3)  # deterministic summation order => bit-identical
+    s.close()
+
+
+def test_many_rhs_and_linearity():
+    n, rp, ci, v = P.poisson2d(90, 80)
+    B = np.random.default_rng(20260927).standard_normal((5, n))
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    X = s.solve_many(B)
+    for k in range(5):
+        assert np.max(np.abs(X[k] - s.solve(B[k]))) <= 1e-13 * np.max(np.abs(X[k]))
+    xsum = s.solve(B[0] + 2.0 * B[1])
+    assert np.max(np.abs(xsum - (X[0] + 2.0 * X[1]))) <= 1e-11 * np.max(np.abs(xsum))
+    s.close()
+
+
+def test_spmv_matches_oracle():
+    n, rp, ci, v = P.convection_diffusion2d(50, 40, scale_decades=1.0)
+    u = np.random.default_rng(4).standard_normal(n)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    y = s.mat_vec_mul(u, alpha=-2.5)
+    yo = O.csr_matvec(n, rp, ci, v, u, alpha=-2.5)
+    assert np.max(np.abs(y - yo)) <= 1e-13 * np.max(np.abs(yo))
+    s.close()
+
+
+def test_phase_order_errors():
+    n, rp, ci, v = P.poisson2d(6, 5)
+    s = Hipmf()
+    x = np.zeros(n)
+    assert s.lib.solver_hipmf_solve(s.h, x, np.ones(n), 0) == 600000  # ERROR_NEED_FACTORIZATION
+    assert s.factorize(v) == 500000  # ERROR_NEED_INITIALIZATION
+    assert s.initialize(n, rp, ci) == 0
+    assert s.initialize(n, rp, ci) == 700000  # ERROR_ALREADY_INITIALIZED
+    s.close()
+
+
+def test_full_size_c2_properties():
+    """BASELINE config 2: 2D 5-point Poisson 1000 x 1000 (n = 1e6, nnz = 4 996 000), size-independent checks."""
+    n, rp, ci, v = P.poisson2d(1000)
+    assert n == 1_000_000 and rp[-1] == 4_996_000
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    x = s.solve(b)
+    assert relative_error_metric(n, rp, ci, v, x, b) <= 1e-10
+    assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) <= 1e-8  # kappa(A) ~ 4e5
+    ones = s.solve(np.ones(n))
+    assert relative_error_metric(n, rp, ci, v, ones, np.ones(n)) <= 1e-10
+    both = s.solve(b + np.ones(n))
+    assert np.max(np.abs(both - (x + ones))) <= 1e-8 * np.max(np.abs(both))
+    st = s.stats()
+    assert st["n_perturbed"] == 0 and st["n_zero_pivot"] == 0
+    s.close()

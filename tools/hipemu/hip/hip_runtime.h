@@ -1,0 +1,334 @@
+// hipemu -- a tiny single-process HIP emulator used ONLY to debug kernel logic on a machine
+// without a GPU (the authoring container).  It is a development/test tool:
+//   * it is never compiled into the product library (russell_amd/lib/librussell_hipmf.so);
+//   * results produced through it are not parity evidence -- parity is measured on a real MI355X.
+// Every GPU thread of a block is a ucontext fiber; __syncthreads() and the wave-level helpers
+// yield to a round-robin scheduler, so barrier semantics (and barrier bugs) are reproduced.
+// Blocks run one after another; streams and events are synchronous.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct hipemu_uint3 {
+    unsigned x, y, z;
+};
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+struct hipemu_event {
+    std::chrono::steady_clock::time_point t;
+};
+typedef hipemu_event *hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+namespace hipemu {
+inline hipemu_uint3 g_threadIdx, g_blockIdx;
+inline dim3 g_blockDim, g_gridDim;
+inline std::vector<char> g_dynshared;
+
+enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    int state = DONE;
+    hipemu_uint3 tid;
+};
+inline std::vector<Fiber> g_fibers;
+inline ucontext_t g_sched;
+inline int g_cur = 0;
+inline std::function<void()> g_body;
+inline unsigned long long g_wave_buf[16][64];
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+inline int linear_tid() { return (int)(g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z)); }
+
+inline void yield_with(int state) {
+    Fiber &f = g_fibers[g_cur];
+    f.state = state;
+    swapcontext(&f.ctx, &g_sched);
+    g_threadIdx = f.tid; // restored by the scheduler as well; keep both for clarity
+}
+inline void sync_block() { yield_with(WAIT_BLOCK); }
+inline void sync_wave() { yield_with(WAIT_WAVE); }
+
+inline void fiber_entry() {
+    g_body();
+    g_fibers[g_cur].state = DONE;
+    swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+
+inline void run_block(int nthreads) {
+    if ((int)g_fibers.size() < nthreads) g_fibers.resize(nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        Fiber &f = g_fibers[t];
+        if (!f.stack) f.stack = (char *)malloc(STACK_BYTES);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK_BYTES;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        f.state = RUNNABLE;
+        f.tid.x = t % g_blockDim.x;
+        f.tid.y = (t / g_blockDim.x) % g_blockDim.y;
+        f.tid.z = t / (g_blockDim.x * g_blockDim.y);
+    }
+    int nwaves = (nthreads + 63) / 64;
+    for (;;) {
+        bool ran = false;
+        for (int t = 0; t < nthreads; t++) {
+            if (g_fibers[t].state != RUNNABLE) continue;
+            g_cur = t;
+            g_threadIdx = g_fibers[t].tid;
+            swapcontext(&g_sched, &g_fibers[t].ctx);
+            ran = true;
+        }
+        int done = 0, wblock = 0;
+        for (int t = 0; t < nthreads; t++) {
+            done += g_fibers[t].state == DONE;
+            wblock += g_fibers[t].state == WAIT_BLOCK;
+        }
+        if (done == nthreads) break;
+        bool released = false;
+        if (done + wblock == nthreads) {
+            for (int t = 0; t < nthreads; t++)
+                if (g_fibers[t].state == WAIT_BLOCK) g_fibers[t].state = RUNNABLE;
+            released = true;
+        }
+        for (int w = 0; w < nwaves; w++) {
+            int lo = w * 64, hi = std::min(nthreads, lo + 64), live = 0, ww = 0;
+            for (int t = lo; t < hi; t++) {
+                live += g_fibers[t].state != DONE;
+                ww += g_fibers[t].state == WAIT_WAVE;
+            }
+            if (live > 0 && ww == live) {
+                for (int t = lo; t < hi; t++)
+                    if (g_fibers[t].state == WAIT_WAVE) g_fibers[t].state = RUNNABLE;
+                released = true;
+            }
+        }
+        if (!ran && !released) {
+            fprintf(stderr, "hipemu: deadlock (divergent barrier) in block (%u,%u,%u)\n", g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
+            abort();
+        }
+    }
+}
+
+template <class K, class... Args>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
+    g_gridDim = grid;
+    g_blockDim = block;
+    if (g_dynshared.size() < shmem + 16) g_dynshared.resize(shmem + 16);
+    int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads > 1024) {
+        fprintf(stderr, "hipemu: block too large\n");
+        abort();
+    }
+    g_body = [=]() { kernel(args...); };
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++)
+            for (unsigned x = 0; x < grid.x; x++) {
+                g_blockIdx = {x, y, z};
+                run_block(nthreads);
+            }
+}
+} // namespace hipemu
+
+#define threadIdx hipemu::g_threadIdx
+#define blockIdx hipemu::g_blockIdx
+#define blockDim hipemu::g_blockDim
+#define gridDim hipemu::g_gridDim
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(kernel, dim3(grid), dim3(block), shmem, ##__VA_ARGS__)
+
+inline void __syncthreads() { hipemu::sync_block(); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+template <class T>
+inline T hipemu_shfl_abs(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shfl type");
+    int lin = hipemu::linear_tid(), lane = lin & 63, wave = lin >> 6;
+    unsigned long long raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    hipemu::g_wave_buf[wave][lane] = raw;
+    hipemu::sync_wave();
+    unsigned long long got = hipemu::g_wave_buf[wave][src_lane & 63];
+    hipemu::sync_wave();
+    T r;
+    memcpy(&r, &got, sizeof(T));
+    return r;
+}
+template <class T>
+inline T __shfl(T v, int src, int width = 64) {
+    int lane = hipemu::linear_tid() & 63;
+    int base = lane & ~(width - 1);
+    return hipemu_shfl_abs(v, base + (src & (width - 1)));
+}
+template <class T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    int lane = hipemu::linear_tid() & 63;
+    (void)width;
+    return hipemu_shfl_abs(v, lane ^ mask);
+}
+template <class T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int lane = hipemu::linear_tid() & 63;
+    int src = lane + (int)delta;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    return hipemu_shfl_abs(v, src);
+}
+inline unsigned long long __ballot(int pred) {
+    unsigned long long mine = pred ? 1ull : 0ull, all = 0;
+    int lin = hipemu::linear_tid(), lane = lin & 63, wave = lin >> 6;
+    hipemu::g_wave_buf[wave][lane] = mine;
+    hipemu::sync_wave();
+    int lo = wave * 64, hi = std::min<int>((int)(blockDim.x * blockDim.y * blockDim.z), lo + 64);
+    for (int t = lo; t < hi; t++)
+        if (hipemu::g_fibers[t].state != hipemu::DONE && hipemu::g_wave_buf[wave][t - lo]) all |= 1ull << (t - lo);
+    hipemu::sync_wave();
+    return all;
+}
+
+inline double atomicAdd(double *p, double v) {
+    double o = *p;
+    *p = o + v;
+    return o;
+}
+inline int atomicAdd(int *p, int v) {
+    int o = *p;
+    *p = o + v;
+    return o;
+}
+inline unsigned atomicAdd(unsigned *p, unsigned v) {
+    unsigned o = *p;
+    *p = o + v;
+    return o;
+}
+inline int atomicMax(int *p, int v) {
+    int o = *p;
+    *p = std::max(o, v);
+    return o;
+}
+inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) {
+    unsigned long long o = *p;
+    *p = std::max(o, v);
+    return o;
+}
+inline long long __double_as_longlong(double d) {
+    long long r;
+    memcpy(&r, &d, 8);
+    return r;
+}
+inline double __longlong_as_double(long long v) {
+    double r;
+    memcpy(&r, &v, 8);
+    return r;
+}
+inline int atomicOr(int *p, int v) {
+    int o = *p;
+    *p = o | v;
+    return o;
+}
+
+// ---- host runtime --------------------------------------------------------------------------------
+inline hipError_t hipMalloc(void **p, size_t bytes) {
+    *p = malloc(bytes ? bytes : 1);
+    if (*p) memset(*p, 0xCD, bytes); // poison: catches reads of uninitialised device memory
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+inline hipError_t hipMalloc(T **p, size_t bytes) {
+    return hipMalloc((void **)p, bytes);
+}
+inline hipError_t hipFree(void *p) {
+    free(p);
+    return hipSuccess;
+}
+inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned = 0) {
+    *p = malloc(bytes ? bytes : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+inline hipError_t hipHostMalloc(T **p, size_t bytes, unsigned f = 0) {
+    return hipHostMalloc((void **)p, bytes, f);
+}
+inline hipError_t hipHostFree(void *p) {
+    free(p);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemset(void *d, int v, size_t n) {
+    memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) {
+    memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreate(hipStream_t *s) {
+    *s = nullptr;
+    return hipSuccess;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) {
+    *d = 0;
+    return hipSuccess;
+}
+inline hipError_t hipGetDeviceCount(int *c) {
+    *c = 1;
+    return hipSuccess;
+}
+inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) {
+    *fr = *tot = (size_t)8 << 30;
+    return hipSuccess;
+}
+inline hipError_t hipEventCreate(hipEvent_t *e) {
+    *e = new hipemu_event();
+    return hipSuccess;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+    delete e;
+    return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+    e->t = std::chrono::steady_clock::now();
+    return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}

@@ -1,0 +1,27 @@
+// CPU-emulator twin of russell_amd/csrc/rt_hip/hipmf_device_rt.h (development tool, see
+// tools/hipemu/hip/hip_runtime.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef double f64x4 __attribute__((vector_size(32)));
+
+inline double hipemu_mfma_a[16][64], hipemu_mfma_b[16][64];
+
+// same operand / result lane maps as v_mfma_f64_16x16x4_f64
+inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+    int lin = hipemu::linear_tid(), lane = lin & 63, wave = lin >> 6;
+    hipemu_mfma_a[wave][lane] = a;
+    hipemu_mfma_b[wave][lane] = b;
+    hipemu::sync_wave();
+    int col = lane & 15;
+    for (int g = 0; g < 4; g++) {
+        int row = (lane >> 4) + 4 * g;
+        double s = c[g];
+        for (int k = 0; k < 4; k++) s = std::fma(hipemu_mfma_a[wave][row + 16 * k], hipemu_mfma_b[wave][col + 16 * k], s);
+        c[g] = s;
+    }
+    hipemu::sync_wave();
+    return c;
+}
+
+#define HIPMF_DYN_SHARED(T, name) T *name = (T *)(((uintptr_t)hipemu::g_dynshared.data() + 15) & ~(uintptr_t)15)
