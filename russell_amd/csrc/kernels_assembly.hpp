@@ -1,0 +1,102 @@
+// kernels_assembly.hpp -- row scaling, scatter of A into the fronts, extend-add.  All HBM-bound.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hipmf {
+
+// rs[i] = 1 / sum_j |a_ij| (mode 1, UMFPACK_SCALE_SUM), 1 / max_j |a_ij| (mode 2), 1 (mode 0).
+// tptr/tidx list, for every row i, the positions of the stored entries (r, i), r != i, that the
+// symmetric-lower storage mirrors into row i (empty for general storage).
+__global__ void k_row_scale(int32_t n, const int32_t *__restrict__ rp, const double *__restrict__ vals,
+                            const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx, int32_t mode,
+                            double *__restrict__ rs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    if (mode != 0) {
+        for (int p = rp[i]; p < rp[i + 1]; p++) {
+            double a = fabs(vals[p]);
+            acc = (mode == 1) ? acc + a : (a > acc ? a : acc);
+        }
+        if (tptr)
+            for (int q = tptr[i]; q < tptr[i + 1]; q++) {
+                double a = fabs(vals[tidx[q]]);
+                acc = (mode == 1) ? acc + a : (a > acc ? a : acc);
+            }
+    }
+    rs[i] = (mode == 0 || acc == 0.0) ? 1.0 : 1.0 / acc;
+}
+
+// max |rs[row] * a| over the stored entries -> *out (as ordered bits of a non-negative double)
+__global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow,
+                         const double *__restrict__ rs, unsigned long long *out) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        double a = fabs(vals[k] * rs[arow[k]]);
+        m = a > m ? a : m;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
+}
+
+// pool[amap[k]] = rs[row(k)] * a_k  (the pool is zero-filled first; every position is hit once)
+__global__ void k_scatter(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow,
+                          const int64_t *__restrict__ amap, const int64_t *__restrict__ amap2,
+                          const double *__restrict__ rs, const int32_t *__restrict__ acol, double *__restrict__ pool) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        double v = vals[k];
+        pool[amap[k]] = v * rs[arow[k]];
+        if (amap2) {
+            int64_t q = amap2[k];
+            if (q >= 0) pool[q] = v * rs[acol[k]]; // mirrored entry lives in row acol[k]
+        }
+    }
+}
+
+// identity blocks of the augmented big fronts: E(i, f+i) = 1 and E'(f+i, i) = 1 (the pool is zero-filled first)
+__global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, double *__restrict__ pool) {
+    FrontDesc fd = FD[list[blockIdx.x]];
+    const int64_t ld = fd.ld, f = (int64_t)fd.p + fd.m;
+    double *F = pool + fd.off;
+    for (int i = threadIdx.x; i < fd.p; i += blockDim.x) {
+        F[i + (f + i) * ld] = 1.0;
+        F[(f + i) + i * ld] = 1.0;
+    }
+}
+
+// extend-add: every task adds the children's contribution blocks into a (column range x row range)
+// tile of the parent front.  Children are visited in ascending order and a parent entry belongs to
+// exactly one task, so the floating-point summation order is fixed (bit-reproducible factors).
+__global__ void k_extend_add(const EaTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+                             const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
+                             double *__restrict__ pool) {
+    EaTask t = tasks[blockIdx.x];
+    FrontDesc fd = FD[t.s];
+    const int64_t ld = fd.ld;
+    double *F = pool + fd.off;
+    for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
+        FrontDesc cd = FD[child_idx[ci]];
+        const int mc = cd.m;
+        if (mc == 0) continue;
+        const int64_t ldc = cd.ld;
+        const double *CB = pool + cd.off + cd.p + (int64_t)cd.p * ldc;
+        const int32_t *relc = rel + cd.rowptr;
+        const int jlo = lower_bound_i32(relc, mc, t.c0), jhi = lower_bound_i32(relc, mc, t.c1);
+        const int ilo = lower_bound_i32(relc, mc, t.r0), ihi = lower_bound_i32(relc, mc, t.r1);
+        const int ni = ihi - ilo;
+        const int total = (jhi - jlo) * ni;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            int j = jlo + e / ni, i = ilo + e % ni;
+            F[relc[i] + (int64_t)relc[j] * ld] += CB[i + (int64_t)j * ldc];
+        }
+        __syncthreads(); // the next child may hit the same parent entries from other threads
+    }
+}
+
+} // namespace hipmf

@@ -1,0 +1,93 @@
+// kernels_common.hpp -- constants, descriptors and small device helpers shared by the HIP kernels.
+//
+// Data layout in HBM
+//   pool   every supernode s owns a column-major frontal matrix at pool + off[s] with leading
+//          dimension ld[s].  f = p + m (p pivot columns, m off-diagonal rows).
+//          * small fronts (f <= SMALL_F): ld = f.  After factorisation the first p columns hold
+//            L11\U11 and L21, rows 0..p of the other columns hold U12, the trailing m x m block is
+//            the contribution block the parent consumes (extend-add).
+//          * big fronts (f > SMALL_F) are AUGMENTED: ld = f + p; columns f..f+p start as [I; 0] and
+//            rows f..f+p start as [I, 0].  The same partial LU leaves
+//                E  = [inv(L11) P ; -L21 inv(L11) P]      in columns f..f+p  (rows 0..f)
+//                E' = [inv(U11) , -inv(U11) U12]           in rows    f..f+p  (columns 0..f)
+//            which turn the triangular solves of a big supernode into dependency-free GEMVs.
+//   lperm  n int32: for pivot row r of front s, the front-local row that partial pivoting moved there
+//          (search restricted to the pivot block for small fronts, to the 32-row diagonal tile for big ones).
+//   work   one f-vector per front for the multifrontal forward/backward substitutions:
+//          work[0..p) = y1 (big fronts), work[p..f) = update vector u handed to the parent.
+#pragma once
+#include <hipmf_device_rt.h>
+
+#include <cstdint>
+
+namespace hipmf {
+
+constexpr int NB = 32;         // pivot-block width of the tiled path
+constexpr int PANEL_T = 128;   // rows (L) / columns (U) handled by one panel workgroup
+constexpr int UPD_T = 64;      // trailing-update tile edge (one 256-thread workgroup, 4 waves of 32x32)
+constexpr int SMALL_F = 64;    // fronts with f <= SMALL_F are factorised by one wavefront in LDS
+constexpr int LS_LD = 80;      // LDS leading dimensions of the update kernel (bank-conflict free, see k_update)
+constexpr int US_LD = 34;
+constexpr int SOLVE_SLAB = 64; // rows of a solve panel per 256-thread workgroup (64 rows x 4 column groups)
+
+struct FrontDesc {
+    int64_t off;    // offset of the front in the pool (doubles)
+    int64_t rowptr; // offset of the row structure / relative indices
+    int64_t woff;   // offset of the f-vector in the solve workspace
+    int32_t p, m;   // pivots, off-diagonal rows
+    int32_t first;  // first permuted column
+    int32_t child_begin, child_end;
+    int32_t parent;
+    int32_t ld;     // leading dimension: f (small fronts) or f + p (augmented big fronts)
+    int32_t pad;
+};
+
+struct EaTask {
+    int32_t s, c0, c1, r0, r1; // parent front, parent-column range [c0, c1), parent-row range [r0, r1)
+};
+
+struct SolveTask {
+    int32_t s, r0, r1; // big front and the slab of rows its workgroup computes in the forward / backward GEMV
+};
+
+// device-side counters written by the factorisation kernels
+struct FactorInfo {
+    int32_t n_perturbed;  // pivots replaced by +-eps (cf. CUDSS_DATA_NPIVOTS, interface_cudss.cu:466-475)
+    int32_t n_zero_pivot; // exactly-zero pivots met (singular in the UMFPACK sense, solver_umfpack.rs:492)
+    int32_t pad0, pad1;
+};
+
+__device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// largest a in [0, n) with pfx[a] <= g  (pfx is an exclusive prefix sum with pfx[n] = total)
+__device__ __forceinline__ int find_slot(const int32_t *pfx, int n, int g) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (pfx[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// wave-wide arg-max of (value, index); ties resolved towards the smaller index (deterministic)
+__device__ __forceinline__ void wave_argmax(double &v, int &i) {
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(v, off);
+        int oi = __shfl_xor(i, off);
+        if (ov > v || (ov == v && oi < i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+}
+
+} // namespace hipmf

@@ -1,0 +1,282 @@
+// kernels_factor.hpp -- dense partial factorisation of the fronts:  P F = [L11 0; L21 I] [U11 U12; 0 S]
+//   k_small_factor   one wavefront per front with f <= SMALL_F, whole front in LDS        (LDS / latency-bound)
+//   k_diag           tiled path: LU of the 32 x 32 diagonal tile, pivoting inside the tile  (latency-bound)
+//   k_panel          tiled path: triangular solves of the row / column block against the tile
+//   k_update         tiled path: trailing update on v_mfma_f64_16x16x4_f64                  (MFMA / HBM-bound)
+// Big fronts are stored augmented (kernels_common.hpp): the tiled kernels work on the index range
+// [k0 + nb, f + k0 + nb) of both dimensions, which covers the not-yet-eliminated part of F, the columns
+// of E that are already non-zero and the rows of E' that are already non-zero.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hipmf {
+
+// One wavefront factorises one small front (f <= SMALL_F) held entirely in LDS.
+// Partial pivoting searches the whole remaining pivot block (rows c..p-1).
+__global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
+                                                     double *__restrict__ pool, int32_t *__restrict__ lperm,
+                                                     const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
+                                                     FactorInfo *info, int32_t ld) {
+    HIPMF_DYN_SHARED(double, sm);
+    __shared__ int32_t lp[SMALL_F];
+    const int tid = threadIdx.x;
+    FrontDesc fd = FD[list[blockIdx.x]];
+    const int p = fd.p, f = fd.p + fd.m;
+    double *F = pool + fd.off;
+    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    for (int e = tid; e < f * f; e += 64) sm[(e % f) + (e / f) * ld] = F[e];
+    if (tid < p) lp[tid] = tid;
+    __syncthreads();
+    for (int c = 0; c < p; c++) {
+        double v = -1.0;
+        int idx = c + tid;
+        if (idx < p) v = fabs(sm[idx + c * ld]);
+        else idx = 1 << 30;
+        wave_argmax(v, idx);
+        const int piv = idx;
+        if (piv != c) {
+            if (tid < f) {
+                double a = sm[c + tid * ld];
+                sm[c + tid * ld] = sm[piv + tid * ld];
+                sm[piv + tid * ld] = a;
+            }
+            if (tid == 0) {
+                int a = lp[c];
+                lp[c] = lp[piv];
+                lp[piv] = a;
+            }
+            __syncthreads();
+        }
+        double d = sm[c + c * ld];
+        if (fabs(d) < eps || d == 0.0) {
+            // static pivoting: replace a tiny pivot by +-eps (wave-uniform branch: d is one LDS word)
+            double dn = (d < 0.0) ? -eps : eps;
+            if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
+            __syncthreads();
+            if (tid == 0) {
+                if (d == 0.0) atomicAdd(&info->n_zero_pivot, 1);
+                atomicAdd(&info->n_perturbed, 1);
+                sm[c + c * ld] = dn;
+            }
+            __syncthreads();
+            d = dn;
+        }
+        const double inv = 1.0 / d;
+        const int w = f - c - 1;
+        if (tid < w) sm[(c + 1 + tid) + c * ld] *= inv;
+        __syncthreads();
+        for (int e = tid; e < w * w; e += 64) {
+            int r = c + 1 + e % w, cc = c + 1 + e / w;
+            sm[r + cc * ld] -= sm[r + c * ld] * sm[c + cc * ld];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < f * f; e += 64) F[e] = sm[(e % f) + (e / f) * ld];
+    if (tid < p) lperm[fd.first + tid] = lp[tid];
+}
+
+// Tiled path, step k0: factorise the nb x nb diagonal tile (pivoting inside the tile).
+__global__ void __launch_bounds__(64) k_diag(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, int32_t k0,
+                                             double *__restrict__ pool, int32_t *__restrict__ lperm,
+                                             const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
+    __shared__ double T[NB][NB + 1];
+    __shared__ int32_t lp[NB];
+    const int tid = threadIdx.x;
+    FrontDesc fd = FD[list[blockIdx.x]];
+    const int64_t ld = fd.ld;
+    const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
+    double *F = pool + fd.off;
+    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    for (int e = tid; e < nb * nb; e += 64) T[e % nb][e / nb] = F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld];
+    if (tid < nb) lp[tid] = tid;
+    __syncthreads();
+    for (int c = 0; c < nb; c++) {
+        double v = -1.0;
+        int idx = c + tid;
+        if (idx < nb) v = fabs(T[idx][c]);
+        else idx = 1 << 30;
+        wave_argmax(v, idx);
+        const int piv = idx;
+        if (piv != c) {
+            if (tid < nb) {
+                double a = T[c][tid];
+                T[c][tid] = T[piv][tid];
+                T[piv][tid] = a;
+            }
+            if (tid == 0) {
+                int a = lp[c];
+                lp[c] = lp[piv];
+                lp[piv] = a;
+            }
+            __syncthreads();
+        }
+        double d = T[c][c];
+        if (fabs(d) < eps || d == 0.0) {
+            double dn = (d < 0.0) ? -eps : eps;
+            if (dn == 0.0) dn = 1.0;
+            __syncthreads();
+            if (tid == 0) {
+                if (d == 0.0) atomicAdd(&info->n_zero_pivot, 1);
+                atomicAdd(&info->n_perturbed, 1);
+                T[c][c] = dn;
+            }
+            __syncthreads();
+            d = dn;
+        }
+        const double inv = 1.0 / d;
+        const int w = nb - c - 1;
+        if (tid < w) T[c + 1 + tid][c] *= inv;
+        __syncthreads();
+        for (int e = tid; e < w * w; e += 64) {
+            int r = c + 1 + e % w, cc = c + 1 + e / w;
+            T[r][cc] -= T[r][c] * T[c][cc];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += 64) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = T[e % nb][e / nb];
+    if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
+}
+
+// Tiled path, step k0: triangular solves against the diagonal tile over the active range
+// [base, f + base), base = k0 + nb:
+//   L tiles  (rows of the range, columns of the tile):   X <- X * U_kk^{-1}       (covers L21 and E')
+//   U tiles  (columns of the range, rows of the tile):   X <- L_kk^{-1} * (P X)   (covers U12 and E)
+// One thread owns one row (L) / one column (U) of the tile and keeps it in registers.
+__global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
+                                                   const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
+                                                   const int32_t *__restrict__ lperm) {
+    __shared__ double D[NB][NB + 1];
+    __shared__ double T[NB][PANEL_T + 1];
+    __shared__ int32_t lp[NB];
+    const int tid = threadIdx.x;
+    const int slot = find_slot(pfx, nactive, blockIdx.x);
+    const int t = blockIdx.x - pfx[slot];
+    FrontDesc fd = FD[list[slot]];
+    const int64_t ld = fd.ld;
+    const int f = fd.p + fd.m;
+    const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
+    const int base = k0 + nb, limit = f + base;
+    const int nT = (f + PANEL_T - 1) / PANEL_T;
+    double *F = pool + fd.off;
+    for (int e = tid; e < nb * nb; e += PANEL_T) D[e % nb][e / nb] = F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld];
+    if (tid < nb) lp[tid] = lperm[fd.first + k0 + tid];
+    __syncthreads();
+    if (t < nT) {
+        // ---- L tile ----
+        const int r0 = base + t * PANEL_T;
+        const int h = (limit - r0) < PANEL_T ? (limit - r0) : PANEL_T;
+        for (int e = tid; e < h * nb; e += PANEL_T) T[e / h][e % h] = F[(r0 + e % h) + (int64_t)(k0 + e / h) * ld];
+        __syncthreads();
+        if (tid < h) {
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; c++) x[c] = (c < nb) ? T[c][tid] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                if (c < nb) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) v -= x[k] * D[k][c];
+                    x[c] = v / D[c][c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; c++)
+                if (c < nb) T[c][tid] = x[c];
+        }
+        __syncthreads();
+        for (int e = tid; e < h * nb; e += PANEL_T) F[(r0 + e % h) + (int64_t)(k0 + e / h) * ld] = T[e / h][e % h];
+    } else {
+        // ---- U tile ----
+        const int c0 = base + (t - nT) * PANEL_T;
+        const int w = (limit - c0) < PANEL_T ? (limit - c0) : PANEL_T;
+        // load with the row interchange applied: new row r <- old row lp[r]
+        for (int e = tid; e < w * nb; e += PANEL_T) T[e % nb][e / nb] = F[lp[e % nb] + (int64_t)(c0 + e / nb) * ld];
+        __syncthreads();
+        if (tid < w) {
+            double x[NB];
+#pragma unroll
+            for (int r = 0; r < NB; r++) x[r] = (r < nb) ? T[r][tid] : 0.0;
+#pragma unroll
+            for (int r = 1; r < NB; r++) {
+                if (r < nb) {
+                    double v = x[r];
+#pragma unroll
+                    for (int k = 0; k < r; k++) v -= D[r][k] * x[k];
+                    x[r] = v;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NB; r++)
+                if (r < nb) T[r][tid] = x[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < w * nb; e += PANEL_T) F[(k0 + e % nb) + (int64_t)(c0 + e / nb) * ld] = T[e % nb][e / nb];
+    }
+}
+
+// Tiled path, step k0: trailing update  A22 -= L21 * U12  on v_mfma_f64_16x16x4_f64 over the active
+// range [base, f + base)^2 minus the (unused) corner where both indices are >= f.
+// A 256-thread workgroup owns a 64 x 64 tile; each of its 4 waves owns 32 x 32 = 2 x 2 MFMA tiles.
+// The product is formed transposed (D = U^T L^T) so that a result register of 16 adjacent lanes
+// maps to 16 consecutive rows of one column: stores are 128-byte contiguous segments.
+// LDS layouts: Ls[kk][r] (ld 80) and Us[c][kk] (ld 34) make the fragment reads of ds_read_b64
+// conflict-free (banks = (dword address) mod 64) and both global->LDS copies conflict-free too.
+__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
+                                                const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool) {
+    __shared__ double Ls[NB * LS_LD];
+    __shared__ double Us[UPD_T * US_LD];
+    const int tid = threadIdx.x;
+    const int slot = find_slot(pfx, nactive, blockIdx.x);
+    const int t = blockIdx.x - pfx[slot];
+    FrontDesc fd = FD[list[slot]];
+    const int64_t ld = fd.ld;
+    const int f = fd.p + fd.m;
+    const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
+    const int base = k0 + nb, limit = f + base;
+    const int nt = (f + UPD_T - 1) / UPD_T;
+    const int r0 = base + (t % nt) * UPD_T, c0 = base + (t / nt) * UPD_T;
+    if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
+    double *F = pool + fd.off;
+    for (int e = tid; e < NB * UPD_T; e += 256) {
+        int r = e % UPD_T, kk = e / UPD_T;
+        Ls[kk * LS_LD + r] = (r0 + r < limit && kk < nb) ? F[(r0 + r) + (int64_t)(k0 + kk) * ld] : 0.0;
+    }
+    for (int e = tid; e < NB * UPD_T; e += 256) {
+        int kk = e % NB, c = e / NB;
+        Us[c * US_LD + kk] = (c0 + c < limit && kk < nb) ? F[(k0 + kk) + (int64_t)(c0 + c) * ld] : 0.0;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk0 = 0; kk0 < NB; kk0 += 4) {
+        double ua[2], lb[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) ua[a] = Us[(wc + a * 16 + l15) * US_LD + kk0 + l4];
+#pragma unroll
+        for (int b = 0; b < 2; b++) lb[b] = Ls[(kk0 + l4) * LS_LD + wr + b * 16 + l15];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = mfma_f64_16x16x4(ua[a], lb[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                int r = r0 + wr + b * 16 + l15;
+                int c = c0 + wc + a * 16 + l4 + 4 * g;
+                if (r < limit && c < limit && !(r >= f && c >= f)) F[r + (int64_t)c * ld] -= acc[a][b][g];
+            }
+}
+
+} // namespace hipmf

@@ -1,0 +1,190 @@
+// kernels_solve.hpp -- level-set sparse triangular solves in multifrontal form (HBM-bound).
+//   small fronts (f <= SMALL_F): k_fwd / k_bwd, one workgroup per supernode, substitution against L11 / U11
+//   big fronts (augmented):      k_fwd_big / k_bwd_big, GEMVs against the inverse-based panels E / E'
+//                                split into 64-row slabs, one 256-thread workgroup per slab
+// Forward pass, leaves to root:   w = [b1; 0] + sum_children u_c;  y1 = L11^{-1} P w1;  u = w2 - L21 y1
+// Backward pass, root to leaves:  x1 = U11^{-1} (y1 - U12 x2),  x2 gathered from the ancestors
+// Every sum has a fixed order (children ascending, columns ascending, 4 fixed column groups), so the
+// solves are bit-reproducible.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hipmf {
+
+__global__ void k_fwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
+                      const int32_t *__restrict__ lperm, const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
+                      double *__restrict__ work, double *__restrict__ x) {
+    __shared__ double xb[NB];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    FrontDesc fd = FD[list[blockIdx.x]];
+    const int p = fd.p, f = fd.p + fd.m;
+    const int64_t ld = fd.ld;
+    const double *F = pool + fd.off;
+    double *W = work + fd.woff;
+    double *xs = x + fd.first;
+    for (int i = tid; i < f; i += nt) W[i] = (i < p) ? xs[i] : 0.0;
+    __syncthreads();
+    for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
+        FrontDesc cd = FD[child_idx[ci]];
+        const double *uc = work + cd.woff + cd.p;
+        const int32_t *relc = rel + cd.rowptr;
+        for (int i = tid; i < cd.m; i += nt) W[relc[i]] += uc[i];
+        __syncthreads();
+    }
+    // row interchanges of the pivot block: xs[r] = W[lperm[r]]
+    for (int i = tid; i < p; i += nt) xs[i] = W[lperm[fd.first + i]];
+    __syncthreads();
+    for (int j0 = 0; j0 < p; j0 += NB) {
+        const int jb = (p - j0) < NB ? (p - j0) : NB;
+        if (tid < 64) {
+            double v = (tid < jb) ? xs[j0 + tid] : 0.0;
+            for (int j = 0; j < jb; j++) {
+                double vj = __shfl(v, j);
+                if (tid > j && tid < jb) v -= F[(j0 + tid) + (int64_t)(j0 + j) * ld] * vj;
+            }
+            if (tid < jb) {
+                xb[tid] = v;
+                xs[j0 + tid] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = j0 + jb + tid; i < f; i += nt) {
+            double acc = 0.0;
+            for (int j = 0; j < jb; j++) acc += F[i + (int64_t)(j0 + j) * ld] * xb[j];
+            if (i < p) xs[i] -= acc;
+            else W[i] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
+                      const int32_t *__restrict__ rows, double *__restrict__ work, double *__restrict__ x) {
+    __shared__ double xb[NB];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    FrontDesc fd = FD[list[blockIdx.x]];
+    const int p = fd.p, m = fd.m;
+    const int64_t ld = fd.ld;
+    const double *F = pool + fd.off;
+    double *W = work + fd.woff;
+    double *xs = x + fd.first;
+    const int32_t *rws = rows + fd.rowptr;
+    for (int i = tid; i < m; i += nt) W[p + i] = x[rws[i]];
+    __syncthreads();
+    for (int i = tid; i < p; i += nt) {
+        double acc = 0.0;
+        for (int j = 0; j < m; j++) acc += F[i + (int64_t)(p + j) * ld] * W[p + j];
+        xs[i] -= acc;
+    }
+    __syncthreads();
+    for (int j0 = ((p - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
+        const int jb = (p - j0) < NB ? (p - j0) : NB;
+        if (tid < 64) {
+            double v = (tid < jb) ? xs[j0 + tid] : 0.0;
+            for (int j = jb - 1; j >= 0; j--) {
+                if (tid == j) v /= F[(j0 + j) + (int64_t)(j0 + j) * ld];
+                double vj = __shfl(v, j);
+                if (tid < j) v -= F[(j0 + tid) + (int64_t)(j0 + j) * ld] * vj;
+            }
+            if (tid < jb) {
+                xb[tid] = v;
+                xs[j0 + tid] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < j0; i += nt) {
+            double acc = 0.0;
+            for (int j = 0; j < jb; j++) acc += F[i + (int64_t)(j0 + j) * ld] * xb[j];
+            xs[i] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
+// Forward step of a big (augmented) front, rows [r0, r1) of its f-vector:
+//   [y1; -delta] = E * w1,  E(r, j) = F[r + (f + j) ld]   ->   work[r] = y1[r] (r < p),  work[r] = w2[r] + (E w1)[r] (r >= p)
+// Every workgroup of the front assembles w1 = b1 + (children's updates to the pivot rows) in LDS itself.
+// Dynamic LDS: p doubles.
+__global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+                                                 const double *__restrict__ pool, const int32_t *__restrict__ child_idx,
+                                                 const int32_t *__restrict__ rel, double *__restrict__ work,
+                                                 const double *__restrict__ x) {
+    HIPMF_DYN_SHARED(double, w1);
+    __shared__ double wsl[SOLVE_SLAB];
+    __shared__ double red[4][SOLVE_SLAB];
+    const int tid = threadIdx.x;
+    SolveTask tk = tasks[blockIdx.x];
+    FrontDesc fd = FD[tk.s];
+    const int p = fd.p, f = fd.p + fd.m;
+    const int64_t ld = fd.ld;
+    const double *E = pool + fd.off + (int64_t)f * ld;
+    double *W = work + fd.woff;
+    const int r0 = tk.r0, r1 = tk.r1;
+    for (int i = tid; i < p; i += 256) w1[i] = x[fd.first + i];
+    if (tid < SOLVE_SLAB) wsl[tid] = 0.0;
+    __syncthreads();
+    const int s0 = r0 > p ? r0 : p; // part of the slab that lies in the update rows
+    for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
+        FrontDesc cd = FD[child_idx[ci]];
+        const double *uc = work + cd.woff + cd.p;
+        const int32_t *relc = rel + cd.rowptr;
+        const int npre = lower_bound_i32(relc, cd.m, p);
+        for (int i = tid; i < npre; i += 256) w1[relc[i]] += uc[i];
+        if (r1 > s0) {
+            const int lo = lower_bound_i32(relc, cd.m, s0), hi = lower_bound_i32(relc, cd.m, r1);
+            for (int i = lo + tid; i < hi; i += 256) wsl[relc[i] - r0] += uc[i];
+        }
+        __syncthreads();
+    }
+    const int rr = tid & (SOLVE_SLAB - 1), g = tid >> 6;
+    const int r = r0 + rr;
+    // rows of inv(L11) P are zero right of their own 32-column block
+    int jmax = p;
+    if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
+    double acc = 0.0;
+    if (r < r1) {
+        const double *Er = E + r;
+        for (int j = g; j < jmax; j += 4) acc += Er[(int64_t)j * ld] * w1[j];
+    }
+    red[g][rr] = acc;
+    __syncthreads();
+    if (g == 0 && r < r1) {
+        double tot = (red[0][rr] + red[1][rr]) + (red[2][rr] + red[3][rr]);
+        W[r] = (r < p) ? tot : wsl[rr] + tot;
+    }
+}
+
+// Backward step of a big front, pivot rows [r0, r1):
+//   x1 = E' * [y1; x2],  E'(i, j) = F[(f + i) + j ld],  y1 = work[0..p),  x2 = x[rows]
+// Dynamic LDS: f doubles.
+__global__ void __launch_bounds__(256) k_bwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+                                                 const double *__restrict__ pool, const int32_t *__restrict__ rows,
+                                                 const double *__restrict__ work, double *__restrict__ x) {
+    HIPMF_DYN_SHARED(double, v);
+    __shared__ double red[4][SOLVE_SLAB];
+    const int tid = threadIdx.x;
+    SolveTask tk = tasks[blockIdx.x];
+    FrontDesc fd = FD[tk.s];
+    const int p = fd.p, f = fd.p + fd.m;
+    const int64_t ld = fd.ld;
+    const double *Ep = pool + fd.off + f;
+    const double *W = work + fd.woff;
+    const int32_t *rws = rows + fd.rowptr;
+    const int r0 = tk.r0, r1 = tk.r1;
+    // columns of inv(U11) left of the slab's first 32-column block are zero
+    const int jmin = (r0 / NB) * NB;
+    for (int j = jmin + tid; j < f; j += 256) v[j] = (j < p) ? W[j] : x[rws[j - p]];
+    __syncthreads();
+    const int rr = tid & (SOLVE_SLAB - 1), g = tid >> 6;
+    const int i = r0 + rr;
+    double acc = 0.0;
+    if (i < r1) {
+        const double *Ei = Ep + i;
+        for (int j = jmin + g; j < f; j += 4) acc += Ei[(int64_t)j * ld] * v[j];
+    }
+    red[g][rr] = acc;
+    __syncthreads();
+    if (g == 0 && i < r1) x[fd.first + i] = (red[0][rr] + red[1][rr]) + (red[2][rr] + red[3][rr]);
+}
+
+} // namespace hipmf

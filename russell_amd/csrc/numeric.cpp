@@ -26,6 +26,8 @@ namespace hipmf {
 
 #define STREAM ((hipStream_t)stream)
 
+constexpr int32_t MAX_LDS_DOUBLES = 7936; // 62 KiB of dynamic LDS for the w1 / v vectors of the big-front solves
+
 template <class T>
 static hipError_t dev_upload(T **dptr, const std::vector<T> &v) {
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
@@ -41,12 +43,13 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_fd,  d_ea,   d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_b,   d_x,    d_du,   d_rows, d_rel,
-                    d_child, d_lists, d_tasks, d_rp,   d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm, d_rs};
+    void *ptrs[] = {d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
+                    d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    d_fd = nullptr, d_ea = nullptr, d_info = nullptr, d_scalar = nullptr;
-    d_work = d_vals = d_xp = d_r = d_b = d_x = d_du = d_pool = d_rs = nullptr;
+    d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
+    d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
     d_amap = d_amap2 = nullptr;
     for (auto &e : ev)
@@ -76,7 +79,9 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
         stream = st;
     }
-    int rc = analyse(n, rp, ci, sym_lower, sopt, S);
+    SymbolicOptions so = sopt;
+    so.augment_above = SMALL_F;
+    int rc = analyse(n, rp, ci, sym_lower, so, S);
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
         return rc <= -30 || rc >= -2 ? ERROR_HIPMF_INVALID_MATRIX : ERROR_HIPMF_SYMBOLIC;
@@ -113,7 +118,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     std::vector<int64_t>().swap(S.amap);
     std::vector<int64_t>().swap(S.amap2);
     HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
-    for (double **p : {&d_xp, &d_r, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
+    for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_scalar, 4 * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
@@ -142,12 +147,15 @@ int32_t Solver::upload_plan() {
         d.child_begin = S.child_ptr[s];
         d.child_end = S.child_ptr[s + 1];
         d.parent = S.sn_parent[s];
+        d.ld = S.front_ld[s];
+        d.pad = 0;
         work_doubles += d.p + d.m;
     }
     pool_doubles = S.front_off[ns];
 
-    std::vector<int32_t> lists, tasks;
+    std::vector<int32_t> lists, tasks, allbig;
     std::vector<EaTask> ea;
+    std::vector<SolveTask> stasks;
     levels.assign((size_t)S.nlevels, LevelPlan());
     for (int32_t l = 0; l < S.nlevels; l++) {
         LevelPlan &L = levels[l];
@@ -163,7 +171,6 @@ int32_t Solver::upload_plan() {
             }
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
-        L.all_off = (int32_t)lists.size();
         L.small_off = (int32_t)lists.size();
         L.small_cnt = (int32_t)small.size();
         L.small_ld = fmax_small | 1;
@@ -171,8 +178,8 @@ int32_t Solver::upload_plan() {
         L.big_off = (int32_t)lists.size();
         L.big_cnt = (int32_t)big.size();
         lists.insert(lists.end(), big.begin(), big.end());
-        L.all_cnt = L.small_cnt + L.big_cnt;
-        // tiled steps
+        allbig.insert(allbig.end(), big.begin(), big.end());
+        // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
         int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
         for (int32_t k0 = 0; k0 < pmax; k0 += NB) {
             StepPlan st;
@@ -181,9 +188,7 @@ int32_t Solver::upload_plan() {
             int64_t acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
-                int32_t s = big[a], f = S.fsize(s), nb = std::min(NB, S.npiv(s) - k0);
-                int32_t below = f - (k0 + nb);
-                acc += 2 * ((below + PANEL_T - 1) / PANEL_T) + (k0 + PANEL_T - 1) / PANEL_T;
+                acc += 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
             }
             tasks.push_back((int32_t)acc);
             st.n_panel = (int32_t)acc;
@@ -191,8 +196,7 @@ int32_t Solver::upload_plan() {
             acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
-                int32_t s = big[a], f = S.fsize(s), nb = std::min(NB, S.npiv(s) - k0);
-                int64_t nt = (f - (k0 + nb) + UPD_T - 1) / UPD_T;
+                int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T;
                 acc += nt * nt;
             }
             tasks.push_back((int32_t)acc);
@@ -200,7 +204,7 @@ int32_t Solver::upload_plan() {
             st.n_update = (int32_t)acc;
             L.steps.push_back(st);
         }
-        // extend-add tasks
+        // extend-add tasks: 32-column x 256-row tiles of the parent
         L.ea_off = (int32_t)ea.size();
         for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
             int32_t s = S.level_sn[k];
@@ -208,13 +212,40 @@ int32_t Solver::upload_plan() {
             for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
             if (!any) continue;
             int32_t f = S.fsize(s);
-            int32_t chunk = f <= 64 ? f : 32;
-            for (int32_t c0 = 0; c0 < f; c0 += chunk) ea.push_back({s, c0, std::min(f, c0 + chunk)});
+            if (f <= 64) {
+                ea.push_back({s, 0, f, 0, f});
+            } else {
+                for (int32_t c0 = 0; c0 < f; c0 += 32)
+                    for (int32_t r0 = 0; r0 < f; r0 += 256) ea.push_back({s, c0, std::min(f, c0 + 32), r0, std::min(f, r0 + 256)});
+            }
         }
         L.ea_cnt = (int32_t)ea.size() - L.ea_off;
+        // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
+        L.fwd_off = (int32_t)stasks.size();
+        for (int32_t s : big) {
+            int32_t f = S.fsize(s);
+            L.big_pmax = std::max(L.big_pmax, S.npiv(s));
+            L.big_fmax = std::max(L.big_fmax, f);
+            for (int32_t r0 = 0; r0 < f; r0 += SOLVE_SLAB) stasks.push_back({s, r0, std::min(f, r0 + SOLVE_SLAB)});
+        }
+        L.fwd_cnt = (int32_t)stasks.size() - L.fwd_off;
+        L.bwd_off = (int32_t)stasks.size();
+        for (int32_t s : big) {
+            int32_t p = S.npiv(s);
+            for (int32_t r0 = 0; r0 < p; r0 += SOLVE_SLAB) stasks.push_back({s, r0, std::min(p, r0 + SOLVE_SLAB)});
+        }
+        L.bwd_cnt = (int32_t)stasks.size() - L.bwd_off;
+        if (L.big_pmax > MAX_LDS_DOUBLES || L.big_fmax > MAX_LDS_DOUBLES) {
+            last_error = "a frontal matrix exceeds the LDS staging limit of this build (f = " + std::to_string(L.big_fmax) + ")";
+            return ERROR_NOT_AVAILABLE;
+        }
     }
+    allbig_off = (int32_t)lists.size();
+    allbig_cnt = (int32_t)allbig.size();
+    lists.insert(lists.end(), allbig.begin(), allbig.end());
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_st, stasks), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_lists, lists), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_tasks, tasks), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
@@ -251,6 +282,10 @@ int32_t Solver::run_factor() {
     HIPC(hipMemsetAsync(d_pool, 0, sizeof(double) * pool_doubles, STREAM), ERROR_HIP_MEMCPY);
     hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_amap, d_amap2, d_rs, d_ci, d_pool);
     launches += 3;
+    if (allbig_cnt > 0) {
+        hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, STREAM, d_lists + allbig_off, d_fd, d_pool);
+        launches++;
+    }
     HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
         if (L.ea_cnt > 0) {
@@ -268,17 +303,11 @@ int32_t Solver::run_factor() {
             const int32_t *blist = d_lists + L.big_off;
             hipLaunchKernelGGL(k_diag, dim3(st.nactive), dim3(64), 0, STREAM, blist, d_fd, k0, d_pool, d_lperm, d_scalar,
                                opt.pivot_epsilon, d_info);
-            launches++;
-            if (st.n_panel > 0) {
-                hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist,
-                                   d_fd, k0, d_pool, d_lperm);
-                launches++;
-            }
-            if (st.n_update > 0) {
-                hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist,
-                                   d_fd, k0, d_pool);
-                launches++;
-            }
+            hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
+                               d_pool, d_lperm);
+            hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
+                               d_pool);
+            launches += 3;
             k0 += NB;
         }
     }
@@ -308,22 +337,29 @@ int32_t Solver::run_triangular(double *xp) {
     int64_t launches = 0;
     HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
-        if (L.small_cnt > 0)
+        if (L.small_cnt > 0) {
             hipLaunchKernelGGL(k_fwd, dim3(L.small_cnt), dim3(64), 0, STREAM, d_lists + L.small_off, d_fd, d_pool, d_lperm, d_child,
                                d_rel, d_work, xp);
-        if (L.big_cnt > 0)
-            hipLaunchKernelGGL(k_fwd, dim3(L.big_cnt), dim3(256), 0, STREAM, d_lists + L.big_off, d_fd, d_pool, d_lperm, d_child,
-                               d_rel, d_work, xp);
-        launches += (L.small_cnt > 0) + (L.big_cnt > 0);
+            launches++;
+        }
+        if (L.fwd_cnt > 0) {
+            hipLaunchKernelGGL(k_fwd_big, dim3(L.fwd_cnt), dim3(256), sizeof(double) * (size_t)L.big_pmax, STREAM, d_st + L.fwd_off, d_fd,
+                               d_pool, d_child, d_rel, d_work, xp);
+            launches++;
+        }
     }
     HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (auto it = levels.rbegin(); it != levels.rend(); ++it) {
         const LevelPlan &L = *it;
-        if (L.big_cnt > 0)
-            hipLaunchKernelGGL(k_bwd, dim3(L.big_cnt), dim3(256), 0, STREAM, d_lists + L.big_off, d_fd, d_pool, d_rows, d_work, xp);
-        if (L.small_cnt > 0)
+        if (L.bwd_cnt > 0) {
+            hipLaunchKernelGGL(k_bwd_big, dim3(L.bwd_cnt), dim3(256), sizeof(double) * (size_t)L.big_fmax, STREAM, d_st + L.bwd_off, d_fd,
+                               d_pool, d_rows, d_work, xp);
+            launches++;
+        }
+        if (L.small_cnt > 0) {
             hipLaunchKernelGGL(k_bwd, dim3(L.small_cnt), dim3(64), 0, STREAM, d_lists + L.small_off, d_fd, d_pool, d_rows, d_work, xp);
-        launches += (L.small_cnt > 0) + (L.big_cnt > 0);
+            launches++;
+        }
     }
     HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
     times.n_kernel_launches_solve = launches;
@@ -352,6 +388,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
     const int32_t n = S.n;
     const dim3 g((n + 255) / 256), b(256);
+    const double EPS = 2.220446049250313e-16;
     refinement_steps_done = 0;
     HIPC(hipEventRecord((hipEvent_t)ev[6], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (int32_t j = 0; j < nrhs; j++) {
@@ -369,24 +406,27 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         int32_t code = run_triangular(d_xp);
         if (code != SUCCESSFUL_EXIT) return code;
         hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_xp, xj, 0);
-        // iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229)
+        // Iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229).
+        // Stopping rule on the sparse backward error omega = max_i |r_i| / (|A||x| + |b|)_i: stop when omega <= eps,
+        // when a step fails to halve it, or after refinement_nstep steps; a step that makes omega worse is taken back.
         double prev = INFINITY;
         for (int32_t it = 0; it <= opt.refinement_nstep && opt.refinement_nstep > 0; it++) {
-            hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj, bj, d_r);
-            HIPC(hipMemsetAsync(d_scalar + 1, 0, sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
-            hipLaunchKernelGGL(k_norminf, dim3(std::min(1024, (n + 255) / 256)), b, 0, STREAM, n, d_r, d_scalar + 1);
-            double rn = 0.0;
-            HIPC(hipMemcpyAsync(&rn, d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+            hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj, bj, d_r, d_den);
+            HIPC(hipMemsetAsync(d_scalar + 1, 0, 2 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
+            hipLaunchKernelGGL(k_norms, dim3(std::min(1024, (n + 255) / 256)), b, 0, STREAM, n, d_r, d_den, d_scalar + 1);
+            double nrm[2] = {0.0, 0.0};
+            HIPC(hipMemcpyAsync(nrm, d_scalar + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
             HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
             harvest_tri();
-            if (it > 0 && !(rn < prev)) {
-                // the last correction did not help: take it back and stop
-                hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_du, xj, 2);
+            const double rn = nrm[0], omega = nrm[1];
+            if (it > 0 && !(omega < prev)) {
+                hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_du, xj, 2); // take the last correction back
                 break;
             }
             last_residual_inf = rn;
-            if (rn == 0.0 || it == opt.refinement_nstep || (it > 0 && rn > 0.5 * prev)) break;
-            prev = rn;
+            last_omega = omega;
+            if (omega <= EPS || it == opt.refinement_nstep || (it > 0 && omega > 0.5 * prev)) break;
+            prev = omega;
             hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_perm, d_rs, d_r, d_du);
             code = run_triangular(d_du);
             if (code != SUCCESSFUL_EXIT) return code;

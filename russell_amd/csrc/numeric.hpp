@@ -10,6 +10,7 @@ namespace hipmf {
 
 struct FrontDesc;
 struct EaTask;
+struct SolveTask;
 struct FactorInfo;
 
 // status codes shared with the reference's C shims (/root/reference/russell_sparse/c_code/constants.h:5-12)
@@ -58,8 +59,9 @@ struct StepPlan {
 struct LevelPlan {
     int32_t small_off = 0, small_cnt = 0, small_ld = 0; // fronts with f <= SMALL_F
     int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
-    int32_t all_off = 0, all_cnt = 0;                   // solve lists: [small..., big...]
     int32_t ea_off = 0, ea_cnt = 0;
+    int32_t fwd_off = 0, fwd_cnt = 0, bwd_off = 0, bwd_cnt = 0; // SolveTask ranges of the big fronts
+    int32_t big_pmax = 0, big_fmax = 0;
     std::vector<StepPlan> steps;
 };
 
@@ -83,7 +85,7 @@ class Solver {
     bool initialized = false, factorized = false;
     int32_t n_perturbed = 0, n_zero_pivot = 0;
     int32_t refinement_steps_done = 0;
-    double last_residual_inf = 0.0;
+    double last_residual_inf = 0.0, last_omega = 0.0;
     int device = 0;
     void *stream = nullptr;
     std::string last_error;
@@ -102,12 +104,15 @@ class Solver {
     bool tri_pending = false;
     std::vector<LevelPlan> levels;
     int64_t work_doubles = 0;
+    int32_t allbig_off = 0, allbig_cnt = 0;
     // device buffers
     FrontDesc *d_fd = nullptr;
     EaTask *d_ea = nullptr;
+    SolveTask *d_st = nullptr;
     FactorInfo *d_info = nullptr;
-    unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] norm scratch
-    double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_b = nullptr, *d_x = nullptr, *d_du = nullptr;
+    unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] |r|_inf bits, [2] omega bits
+    double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_den = nullptr, *d_b = nullptr, *d_x = nullptr,
+           *d_du = nullptr;
     int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
     int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
     int64_t *d_amap = nullptr, *d_amap2 = nullptr;

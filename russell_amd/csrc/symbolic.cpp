@@ -613,10 +613,18 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     }
 
     // ---- front pool layout and statistics ----------------------------------------------------
+    // Fronts larger than opt.augment_above are stored AUGMENTED: an (f+p) x (f+p) array whose extra
+    // p columns / p rows start as identity blocks.  Running the same partial LU on it leaves
+    //   E  = [inv(L11) P ; -L21 inv(L11) P]   in columns f..f+p   (forward-solve panel)
+    //   E' = [inv(U11) , -inv(U11) U12]       in rows    f..f+p   (backward-solve panel)
+    // so the triangular solves of big supernodes become dependency-free GEMVs (see kernels.hpp).
     S.front_off.assign((size_t)S.nsuper + 1, 0);
+    S.front_ld.assign((size_t)S.nsuper, 0);
     for (int32_t s = 0; s < S.nsuper; s++) {
         int64_t p = S.npiv(s), m = S.nrow(s), f = p + m;
-        S.front_off[s + 1] = S.front_off[s] + f * f;
+        int64_t ld = (f > opt.augment_above) ? f + p : f;
+        S.front_ld[s] = (int32_t)ld;
+        S.front_off[s + 1] = S.front_off[s] + ld * ld;
         S.nnz_l += p * (p - 1) / 2 + p * m;
         S.nnz_u += p * (p + 1) / 2 + p * m;
         double dp = (double)p, dm = (double)m;
@@ -642,7 +650,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             int32_t i = S.pinv[r], j = S.pinv[ci[p]];
             if (sym_lower && ci[p] > r) return -30; // lower storage promised
             int32_t s = S.sn_of[std::min(i, j)];
-            int64_t f = S.fsize(s);
+            int64_t f = S.front_ld[s];
             int64_t li = local(s, i), lj = local(s, j);
             if (li < 0 || lj < 0) return -31;
             S.amap[p] = S.front_off[s] + li + lj * f;

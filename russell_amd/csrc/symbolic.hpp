@@ -22,6 +22,7 @@ struct SymbolicOptions {
     int32_t ordering = ORDERING_NESTED_DISSECTION;
     int32_t nd_leaf = 64;         // leaf regions are ordered by bitset minimum degree (<= 64 vertices)
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
+    int32_t augment_above = 64;   // fronts with f > this are stored augmented (must equal kernels.hpp SMALL_F)
     int32_t relax_ncol[3] = {4, 16, 48};
     double relax_zeros[3] = {0.8, 0.1, 0.05};
 };
@@ -47,7 +48,8 @@ struct Symbolic {
     std::vector<int32_t> child_ptr;  // nsuper+1
     std::vector<int32_t> child_idx;  // children of each supernode, ascending
     std::vector<int32_t> rel;        // aligned with sn_rows: position of the row in the PARENT's front
-    std::vector<int64_t> front_off;  // nsuper+1: offset (in doubles) of each f x f front in the pool
+    std::vector<int64_t> front_off;  // nsuper+1: offset (in doubles) of each ld x ld front in the pool
+    std::vector<int32_t> front_ld;   // nsuper: leading dimension: f, or f + p for augmented (big) fronts
     std::vector<int64_t> amap;       // nnz_a: pool offset every input entry is added to
     std::vector<int64_t> amap2;      // nnz_a when sym_lower: mirrored position (-1 on the diagonal)
 
