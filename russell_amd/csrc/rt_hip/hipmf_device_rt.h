@@ -13,3 +13,11 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
 }
 
 #define HIPMF_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+
+// broadcast of lane `src` (wave-uniform) to every lane: two v_readlane_b32, result lives in SGPRs
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
