@@ -73,7 +73,9 @@ __global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc
 // extend-add: every task adds the children's contribution blocks into a (column range x row range)
 // tile of the parent front.  Children are visited in ascending order and a parent entry belongs to
 // exactly one task, so the floating-point summation order is fixed (bit-reproducible factors).
-__global__ void k_extend_add(const EaTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+// The sub-ranges of every child's (sorted) relative-index list that fall into the tile are precomputed on
+// the host (EaRange, one per task and child): no dependent binary searches on the device.
+__global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const FrontDesc *__restrict__ FD,
                              const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
                              double *__restrict__ pool) {
     EaTask t = tasks[blockIdx.x];
@@ -87,8 +89,8 @@ __global__ void k_extend_add(const EaTask *__restrict__ tasks, const FrontDesc *
         const int64_t ldc = cd.ld;
         const double *CB = pool + cd.off + cd.p + (int64_t)cd.p * ldc;
         const int32_t *relc = rel + cd.rowptr;
-        const int jlo = lower_bound_i32(relc, mc, t.c0), jhi = lower_bound_i32(relc, mc, t.c1);
-        const int ilo = lower_bound_i32(relc, mc, t.r0), ihi = lower_bound_i32(relc, mc, t.r1);
+        const EaRange rg = ranges[t.range_off + (ci - fd.child_begin)];
+        const int jlo = rg.jlo, jhi = rg.jhi, ilo = rg.ilo, ihi = rg.ihi;
         const int ni = ihi - ilo;
         const int total = (jhi - jlo) * ni;
         for (int e = threadIdx.x; e < total; e += blockDim.x) {

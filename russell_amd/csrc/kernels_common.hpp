@@ -44,6 +44,11 @@ struct FrontDesc {
 
 struct EaTask {
     int32_t s, c0, c1, r0, r1; // parent front, parent-column range [c0, c1), parent-row range [r0, r1)
+    int32_t range_off;         // first EaRange of this task (one per child of s, in child order)
+};
+
+struct EaRange {
+    int32_t jlo, jhi, ilo, ihi; // child entries whose relative index falls in [c0, c1) resp. [r0, r1)
 };
 
 struct SolveTask {

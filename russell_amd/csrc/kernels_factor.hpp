@@ -1,8 +1,10 @@
 // kernels_factor.hpp -- dense partial factorisation of the fronts:  P F = [L11 0; L21 I] [U11 U12; 0 S]
-//   k_small_factor   one wavefront per front with f <= SMALL_F, whole front in LDS        (LDS / latency-bound)
-//   k_diag           tiled path: LU of the 32 x 32 diagonal tile, pivoting inside the tile  (latency-bound)
-//   k_panel          tiled path: triangular solves of the row / column block against the tile
-//   k_update         tiled path: trailing update on v_mfma_f64_16x16x4_f64                  (MFMA / HBM-bound)
+//   k_small_factor   one wavefront per front with f <= SMALL_F, whole front in LDS            (LDS / latency-bound)
+//   k_panel          tiled path, step k0: every workgroup factorises the 32 x 32 diagonal tile in
+//                    REGISTERS (one row per lane, v_readlane broadcasts; redundant per workgroup, which
+//                    removes a dependent launch from the critical path) and then solves its own row /
+//                    column tile against it                                                     (latency-bound)
+//   k_update         tiled path, step k0: trailing update on v_mfma_f64_16x16x4_f64            (MFMA / HBM-bound)
 // Big fronts are stored augmented (kernels_common.hpp): the tiled kernels work on the index range
 // [k0 + nb, f + k0 + nb) of both dimensions, which covers the not-yet-eliminated part of F, the columns
 // of E that are already non-zero and the rows of E' that are already non-zero.
@@ -75,78 +77,62 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     if (tid < p) lperm[fd.first + tid] = lp[tid];
 }
 
-// Tiled path, step k0: factorise the nb x nb diagonal tile (pivoting inside the tile).
-__global__ void __launch_bounds__(64) k_diag(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, int32_t k0,
-                                             double *__restrict__ pool, int32_t *__restrict__ lperm,
-                                             const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
-    __shared__ double T[NB][NB + 1];
-    __shared__ int32_t lp[NB];
-    const int tid = threadIdx.x;
-    FrontDesc fd = FD[list[blockIdx.x]];
-    const int64_t ld = fd.ld;
-    const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
-    double *F = pool + fd.off;
-    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
-    for (int e = tid; e < nb * nb; e += 64) T[e % nb][e / nb] = F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld];
-    if (tid < nb) lp[tid] = tid;
-    __syncthreads();
-    for (int c = 0; c < nb; c++) {
-        double v = -1.0;
-        int idx = c + tid;
-        if (idx < nb) v = fabs(T[idx][c]);
-        else idx = 1 << 30;
-        wave_argmax(v, idx);
-        const int piv = idx;
-        if (piv != c) {
-            if (tid < nb) {
-                double a = T[c][tid];
-                T[c][tid] = T[piv][tid];
-                T[piv][tid] = a;
+// LU with partial pivoting of an nb x nb tile (nb <= 32) held one ROW PER LANE in registers.
+// On exit a[] holds L\U of the interchanged tile, src the tile row that was moved into this lane's row,
+// npert / nzero the number of perturbed / exactly-zero pivots (wave-uniform).
+__device__ __forceinline__ void tile_lu32(double (&a)[NB], int nb, int lane, double eps, int &src, int &npert, int &nzero) {
+    src = lane;
+    npert = 0;
+    nzero = 0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+        if (c < nb) {
+            const bool cand = lane >= c && lane < nb;
+            double v = cand ? fabs(a[c]) : -1.0;
+            int idx = cand ? lane : (1 << 30);
+            wave_argmax(v, idx);
+            const int piv = idx; // wave-uniform
+            if (piv != c) {
+                const int partner = (lane == c) ? piv : ((lane == piv) ? c : lane);
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) a[cc] = __shfl(a[cc], partner);
+                src = __shfl(src, partner);
             }
-            if (tid == 0) {
-                int a = lp[c];
-                lp[c] = lp[piv];
-                lp[piv] = a;
+            double d = wave_bcast(a[c], c);
+            if (fabs(d) < eps || d == 0.0) {
+                double dn = (d < 0.0) ? -eps : eps;
+                if (dn == 0.0) dn = 1.0;
+                if (lane == c) a[c] = dn;
+                npert++;
+                if (d == 0.0) nzero++;
+                d = dn;
             }
-            __syncthreads();
-        }
-        double d = T[c][c];
-        if (fabs(d) < eps || d == 0.0) {
-            double dn = (d < 0.0) ? -eps : eps;
-            if (dn == 0.0) dn = 1.0;
-            __syncthreads();
-            if (tid == 0) {
-                if (d == 0.0) atomicAdd(&info->n_zero_pivot, 1);
-                atomicAdd(&info->n_perturbed, 1);
-                T[c][c] = dn;
+            const double inv = 1.0 / d;
+            if (lane > c && lane < nb) a[c] *= inv;
+#pragma unroll
+            for (int cc = c + 1; cc < NB; cc++) {
+                const double u = wave_bcast(a[cc], c);
+                if (lane > c) a[cc] -= a[c] * u;
             }
-            __syncthreads();
-            d = dn;
         }
-        const double inv = 1.0 / d;
-        const int w = nb - c - 1;
-        if (tid < w) T[c + 1 + tid][c] *= inv;
-        __syncthreads();
-        for (int e = tid; e < w * w; e += 64) {
-            int r = c + 1 + e % w, cc = c + 1 + e / w;
-            T[r][cc] -= T[r][c] * T[c][cc];
-        }
-        __syncthreads();
     }
-    for (int e = tid; e < nb * nb; e += 64) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = T[e % nb][e / nb];
-    if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
 }
 
-// Tiled path, step k0: triangular solves against the diagonal tile over the active range
-// [base, f + base), base = k0 + nb:
+// Tiled path, step k0 (base = k0 + nb, active range [base, f + base)):
+//   every workgroup factorises the diagonal tile itself (wave 0, registers) while all its threads prefetch
+//   the workgroup's own tile;  then
 //   L tiles  (rows of the range, columns of the tile):   X <- X * U_kk^{-1}       (covers L21 and E')
 //   U tiles  (columns of the range, rows of the tile):   X <- L_kk^{-1} * (P X)   (covers U12 and E)
-// One thread owns one row (L) / one column (U) of the tile and keeps it in registers.
+// One thread owns one row (L) / one column (U) and runs a right-looking substitution in registers.
+// The factorised tile is NOT written into F here (other workgroups still read the original): workgroup 0
+// of each front parks it in dws, k_update moves it into place.
 __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                    const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
-                                                   const int32_t *__restrict__ lperm) {
+                                                   int32_t *__restrict__ lperm, double *__restrict__ dws,
+                                                   const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
     __shared__ double D[NB][NB + 1];
     __shared__ double T[NB][PANEL_T + 1];
+    __shared__ double dinv[NB];
     __shared__ int32_t lp[NB];
     const int tid = threadIdx.x;
     const int slot = find_slot(pfx, nactive, blockIdx.x);
@@ -158,60 +144,83 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int base = k0 + nb, limit = f + base;
     const int nT = (f + PANEL_T - 1) / PANEL_T;
     double *F = pool + fd.off;
-    for (int e = tid; e < nb * nb; e += PANEL_T) D[e % nb][e / nb] = F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld];
-    if (tid < nb) lp[tid] = lperm[fd.first + k0 + tid];
+    const bool ltile = t < nT;
+    const int o0 = base + (ltile ? t : t - nT) * PANEL_T;               // first row (L) / column (U) of this tile
+    const int ext = (limit - o0) < PANEL_T ? (limit - o0) : PANEL_T;     // rows (L) / columns (U) in this tile
+    // 1. prefetch the tile, no interchange yet
+    if (ltile) {
+        for (int e = tid; e < ext * nb; e += PANEL_T) T[e / ext][e % ext] = F[(o0 + e % ext) + (int64_t)(k0 + e / ext) * ld];
+    } else {
+        for (int e = tid; e < ext * nb; e += PANEL_T) T[e % nb][e / nb] = F[(k0 + e % nb) + (int64_t)(o0 + e / nb) * ld];
+    }
+    // 2. wave 0: LU of the diagonal tile, one row per lane
+    if (tid < 64) {
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? F[(k0 + tid) + (int64_t)(k0 + c) * ld] : 0.0;
+        const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        int src, npert, nzero;
+        tile_lu32(a, nb, tid, eps, src, npert, nzero);
+        if (tid < nb) {
+            double diag = 1.0;
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                D[tid][c] = a[c];
+                if (c == tid) diag = a[c];
+            }
+            dinv[tid] = 1.0 / diag;
+            lp[tid] = src;
+        }
+        if (t == 0 && tid == 0 && npert > 0) {
+            atomicAdd(&info->n_perturbed, npert);
+            if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
+        }
+    }
     __syncthreads();
-    if (t < nT) {
-        // ---- L tile ----
-        const int r0 = base + t * PANEL_T;
-        const int h = (limit - r0) < PANEL_T ? (limit - r0) : PANEL_T;
-        for (int e = tid; e < h * nb; e += PANEL_T) T[e / h][e % h] = F[(r0 + e % h) + (int64_t)(k0 + e / h) * ld];
-        __syncthreads();
-        if (tid < h) {
-            double x[NB];
+    if (t == 0) {
+        double *dw = dws + (int64_t)slot * NB * NB;
+        for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
+        if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
+    }
+    // 3. substitution, right-looking, one row / column per thread
+    if (tid < ext) {
+        double x[NB];
+        if (ltile) {
 #pragma unroll
             for (int c = 0; c < NB; c++) x[c] = (c < nb) ? T[c][tid] : 0.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
                 if (c < nb) {
-                    double v = x[c];
+                    x[c] *= dinv[c];
 #pragma unroll
-                    for (int k = 0; k < c; k++) v -= x[k] * D[k][c];
-                    x[c] = v / D[c][c];
+                    for (int cc = c + 1; cc < NB; cc++)
+                        if (cc < nb) x[cc] -= x[c] * D[c][cc];
                 }
             }
 #pragma unroll
             for (int c = 0; c < NB; c++)
                 if (c < nb) T[c][tid] = x[c];
-        }
-        __syncthreads();
-        for (int e = tid; e < h * nb; e += PANEL_T) F[(r0 + e % h) + (int64_t)(k0 + e / h) * ld] = T[e / h][e % h];
-    } else {
-        // ---- U tile ----
-        const int c0 = base + (t - nT) * PANEL_T;
-        const int w = (limit - c0) < PANEL_T ? (limit - c0) : PANEL_T;
-        // load with the row interchange applied: new row r <- old row lp[r]
-        for (int e = tid; e < w * nb; e += PANEL_T) T[e % nb][e / nb] = F[lp[e % nb] + (int64_t)(c0 + e / nb) * ld];
-        __syncthreads();
-        if (tid < w) {
-            double x[NB];
+        } else {
 #pragma unroll
-            for (int r = 0; r < NB; r++) x[r] = (r < nb) ? T[r][tid] : 0.0;
+            for (int r = 0; r < NB; r++) x[r] = (r < nb) ? T[lp[r]][tid] : 0.0; // row interchange applied here
 #pragma unroll
-            for (int r = 1; r < NB; r++) {
-                if (r < nb) {
-                    double v = x[r];
+            for (int k = 0; k < NB; k++) {
+                if (k < nb) {
 #pragma unroll
-                    for (int k = 0; k < r; k++) v -= D[r][k] * x[k];
-                    x[r] = v;
+                    for (int r = k + 1; r < NB; r++)
+                        if (r < nb) x[r] -= D[r][k] * x[k];
                 }
             }
 #pragma unroll
             for (int r = 0; r < NB; r++)
                 if (r < nb) T[r][tid] = x[r];
         }
-        __syncthreads();
-        for (int e = tid; e < w * nb; e += PANEL_T) F[(k0 + e % nb) + (int64_t)(c0 + e / nb) * ld] = T[e % nb][e / nb];
+    }
+    __syncthreads();
+    if (ltile) {
+        for (int e = tid; e < ext * nb; e += PANEL_T) F[(o0 + e % ext) + (int64_t)(k0 + e / ext) * ld] = T[e / ext][e % ext];
+    } else {
+        for (int e = tid; e < ext * nb; e += PANEL_T) F[(k0 + e % nb) + (int64_t)(o0 + e / nb) * ld] = T[e % nb][e / nb];
     }
 }
 
@@ -222,8 +231,10 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // maps to 16 consecutive rows of one column: stores are 128-byte contiguous segments.
 // LDS layouts: Ls[kk][r] (ld 80) and Us[c][kk] (ld 34) make the fragment reads of ds_read_b64
 // conflict-free (banks = (dword address) mod 64) and both global->LDS copies conflict-free too.
+// Workgroup 0 of every front also moves the factorised diagonal tile from dws into the front.
 __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
-                                                const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool) {
+                                                const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
+                                                const double *__restrict__ dws) {
     __shared__ double Ls[NB * LS_LD];
     __shared__ double Us[UPD_T * US_LD];
     const int tid = threadIdx.x;
@@ -236,8 +247,12 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int base = k0 + nb, limit = f + base;
     const int nt = (f + UPD_T - 1) / UPD_T;
     const int r0 = base + (t % nt) * UPD_T, c0 = base + (t / nt) * UPD_T;
-    if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
     double *F = pool + fd.off;
+    if (t == 0) {
+        const double *dw = dws + (int64_t)slot * NB * NB;
+        for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];
+    }
+    if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
     for (int e = tid; e < NB * UPD_T; e += 256) {
         int r = e % UPD_T, kk = e / UPD_T;
         Ls[kk * LS_LD + r] = (r0 + r < limit && kk < nb) ? F[(r0 + r) + (int64_t)(k0 + kk) * ld] : 0.0;

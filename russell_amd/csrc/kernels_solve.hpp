@@ -101,10 +101,29 @@ __global__ void k_bwd(const int32_t *__restrict__ list, const FrontDesc *__restr
     }
 }
 
+// 8-way unrolled strided dot product: acc += sum_j col[j * ld] * w[j], j = j0, j0 + step, ... < j1.
+// Eight independent loads are in flight per lane before the first FMA (the loop is HBM-latency-bound otherwise).
+__device__ __forceinline__ double strided_dot(const double *__restrict__ col, int64_t ld, const double *w, int j0, int j1, int step) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = j0;
+    for (; j + 7 * step < j1; j += 8 * step) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) e[u] = col[(int64_t)(j + u * step) * ld];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 += e[u] * w[j + u * step];
+            acc1 += e[u + 1] * w[j + (u + 1) * step];
+        }
+    }
+    for (; j < j1; j += step) acc0 += col[(int64_t)j * ld] * w[j];
+    return acc0 + acc1;
+}
+
 // Forward step of a big (augmented) front, rows [r0, r1) of its f-vector:
 //   [y1; -delta] = E * w1,  E(r, j) = F[r + (f + j) ld]   ->   work[r] = y1[r] (r < p),  work[r] = w2[r] + (E w1)[r] (r >= p)
-// Every workgroup of the front assembles w1 = b1 + (children's updates to the pivot rows) in LDS itself.
-// Dynamic LDS: p doubles.
+// Every workgroup of the front assembles w1 = b1 + (children's updates to the pivot rows) in LDS itself;
+// the children's entries are swept linearly (no searches), in child order.  Dynamic LDS: p doubles.
 __global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                  const double *__restrict__ pool, const int32_t *__restrict__ child_idx,
                                                  const int32_t *__restrict__ rel, double *__restrict__ work,
@@ -123,16 +142,14 @@ __global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ t
     for (int i = tid; i < p; i += 256) w1[i] = x[fd.first + i];
     if (tid < SOLVE_SLAB) wsl[tid] = 0.0;
     __syncthreads();
-    const int s0 = r0 > p ? r0 : p; // part of the slab that lies in the update rows
     for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
         FrontDesc cd = FD[child_idx[ci]];
         const double *uc = work + cd.woff + cd.p;
         const int32_t *relc = rel + cd.rowptr;
-        const int npre = lower_bound_i32(relc, cd.m, p);
-        for (int i = tid; i < npre; i += 256) w1[relc[i]] += uc[i];
-        if (r1 > s0) {
-            const int lo = lower_bound_i32(relc, cd.m, s0), hi = lower_bound_i32(relc, cd.m, r1);
-            for (int i = lo + tid; i < hi; i += 256) wsl[relc[i] - r0] += uc[i];
+        for (int i = tid; i < cd.m; i += 256) {
+            const int r = relc[i];
+            if (r < p) w1[r] += uc[i];
+            else if (r >= r0 && r < r1) wsl[r - r0] += uc[i];
         }
         __syncthreads();
     }
@@ -142,10 +159,7 @@ __global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ t
     int jmax = p;
     if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
     double acc = 0.0;
-    if (r < r1) {
-        const double *Er = E + r;
-        for (int j = g; j < jmax; j += 4) acc += Er[(int64_t)j * ld] * w1[j];
-    }
+    if (r < r1) acc = strided_dot(E + r, ld, w1, g, jmax, 4);
     red[g][rr] = acc;
     __syncthreads();
     if (g == 0 && r < r1) {
@@ -178,10 +192,7 @@ __global__ void __launch_bounds__(256) k_bwd_big(const SolveTask *__restrict__ t
     const int rr = tid & (SOLVE_SLAB - 1), g = tid >> 6;
     const int i = r0 + rr;
     double acc = 0.0;
-    if (i < r1) {
-        const double *Ei = Ep + i;
-        for (int j = jmin + g; j < f; j += 4) acc += Ei[(int64_t)j * ld] * v[j];
-    }
+    if (i < r1) acc = strided_dot(Ep + i, ld, v, jmin + g, f, 4);
     red[g][rr] = acc;
     __syncthreads();
     if (g == 0 && i < r1) x[fd.first + i] = (red[0][rr] + red[1][rr]) + (red[2][rr] + red[3][rr]);

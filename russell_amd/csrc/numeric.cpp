@@ -43,11 +43,12 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+    void *ptrs[] = {d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    d_dws = nullptr, d_ear = nullptr;
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
@@ -155,6 +156,8 @@ int32_t Solver::upload_plan() {
 
     std::vector<int32_t> lists, tasks, allbig;
     std::vector<EaTask> ea;
+    std::vector<EaRange> ear;
+    int32_t max_big = 0;
     std::vector<SolveTask> stasks;
     levels.assign((size_t)S.nlevels, LevelPlan());
     for (int32_t l = 0; l < S.nlevels; l++) {
@@ -179,6 +182,7 @@ int32_t Solver::upload_plan() {
         L.big_cnt = (int32_t)big.size();
         lists.insert(lists.end(), big.begin(), big.end());
         allbig.insert(allbig.end(), big.begin(), big.end());
+        max_big = std::max(max_big, L.big_cnt);
         // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
         int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
         for (int32_t k0 = 0; k0 < pmax; k0 += NB) {
@@ -212,12 +216,22 @@ int32_t Solver::upload_plan() {
             for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
             if (!any) continue;
             int32_t f = S.fsize(s);
-            if (f <= 64) {
-                ea.push_back({s, 0, f, 0, f});
-            } else {
-                for (int32_t c0 = 0; c0 < f; c0 += 32)
-                    for (int32_t r0 = 0; r0 < f; r0 += 256) ea.push_back({s, c0, std::min(f, c0 + 32), r0, std::min(f, r0 + 256)});
-            }
+            const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
+            for (int32_t c0 = 0; c0 < f; c0 += cstep)
+                for (int32_t r0 = 0; r0 < f; r0 += rstep) {
+                    EaTask tk = {s, c0, std::min(f, c0 + cstep), r0, std::min(f, r0 + rstep), (int32_t)ear.size()};
+                    for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
+                        int32_t ch = S.child_idx[c];
+                        const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
+                        EaRange rg;
+                        rg.jlo = (int32_t)(std::lower_bound(rb, re, tk.c0) - rb);
+                        rg.jhi = (int32_t)(std::lower_bound(rb, re, tk.c1) - rb);
+                        rg.ilo = (int32_t)(std::lower_bound(rb, re, tk.r0) - rb);
+                        rg.ihi = (int32_t)(std::lower_bound(rb, re, tk.r1) - rb);
+                        ear.push_back(rg);
+                    }
+                    ea.push_back(tk);
+                }
         }
         L.ea_cnt = (int32_t)ea.size() - L.ea_off;
         // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
@@ -245,6 +259,8 @@ int32_t Solver::upload_plan() {
     lists.insert(lists.end(), allbig.begin(), allbig.end());
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_ear, ear), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_dws, sizeof(double) * NB * NB * (size_t)std::max(max_big, 1)), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_st, stasks), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_lists, lists), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_tasks, tasks), ERROR_HIP_MALLOC);
@@ -289,7 +305,7 @@ int32_t Solver::run_factor() {
     HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
         if (L.ea_cnt > 0) {
-            hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_fd, d_child, d_rel, d_pool);
+            hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_fd, d_child, d_rel, d_pool);
             launches++;
         }
         if (L.small_cnt > 0) {
@@ -301,13 +317,11 @@ int32_t Solver::run_factor() {
         int32_t k0 = 0;
         for (const StepPlan &st : L.steps) {
             const int32_t *blist = d_lists + L.big_off;
-            hipLaunchKernelGGL(k_diag, dim3(st.nactive), dim3(64), 0, STREAM, blist, d_fd, k0, d_pool, d_lperm, d_scalar,
-                               opt.pivot_epsilon, d_info);
             hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
-                               d_pool, d_lperm);
+                               d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info);
             hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
-                               d_pool);
-            launches += 3;
+                               d_pool, d_dws);
+            launches += 2;
             k0 += NB;
         }
     }

@@ -10,6 +10,7 @@ namespace hipmf {
 
 struct FrontDesc;
 struct EaTask;
+struct EaRange;
 struct SolveTask;
 struct FactorInfo;
 
@@ -108,6 +109,8 @@ class Solver {
     // device buffers
     FrontDesc *d_fd = nullptr;
     EaTask *d_ea = nullptr;
+    EaRange *d_ear = nullptr;
+    double *d_dws = nullptr; // factorised diagonal tiles of the current tiled step, one per active big front
     SolveTask *d_st = nullptr;
     FactorInfo *d_info = nullptr;
     unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] |r|_inf bits, [2] omega bits
