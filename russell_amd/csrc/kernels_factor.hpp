@@ -78,41 +78,39 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
 }
 
 // LU with partial pivoting of an nb x nb tile (nb <= 32) held one ROW PER LANE in registers.
-// On exit a[] holds L\U of the interchanged tile, src the tile row that was moved into this lane's row,
-// npert / nzero the number of perturbed / exactly-zero pivots (wave-uniform).
-__device__ __forceinline__ void tile_lu32(double (&a)[NB], int nb, int lane, double eps, int &src, int &npert, int &nzero) {
-    src = lane;
+// Pivoting is implicit: rows never move between lanes; `step` records at which elimination step this
+// lane's row was chosen as the pivot row (ties go to the lowest row: deterministic).  On exit the row
+// holds its multipliers in columns < step and its row of U in columns >= step; npert / nzero count the
+// perturbed / exactly-zero pivots (wave-uniform).
+__device__ __forceinline__ void tile_lu32(double (&a)[NB], int nb, int lane, double eps, int &step, int &npert, int &nzero) {
+    step = -1;
     npert = 0;
     nzero = 0;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int c = 0; c < NB; c++) {
         if (c < nb) {
-            const bool cand = lane >= c && lane < nb;
-            double v = cand ? fabs(a[c]) : -1.0;
-            int idx = cand ? lane : (1 << 30);
-            wave_argmax(v, idx);
-            const int piv = idx; // wave-uniform
-            if (piv != c) {
-                const int partner = (lane == c) ? piv : ((lane == piv) ? c : lane);
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) a[cc] = __shfl(a[cc], partner);
-                src = __shfl(src, partner);
-            }
-            double d = wave_bcast(a[c], c);
+            // arg-max as ONE 64-bit max-reduction: key = |a| (low 6 mantissa bits dropped) | candidate flag | 31 - lane
+            const bool cand = lane < nb && step < 0;
+            const unsigned long long mag = (unsigned long long)__double_as_longlong(fabs(a[c]));
+            const unsigned long long key = cand ? (((mag >> 6) << 6) | 32ull | (unsigned long long)(31 - lane)) : 0ull;
+            const int pv = 31 - (int)(wave_max_u64(key) & 31ull);
+            if (lane == pv) step = c;
+            double d = wave_bcast(a[c], pv);
             if (fabs(d) < eps || d == 0.0) {
                 double dn = (d < 0.0) ? -eps : eps;
                 if (dn == 0.0) dn = 1.0;
-                if (lane == c) a[c] = dn;
+                if (lane == pv) a[c] = dn;
                 npert++;
                 if (d == 0.0) nzero++;
                 d = dn;
             }
             const double inv = 1.0 / d;
-            if (lane > c && lane < nb) a[c] *= inv;
-#pragma unroll
+            const bool below = lane < nb && step < 0; // rows not yet chosen as pivot
+            if (below) a[c] *= inv;
+#pragma clang loop unroll(full)
             for (int cc = c + 1; cc < NB; cc++) {
-                const double u = wave_bcast(a[cc], c);
-                if (lane > c) a[cc] -= a[c] * u;
+                const double u = wave_bcast(a[cc], pv);
+                if (below) a[cc] -= a[c] * u;
             }
         }
     }
@@ -159,17 +157,18 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 #pragma unroll
         for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? F[(k0 + tid) + (int64_t)(k0 + c) * ld] : 0.0;
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
-        int src, npert, nzero;
-        tile_lu32(a, nb, tid, eps, src, npert, nzero);
+        int step, npert, nzero;
+        tile_lu32(a, nb, tid, eps, step, npert, nzero);
         if (tid < nb) {
+            // rows go to LDS in pivot order: row `step` of the interchanged tile is this lane's row
             double diag = 1.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                D[tid][c] = a[c];
-                if (c == tid) diag = a[c];
+                D[step][c] = a[c];
+                if (c == step) diag = a[c];
             }
-            dinv[tid] = 1.0 / diag;
-            lp[tid] = src;
+            dinv[step] = 1.0 / diag;
+            lp[step] = tid;
         }
         if (t == 0 && tid == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);

@@ -21,3 +21,34 @@ __device__ __forceinline__ double wave_bcast(double v, int src) {
     hi = __builtin_amdgcn_readlane(hi, src);
     return __hiloint2double(hi, lo);
 }
+
+// tells the compiler that a value equal on all lanes is wave-uniform (moves it to an SGPR)
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// wave-wide maximum of a 64-bit key (result wave-uniform).  16-lane rows are reduced with DPP
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar round trips), the four row
+// maxima are combined through v_readlane.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key) {
+#define HIPMF_DPP_MAX_STEP(ctrl)                                                         \
+    {                                                                                    \
+        int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);                    \
+        int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);            \
+        int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);            \
+        unsigned long long o = ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo; \
+        key = o > key ? o : key;                                                         \
+    }
+    HIPMF_DPP_MAX_STEP(0xB1)  // quad_perm [1,0,3,2]
+    HIPMF_DPP_MAX_STEP(0x4E)  // quad_perm [2,3,0,1]
+    HIPMF_DPP_MAX_STEP(0x141) // row_half_mirror
+    HIPMF_DPP_MAX_STEP(0x140) // row_mirror
+#undef HIPMF_DPP_MAX_STEP
+    unsigned long long best = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, row * 16);
+        unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), row * 16);
+        unsigned long long k = ((unsigned long long)hi << 32) | lo;
+        best = k > best ? k : best;
+    }
+    return best;
+}

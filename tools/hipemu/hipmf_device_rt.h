@@ -27,3 +27,13 @@ inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
 #define HIPMF_DYN_SHARED(T, name) T *name = (T *)(((uintptr_t)hipemu::g_dynshared.data() + 15) & ~(uintptr_t)15)
 
 inline double wave_bcast(double v, int src) { return __shfl(v, src); }
+
+inline int wave_uniform(int v) { return v; }
+
+inline unsigned long long wave_max_u64(unsigned long long key) {
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(key, off);
+        key = o > key ? o : key;
+    }
+    return key;
+}
