@@ -77,41 +77,41 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     if (tid < p) lperm[fd.first + tid] = lp[tid];
 }
 
-// LU with partial pivoting of an nb x nb tile (nb <= 32) held one ROW PER LANE in registers.
+// LU with partial pivoting of a 32 x 32 tile held one ROW PER LANE in registers (lanes 0..31).  A smaller
+// tile is padded by the caller with identity rows / columns: its pivots are 1, they are chosen last and
+// change nothing, so no size guards are needed in the (fully unrolled, branch-free) elimination.
 // Pivoting is implicit: rows never move between lanes; `step` records at which elimination step this
 // lane's row was chosen as the pivot row (ties go to the lowest row: deterministic).  On exit the row
 // holds its multipliers in columns < step and its row of U in columns >= step; npert / nzero count the
 // perturbed / exactly-zero pivots (wave-uniform).
-__device__ __forceinline__ void tile_lu32(double (&a)[NB], int nb, int lane, double eps, int &step, int &npert, int &nzero) {
+__device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero) {
     step = -1;
     npert = 0;
     nzero = 0;
 #pragma clang loop unroll(full)
     for (int c = 0; c < NB; c++) {
-        if (c < nb) {
-            // arg-max as ONE 64-bit max-reduction: key = |a| (low 6 mantissa bits dropped) | candidate flag | 31 - lane
-            const bool cand = lane < nb && step < 0;
-            const unsigned long long mag = (unsigned long long)__double_as_longlong(fabs(a[c]));
-            const unsigned long long key = cand ? (((mag >> 6) << 6) | 32ull | (unsigned long long)(31 - lane)) : 0ull;
-            const int pv = 31 - (int)(wave_max_u64(key) & 31ull);
-            if (lane == pv) step = c;
-            double d = wave_bcast(a[c], pv);
-            if (fabs(d) < eps || d == 0.0) {
-                double dn = (d < 0.0) ? -eps : eps;
-                if (dn == 0.0) dn = 1.0;
-                if (lane == pv) a[c] = dn;
-                npert++;
-                if (d == 0.0) nzero++;
-                d = dn;
-            }
-            const double inv = 1.0 / d;
-            const bool below = lane < nb && step < 0; // rows not yet chosen as pivot
-            if (below) a[c] *= inv;
+        // arg-max as ONE 64-bit max-reduction: key = |a| (low 6 mantissa bits dropped) | candidate flag | 31 - lane
+        const bool cand = lane < NB && step < 0;
+        const unsigned long long mag = (unsigned long long)__double_as_longlong(fabs(a[c]));
+        const unsigned long long key = cand ? (((mag >> 6) << 6) | 32ull | (unsigned long long)(31 - lane)) : 0ull;
+        const int pv = 31 - (int)(wave_max_u64(key) & 31ull);
+        if (lane == pv) step = c;
+        double d = wave_bcast(a[c], pv);
+        if (fabs(d) < eps || d == 0.0) {
+            double dn = (d < 0.0) ? -eps : eps;
+            if (dn == 0.0) dn = 1.0;
+            if (lane == pv) a[c] = dn;
+            npert++;
+            if (d == 0.0) nzero++;
+            d = dn;
+        }
+        const double inv = 1.0 / d;
+        const bool below = lane < NB && step < 0; // rows not yet chosen as pivot
+        if (below) a[c] *= inv;
 #pragma clang loop unroll(full)
-            for (int cc = c + 1; cc < NB; cc++) {
-                const double u = wave_bcast(a[cc], pv);
-                if (below) a[cc] -= a[c] * u;
-            }
+        for (int cc = c + 1; cc < NB; cc++) {
+            const double u = wave_bcast(a[cc], pv);
+            if (below) a[cc] -= a[c] * u;
         }
     }
 }
@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
                                                    const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws,
                                                    const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
-    __shared__ double D[NB][NB + 1];
+    // D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
+    // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
+    __shared__ __attribute__((aligned(16))) double D[NB][NB + 2];
+    __shared__ __attribute__((aligned(16))) double DT[NB][NB + 2];
     __shared__ double T[NB][PANEL_T + 1];
     __shared__ double dinv[NB];
     __shared__ int32_t lp[NB];
@@ -146,25 +149,33 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int o0 = base + (ltile ? t : t - nT) * PANEL_T;               // first row (L) / column (U) of this tile
     const int ext = (limit - o0) < PANEL_T ? (limit - o0) : PANEL_T;     // rows (L) / columns (U) in this tile
     // 1. prefetch the tile, no interchange yet
+    // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
     if (ltile) {
-        for (int e = tid; e < ext * nb; e += PANEL_T) T[e / ext][e % ext] = F[(o0 + e % ext) + (int64_t)(k0 + e / ext) * ld];
+        for (int e = tid; e < ext * NB; e += PANEL_T) {
+            const int k = e / ext, rr = e % ext;
+            T[k][rr] = (k < nb) ? F[(o0 + rr) + (int64_t)(k0 + k) * ld] : 0.0;
+        }
     } else {
-        for (int e = tid; e < ext * nb; e += PANEL_T) T[e % nb][e / nb] = F[(k0 + e % nb) + (int64_t)(o0 + e / nb) * ld];
+        for (int e = tid; e < ext * NB; e += PANEL_T) {
+            const int k = e % NB, cc = e / NB;
+            T[k][cc] = (k < nb) ? F[(k0 + k) + (int64_t)(o0 + cc) * ld] : 0.0;
+        }
     }
     // 2. wave 0: LU of the diagonal tile, one row per lane
     if (tid < 64) {
         double a[NB];
 #pragma unroll
-        for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? F[(k0 + tid) + (int64_t)(k0 + c) * ld] : 0.0;
+        for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? F[(k0 + tid) + (int64_t)(k0 + c) * ld] : (tid == c ? 1.0 : 0.0);
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32(a, nb, tid, eps, step, npert, nzero);
-        if (tid < nb) {
+        tile_lu32(a, tid, eps, step, npert, nzero);
+        if (tid < NB) {
             // rows go to LDS in pivot order: row `step` of the interchanged tile is this lane's row
             double diag = 1.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
                 D[step][c] = a[c];
+                DT[c][step] = a[c];
                 if (c == step) diag = a[c];
             }
             dinv[step] = 1.0 / diag;
@@ -181,38 +192,37 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
         if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
     }
-    // 3. substitution, right-looking, one row / column per thread
+    // 3. substitution, right-looking, one row / column per thread, branch-free over the padded 32 steps
     if (tid < ext) {
         double x[NB];
         if (ltile) {
 #pragma unroll
-            for (int c = 0; c < NB; c++) x[c] = (c < nb) ? T[c][tid] : 0.0;
+            for (int c = 0; c < NB; c++) x[c] = T[c][tid];
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                if (c < nb) {
-                    x[c] *= dinv[c];
+                // the whole row of U is fetched before the FMA chain (otherwise every FMA waits on its own LDS read)
+                double u[NB];
 #pragma unroll
-                    for (int cc = c + 1; cc < NB; cc++)
-                        if (cc < nb) x[cc] -= x[c] * D[c][cc];
-                }
+                for (int cc = 0; cc < NB; cc++) u[cc] = D[c][cc];
+                x[c] *= dinv[c];
+#pragma unroll
+                for (int cc = c + 1; cc < NB; cc++) x[cc] -= x[c] * u[cc];
             }
 #pragma unroll
-            for (int c = 0; c < NB; c++)
-                if (c < nb) T[c][tid] = x[c];
+            for (int c = 0; c < NB; c++) T[c][tid] = x[c];
         } else {
 #pragma unroll
-            for (int r = 0; r < NB; r++) x[r] = (r < nb) ? T[lp[r]][tid] : 0.0; // row interchange applied here
+            for (int r = 0; r < NB; r++) x[r] = T[lp[r]][tid]; // row interchange applied here
 #pragma unroll
             for (int k = 0; k < NB; k++) {
-                if (k < nb) {
+                double l[NB];
 #pragma unroll
-                    for (int r = k + 1; r < NB; r++)
-                        if (r < nb) x[r] -= D[r][k] * x[k];
-                }
+                for (int r = 0; r < NB; r++) l[r] = DT[k][r]; // column k of L, one aligned row of DT
+#pragma unroll
+                for (int r = k + 1; r < NB; r++) x[r] -= l[r] * x[k];
             }
 #pragma unroll
-            for (int r = 0; r < NB; r++)
-                if (r < nb) T[r][tid] = x[r];
+            for (int r = 0; r < NB; r++) T[r][tid] = x[r];
         }
     }
     __syncthreads();
