@@ -108,11 +108,11 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
         const double inv = 1.0 / d;
         const bool below = lane < NB && step < 0; // rows not yet chosen as pivot
         if (below) a[c] *= inv;
+        // rows already chosen as pivots take part with a zero multiplier: the update needs no per-element
+        // select (3 instructions per element: two v_readlane and one FMA), which also keeps the code small
+        const double lmul = below ? a[c] : 0.0;
 #pragma clang loop unroll(full)
-        for (int cc = c + 1; cc < NB; cc++) {
-            const double u = wave_bcast(a[cc], pv);
-            if (below) a[cc] -= a[c] * u;
-        }
+        for (int cc = c + 1; cc < NB; cc++) a[cc] -= lmul * wave_bcast(a[cc], pv);
     }
 }
 
