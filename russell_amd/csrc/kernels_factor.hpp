@@ -90,22 +90,26 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
     nzero = 0;
 #pragma clang loop unroll(full)
     for (int c = 0; c < NB; c++) {
-        // arg-max as ONE 64-bit max-reduction: key = |a| (low 6 mantissa bits dropped) | candidate flag | 31 - lane
+        // arg-max as ONE 32-bit max-reduction (4 DPP max steps): key = float(|a|) bits with the low 6 bits
+        // replaced by a candidate flag and 31 - lane.  Candidates within 2^-18 of each other may be ordered by
+        // lane instead of by magnitude, which is immaterial for the pivot choice.  Every candidate computes the
+        // reciprocal of its own entry meanwhile, so the divide is off the dependent chain of the reduction.
         const bool cand = lane < NB && step < 0;
-        const unsigned long long mag = (unsigned long long)__double_as_longlong(fabs(a[c]));
-        const unsigned long long key = cand ? (((mag >> 6) << 6) | 32ull | (unsigned long long)(31 - lane)) : 0ull;
-        const int pv = 31 - (int)(wave_max_u64(key) & 31ull);
+        const unsigned mag = __float_as_uint((float)fabs(a[c]));
+        const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
+        const double myinv = 1.0 / a[c];
+        const int pv = 31 - (int)(wave_max_u32(key) & 31u);
         if (lane == pv) step = c;
         double d = wave_bcast(a[c], pv);
+        double inv = wave_bcast(myinv, pv);
         if (fabs(d) < eps || d == 0.0) {
             double dn = (d < 0.0) ? -eps : eps;
             if (dn == 0.0) dn = 1.0;
             if (lane == pv) a[c] = dn;
             npert++;
             if (d == 0.0) nzero++;
-            d = dn;
+            inv = 1.0 / dn;
         }
-        const double inv = 1.0 / d;
         const bool below = lane < NB && step < 0; // rows not yet chosen as pivot
         if (below) a[c] *= inv;
         // rows already chosen as pivots take part with a zero multiplier: the update needs no per-element

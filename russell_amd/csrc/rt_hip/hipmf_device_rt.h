@@ -52,3 +52,26 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long ke
     }
     return best;
 }
+
+// wave-wide maximum of a 32-bit key (result wave-uniform): four DPP max steps per 16-lane row, then the
+// four row maxima through v_readlane.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned key) {
+    int k = (int)key;
+#define HIPMF_DPP_MAX32(ctrl)                                                  \
+    {                                                                          \
+        unsigned o = (unsigned)__builtin_amdgcn_update_dpp(k, k, ctrl, 0xf, 0xf, false); \
+        k = (int)(o > (unsigned)k ? o : (unsigned)k);                          \
+    }
+    HIPMF_DPP_MAX32(0xB1)  // quad_perm [1,0,3,2]
+    HIPMF_DPP_MAX32(0x4E)  // quad_perm [2,3,0,1]
+    HIPMF_DPP_MAX32(0x141) // row_half_mirror
+    HIPMF_DPP_MAX32(0x140) // row_mirror
+#undef HIPMF_DPP_MAX32
+    unsigned best = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        unsigned v = (unsigned)__builtin_amdgcn_readlane(k, row * 16);
+        best = v > best ? v : best;
+    }
+    return best;
+}

@@ -37,3 +37,16 @@ inline unsigned long long wave_max_u64(unsigned long long key) {
     }
     return key;
 }
+
+inline unsigned wave_max_u32(unsigned key) {
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_xor(key, off);
+        key = o > key ? o : key;
+    }
+    return key;
+}
+inline unsigned __float_as_uint(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}
