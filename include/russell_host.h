@@ -1,0 +1,71 @@
+/*
+ * russell_host.h -- flat C API of the host-side mirror of russell_sparse's Rust layer
+ * (russell_amd/csrc/host/russell_host.hpp).  It exists because this image has no Rust toolchain: the
+ * layer ABOVE the solver C-ABI (include/russell_hipmf.h) -- CooMatrix / CscMatrix / CsrMatrix, LinSolParams,
+ * Genie, LinSolver (LinSolTrait), VerifyLinSys, StatsLinSol, read_matrix_market -- is written in C++ with
+ * the reference's names, argument meaning and error strings, and exported here for ctypes and other FFIs.
+ * Functions that can fail return a static error string (NULL = Ok), the analogue of Rust's StrError.
+ * Reference files mirrored: russell_sparse/src/{coo,csc,csr}_matrix.rs, lin_solver.rs, lin_sol_params.rs,
+ * enums.rs, verify_lin_sys.rs, stats_lin_sol.rs, read_matrix_market.rs, solver_cudss.rs (template of SolverHIPMF).
+ */
+#ifndef RUSSELL_HOST_H
+#define RUSSELL_HOST_H
+#include <inttypes.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enums.rs: Sym {No, YesFull, YesLower, YesUpper} = 0..3; Genie {Hipmf, Umfpack, Mumps, Cudss} = 0..3;
+ * Ordering {Amd, Amf, Auto, Best, BtfColamd, Cholmod, Colamd, Metis, No, Pord, Qamd, Scotch} = 0..11;
+ * Scaling {Auto, Column, Diagonal, Max, No, RowCol, RowColIter, RowColRig, Sum} = 0..8;
+ * MMsym {LeaveAsLower, SwapToUpper, MakeItFull} = 0..2 */
+struct RhParams { /* lin_sol_params.rs:5-107, the fields this backend honours */
+    int32_t ordering, scaling;
+    int32_t has_pivot_epsilon;
+    double pivot_epsilon;
+    int32_t has_refinement_nstep, refinement_nstep;
+    int32_t positive_definite, compute_determinant, verbose;
+};
+
+void rh_set_hipmf_library(const char *path);
+
+void *rh_coo_new(int64_t nrow, int64_t ncol, int64_t max_nnz, int32_t sym, const char **err);
+void rh_coo_free(void *coo);
+const char *rh_coo_put(void *coo, int64_t i, int64_t j, double aij);
+void rh_coo_reset(void *coo);
+void rh_coo_info(void *coo, int64_t *nrow, int64_t *ncol, int64_t *nnz, int64_t *max_nnz, int32_t *sym);
+void rh_coo_arrays(void *coo, const int32_t **ai, const int32_t **aj, const double **ax);
+const char *rh_coo_mat_vec_mul(void *coo, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
+
+void *rh_csc_from_coo(void *coo, const char **err);
+const char *rh_csc_update_from_coo(void *csc, void *coo);
+void rh_csc_arrays(void *csc, const int32_t **col_pointers, const int32_t **row_indices, const double **values, int64_t *ncol, int64_t *nnz);
+const char *rh_csc_mat_vec_mul(void *csc, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
+void rh_csc_free(void *csc);
+
+void *rh_csr_from_coo(void *coo, const char **err);
+const char *rh_csr_update_from_coo(void *csr, void *coo);
+void rh_csr_arrays(void *csr, const int32_t **row_pointers, const int32_t **col_indices, const double **values, int64_t *nrow, int64_t *nnz);
+const char *rh_csr_mat_vec_mul(void *csr, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
+void rh_csr_free(void *csr);
+
+const char *rh_verify(void *coo, const double *x, int64_t nx, const double *rhs, int64_t nr, double *out4);
+void *rh_read_matrix_market(const char *path, int32_t mmsym, const char **err);
+
+void *rh_linsolver_new(int32_t genie, const char **err);
+void rh_linsolver_free(void *solver);
+const char *rh_linsolver_factorize(void *solver, void *coo, const struct RhParams *params_or_null);
+const char *rh_linsolver_solve(void *solver, double *x, int64_t nx, const double *rhs, int64_t nr, int32_t verbose);
+const char *rh_linsolver_solve_many(void *solver, double *x, const double *rhs, int64_t n, int64_t nrhs);
+void rh_linsolver_times(void *solver, uint64_t *ns3);
+void rh_linsolver_outputs(void *solver, double *det_coef, double *det_exp, double *rcond, int32_t *eff_ordering, int32_t *eff_scaling, int32_t *npert);
+const char *rh_linsolver_stats_json(void *solver, void *coo, const char *name, const double *x, const double *rhs);
+
+const char *rh_error_string(int32_t code);
+const char *rh_enum_name(int32_t which, int32_t value);
+int32_t rh_genie_get_sym(int32_t genie, int32_t symmetric);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,848 @@
+// host_api.cpp -- implementation of russell_host.hpp and its flat C API (include/russell_host.h).
+// Plain C++ (g++): this library loads without a GPU; the HIP backend (librussell_hipmf.so) is opened with
+// dlopen when the first SolverHIPMF is allocated.  There is no CPU solver here: without the HIP library and
+// a device, LinSolver::new fails with "HIPMF solver is not available" (cf. lin_solver.rs:125,132,137-138).
+#include "russell_host.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "../../../include/russell_hipmf.h"
+
+namespace russell {
+
+// ---- enums ------------------------------------------------------------------------------------------
+const char *genie_to_string(Genie g) {
+    switch (g) {
+    case Genie::Hipmf: return "hipmf";
+    case Genie::Umfpack: return "umfpack";
+    case Genie::Mumps: return "mumps";
+    case Genie::Cudss: return "cudss";
+    }
+    return "hipmf";
+}
+
+Genie genie_from(const std::string &name) {
+    std::string s = name;
+    std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+    if (s == "umfpack") return Genie::Umfpack;
+    if (s == "mumps") return Genie::Mumps;
+    if (s == "cudss") return Genie::Cudss;
+    return Genie::Hipmf;
+}
+
+Sym genie_get_sym(Genie g, bool symmetric) {
+    if (!symmetric) return Sym::No;
+    return g == Genie::Umfpack ? Sym::YesFull : Sym::YesLower;
+}
+
+static const char *sym_name(Sym s) {
+    switch (s) {
+    case Sym::No: return "No";
+    case Sym::YesFull: return "YesFull";
+    case Sym::YesLower: return "YesLower";
+    case Sym::YesUpper: return "YesUpper";
+    }
+    return "No";
+}
+static const char *ORDERING_NAMES[] = {"Amd", "Amf", "Auto", "Best", "BtfColamd", "Cholmod", "Colamd", "Metis", "No", "Pord", "Qamd", "Scotch"};
+static const char *SCALING_NAMES[] = {"Auto", "Column", "Diagonal", "Max", "No", "RowCol", "RowColIter", "RowColRig", "Sum"};
+
+// ---- COO ---------------------------------------------------------------------------------------------
+StrError CooMatrix::create(CooMatrix &out, size_t nrow, size_t ncol, size_t max_nnz, Sym symmetric) {
+    if (nrow < 1) return "nrow must be ≥ 1";
+    if (ncol < 1) return "ncol must be ≥ 1";
+    if (max_nnz < 1) return "max_nnz must be ≥ 1";
+    if (symmetric != Sym::No && nrow != ncol) return "symmetric storage requires a square matrix";
+    out.symmetric = symmetric;
+    out.nrow = nrow, out.ncol = ncol, out.nnz = 0, out.max_nnz = max_nnz;
+    out.indices_i.assign(max_nnz, 0);
+    out.indices_j.assign(max_nnz, 0);
+    out.values.assign(max_nnz, 0.0);
+    return nullptr;
+}
+
+StrError CooMatrix::put(size_t i, size_t j, double aij) {
+    if (i >= nrow) return "COO matrix: index of row is outside range";
+    if (j >= ncol) return "COO matrix: index of column is outside range";
+    if (nnz >= max_nnz) return "COO matrix: max number of items has been reached";
+    if (symmetric == Sym::YesLower && j > i) return "COO matrix: j > i is incorrect for lower triangular storage";
+    if (symmetric == Sym::YesUpper && j < i) return "COO matrix: j < i is incorrect for upper triangular storage";
+    indices_i[nnz] = (int32_t)i;
+    indices_j[nnz] = (int32_t)j;
+    values[nnz] = aij;
+    nnz++;
+    return nullptr;
+}
+
+static inline bool triangular(Sym s) { return s == Sym::YesLower || s == Sym::YesUpper; }
+
+StrError CooMatrix::mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const {
+    if (u.size() < ncol) return "u.dim() must be ≥ the number of columns of the matrix";
+    if (v.size() < nrow) return "v.dim() must be ≥ the number of rows of the matrix";
+    std::fill(v.begin(), v.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t p = 0; p < nnz; p++) {
+        size_t i = (size_t)indices_i[p], j = (size_t)indices_j[p];
+        v[i] += alpha * values[p] * u[j];
+        if (mirror && i != j) v[j] += alpha * values[p] * u[i];
+    }
+    return nullptr;
+}
+
+// ---- CSC (csc_matrix.rs:337-505) -------------------------------------------------------------------------
+StrError CscMatrix::from_coo(CscMatrix &out, const CooMatrix &coo) {
+    if (coo.nnz < 1) return "COO to CSC requires nnz > 0";
+    out.symmetric = coo.symmetric;
+    out.nrow = coo.nrow, out.ncol = coo.ncol;
+    out.col_pointers.assign(coo.ncol + 1, 0);
+    out.row_indices.assign(coo.nnz, 0);
+    out.values.assign(coo.nnz, 0.0);
+    out.temp_w.clear();
+    return out.update_from_coo(coo);
+}
+
+StrError CscMatrix::update_from_coo(const CooMatrix &coo) {
+    if (coo.symmetric != symmetric) return "coo.symmetric must be equal to csc.symmetric";
+    if (coo.nrow != nrow) return "coo.nrow must be equal to csc.nrow";
+    if (coo.ncol != ncol) return "coo.ncol must be equal to csc.ncol";
+    if (coo.nnz != values.size()) return "coo.nnz must be equal to nnz(dup) = csc.row_indices.len() = csc.values.len()";
+    const size_t nnz = coo.nnz, ndim = std::max(nrow, ncol);
+    if (temp_w.empty()) {
+        temp_rp.assign(nrow + 1, 0);
+        temp_rj.assign(nnz, 0);
+        temp_rx.assign(nnz, 0.0);
+        temp_rc.assign(nrow, 0);
+        temp_w.assign(ndim, 0);
+    } else {
+        std::fill(temp_w.begin(), temp_w.begin() + nrow, 0);
+    }
+    auto &rp = temp_rp;
+    auto &rj = temp_rj;
+    auto &rx = temp_rx;
+    auto &rc = temp_rc;
+    auto &w = temp_w;
+    for (size_t k = 0; k < nnz; k++) w[coo.indices_i[k]]++;
+    rp[0] = 0;
+    for (size_t i = 0; i < nrow; i++) {
+        rp[i + 1] = rp[i] + w[i];
+        w[i] = rp[i];
+    }
+    for (size_t k = 0; k < nnz; k++) {
+        size_t p = (size_t)w[coo.indices_i[k]]++;
+        rj[p] = coo.indices_j[k];
+        rx[p] = coo.values[k];
+    }
+    for (size_t j = 0; j < ncol; j++) w[j] = -1;
+    for (size_t i = 0; i < nrow; i++) {
+        size_t p1 = (size_t)rp[i], p2 = (size_t)rp[i + 1], dest = p1;
+        for (size_t p = p1; p < p2; p++) {
+            size_t j = (size_t)rj[p];
+            if (w[j] >= (int32_t)p1) {
+                rx[(size_t)w[j]] += rx[p];
+            } else {
+                w[j] = (int32_t)dest;
+                if (dest != p) {
+                    rj[dest] = (int32_t)j;
+                    rx[dest] = rx[p];
+                }
+                dest++;
+            }
+        }
+        rc[i] = dest - p1;
+    }
+    for (size_t j = 0; j < ncol; j++) w[j] = 0;
+    for (size_t i = 0; i < nrow; i++)
+        for (size_t p = (size_t)rp[i]; p < (size_t)rp[i] + rc[i]; p++) w[rj[p]]++;
+    col_pointers[0] = 0;
+    for (size_t j = 0; j < ncol; j++) col_pointers[j + 1] = col_pointers[j] + w[j];
+    for (size_t j = 0; j < ncol; j++) w[j] = col_pointers[j];
+    for (size_t i = 0; i < nrow; i++)
+        for (size_t p = (size_t)rp[i]; p < (size_t)rp[i] + rc[i]; p++) {
+            size_t cp = (size_t)w[rj[p]]++;
+            row_indices[cp] = (int32_t)i;
+            values[cp] = rx[p];
+        }
+    return nullptr;
+}
+
+StrError CscMatrix::mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const {
+    if (u.size() < ncol) return "u.dim() must be ≥ the number of columns of the matrix";
+    if (v.size() < nrow) return "v.dim() must be ≥ the number of rows of the matrix";
+    std::fill(v.begin(), v.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t j = 0; j < ncol; j++)
+        for (int32_t p = col_pointers[j]; p < col_pointers[j + 1]; p++) {
+            size_t i = (size_t)row_indices[p];
+            v[i] += alpha * values[p] * u[j];
+            if (mirror && i != j) v[j] += alpha * values[p] * u[i];
+        }
+    return nullptr;
+}
+
+// ---- CSR (csr_matrix.rs:332-480) -------------------------------------------------------------------------
+StrError CsrMatrix::from_coo(CsrMatrix &out, const CooMatrix &coo) {
+    if (coo.nnz < 1) return "COO to CSR requires nnz > 0";
+    out.symmetric = coo.symmetric;
+    out.nrow = coo.nrow, out.ncol = coo.ncol;
+    out.row_pointers.assign(coo.nrow + 1, 0);
+    out.col_indices.assign(coo.nnz, 0);
+    out.values.assign(coo.nnz, 0.0);
+    out.temp_w.clear();
+    return out.update_from_coo(coo);
+}
+
+StrError CsrMatrix::update_from_coo(const CooMatrix &coo) {
+    if (coo.symmetric != symmetric) return "coo.symmetric must be equal to csr.symmetric";
+    if (coo.nrow != nrow) return "coo.nrow must be equal to csr.nrow";
+    if (coo.ncol != ncol) return "coo.ncol must be equal to csr.ncol";
+    if (coo.nnz != values.size()) return "coo.nnz must be equal to nnz(dup) = self.col_indices.len() = csr.values.len()";
+    const size_t nnz = coo.nnz, ndim = std::max(nrow, ncol);
+    if (temp_w.empty()) {
+        temp_rp.assign(nrow + 1, 0);
+        temp_rjx.assign(nnz, std::make_pair(0, 0.0));
+        temp_rc.assign(nrow, 0);
+        temp_w.assign(ndim, 0);
+    } else {
+        std::fill(temp_w.begin(), temp_w.begin() + nrow, 0);
+    }
+    auto &rp = temp_rp;
+    auto &rjx = temp_rjx;
+    auto &rc = temp_rc;
+    auto &w = temp_w;
+    for (size_t k = 0; k < nnz; k++) w[coo.indices_i[k]]++;
+    rp[0] = 0;
+    for (size_t i = 0; i < nrow; i++) {
+        rp[i + 1] = rp[i] + w[i];
+        w[i] = rp[i];
+    }
+    for (size_t k = 0; k < nnz; k++) {
+        size_t p = (size_t)w[coo.indices_i[k]]++;
+        rjx[p].first = coo.indices_j[k];
+        rjx[p].second = coo.values[k];
+    }
+    for (size_t j = 0; j < ncol; j++) w[j] = -1;
+    for (size_t i = 0; i < nrow; i++) {
+        size_t p1 = (size_t)rp[i], p2 = (size_t)rp[i + 1], dest = p1;
+        for (size_t p = p1; p < p2; p++) {
+            size_t j = (size_t)rjx[p].first;
+            if (w[j] >= (int32_t)p1) {
+                rjx[(size_t)w[j]].second += rjx[p].second;
+            } else {
+                w[j] = (int32_t)dest;
+                if (dest != p) rjx[dest] = rjx[p];
+                dest++;
+            }
+        }
+        rc[i] = dest - p1;
+    }
+    row_pointers[0] = 0;
+    for (size_t i = 0; i < nrow; i++) row_pointers[i + 1] = row_pointers[i] + (int32_t)rc[i];
+    size_t k = 0;
+    for (size_t i = 0; i < nrow; i++) {
+        size_t p1 = (size_t)rp[i], p2 = p1 + rc[i];
+        std::stable_sort(rjx.begin() + p1, rjx.begin() + p2, [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) { return a.first < b.first; });
+        for (size_t p = p1; p < p2; p++) {
+            col_indices[k] = rjx[p].first;
+            values[k] = rjx[p].second;
+            k++;
+        }
+    }
+    return nullptr;
+}
+
+StrError CsrMatrix::mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const {
+    if (u.size() < ncol) return "u.dim() must be ≥ the number of columns of the matrix";
+    if (v.size() < nrow) return "v.dim() must be ≥ the number of rows of the matrix";
+    std::fill(v.begin(), v.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t i = 0; i < nrow; i++)
+        for (int32_t p = row_pointers[i]; p < row_pointers[i + 1]; p++) {
+            size_t j = (size_t)col_indices[p];
+            v[i] += alpha * values[p] * u[j];
+            if (mirror && i != j) v[j] += alpha * values[p] * u[i];
+        }
+    return nullptr;
+}
+
+// ---- verify (verify_lin_sys.rs:60-96) -------------------------------------------------------------------
+StrError VerifyLinSys::from(VerifyLinSys &out, const CooMatrix &mat, const std::vector<double> &x, const std::vector<double> &rhs) {
+    if (x.size() != mat.ncol) return "x.dim() must be equal to ncol";
+    if (rhs.size() != mat.nrow) return "rhs.dim() must be equal to nrow";
+    if (mat.nnz < 1) return "matrix is empty";
+    double max_abs_a = 0.0;
+    for (size_t p = 0; p < mat.nnz; p++) max_abs_a = std::max(max_abs_a, std::fabs(mat.values[p]));
+    std::vector<double> ax(mat.nrow, 0.0);
+    mat.mat_vec_mul(ax, 1.0, x);
+    double max_abs_ax = 0.0, max_abs_diff = 0.0;
+    for (size_t i = 0; i < mat.nrow; i++) {
+        max_abs_ax = std::max(max_abs_ax, std::fabs(ax[i]));
+        max_abs_diff = std::max(max_abs_diff, std::fabs(ax[i] - rhs[i]));
+    }
+    out.max_abs_a = max_abs_a;
+    out.max_abs_ax = max_abs_ax;
+    out.max_abs_diff = max_abs_diff;
+    out.relative_error = max_abs_diff / (max_abs_a + 1.0);
+    return nullptr;
+}
+
+// ---- stats -------------------------------------------------------------------------------------------
+static uint64_t avg(const std::vector<uint64_t> &v) {
+    if (v.empty()) return 0;
+    uint64_t s = 0;
+    for (auto x : v) s += x;
+    return s / v.size();
+}
+static std::string arr(const std::vector<uint64_t> &v) {
+    std::ostringstream o;
+    o << "[";
+    for (size_t i = 0; i < v.size(); i++) o << (i ? "," : "") << v[i];
+    o << "]";
+    return o.str();
+}
+std::string StatsLinSol::to_json() const {
+    std::vector<uint64_t> total;
+    for (size_t i = 0; i < std::min(initialize_ns.size(), std::min(factorize_ns.size(), solve_ns.size())); i++)
+        total.push_back(initialize_ns[i] + factorize_ns[i] + solve_ns[i]);
+    char num[64];
+    std::ostringstream o;
+    auto f = [&](double v) {
+        snprintf(num, sizeof num, "%.17g", v);
+        return std::string(num);
+    };
+    o << "{\"main\":{\"platform\":\"MI355X gfx950\",\"blas_lib\":\"none (hand-written HIP kernels)\",\"solver\":\"" << solver
+      << "\",\"out_of_memory\":false},"
+      << "\"matrix\":{\"name\":\"" << matrix_name << "\",\"nrow\":" << nrow << ",\"ncol\":" << ncol << ",\"nnz\":" << nnz
+      << ",\"nnz_actual\":" << nnz_actual << ",\"complex\":false,\"symmetric\":\"" << symmetric << "\"},"
+      << "\"requests\":{\"ordering\":\"" << ordering << "\",\"scaling\":\"" << scaling
+      << "\",\"positive_definite\":" << (positive_definite ? "true" : "false") << "},"
+      << "\"output\":{\"effective_ordering\":\"" << effective_ordering << "\",\"effective_scaling\":\"" << effective_scaling
+      << "\",\"rcond_estimate\":" << f(rcond_estimate) << ",\"perturbed_pivots\":" << perturbed_pivots << "},"
+      << "\"determinant\":{\"mantissa_real\":" << f(det_mantissa) << ",\"mantissa_imag\":0.0,\"base\":" << f(det_base)
+      << ",\"exponent\":" << f(det_exponent) << "},"
+      << "\"verify\":{\"max_abs_a\":" << f(verify.max_abs_a) << ",\"max_abs_ax\":" << f(verify.max_abs_ax)
+      << ",\"max_abs_diff\":" << f(verify.max_abs_diff) << ",\"relative_error\":" << f(verify.relative_error) << "},"
+      << "\"time_nanoseconds\":{\"initialize_array\":" << arr(initialize_ns) << ",\"initialize\":" << avg(initialize_ns)
+      << ",\"factorize_array\":" << arr(factorize_ns) << ",\"factorize\":" << avg(factorize_ns) << ",\"solve_array\":" << arr(solve_ns)
+      << ",\"solve\":" << avg(solve_ns) << ",\"total_ifs_array\":" << arr(total) << ",\"total_ifs\":" << avg(total) << "}}";
+    return o.str();
+}
+
+// ---- the HIP backend, loaded at run time ---------------------------------------------------------------------
+namespace {
+struct Backend {
+    void *dl = nullptr;
+    decltype(&solver_hipmf_new) new_ = nullptr;
+    decltype(&solver_hipmf_drop) drop = nullptr;
+    decltype(&solver_hipmf_initialize) initialize = nullptr;
+    decltype(&solver_hipmf_factorize) factorize = nullptr;
+    decltype(&solver_hipmf_solve) solve = nullptr;
+    decltype(&solver_hipmf_solve_many) solve_many = nullptr;
+    bool tried = false;
+};
+Backend g_backend;
+std::string g_lib_path;
+
+bool load_backend() {
+    if (g_backend.tried) return g_backend.dl != nullptr;
+    g_backend.tried = true;
+    std::string path = g_lib_path;
+    if (path.empty()) {
+        const char *env = getenv("RUSSELL_HIPMF_LIB");
+        if (env) path = env;
+    }
+    if (path.empty()) {
+        Dl_info info;
+        if (dladdr((void *)&load_backend, &info) && info.dli_fname) {
+            std::string self = info.dli_fname;
+            size_t slash = self.rfind('/');
+            path = (slash == std::string::npos ? std::string(".") : self.substr(0, slash)) + "/librussell_hipmf.so";
+        }
+    }
+    void *dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return false;
+#define BIND(field, name)                                              \
+    g_backend.field = (decltype(g_backend.field))dlsym(dl, name);      \
+    if (!g_backend.field) {                                            \
+        dlclose(dl);                                                   \
+        return false;                                                  \
+    }
+    BIND(new_, "solver_hipmf_new")
+    BIND(drop, "solver_hipmf_drop")
+    BIND(initialize, "solver_hipmf_initialize")
+    BIND(factorize, "solver_hipmf_factorize")
+    BIND(solve, "solver_hipmf_solve")
+    BIND(solve_many, "solver_hipmf_solve_many")
+#undef BIND
+    g_backend.dl = dl;
+    return true;
+}
+
+uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} // namespace
+
+void set_hipmf_library_path(const std::string &path) {
+    g_lib_path = path;
+    g_backend.tried = false;
+}
+
+// Ordering -> C-ABI constant (all fill-reducing requests map to nested dissection, the only one implemented)
+static int32_t hipmf_ordering(Ordering o) { return o == Ordering::No ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_DEFAULT; }
+// Scaling -> C-ABI constant, same mapping as umfpack_scaling (solver_umfpack.rs:475-487)
+static int32_t hipmf_scaling(Scaling s) {
+    switch (s) {
+    case Scaling::Max: return HIPMF_SCALE_MAX;
+    case Scaling::No: return HIPMF_SCALE_NONE;
+    default: return HIPMF_SCALE_SUM;
+    }
+}
+
+StrError handle_hipmf_error_code(int32_t err) {
+    switch (err) {
+    case HIPMF_WARNING_SINGULAR_MATRIX: return "Error(1): Matrix is singular";
+    case ERROR_NULL_POINTER: return "Error: c-code returned null pointer (HIPMF)";
+    case ERROR_MALLOC: return "Error: c-code failed to allocate memory (HIPMF)";
+    case ERROR_VERSION: return "Error: c-code returned version error (HIPMF)";
+    case ERROR_NOT_AVAILABLE: return "Error: c-code returned not available (HIPMF): a frontal matrix exceeds the LDS staging limit";
+    case ERROR_NEED_INITIALIZATION: return "Error: c-code requires initialization (HIPMF)";
+    case ERROR_NEED_FACTORIZATION: return "Error: c-code requires factorization (HIPMF)";
+    case ERROR_ALREADY_INITIALIZED: return "Error: c-code requires no previous initialization (HIPMF)";
+    case ERROR_HIP_MALLOC: return "hipMalloc failed in the C code (HIPMF): Not enough memory";
+    case ERROR_HIP_MEMCPY: return "hipMemcpy failed in the C code (HIPMF)";
+    case ERROR_HIP_SYNCHRONIZE: return "hipStreamSynchronize failed in the C code (HIPMF)";
+    case ERROR_HIP_LAUNCH: return "a HIP kernel launch failed in the C code (HIPMF)";
+    case ERROR_HIPMF_INVALID_MATRIX: return "HIPMF symbolic analysis failed: invalid CSR structure";
+    case ERROR_HIPMF_SYMBOLIC: return "HIPMF symbolic analysis failed: internal error";
+    case ERROR_HIPMF_INVALID_VALUE: return "HIPMF solve failed: invalid value";
+    case ERROR_HIPMF_NO_DEVICE: return "HIPMF: no HIP device is visible";
+    default: return "Error: unknown error returned by c-code (HIPMF)";
+    }
+}
+
+StrError SolverHIPMF::create(std::unique_ptr<SolverHIPMF> &out) {
+    if (!load_backend()) return "HIPMF solver is not available";
+    void *h = g_backend.new_();
+    if (!h) return "c-code failed to allocate the HIPMF solver";
+    out.reset(new SolverHIPMF());
+    out->solver = h;
+    return nullptr;
+}
+
+SolverHIPMF::~SolverHIPMF() {
+    if (solver && g_backend.drop) g_backend.drop((InterfaceHIPMF *)solver);
+}
+
+// solver_cudss.rs:194-311 with this backend's symmetry rule and parameters
+StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params) {
+    if (initialized) {
+        if (mat.symmetric != initialized_sym) return "subsequent factorizations must use the same matrix (symmetric differs)";
+        if (mat.nrow != initialized_ndim) return "subsequent factorizations must use the same matrix (ndim differs)";
+        if (mat.nnz != initialized_nnz) return "subsequent factorizations must use the same matrix (nnz differs)";
+        if (params) return "subsequent factorizations must not change LinSolParams";
+        StrError e = csr.update_from_coo(mat);
+        if (e) return e;
+    } else {
+        if (mat.nrow != mat.ncol) return "the matrix must be square";
+        if (mat.nnz < 1) return "the COO matrix must have at least one non-zero value";
+        if (mat.symmetric == Sym::YesFull || mat.symmetric == Sym::YesUpper) return "HIPMF requires Sym::YesLower for symmetric matrices";
+        initialized_sym = mat.symmetric;
+        initialized_ndim = mat.nrow;
+        initialized_nnz = mat.nnz;
+        StrError e = CsrMatrix::from_coo(csr, mat);
+        if (e) return e;
+    }
+    LinSolParams par = params ? *params : LinSolParams();
+    const int32_t verbose = par.verbose ? 1 : 0;
+    if (!initialized) {
+        compute_determinant = par.compute_determinant;
+        uint64_t t0 = now_ns();
+        int32_t status = g_backend.initialize((InterfaceHIPMF *)solver, hipmf_ordering(par.ordering), hipmf_scaling(par.scaling),
+                                              par.has_pivot_epsilon ? par.pivot_epsilon : -1.0,
+                                              par.has_refinement_nstep ? par.refinement_nstep : -1, verbose,
+                                              mat.symmetric == Sym::YesLower ? 1 : 0, par.positive_definite ? 1 : 0, (int32_t)csr.nrow,
+                                              csr.row_pointers.data(), csr.col_indices.data(), csr.values.data());
+        if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+        time_initialize_ns = now_ns() - t0;
+        initialized = true;
+    }
+    uint64_t t0 = now_ns();
+    int32_t status = g_backend.factorize((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
+                                         &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose, csr.values.data());
+    if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+    time_factorize_ns = now_ns() - t0;
+    factorized = true;
+    return nullptr;
+}
+
+StrError SolverHIPMF::solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) {
+    if (!factorized) return "the function factorize must be called before solve";
+    if (x.size() != initialized_ndim) return "the dimension of the vector of unknown values x is incorrect";
+    if (rhs.size() != initialized_ndim) return "the dimension of the right-hand side vector is incorrect";
+    uint64_t t0 = now_ns();
+    int32_t status = g_backend.solve((InterfaceHIPMF *)solver, x.data(), rhs.data(), verbose ? 1 : 0);
+    if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+    time_solve_ns = now_ns() - t0;
+    return nullptr;
+}
+
+StrError SolverHIPMF::solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs) {
+    if (!factorized) return "the function factorize must be called before solve";
+    if (nrhs < 1 || x.size() != initialized_ndim * nrhs) return "the dimension of the vector of unknown values x is incorrect";
+    if (rhs.size() != initialized_ndim * nrhs) return "the dimension of the right-hand side vector is incorrect";
+    uint64_t t0 = now_ns();
+    int32_t status = g_backend.solve_many((InterfaceHIPMF *)solver, x.data(), rhs.data(), (int32_t)nrhs, (int32_t)initialized_ndim, 0);
+    if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+    time_solve_ns = now_ns() - t0;
+    return nullptr;
+}
+
+void SolverHIPMF::update_stats(StatsLinSol &stats) const {
+    stats.solver = "HIPMF";
+    stats.initialize_ns.push_back(time_initialize_ns);
+    stats.factorize_ns.push_back(time_factorize_ns);
+    stats.solve_ns.push_back(time_solve_ns);
+    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Metis"; // nested dissection
+    stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
+    stats.rcond_estimate = rcond_estimate;
+    stats.det_mantissa = determinant_coefficient;
+    stats.det_base = 10.0;
+    stats.det_exponent = determinant_exponent;
+    stats.perturbed_pivots = perturbed_pivots;
+}
+
+StrError LinSolver::create(LinSolver &out, Genie genie) {
+    switch (genie) {
+    case Genie::Hipmf: {
+        std::unique_ptr<SolverHIPMF> s;
+        StrError e = SolverHIPMF::create(s);
+        if (e) return e;
+        out.actual = std::move(s);
+        return nullptr;
+    }
+    case Genie::Umfpack: return "UMFPACK solver is not available";
+    case Genie::Mumps: return "MUMPS solver is not available";
+    case Genie::Cudss: return "cuDSS solver is not available";
+    }
+    return "unknown genie";
+}
+
+StrError LinSolver::compute(Genie genie, std::vector<double> &x, const CooMatrix &mat, const std::vector<double> &rhs, const LinSolParams *params) {
+    LinSolver solver;
+    StrError e = LinSolver::create(solver, genie);
+    if (e) return e;
+    e = solver.actual->factorize(mat, params);
+    if (e) return e;
+    return solver.actual->solve(x, rhs, false);
+}
+
+// ---- MatrixMarket (read_matrix_market.rs:44-184,346-475) -------------------------------------------------------
+StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym handling) {
+    std::ifstream in(full_path);
+    if (!in) return "cannot open file";
+    std::string line;
+    if (!std::getline(in, line)) return "the file is empty";
+    bool complex = false, symmetric = false;
+    {
+        std::istringstream hs(line);
+        std::string w;
+        if (!(hs >> w)) return "cannot find the keyword %%MatrixMarket on the first line";
+        if (w != "%%MatrixMarket") return "the header (first line) must start with %%MatrixMarket";
+        if (!(hs >> w)) return "cannot find the first option in the header line";
+        if (w != "matrix") return "after %%MatrixMarket, the first option must be \"matrix\"";
+        if (!(hs >> w)) return "cannot find the second option in the header line";
+        if (w != "coordinate") return "after %%MatrixMarket, the second option must be \"coordinate\"";
+        if (!(hs >> w)) return "cannot find the third option in the header line";
+        if (w == "real") complex = false;
+        else if (w == "complex") complex = true;
+        else return "after %%MatrixMarket, the third option must be \"real\" or \"complex\"";
+        if (!(hs >> w)) return "cannot find the fourth option in the header line";
+        if (w == "general") symmetric = false;
+        else if (w == "symmetric") symmetric = true;
+        else if (w == "Hermitian") {
+            if (!complex) return "\"Hermitian\" keyword can only be used with the \"complex\" type";
+            symmetric = true;
+        } else
+            return "after %%MatrixMarket, the fourth option must be either \"general\", \"symmetric\", or \"Hermitian\"";
+    }
+    long m = 0, n = 0, nnz = 0;
+    bool have_dims = false;
+    while (std::getline(in, line)) {
+        size_t b = line.find_first_not_of(" \t\r");
+        if (b == std::string::npos || line[b] == '%') continue;
+        std::istringstream ds(line);
+        std::string a, c, d;
+        if (!(ds >> a)) continue;
+        char *end;
+        m = strtol(a.c_str(), &end, 10);
+        if (*end) return "cannot parse number of rows";
+        if (!(ds >> c)) return "cannot read number of columns";
+        n = strtol(c.c_str(), &end, 10);
+        if (*end) return "cannot parse number of columns";
+        if (!(ds >> d)) return "cannot read number of non-zeros";
+        nnz = strtol(d.c_str(), &end, 10);
+        if (*end) return "cannot parse number of non-zeros";
+        if (m < 1 || n < 1 || nnz < 1) return "found invalid (zero or negative) dimensions";
+        have_dims = true;
+        break;
+    }
+    if (!have_dims) return "cannot read the dimensions line";
+    Sym sym = Sym::No;
+    if (symmetric) {
+        if (m != n) return "MatrixMarket data is invalid: the number of rows must equal the number of columns for symmetric matrices";
+        sym = handling == MMsym::LeaveAsLower ? Sym::YesLower : (handling == MMsym::SwapToUpper ? Sym::YesUpper : Sym::YesFull);
+    }
+    size_t max = (size_t)nnz;
+    if (symmetric && handling == MMsym::MakeItFull) max = 2 * (size_t)nnz;
+    StrError e = CooMatrix::create(out, (size_t)m, (size_t)n, max, sym);
+    if (e) return e;
+    long pos = 0;
+    while (std::getline(in, line)) {
+        size_t b = line.find_first_not_of(" \t\r");
+        if (b == std::string::npos || line[b] == '%') continue;
+        if (pos == nnz) return "there are more values than specified";
+        std::istringstream vs(line);
+        std::string si, sj, sa;
+        if (!(vs >> si)) continue;
+        char *end;
+        long i = strtol(si.c_str(), &end, 10);
+        if (*end) return "cannot parse i";
+        if (!(vs >> sj)) return "cannot read j";
+        long j = strtol(sj.c_str(), &end, 10);
+        if (*end) return "cannot parse j";
+        if (!(vs >> sa)) return "cannot read aij";
+        double aij = strtod(sa.c_str(), &end);
+        if (*end) return "cannot parse aij";
+        if (complex) {
+            std::string sb;
+            if (!(vs >> sb)) return "cannot read bij";
+            strtod(sb.c_str(), &end);
+            if (*end) return "cannot parse bij";
+        }
+        i -= 1, j -= 1; // MatrixMarket is one-based
+        if (i < 0 || i >= m || j < 0 || j >= n) return "found an invalid index";
+        pos++;
+        if (symmetric) {
+            if (handling == MMsym::LeaveAsLower) out.put((size_t)i, (size_t)j, aij);
+            else if (handling == MMsym::SwapToUpper) out.put((size_t)j, (size_t)i, aij);
+            else {
+                out.put((size_t)i, (size_t)j, aij);
+                if (i != j) out.put((size_t)j, (size_t)i, aij);
+            }
+        } else {
+            out.put((size_t)i, (size_t)j, aij);
+        }
+    }
+    if (pos != nnz) return "not all values have been found";
+    if (complex) return "complex MatrixMarket files are not supported by this backend yet";
+    return nullptr;
+}
+
+} // namespace russell
+
+// ====================================================================================================
+// flat C API (include/russell_host.h) for ctypes / other FFI users
+// ====================================================================================================
+using namespace russell;
+
+extern "C" {
+
+struct RhParams {
+    int32_t ordering, scaling;
+    int32_t has_pivot_epsilon;
+    double pivot_epsilon;
+    int32_t has_refinement_nstep, refinement_nstep;
+    int32_t positive_definite, compute_determinant, verbose;
+};
+
+static LinSolParams to_params(const RhParams *p) {
+    LinSolParams q;
+    q.ordering = (Ordering)p->ordering;
+    q.scaling = (Scaling)p->scaling;
+    q.has_pivot_epsilon = p->has_pivot_epsilon != 0;
+    q.pivot_epsilon = p->pivot_epsilon;
+    q.has_refinement_nstep = p->has_refinement_nstep != 0;
+    q.refinement_nstep = p->refinement_nstep;
+    q.positive_definite = p->positive_definite != 0;
+    q.compute_determinant = p->compute_determinant != 0;
+    q.verbose = p->verbose != 0;
+    return q;
+}
+
+void rh_set_hipmf_library(const char *path) { set_hipmf_library_path(path ? path : ""); }
+
+void *rh_coo_new(int64_t nrow, int64_t ncol, int64_t max_nnz, int32_t sym, const char **err) {
+    CooMatrix *c = new CooMatrix();
+    *err = (nrow < 0 || ncol < 0 || max_nnz < 0) ? "negative dimension" : CooMatrix::create(*c, (size_t)nrow, (size_t)ncol, (size_t)max_nnz, (Sym)sym);
+    if (*err) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+void rh_coo_free(void *h) { delete (CooMatrix *)h; }
+const char *rh_coo_put(void *h, int64_t i, int64_t j, double aij) {
+    if (i < 0) return "COO matrix: index of row is outside range";
+    if (j < 0) return "COO matrix: index of column is outside range";
+    return ((CooMatrix *)h)->put((size_t)i, (size_t)j, aij);
+}
+void rh_coo_reset(void *h) { ((CooMatrix *)h)->reset(); }
+void rh_coo_info(void *h, int64_t *nrow, int64_t *ncol, int64_t *nnz, int64_t *max_nnz, int32_t *sym) {
+    CooMatrix *c = (CooMatrix *)h;
+    *nrow = (int64_t)c->nrow, *ncol = (int64_t)c->ncol, *nnz = (int64_t)c->nnz, *max_nnz = (int64_t)c->max_nnz, *sym = (int32_t)c->symmetric;
+}
+void rh_coo_arrays(void *h, const int32_t **ai, const int32_t **aj, const double **ax) {
+    CooMatrix *c = (CooMatrix *)h;
+    *ai = c->indices_i.data(), *aj = c->indices_j.data(), *ax = c->values.data();
+}
+const char *rh_coo_mat_vec_mul(void *h, double *v, int64_t nv, double alpha, const double *u, int64_t nu) {
+    std::vector<double> vv((size_t)nv), uu(u, u + nu);
+    StrError e = ((CooMatrix *)h)->mat_vec_mul(vv, alpha, uu);
+    if (!e) std::copy(vv.begin(), vv.end(), v);
+    return e;
+}
+
+void *rh_csc_from_coo(void *coo, const char **err) {
+    CscMatrix *m = new CscMatrix();
+    *err = CscMatrix::from_coo(*m, *(CooMatrix *)coo);
+    if (*err) {
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+const char *rh_csc_update_from_coo(void *h, void *coo) { return ((CscMatrix *)h)->update_from_coo(*(CooMatrix *)coo); }
+void rh_csc_arrays(void *h, const int32_t **cp, const int32_t **ri, const double **vx, int64_t *ncol, int64_t *nnz) {
+    CscMatrix *m = (CscMatrix *)h;
+    *cp = m->col_pointers.data(), *ri = m->row_indices.data(), *vx = m->values.data(), *ncol = (int64_t)m->ncol, *nnz = (int64_t)m->nnz_final();
+}
+const char *rh_csc_mat_vec_mul(void *h, double *v, int64_t nv, double alpha, const double *u, int64_t nu) {
+    std::vector<double> vv((size_t)nv), uu(u, u + nu);
+    StrError e = ((CscMatrix *)h)->mat_vec_mul(vv, alpha, uu);
+    if (!e) std::copy(vv.begin(), vv.end(), v);
+    return e;
+}
+void rh_csc_free(void *h) { delete (CscMatrix *)h; }
+
+void *rh_csr_from_coo(void *coo, const char **err) {
+    CsrMatrix *m = new CsrMatrix();
+    *err = CsrMatrix::from_coo(*m, *(CooMatrix *)coo);
+    if (*err) {
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+const char *rh_csr_update_from_coo(void *h, void *coo) { return ((CsrMatrix *)h)->update_from_coo(*(CooMatrix *)coo); }
+void rh_csr_arrays(void *h, const int32_t **rp, const int32_t **cj, const double **vx, int64_t *nrow, int64_t *nnz) {
+    CsrMatrix *m = (CsrMatrix *)h;
+    *rp = m->row_pointers.data(), *cj = m->col_indices.data(), *vx = m->values.data(), *nrow = (int64_t)m->nrow, *nnz = (int64_t)m->nnz_final();
+}
+const char *rh_csr_mat_vec_mul(void *h, double *v, int64_t nv, double alpha, const double *u, int64_t nu) {
+    std::vector<double> vv((size_t)nv), uu(u, u + nu);
+    StrError e = ((CsrMatrix *)h)->mat_vec_mul(vv, alpha, uu);
+    if (!e) std::copy(vv.begin(), vv.end(), v);
+    return e;
+}
+void rh_csr_free(void *h) { delete (CsrMatrix *)h; }
+
+const char *rh_verify(void *coo, const double *x, int64_t nx, const double *rhs, int64_t nr, double *out4) {
+    VerifyLinSys v;
+    StrError e = VerifyLinSys::from(v, *(CooMatrix *)coo, std::vector<double>(x, x + nx), std::vector<double>(rhs, rhs + nr));
+    if (!e) out4[0] = v.max_abs_a, out4[1] = v.max_abs_ax, out4[2] = v.max_abs_diff, out4[3] = v.relative_error;
+    return e;
+}
+
+void *rh_read_matrix_market(const char *path, int32_t mmsym, const char **err) {
+    CooMatrix *c = new CooMatrix();
+    *err = read_matrix_market(*c, path, (MMsym)mmsym);
+    if (*err) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+struct RhSolver {
+    LinSolver ls;
+    StatsLinSol stats;
+    std::string json;
+};
+
+void *rh_linsolver_new(int32_t genie, const char **err) {
+    RhSolver *s = new RhSolver();
+    *err = LinSolver::create(s->ls, (Genie)genie);
+    if (*err) {
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+void rh_linsolver_free(void *h) { delete (RhSolver *)h; }
+const char *rh_linsolver_factorize(void *h, void *coo, const RhParams *params) {
+    RhSolver *s = (RhSolver *)h;
+    if (params) {
+        LinSolParams p = to_params(params);
+        return s->ls.actual->factorize(*(CooMatrix *)coo, &p);
+    }
+    return s->ls.actual->factorize(*(CooMatrix *)coo, nullptr);
+}
+const char *rh_linsolver_solve(void *h, double *x, int64_t nx, const double *rhs, int64_t nr, int32_t verbose) {
+    RhSolver *s = (RhSolver *)h;
+    std::vector<double> xx((size_t)nx), rr(rhs, rhs + nr);
+    StrError e = s->ls.actual->solve(xx, rr, verbose != 0);
+    if (!e) std::copy(xx.begin(), xx.end(), x);
+    return e;
+}
+const char *rh_linsolver_solve_many(void *h, double *x, const double *rhs, int64_t n, int64_t nrhs) {
+    RhSolver *s = (RhSolver *)h;
+    SolverHIPMF *a = dynamic_cast<SolverHIPMF *>(s->ls.actual.get());
+    if (!a) return "solve_many is only available with Genie::Hipmf";
+    std::vector<double> xx((size_t)(n * nrhs)), rr(rhs, rhs + n * nrhs);
+    StrError e = a->solve_many(xx, rr, (size_t)nrhs);
+    if (!e) std::copy(xx.begin(), xx.end(), x);
+    return e;
+}
+void rh_linsolver_times(void *h, uint64_t *ns3) {
+    RhSolver *s = (RhSolver *)h;
+    ns3[0] = s->ls.actual->get_ns_init(), ns3[1] = s->ls.actual->get_ns_fact(), ns3[2] = s->ls.actual->get_ns_solve();
+}
+void rh_linsolver_outputs(void *h, double *det_coef, double *det_exp, double *rcond, int32_t *eff_ordering, int32_t *eff_scaling, int32_t *npert) {
+    RhSolver *s = (RhSolver *)h;
+    SolverHIPMF *a = dynamic_cast<SolverHIPMF *>(s->ls.actual.get());
+    if (!a) return;
+    *det_coef = a->determinant_coefficient, *det_exp = a->determinant_exponent, *rcond = a->rcond_estimate;
+    *eff_ordering = a->effective_ordering, *eff_scaling = a->effective_scaling, *npert = a->perturbed_pivots;
+}
+const char *rh_linsolver_stats_json(void *h, void *coo, const char *name, const double *x, const double *rhs) {
+    RhSolver *s = (RhSolver *)h;
+    s->stats = StatsLinSol();
+    s->ls.actual->update_stats(s->stats);
+    if (coo) {
+        CooMatrix *c = (CooMatrix *)coo;
+        s->stats.matrix_name = name ? name : "";
+        s->stats.nrow = c->nrow, s->stats.ncol = c->ncol, s->stats.nnz = c->nnz;
+        s->stats.symmetric = sym_name(c->symmetric);
+        if (x && rhs) VerifyLinSys::from(s->stats.verify, *c, std::vector<double>(x, x + c->ncol), std::vector<double>(rhs, rhs + c->nrow));
+    }
+    s->json = s->stats.to_json();
+    return s->json.c_str();
+}
+const char *rh_error_string(int32_t code) { return handle_hipmf_error_code(code); }
+const char *rh_enum_name(int32_t which, int32_t value) {
+    if (which == 0 && value >= 0 && value < 12) return ORDERING_NAMES[value];
+    if (which == 1 && value >= 0 && value < 9) return SCALING_NAMES[value];
+    if (which == 2) return genie_to_string((Genie)value);
+    if (which == 3) return sym_name((Sym)value);
+    return "";
+}
+int32_t rh_genie_get_sym(int32_t genie, int32_t symmetric) { return (int32_t)genie_get_sym((Genie)genie, symmetric != 0); }
+
+} // extern "C"

@@ -1,0 +1,164 @@
+// russell_host.hpp -- C++ mirror of the Rust host layer of russell_sparse for the solver path.
+//
+// The reference's host layer is Rust (no Rust toolchain in this image), so the layer that sits ABOVE the
+// C-ABI of include/russell_hipmf.h is written here in C++ with the same names, argument meaning and error
+// strings, so that a russell_sparse user finds what the trait boundary promises:
+//   CooMatrix::new/put/reset/mat_vec_mul      /root/reference/russell_sparse/src/coo_matrix.rs:173-196,324-354,388,547-566
+//   CscMatrix::from_coo/update_from_coo       .../csc_matrix.rs:337-356,365-505 ; mat_vec_mul :735-755
+//   CsrMatrix::from_coo/update_from_coo       .../csr_matrix.rs:332-351,359-480 ; mat_vec_mul :709-729
+//   LinSolParams                              .../lin_sol_params.rs:5-107
+//   Genie / Sym / Ordering / Scaling / MMsym  .../enums.rs:5-20,27-39,45-66,71-155,159-222,334-366
+//   LinSolTrait, LinSolver::new / compute     .../lin_solver.rs:12-64,116-142,212-224
+//   SolverHIPMF (the new backend)             modelled on .../solver_cudss.rs:92-131,194-360,501-558
+//   VerifyLinSys::from                        .../verify_lin_sys.rs:60-96
+//   StatsLinSol (subset, JSON)                .../stats_lin_sol.rs:14-113
+//   read_matrix_market                        .../read_matrix_market.rs:44-184,346-475
+// Errors are `StrError` = static C strings (nullptr means Ok), the analogue of Result<(), &'static str>.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace russell {
+
+typedef const char *StrError;
+
+enum class Sym : int32_t { No = 0, YesFull = 1, YesLower = 2, YesUpper = 3 };
+enum class Genie : int32_t { Hipmf = 0, Umfpack = 1, Mumps = 2, Cudss = 3 };
+enum class Ordering : int32_t { Amd = 0, Amf, Auto, Best, BtfColamd, Cholmod, Colamd, Metis, No, Pord, Qamd, Scotch };
+enum class Scaling : int32_t { Auto = 0, Column, Diagonal, Max, No, RowCol, RowColIter, RowColRig, Sum };
+enum class MMsym : int32_t { LeaveAsLower = 0, SwapToUpper = 1, MakeItFull = 2 };
+
+const char *genie_to_string(Genie g);
+Genie genie_from(const std::string &name); // default Hipmf here (the reference defaults to umfpack, enums.rs:336-343)
+Sym genie_get_sym(Genie g, bool symmetric); // enums.rs:355-365; Hipmf follows the cuDSS rule (YesLower)
+
+struct LinSolParams {
+    Ordering ordering = Ordering::Auto;
+    Scaling scaling = Scaling::Auto;
+    bool has_pivot_epsilon = false;
+    double pivot_epsilon = 0.0;
+    bool has_refinement_nstep = false;
+    int32_t refinement_nstep = 0;
+    bool positive_definite = false;
+    bool compute_determinant = false;
+    bool verbose = false;
+};
+
+struct CooMatrix {
+    Sym symmetric = Sym::No;
+    size_t nrow = 0, ncol = 0, nnz = 0, max_nnz = 0;
+    std::vector<int32_t> indices_i, indices_j;
+    std::vector<double> values;
+    static StrError create(CooMatrix &out, size_t nrow, size_t ncol, size_t max_nnz, Sym symmetric);
+    StrError put(size_t i, size_t j, double aij);
+    void reset() { nnz = 0; }
+    StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
+};
+
+struct CscMatrix {
+    Sym symmetric = Sym::No;
+    size_t nrow = 0, ncol = 0;
+    std::vector<int32_t> col_pointers, row_indices;
+    std::vector<double> values;
+    static StrError from_coo(CscMatrix &out, const CooMatrix &coo);
+    StrError update_from_coo(const CooMatrix &coo);
+    StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
+    size_t nnz_final() const { return col_pointers.empty() ? 0 : (size_t)col_pointers[ncol]; }
+
+  private:
+    std::vector<int32_t> temp_rp, temp_rj, temp_w;
+    std::vector<double> temp_rx;
+    std::vector<size_t> temp_rc;
+};
+
+struct CsrMatrix {
+    Sym symmetric = Sym::No;
+    size_t nrow = 0, ncol = 0;
+    std::vector<int32_t> row_pointers, col_indices;
+    std::vector<double> values;
+    static StrError from_coo(CsrMatrix &out, const CooMatrix &coo);
+    StrError update_from_coo(const CooMatrix &coo);
+    StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
+    size_t nnz_final() const { return row_pointers.empty() ? 0 : (size_t)row_pointers[nrow]; }
+
+  private:
+    std::vector<int32_t> temp_rp, temp_w;
+    std::vector<std::pair<int32_t, double>> temp_rjx;
+    std::vector<size_t> temp_rc;
+};
+
+struct VerifyLinSys {
+    double max_abs_a = 0, max_abs_ax = 0, max_abs_diff = 0, relative_error = 0;
+    static StrError from(VerifyLinSys &out, const CooMatrix &mat, const std::vector<double> &x, const std::vector<double> &rhs);
+};
+
+struct StatsLinSol {
+    std::string solver, matrix_name, symmetric, ordering, scaling, effective_ordering, effective_scaling;
+    size_t nrow = 0, ncol = 0, nnz = 0, nnz_actual = 0;
+    bool positive_definite = false;
+    double rcond_estimate = 0.0, det_mantissa = 0.0, det_base = 10.0, det_exponent = 0.0;
+    int32_t perturbed_pivots = 0;
+    VerifyLinSys verify;
+    std::vector<uint64_t> initialize_ns, factorize_ns, solve_ns;
+    std::string to_json() const; // field names follow stats_lin_sol.rs (time_nanoseconds.*, total_ifs, verify, determinant)
+};
+
+class LinSolTrait {
+  public:
+    virtual ~LinSolTrait() {}
+    virtual StrError factorize(const CooMatrix &mat, const LinSolParams *params) = 0;
+    virtual StrError solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) = 0;
+    virtual void update_stats(StatsLinSol &stats) const = 0;
+    virtual uint64_t get_ns_init() const = 0;
+    virtual uint64_t get_ns_fact() const = 0;
+    virtual uint64_t get_ns_solve() const = 0;
+};
+
+// The new backend: COO -> CSR on the host, then the three C-ABI phases of include/russell_hipmf.h.
+class SolverHIPMF : public LinSolTrait {
+  public:
+    static StrError create(std::unique_ptr<SolverHIPMF> &out);
+    ~SolverHIPMF() override;
+    StrError factorize(const CooMatrix &mat, const LinSolParams *params) override;
+    StrError solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) override;
+    void update_stats(StatsLinSol &stats) const override;
+    uint64_t get_ns_init() const override { return time_initialize_ns; }
+    uint64_t get_ns_fact() const override { return time_factorize_ns; }
+    uint64_t get_ns_solve() const override { return time_solve_ns; }
+    // extension: many right-hand sides, column-major n x nrhs
+    StrError solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs);
+
+    bool factorized = false;
+    int32_t effective_ordering = -1, effective_scaling = -1, perturbed_pivots = 0;
+    double rcond_estimate = 0.0, determinant_coefficient = 0.0, determinant_exponent = 0.0;
+
+  private:
+    SolverHIPMF() {}
+    void *solver = nullptr; // struct InterfaceHIPMF*
+    CsrMatrix csr;
+    bool initialized = false;
+    Sym initialized_sym = Sym::No;
+    size_t initialized_ndim = 0, initialized_nnz = 0;
+    uint64_t time_initialize_ns = 0, time_factorize_ns = 0, time_solve_ns = 0;
+    bool compute_determinant = false;
+};
+
+class LinSolver {
+  public:
+    std::unique_ptr<LinSolTrait> actual;
+    static StrError create(LinSolver &out, Genie genie);
+    // lin_solver.rs:212-224: allocate, factorize, solve in one go
+    static StrError compute(Genie genie, std::vector<double> &x, const CooMatrix &mat, const std::vector<double> &rhs,
+                            const LinSolParams *params);
+};
+
+StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym symmetric_handling);
+
+StrError handle_hipmf_error_code(int32_t err);
+
+// where the HIP library is looked for: $RUSSELL_HIPMF_LIB, else librussell_hipmf.so next to this library
+void set_hipmf_library_path(const std::string &path);
+
+} // namespace russell

@@ -1,0 +1,372 @@
+"""Python face of the host layer (include/russell_host.h): the russell_sparse names a user of the reference knows.
+
+    from russell_amd.sparse import CooMatrix, Genie, LinSolver, LinSolParams, Sym
+
+    coo = CooMatrix(5, 5, 13, Sym.No); coo.put(0, 0, 2.0); ...
+    solver = LinSolver(Genie.Hipmf)
+    solver.actual.factorize(coo, None)
+    x = solver.actual.solve(rhs)
+
+Everything below is a thin ctypes veneer: validation, COO->CSC/CSR conversion, error strings and the solver calls
+live in C++ (russell_amd/csrc/host/) and in the HIP library.  Errors surface as `StrError` carrying the exact
+string the Rust layer would return (e.g. "the matrix must be square").
+"""
+import ctypes as C
+import enum
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_HOSTLIB = os.path.join(_HERE, "lib", "librussell_host.so")
+_lib = None
+
+
+class StrError(Exception):
+    """The analogue of Rust's `StrError = &'static str`."""
+
+
+class Sym(enum.IntEnum):
+    No = 0
+    YesFull = 1
+    YesLower = 2
+    YesUpper = 3
+
+
+class Genie(enum.IntEnum):
+    Hipmf = 0
+    Umfpack = 1
+    Mumps = 2
+    Cudss = 3
+
+    def to_string(self):
+        return _L().rh_enum_name(2, int(self)).decode()
+
+    def get_sym(self, symmetric):
+        return Sym(_L().rh_genie_get_sym(int(self), int(bool(symmetric))))
+
+    @staticmethod
+    def from_name(name):
+        return {"umfpack": Genie.Umfpack, "mumps": Genie.Mumps, "cudss": Genie.Cudss}.get(name.lower(), Genie.Hipmf)
+
+
+class Ordering(enum.IntEnum):
+    Amd = 0
+    Amf = 1
+    Auto = 2
+    Best = 3
+    BtfColamd = 4
+    Cholmod = 5
+    Colamd = 6
+    Metis = 7
+    No = 8
+    Pord = 9
+    Qamd = 10
+    Scotch = 11
+
+
+class Scaling(enum.IntEnum):
+    Auto = 0
+    Column = 1
+    Diagonal = 2
+    Max = 3
+    No = 4
+    RowCol = 5
+    RowColIter = 6
+    RowColRig = 7
+    Sum = 8
+
+
+class MMsym(enum.IntEnum):
+    LeaveAsLower = 0
+    SwapToUpper = 1
+    MakeItFull = 2
+
+
+class _RhParams(C.Structure):
+    _fields_ = [("ordering", C.c_int32), ("scaling", C.c_int32), ("has_pivot_epsilon", C.c_int32), ("pivot_epsilon", C.c_double),
+                ("has_refinement_nstep", C.c_int32), ("refinement_nstep", C.c_int32), ("positive_definite", C.c_int32),
+                ("compute_determinant", C.c_int32), ("verbose", C.c_int32)]
+
+
+class LinSolParams:
+    """lin_sol_params.rs:5-107 (the fields this backend honours)."""
+
+    def __init__(self):
+        self.ordering = Ordering.Auto
+        self.scaling = Scaling.Auto
+        self.pivot_epsilon = None
+        self.refinement_nstep = None
+        self.positive_definite = False
+        self.compute_determinant = False
+        self.verbose = False
+
+    def _c(self):
+        return _RhParams(int(self.ordering), int(self.scaling), int(self.pivot_epsilon is not None), float(self.pivot_epsilon or 0.0),
+                         int(self.refinement_nstep is not None), int(self.refinement_nstep or 0), int(self.positive_definite),
+                         int(self.compute_determinant), int(self.verbose))
+
+
+def _L():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_HOSTLIB):
+        raise RuntimeError("russell_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`" % _HOSTLIB)
+    lib = C.CDLL(_HOSTLIB)
+    vp, cp, i64, i32, f64 = C.c_void_p, C.c_char_p, C.c_int64, C.c_int32, C.c_double
+    pp = C.POINTER
+    sig = {
+        "rh_set_hipmf_library": (None, [cp]),
+        "rh_coo_new": (vp, [i64, i64, i64, i32, pp(cp)]),
+        "rh_coo_free": (None, [vp]),
+        "rh_coo_put": (cp, [vp, i64, i64, f64]),
+        "rh_coo_reset": (None, [vp]),
+        "rh_coo_info": (None, [vp, pp(i64), pp(i64), pp(i64), pp(i64), pp(i32)]),
+        "rh_coo_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64))]),
+        "rh_coo_mat_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_csc_from_coo": (vp, [vp, pp(cp)]),
+        "rh_csc_update_from_coo": (cp, [vp, vp]),
+        "rh_csc_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64)), pp(i64), pp(i64)]),
+        "rh_csc_mat_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_csc_free": (None, [vp]),
+        "rh_csr_from_coo": (vp, [vp, pp(cp)]),
+        "rh_csr_update_from_coo": (cp, [vp, vp]),
+        "rh_csr_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64)), pp(i64), pp(i64)]),
+        "rh_csr_mat_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_csr_free": (None, [vp]),
+        "rh_verify": (cp, [vp, vp, i64, vp, i64, vp]),
+        "rh_read_matrix_market": (vp, [cp, i32, pp(cp)]),
+        "rh_linsolver_new": (vp, [i32, pp(cp)]),
+        "rh_linsolver_free": (None, [vp]),
+        "rh_linsolver_factorize": (cp, [vp, vp, pp(_RhParams)]),
+        "rh_linsolver_solve": (cp, [vp, vp, i64, vp, i64, i32]),
+        "rh_linsolver_solve_many": (cp, [vp, vp, vp, i64, i64]),
+        "rh_linsolver_times": (None, [vp, pp(C.c_uint64)]),
+        "rh_linsolver_outputs": (None, [vp, pp(f64), pp(f64), pp(f64), pp(i32), pp(i32), pp(i32)]),
+        "rh_linsolver_stats_json": (cp, [vp, vp, cp, vp, vp]),
+        "rh_error_string": (cp, [i32]),
+        "rh_enum_name": (cp, [i32, i32]),
+        "rh_genie_get_sym": (i32, [i32, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    lib.rh_set_hipmf_library(os.path.join(_HERE, "lib", "librussell_hipmf.so").encode())
+    _lib = lib
+    return lib
+
+
+def _check(err):
+    if err:
+        raise StrError(err.decode())
+
+
+def _vec(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CooMatrix:
+    """coo_matrix.rs:21-73: triplets with duplicates allowed, nnz <= max_nnz, triangular-storage guard in put()."""
+
+    def __init__(self, nrow, ncol, max_nnz, symmetric=Sym.No, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        err = C.c_char_p()
+        self._h = _L().rh_coo_new(int(nrow), int(ncol), int(max_nnz), int(symmetric), C.byref(err))
+        _check(err.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rh_coo_free(self._h)
+            self._h = None
+
+    def put(self, i, j, aij):
+        _check(_L().rh_coo_put(self._h, int(i), int(j), float(aij)))
+
+    def reset(self):
+        _L().rh_coo_reset(self._h)
+
+    def get_info(self):
+        a, b, c, d, s = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        _L().rh_coo_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(s))
+        return a.value, b.value, c.value, Sym(s.value)
+
+    @property
+    def nrow(self):
+        return self.get_info()[0]
+
+    @property
+    def ncol(self):
+        return self.get_info()[1]
+
+    @property
+    def nnz(self):
+        return self.get_info()[2]
+
+    @property
+    def symmetric(self):
+        return self.get_info()[3]
+
+    def triplets(self):
+        ai, aj, ax = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        _L().rh_coo_arrays(self._h, C.byref(ai), C.byref(aj), C.byref(ax))
+        n = self.nnz
+        return (np.ctypeslib.as_array(ai, (n,)).copy(), np.ctypeslib.as_array(aj, (n,)).copy(), np.ctypeslib.as_array(ax, (n,)).copy())
+
+    def mat_vec_mul(self, u, alpha=1.0, nv=None):
+        u = _vec(u)
+        v = np.zeros(self.nrow if nv is None else nv)
+        _check(_L().rh_coo_mat_vec_mul(self._h, _ptr(v), v.size, float(alpha), _ptr(u), u.size))
+        return v
+
+
+class _Compressed:
+    _kind = ""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_coo(cls, coo):
+        err = C.c_char_p()
+        h = getattr(_L(), "rh_%s_from_coo" % cls._kind)(coo._h, C.byref(err))
+        _check(err.value)
+        return cls(h)
+
+    def update_from_coo(self, coo):
+        _check(getattr(_L(), "rh_%s_update_from_coo" % self._kind)(self._h, coo._h))
+
+    def arrays(self):
+        p, i, x = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        nd, nnz = C.c_int64(), C.c_int64()
+        getattr(_L(), "rh_%s_arrays" % self._kind)(self._h, C.byref(p), C.byref(i), C.byref(x), C.byref(nd), C.byref(nnz))
+        return (np.ctypeslib.as_array(p, (nd.value + 1,)).copy(), np.ctypeslib.as_array(i, (max(nnz.value, 1),))[:nnz.value].copy(),
+                np.ctypeslib.as_array(x, (max(nnz.value, 1),))[:nnz.value].copy())
+
+    def mat_vec_mul(self, u, nrow, alpha=1.0):
+        u = _vec(u)
+        v = np.zeros(nrow)
+        _check(getattr(_L(), "rh_%s_mat_vec_mul" % self._kind)(self._h, _ptr(v), v.size, float(alpha), _ptr(u), u.size))
+        return v
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            getattr(_lib, "rh_%s_free" % self._kind)(self._h)
+            self._h = None
+
+
+class CscMatrix(_Compressed):
+    """csc_matrix.rs:337-505 (col_pointers, row_indices, values)."""
+    _kind = "csc"
+
+
+class CsrMatrix(_Compressed):
+    """csr_matrix.rs:332-480 (row_pointers, col_indices, values)."""
+    _kind = "csr"
+
+
+class VerifyLinSys:
+    """verify_lin_sys.rs:60-96."""
+
+    def __init__(self, mat, x, rhs):
+        out = np.zeros(4)
+        x, rhs = _vec(x), _vec(rhs)
+        _check(_L().rh_verify(mat._h, _ptr(x), x.size, _ptr(rhs), rhs.size, _ptr(out)))
+        self.max_abs_a, self.max_abs_ax, self.max_abs_diff, self.relative_error = (float(v) for v in out)
+
+
+def read_matrix_market(full_path, symmetric_handling=MMsym.LeaveAsLower):
+    """read_matrix_market.rs:346-475 (real matrices)."""
+    err = C.c_char_p()
+    h = _L().rh_read_matrix_market(os.fspath(full_path).encode(), int(symmetric_handling), C.byref(err))
+    _check(err.value)
+    return CooMatrix(0, 0, 0, _handle=h)
+
+
+class _Actual:
+    """What `solver.actual` exposes: the LinSolTrait methods (lin_solver.rs:12-64)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._ndim = None
+
+    def factorize(self, mat, params=None):
+        p = C.byref(params._c()) if params is not None else None
+        _check(_L().rh_linsolver_factorize(self._h, mat._h, p))
+        self._ndim = mat.nrow
+
+    def solve(self, rhs, x=None, verbose=False):
+        rhs = _vec(rhs)
+        out = np.zeros(self._ndim if (x is None and self._ndim is not None) else (len(x) if x is not None else rhs.size))
+        _check(_L().rh_linsolver_solve(self._h, _ptr(out), out.size, _ptr(rhs), rhs.size, int(verbose)))
+        if x is not None:
+            x[:] = out
+        return out
+
+    def solve_many(self, rhs_rows):
+        b = _vec(rhs_rows)
+        nrhs, n = b.shape
+        x = np.zeros_like(b)
+        _check(_L().rh_linsolver_solve_many(self._h, _ptr(x), _ptr(b), n, nrhs))
+        return x
+
+    def get_ns(self):
+        ns = (C.c_uint64 * 3)()
+        _L().rh_linsolver_times(self._h, ns)
+        return int(ns[0]), int(ns[1]), int(ns[2])
+
+    def get_ns_init(self):
+        return self.get_ns()[0]
+
+    def get_ns_fact(self):
+        return self.get_ns()[1]
+
+    def get_ns_solve(self):
+        return self.get_ns()[2]
+
+    def outputs(self):
+        dc, de, rc = C.c_double(), C.c_double(), C.c_double()
+        eo, es, npv = C.c_int32(), C.c_int32(), C.c_int32()
+        _L().rh_linsolver_outputs(self._h, C.byref(dc), C.byref(de), C.byref(rc), C.byref(eo), C.byref(es), C.byref(npv))
+        return dict(determinant_coefficient=dc.value, determinant_exponent=de.value, rcond_estimate=rc.value, effective_ordering=eo.value,
+                    effective_scaling=es.value, perturbed_pivots=npv.value)
+
+    def stats(self, mat=None, name="", x=None, rhs=None):
+        xx = _vec(x) if x is not None else None
+        rr = _vec(rhs) if rhs is not None else None
+        s = _L().rh_linsolver_stats_json(self._h, mat._h if mat is not None else None, name.encode(), _ptr(xx) if xx is not None else None,
+                                         _ptr(rr) if rr is not None else None)
+        return json.loads(s.decode())
+
+
+class LinSolver:
+    """lin_solver.rs:105-142: `LinSolver::new(genie)` boxes a backend behind `actual`."""
+
+    def __init__(self, genie=Genie.Hipmf):
+        err = C.c_char_p()
+        self._h = _L().rh_linsolver_new(int(genie), C.byref(err))
+        _check(err.value)
+        self.actual = _Actual(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rh_linsolver_free(self._h)
+            self._h = None
+
+    @staticmethod
+    def compute(genie, mat, rhs, params=None):
+        """lin_solver.rs:212-224: allocate, factorize and solve in one call; returns (solver, x)."""
+        s = LinSolver(genie)
+        s.actual.factorize(mat, params)
+        return s, s.actual.solve(rhs)
+
+
+def handle_hipmf_error_code(code):
+    return _L().rh_error_string(int(code)).decode()
