@@ -294,8 +294,13 @@ class _Actual:
     """What `solver.actual` exposes: the LinSolTrait methods (lin_solver.rs:12-64)."""
 
     def __init__(self, handle):
-        self._h = handle
+        self._h = handle  # owned here: `LinSolver(g).actual.factorize(...)` must keep the C++ object alive
         self._ndim = None
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rh_linsolver_free(self._h)
+            self._h = None
 
     def factorize(self, mat, params=None):
         p = C.byref(params._c()) if params is not None else None
@@ -351,14 +356,9 @@ class LinSolver:
 
     def __init__(self, genie=Genie.Hipmf):
         err = C.c_char_p()
-        self._h = _L().rh_linsolver_new(int(genie), C.byref(err))
+        h = _L().rh_linsolver_new(int(genie), C.byref(err))
         _check(err.value)
-        self.actual = _Actual(self._h)
-
-    def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
-            _lib.rh_linsolver_free(self._h)
-            self._h = None
+        self.actual = _Actual(h)
 
     @staticmethod
     def compute(genie, mat, rhs, params=None):
