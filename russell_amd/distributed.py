@@ -1,0 +1,43 @@
+"""Many-RHS sharding across the GPUs of one node: one process per GPU, columns of B split into
+contiguous blocks, no data-path collective for the solves themselves.  torch.distributed (RCCL on GPUs, gloo in the CPU
+tests) is used only for barriers, the max-over-ranks timing reduction and, optionally, gathering X on rank 0."""
+import numpy as np
+
+
+def rhs_block(nrhs_total, world_size, rank):
+    """Contiguous block [start, start + count) of right-hand sides owned by `rank` (sizes differ by at most one)."""
+    if nrhs_total < 0 or world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("invalid sharding request")
+    base, extra = divmod(nrhs_total, world_size)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def max_over_ranks(value, dist=None, device=None):
+    """max of a python float over all ranks (identity without an initialised process group)."""
+    if dist is None or not dist.is_initialized():
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def solve_sharded(local_solve, B, dist=None, gather=True):
+    """B: (nrhs_total, n) array known to every rank (rows = right-hand sides).  Every rank solves its block with
+    `local_solve(block) -> X_block`; with gather=True rank 0 returns the full (nrhs_total, n) solution, other ranks None."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    start, count = rhs_block(B.shape[0], world, rank)
+    x_local = local_solve(B[start:start + count]) if count > 0 else np.zeros((0, B.shape[1]))
+    if world == 1 or not gather:
+        return x_local
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((start, np.asarray(x_local)), parts, dst=0)
+    if rank != 0:
+        return None
+    X = np.zeros_like(B, dtype=np.float64)
+    for s, xb in parts:
+        X[s:s + xb.shape[0]] = xb
+    return X
