@@ -82,6 +82,10 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     }
     SymbolicOptions so = sopt;
     so.augment_above = SMALL_F;
+    // fewer, fatter fronts: nested-dissection leaves of <= 16 vertices become single dense supernodes
+    // (1000^2 Poisson: 503 796 -> 113 068 fronts, 29 -> 20 levels, nnz(L) +18 %); see DESIGN.md section 4
+    so.nd_leaf = 16;
+    so.dense_leaves = true;
     int rc = analyse(n, rp, ci, sym_lower, so, S);
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";

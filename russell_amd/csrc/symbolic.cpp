@@ -165,9 +165,11 @@ static void leaf_min_degree(NDWork &w, int32_t begin, int32_t end, int32_t id, i
     }
 }
 
-static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm) {
+static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm, std::vector<int32_t> &leaf_of) {
     int32_t n = g.n;
     perm.assign((size_t)n, -1);
+    leaf_of.assign((size_t)n, -1);
+    int32_t next_leaf = 0;
     NDWork w(g);
     w.part.assign((size_t)n, 0);
     w.verts.resize((size_t)n);
@@ -228,6 +230,10 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
             }
         }
         if (size <= leaf) {
+            if (opt.dense_leaves && size > 1) {
+                for (int32_t k = R.begin; k < R.end; k++) leaf_of[w.verts[k]] = next_leaf;
+                next_leaf++;
+            }
             leaf_min_degree(w, R.begin, R.end, R.id, R.pos, perm);
             continue;
         }
@@ -427,12 +433,12 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
 
     // ---- ordering --------------------------------------------------------------------------
     auto t_ord = clk::now();
-    std::vector<int32_t> perm0((size_t)n), pinv0((size_t)n);
+    std::vector<int32_t> perm0((size_t)n), pinv0((size_t)n), leaf_of;
     bool single_front = n <= opt.dense_n;
     if (single_front || opt.ordering == ORDERING_NATURAL) {
         std::iota(perm0.begin(), perm0.end(), 0);
     } else {
-        nested_dissection(g, opt, perm0);
+        nested_dissection(g, opt, perm0, leaf_of);
     }
     for (int32_t k = 0; k < n; k++) {
         if (perm0[k] < 0 || perm0[k] >= n) return -10;
@@ -467,9 +473,16 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         std::vector<int32_t> nchild((size_t)n, 0);
         for (int32_t j = 0; j < n; j++)
             if (parent[j] >= 0) nchild[parent[j]]++;
+        // columns of one nested-dissection leaf region form ONE dense supernode when opt.dense_leaves is set:
+        // fewer, fatter fronts (the solves and the factorisation are latency-bound, not bandwidth-bound)
+        std::vector<int32_t> lid((size_t)n, -1);
+        if (!leaf_of.empty())
+            for (int32_t j = 0; j < n; j++) lid[j] = leaf_of[S.perm[j]];
         fs_first.push_back(0);
         for (int32_t j = 1; j < n; j++) {
-            bool same = parent[j - 1] == j && cc[j - 1] == cc[j] + 1 && nchild[j] == 1;
+            bool same;
+            if (lid[j] >= 0 || lid[j - 1] >= 0) same = lid[j] == lid[j - 1] && parent[j - 1] >= 0;
+            else same = parent[j - 1] == j && cc[j - 1] == cc[j] + 1 && nchild[j] == 1;
             if (!same) fs_first.push_back(j);
         }
     }
