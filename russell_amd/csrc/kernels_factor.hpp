@@ -165,8 +165,19 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
             T[k][cc] = (k < nb) ? F[(k0 + k) + (int64_t)(o0 + cc) * ld] : 0.0;
         }
     }
-    // 2. wave 0: LU of the diagonal tile, one row per lane
-    if (tid < 64) {
+    // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
+    //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
+    if (k0 > 0) {
+        const double *dw = dws + (int64_t)slot * NB * NB;
+        for (int e = tid; e < NB * NB; e += PANEL_T) {
+            const int r = e % NB, c = e / NB;
+            const double v = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
+            D[r][c] = v;
+            DT[c][r] = v;
+            if (r == c) dinv[r] = 1.0 / v;
+        }
+        if (tid < NB) lp[tid] = (tid < nb) ? lperm[fd.first + k0 + tid] - k0 : tid;
+    } else if (tid < 64) {
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? F[(k0 + tid) + (int64_t)(k0 + c) * ld] : (tid == c ? 1.0 : 0.0);
@@ -191,7 +202,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         }
     }
     __syncthreads();
-    if (t == 0) {
+    if (t == 0 && k0 == 0) {
         double *dw = dws + (int64_t)slot * NB * NB;
         for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
         if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
@@ -247,8 +258,10 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // Workgroup 0 of every front also moves the factorised diagonal tile from dws into the front.
 __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                 const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
-                                                const double *__restrict__ dws) {
+                                                double *__restrict__ dws, int32_t *__restrict__ lperm,
+                                                const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
     __shared__ double Ls[NB * LS_LD];
+    __shared__ double Tn[NB * (NB + 1)];
     __shared__ double Us[UPD_T * US_LD];
     const int tid = threadIdx.x;
     const int slot = find_slot(pfx, nactive, blockIdx.x);
@@ -266,6 +279,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];
     }
     if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
+    const bool lookahead = t == 0 && fd.p > base; // this tile holds the next diagonal tile
     for (int e = tid; e < NB * UPD_T; e += 256) {
         int r = e % UPD_T, kk = e / UPD_T;
         Ls[kk * LS_LD + r] = (r0 + r < limit && kk < nb) ? F[(r0 + r) + (int64_t)(k0 + kk) * ld] : 0.0;
@@ -303,8 +317,36 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             for (int g = 0; g < 4; g++) {
                 int r = r0 + wr + b * 16 + l15;
                 int c = c0 + wc + a * 16 + l4 + 4 * g;
-                if (r < limit && c < limit && !(r >= f && c >= f)) F[r + (int64_t)c * ld] -= acc[a][b][g];
+                if (r < limit && c < limit && !(r >= f && c >= f)) {
+                    const double nv = F[r + (int64_t)c * ld] - acc[a][b][g];
+                    F[r + (int64_t)c * ld] = nv;
+                    if (lookahead && wave == 0) Tn[(b * 16 + l15) * (NB + 1) + a * 16 + l4 + 4 * g] = nv; // next diagonal tile
+                }
             }
+    // Look-ahead: workgroup 0 owns the tile that contains the NEXT diagonal tile (rows/columns base..base+32).
+    // Its wave 0 factorises it now, while the other workgroups are still updating the rest of the trailing
+    // matrix, so the 32 x 32 LU leaves the critical path of the next step.
+    if (lookahead) __syncthreads(); // block-uniform: the lanes of wave 0 exchange the tile through LDS (Tn)
+    if (lookahead && wave == 0) {
+        const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB;
+        double a2[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) a2[c] = (lane < nb2 && c < nb2) ? Tn[lane * (NB + 1) + c] : (lane == c ? 1.0 : 0.0);
+        const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        int step, npert, nzero;
+        tile_lu32(a2, lane, eps, step, npert, nzero);
+        if (lane < nb2) {
+            double *dwo = dws + (int64_t)slot * NB * NB;
+#pragma unroll
+            for (int c = 0; c < NB; c++)
+                if (c < nb2) dwo[step + c * nb2] = a2[c];
+            lperm[fd.first + base + step] = base + lane;
+        }
+        if (lane == 0 && npert > 0) {
+            atomicAdd(&info->n_perturbed, npert);
+            if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
+        }
+    }
 }
 
 } // namespace hipmf

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.hpp"
@@ -86,6 +87,11 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     // (1000^2 Poisson: 503 796 -> 113 068 fronts, 29 -> 20 levels, nnz(L) +18 %); see DESIGN.md section 4
     so.nd_leaf = 16;
     so.dense_leaves = true;
+    if (const char *e = getenv("HIPMF_ND_LEAF")) { // tuning knob: leaf size (1..64); 0 = classic minimum-degree leaves of 64
+        int v = atoi(e);
+        so.dense_leaves = v > 0;
+        so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
+    }
     int rc = analyse(n, rp, ci, sym_lower, so, S);
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
@@ -324,7 +330,7 @@ int32_t Solver::run_factor() {
             hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
                                d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info);
             hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
-                               d_pool, d_dws);
+                               d_pool, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info);
             launches += 2;
             k0 += NB;
         }
