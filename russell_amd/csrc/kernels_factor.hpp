@@ -154,15 +154,32 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int ext = (limit - o0) < PANEL_T ? (limit - o0) : PANEL_T;     // rows (L) / columns (U) in this tile
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
+    // (no integer divisions, loads issued in batches of 8 before the LDS stores: the loop is latency-bound otherwise)
     if (ltile) {
-        for (int e = tid; e < ext * NB; e += PANEL_T) {
-            const int k = e / ext, rr = e % ext;
-            T[k][rr] = (k < nb) ? F[(o0 + rr) + (int64_t)(k0 + k) * ld] : 0.0;
+        if (tid < ext) {
+            const double *src = F + (o0 + tid) + (int64_t)k0 * ld; // row tid of the tile, column k at src[k * ld]
+#pragma unroll
+            for (int kb = 0; kb < NB; kb += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = (kb + u < nb) ? src[(int64_t)(kb + u) * ld] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) T[kb + u][tid] = v[u];
+            }
         }
     } else {
-        for (int e = tid; e < ext * NB; e += PANEL_T) {
-            const int k = e % NB, cc = e / NB;
-            T[k][cc] = (k < nb) ? F[(k0 + k) + (int64_t)(o0 + cc) * ld] : 0.0;
+        const int k = tid & (NB - 1), cq = tid >> 5; // 4 columns x 32 rows per pass
+        const double *src = F + (k0 + k) + (int64_t)o0 * ld;
+#pragma unroll
+        for (int cb = 0; cb < PANEL_T; cb += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int cc = cb + 4 * u + cq;
+                v[u] = (k < nb && cc < ext) ? src[(int64_t)cc * ld] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) T[k][cb + 4 * u + cq] = v[u];
         }
     }
     // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
@@ -242,9 +259,20 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     }
     __syncthreads();
     if (ltile) {
-        for (int e = tid; e < ext * nb; e += PANEL_T) F[(o0 + e % ext) + (int64_t)(k0 + e / ext) * ld] = T[e / ext][e % ext];
+        if (tid < ext) {
+            double *dst = F + (o0 + tid) + (int64_t)k0 * ld;
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+                if (k < nb) dst[(int64_t)k * ld] = T[k][tid];
+        }
     } else {
-        for (int e = tid; e < ext * nb; e += PANEL_T) F[(k0 + e % nb) + (int64_t)(o0 + e / nb) * ld] = T[e % nb][e / nb];
+        const int k = tid & (NB - 1), cq = tid >> 5;
+        double *dst = F + (k0 + k) + (int64_t)o0 * ld;
+#pragma unroll
+        for (int cb = 0; cb < PANEL_T; cb += 4) {
+            const int cc = cb + cq;
+            if (k < nb && cc < ext) dst[(int64_t)cc * ld] = T[k][cc];
+        }
     }
 }
 
