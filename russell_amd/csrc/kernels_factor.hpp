@@ -13,8 +13,9 @@
 
 namespace hipmf {
 
-// One wavefront factorises one small front (f <= SMALL_F) held entirely in LDS.
-// Partial pivoting searches the whole remaining pivot block (rows c..p-1).
+// One wavefront factorises one small front (f <= SMALL_F = 64) held entirely in LDS: lane r owns row r.
+// Partial pivoting searches the whole remaining pivot block (rows c..p-1) with one 32-bit DPP max-reduction.
+// No integer divisions and no per-element index arithmetic: every loop runs over columns with lane = row.
 __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
                                                      double *__restrict__ pool, int32_t *__restrict__ lperm,
                                                      const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
@@ -26,16 +27,17 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     const int p = fd.p, f = fd.p + fd.m;
     double *F = pool + fd.off;
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
-    for (int e = tid; e < f * f; e += 64) sm[(e % f) + (e / f) * ld] = F[e];
+    if (tid < f)
+        for (int c = 0; c < f; c++) sm[tid + c * ld] = F[tid + c * f];
     if (tid < p) lp[tid] = tid;
     __syncthreads();
     for (int c = 0; c < p; c++) {
-        double v = -1.0;
-        int idx = c + tid;
-        if (idx < p) v = fabs(sm[idx + c * ld]);
-        else idx = 1 << 30;
-        wave_argmax(v, idx);
-        const int piv = idx;
+        // arg-max over rows c..p-1 of column c: key = float(|a|) bits, low 7 bits = candidate flag | 63 - row
+        const bool cand = tid >= c && tid < p;
+        const double mine = cand ? sm[tid + c * ld] : 0.0;
+        const unsigned mag = __float_as_uint((float)fabs(mine));
+        const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - tid)) : 0u;
+        const int piv = 63 - (int)(wave_max_u32(key) & 63u);
         if (piv != c) {
             if (tid < f) {
                 double a = sm[c + tid * ld];
@@ -63,17 +65,18 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
             __syncthreads();
             d = dn;
         }
-        const double inv = 1.0 / d;
-        const int w = f - c - 1;
-        if (tid < w) sm[(c + 1 + tid) + c * ld] *= inv;
-        __syncthreads();
-        for (int e = tid; e < w * w; e += 64) {
-            int r = c + 1 + e % w, cc = c + 1 + e / w;
-            sm[r + cc * ld] -= sm[r + c * ld] * sm[c + cc * ld];
+        // lane = row: multiplier, then the rank-1 update of this row across the remaining columns
+        const bool below = tid > c && tid < f;
+        double l = 0.0;
+        if (below) {
+            l = sm[tid + c * ld] / d;
+            sm[tid + c * ld] = l;
+            for (int cc = c + 1; cc < f; cc++) sm[tid + cc * ld] -= l * sm[c + cc * ld];
         }
         __syncthreads();
     }
-    for (int e = tid; e < f * f; e += 64) F[e] = sm[(e % f) + (e / f) * ld];
+    if (tid < f)
+        for (int c = 0; c < f; c++) F[tid + c * f] = sm[tid + c * ld];
     if (tid < p) lperm[fd.first + tid] = lp[tid];
 }
 
@@ -130,7 +133,7 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
 // of each front parks it in dws, k_update moves it into place.
 __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                    const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
-                                                   int32_t *__restrict__ lperm, double *__restrict__ dws,
+                                                   int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
                                                    const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
     // D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
     // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
     //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
     if (k0 > 0) {
-        const double *dw = dws + (int64_t)slot * NB * NB;
+        const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         for (int e = tid; e < NB * NB; e += PANEL_T) {
             const int r = e % NB, c = e / NB;
             const double v = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     }
     __syncthreads();
     if (t == 0 && k0 == 0) {
-        double *dw = dws + (int64_t)slot * NB * NB;
+        double *dw = dws + (int64_t)slot * NB * NB; // step 0 uses buffer 0
         for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
         if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
     }
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // Workgroup 0 of every front also moves the factorised diagonal tile from dws into the front.
 __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                 const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
-                                                double *__restrict__ dws, int32_t *__restrict__ lperm,
+                                                double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
     __shared__ double Ls[NB * LS_LD];
     __shared__ double Tn[NB * (NB + 1)];
@@ -300,14 +303,19 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
     const int nt = (f + UPD_T - 1) / UPD_T;
-    const int r0 = base + (t % nt) * UPD_T, c0 = base + (t / nt) * UPD_T;
+    // one extra workgroup per front (t == nt * nt) re-computes the tile that holds the NEXT diagonal tile and
+    // factorises it (look-ahead): that LU runs beside the trailing update instead of after it
+    const bool la = t == nt * nt;
+    const int r0 = la ? base : base + (t % nt) * UPD_T, c0 = la ? base : base + (t / nt) * UPD_T;
+    const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
     double *F = pool + fd.off;
     if (t == 0) {
-        const double *dw = dws + (int64_t)slot * NB * NB;
+        const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];
     }
     if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
-    const bool lookahead = t == 0 && fd.p > base; // this tile holds the next diagonal tile
+    const bool lookahead = la; // this workgroup only factorises the next diagonal tile, it stores nothing into F
+    const bool owner0 = t == 0 && nb2 > 0; // the regular owner of that tile leaves the nb2 x nb2 corner alone
     for (int e = tid; e < NB * UPD_T; e += 256) {
         int r = e % UPD_T, kk = e / UPD_T;
         Ls[kk * LS_LD + r] = (r0 + r < limit && kk < nb) ? F[(r0 + r) + (int64_t)(k0 + kk) * ld] : 0.0;
@@ -346,9 +354,13 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
                 int r = r0 + wr + b * 16 + l15;
                 int c = c0 + wc + a * 16 + l4 + 4 * g;
                 if (r < limit && c < limit && !(r >= f && c >= f)) {
-                    const double nv = F[r + (int64_t)c * ld] - acc[a][b][g];
-                    F[r + (int64_t)c * ld] = nv;
-                    if (lookahead && wave == 0) Tn[(b * 16 + l15) * (NB + 1) + a * 16 + l4 + 4 * g] = nv; // next diagonal tile
+                    const int rr = b * 16 + l15, cc = a * 16 + l4 + 4 * g; // position inside this wave's 32 x 32 block
+                    const bool corner = wave == 0 && rr < nb2 && cc < nb2;
+                    if (lookahead) {
+                        if (corner) Tn[rr * (NB + 1) + cc] = F[r + (int64_t)c * ld] - acc[a][b][g];
+                    } else if (!(owner0 && corner)) {
+                        F[r + (int64_t)c * ld] -= acc[a][b][g];
+                    }
                 }
             }
     // Look-ahead: workgroup 0 owns the tile that contains the NEXT diagonal tile (rows/columns base..base+32).
@@ -356,7 +368,6 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     // matrix, so the 32 x 32 LU leaves the critical path of the next step.
     if (lookahead) __syncthreads(); // block-uniform: the lanes of wave 0 exchange the tile through LDS (Tn)
     if (lookahead && wave == 0) {
-        const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB;
         double a2[NB];
 #pragma unroll
         for (int c = 0; c < NB; c++) a2[c] = (lane < nb2 && c < nb2) ? Tn[lane * (NB + 1) + c] : (lane == c ? 1.0 : 0.0);
@@ -364,7 +375,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         int step, npert, nzero;
         tile_lu32(a2, lane, eps, step, npert, nzero);
         if (lane < nb2) {
-            double *dwo = dws + (int64_t)slot * NB * NB;
+            double *dwo = dws + ((int64_t)(((k0 / NB) + 1) & 1) * dws_stride + slot) * NB * NB;
 #pragma unroll
             for (int c = 0; c < NB; c++)
                 if (c < nb2) dwo[step + c * nb2] = a2[c];

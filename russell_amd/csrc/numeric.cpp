@@ -211,7 +211,7 @@ int32_t Solver::upload_plan() {
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
                 int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T;
-                acc += nt * nt;
+                acc += nt * nt + (S.npiv(big[a]) > k0 + NB ? 1 : 0); // + the look-ahead workgroup
             }
             tasks.push_back((int32_t)acc);
             if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
@@ -270,7 +270,8 @@ int32_t Solver::upload_plan() {
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ear, ear), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_dws, sizeof(double) * NB * NB * (size_t)std::max(max_big, 1)), ERROR_HIP_MALLOC);
+    dws_stride = std::max(max_big, 1);
+    HIPC(hipMalloc((void **)&d_dws, sizeof(double) * 2 * NB * NB * (size_t)std::max(max_big, 1)), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_st, stasks), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_lists, lists), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_tasks, tasks), ERROR_HIP_MALLOC);
@@ -328,9 +329,9 @@ int32_t Solver::run_factor() {
         for (const StepPlan &st : L.steps) {
             const int32_t *blist = d_lists + L.big_off;
             hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
-                               d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info);
+                               d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info);
             hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
-                               d_pool, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info);
+                               d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info);
             launches += 2;
             k0 += NB;
         }

@@ -105,7 +105,7 @@ class Solver {
     bool tri_pending = false;
     std::vector<LevelPlan> levels;
     int64_t work_doubles = 0;
-    int32_t allbig_off = 0, allbig_cnt = 0;
+    int32_t allbig_off = 0, allbig_cnt = 0, dws_stride = 1;
     // device buffers
     FrontDesc *d_fd = nullptr;
     EaTask *d_ea = nullptr;
