@@ -1,10 +1,9 @@
 // kernels_factor.hpp -- dense partial factorisation of the fronts:  P F = [L11 0; L21 I] [U11 U12; 0 S]
 //   k_small_factor   one wavefront per front with f <= SMALL_F, whole front in LDS            (LDS / latency-bound)
-//   k_panel          tiled path, step k0: triangular solves of the row / column block against the 32 x 32
-//                    diagonal tile; ONE workgroup per front (the "S" workgroup) owns the critical 32 rows and
-//                    32 columns, updates the NEXT diagonal tile from them and factorises it in REGISTERS
-//                    (one row per lane, DPP arg-max, v_readlane broadcasts) while the other workgroups solve
-//                    the rest of the panel: the LU never waits for the trailing update        (latency-bound)
+//   k_panel          tiled path, step k0: every workgroup factorises the 32 x 32 diagonal tile in
+//                    REGISTERS (one row per lane, v_readlane broadcasts; redundant per workgroup, which
+//                    removes a dependent launch from the critical path) and then solves its own row /
+//                    column tile against it                                                     (latency-bound)
 //   k_update         tiled path, step k0: trailing update on v_mfma_f64_16x16x4_f64            (MFMA / HBM-bound)
 // Big fronts are stored augmented (kernels_common.hpp): the tiled kernels work on the index range
 // [k0 + nb, f + k0 + nb) of both dimensions, which covers the not-yet-eliminated part of F, the columns
@@ -124,50 +123,22 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
     }
 }
 
-// right-looking substitutions of one row / one column of a panel tile held in registers (padded to 32 steps)
-__device__ __forceinline__ void subst_row_against_u(double (&x)[NB], const double (*D)[NB + 2], const double *dinv) {
-#pragma unroll
-    for (int c = 0; c < NB; c++) {
-        // the whole row of U is fetched before the FMA chain (otherwise every FMA waits on its own LDS read)
-        double u[NB];
-#pragma unroll
-        for (int cc = 0; cc < NB; cc++) u[cc] = D[c][cc];
-        x[c] *= dinv[c];
-#pragma unroll
-        for (int cc = c + 1; cc < NB; cc++) x[cc] -= x[c] * u[cc];
-    }
-}
-__device__ __forceinline__ void subst_col_against_l(double (&x)[NB], const double (*DT)[NB + 2]) {
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        double l[NB];
-#pragma unroll
-        for (int r = 0; r < NB; r++) l[r] = DT[k][r]; // column k of L, one aligned row of DT
-#pragma unroll
-        for (int r = k + 1; r < NB; r++) x[r] -= l[r] * x[k];
-    }
-}
-
-// Tiled path, step k0 (nb = min(32, p - k0), base = k0 + nb, active range [base, f + base)):
+// Tiled path, step k0 (base = k0 + nb, active range [base, f + base)):
+//   every workgroup factorises the diagonal tile itself (wave 0, registers) while all its threads prefetch
+//   the workgroup's own tile;  then
 //   L tiles  (rows of the range, columns of the tile):   X <- X * U_kk^{-1}       (covers L21 and E')
 //   U tiles  (columns of the range, rows of the tile):   X <- L_kk^{-1} * (P X)   (covers U12 and E)
 // One thread owns one row (L) / one column (U) and runs a right-looking substitution in registers.
-// The factorised diagonal tile of step k0 comes from dws (buffer k0/32 mod 2); only at k0 = 0 it is
-// computed here (by every workgroup, redundantly, in registers).  While a next diagonal tile exists
-// (p > base) workgroup 0 of the front is the "S" workgroup: it owns rows AND columns base..base+32, and
-// after solving them it forms the next diagonal tile  A - L U  itself, factorises it (tile_lu32) and parks
-// it in dws (other buffer) with its row interchanges: the 32 x 32 LU of step k0 + 32 overlaps with the panel
-// solves and the whole trailing update of step k0.  Nobody writes the tile of step k0 into F here (other
-// workgroups may still read the original at k0 = 0): k_update moves it into place.
+// The factorised tile is NOT written into F here (other workgroups still read the original): workgroup 0
+// of each front parks it in dws, k_update moves it into place.
 __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                    const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
                                                    const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
     // D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
-    // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L); UM: the solved 32 x 32 U block of S
+    // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
     __shared__ __attribute__((aligned(16))) double D[NB][NB + 2];
     __shared__ __attribute__((aligned(16))) double DT[NB][NB + 2];
-    __shared__ __attribute__((aligned(16))) double UM[NB][NB + 2];
     __shared__ double T[NB][PANEL_T + 1];
     __shared__ double dinv[NB];
     __shared__ int32_t lp[NB];
@@ -179,34 +150,15 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
-    const bool la = fd.p > base;          // a next diagonal tile exists: workgroup 0 is the S workgroup
-    const int skip = la ? NB : 0;         // rows / columns base..base+32 belong to S
-    const int nT = (f - skip + PANEL_T - 1) / PANEL_T;
-    const bool sblock = la && t == 0;
-    const int tt = la ? t - 1 : t;
-    const bool ltile = !sblock && tt < nT;
-    const int o0 = base + skip + (ltile ? tt : tt - nT) * PANEL_T;               // first row (L) / column (U) of this tile
-    const int ext = sblock ? 0 : ((limit - o0) < PANEL_T ? (limit - o0) : PANEL_T); // rows (L) / columns (U) in this tile
+    const int nT = (f + PANEL_T - 1) / PANEL_T;
     double *F = pool + fd.off;
-    // 1. prefetch the tile, no interchange yet (rows >= nb of T are zero: a partial tile is treated as a full one
-    //    padded with identity; no integer divisions, loads issued in batches of 8 before the LDS stores)
-    if (sblock) {
-        // T columns 0..31 = the 32 critical rows of L, T columns 64..95 = the 32 critical columns of U
-        if (tid < NB || (tid >= 64 && tid < 64 + NB)) {
-            const bool lrow = tid < NB;
-            const int j = lrow ? tid : tid - 64;
-            const double *src = lrow ? F + (base + j) + (int64_t)k0 * ld : F + k0 + (int64_t)(base + j) * ld;
-            const int64_t st = lrow ? ld : 1;
-#pragma unroll
-            for (int kb = 0; kb < NB; kb += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = (kb + u < nb) ? src[(int64_t)(kb + u) * st] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; u++) T[kb + u][tid] = v[u];
-            }
-        }
-    } else if (ltile) {
+    const bool ltile = t < nT;
+    const int o0 = base + (ltile ? t : t - nT) * PANEL_T;               // first row (L) / column (U) of this tile
+    const int ext = (limit - o0) < PANEL_T ? (limit - o0) : PANEL_T;     // rows (L) / columns (U) in this tile
+    // 1. prefetch the tile, no interchange yet
+    // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
+    // (no integer divisions, loads issued in batches of 8 before the LDS stores: the loop is latency-bound otherwise)
+    if (ltile) {
         if (tid < ext) {
             const double *src = F + (o0 + tid) + (int64_t)k0 * ld; // row tid of the tile, column k at src[k * ld]
 #pragma unroll
@@ -233,7 +185,8 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
             for (int u = 0; u < 8; u++) T[k][cb + 4 * u + cq] = v[u];
         }
     }
-    // 2. the factorised diagonal tile of this step
+    // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
+    //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
     if (k0 > 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         for (int e = tid; e < NB * NB; e += PANEL_T) {
@@ -275,42 +228,40 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
     }
     // 3. substitution, right-looking, one row / column per thread, branch-free over the padded 32 steps
-    const bool do_l = sblock ? tid < NB : (ltile && tid < ext);
-    const bool do_u = sblock ? (tid >= 64 && tid < 64 + NB) : (!ltile && tid < ext);
-    if (do_l) {
+    if (tid < ext) {
         double x[NB];
+        if (ltile) {
 #pragma unroll
-        for (int c = 0; c < NB; c++) x[c] = T[c][tid];
-        subst_row_against_u(x, D, dinv);
+            for (int c = 0; c < NB; c++) x[c] = T[c][tid];
 #pragma unroll
-        for (int c = 0; c < NB; c++) T[c][tid] = x[c];
-    } else if (do_u) {
-        double x[NB];
+            for (int c = 0; c < NB; c++) {
+                // the whole row of U is fetched before the FMA chain (otherwise every FMA waits on its own LDS read)
+                double u[NB];
 #pragma unroll
-        for (int r = 0; r < NB; r++) x[r] = T[lp[r]][tid]; // row interchange applied here
-        subst_col_against_l(x, DT);
+                for (int cc = 0; cc < NB; cc++) u[cc] = D[c][cc];
+                x[c] *= dinv[c];
 #pragma unroll
-        for (int r = 0; r < NB; r++) T[r][tid] = x[r];
-        if (sblock) {
+                for (int cc = c + 1; cc < NB; cc++) x[cc] -= x[c] * u[cc];
+            }
 #pragma unroll
-            for (int r = 0; r < NB; r++) UM[r][tid - 64] = x[r];
+            for (int c = 0; c < NB; c++) T[c][tid] = x[c];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NB; r++) x[r] = T[lp[r]][tid]; // row interchange applied here
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                double l[NB];
+#pragma unroll
+                for (int r = 0; r < NB; r++) l[r] = DT[k][r]; // column k of L, one aligned row of DT
+#pragma unroll
+                for (int r = k + 1; r < NB; r++) x[r] -= l[r] * x[k];
+            }
+#pragma unroll
+            for (int r = 0; r < NB; r++) T[r][tid] = x[r];
         }
     }
     __syncthreads();
-    // 4. write the solved tile back
-    if (sblock) {
-        if (tid < NB) {
-            double *dst = F + (base + tid) + (int64_t)k0 * ld;
-#pragma unroll
-            for (int k = 0; k < NB; k++)
-                if (k < nb) dst[(int64_t)k * ld] = T[k][tid];
-        } else if (tid >= 64 && tid < 64 + NB) {
-            double *dst = F + k0 + (int64_t)(base + tid - 64) * ld;
-#pragma unroll
-            for (int k = 0; k < NB; k++)
-                if (k < nb) dst[k] = T[k][tid];
-        }
-    } else if (ltile) {
+    if (ltile) {
         if (tid < ext) {
             double *dst = F + (o0 + tid) + (int64_t)k0 * ld;
 #pragma unroll
@@ -326,30 +277,78 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
             if (k < nb && cc < ext) dst[(int64_t)cc * ld] = T[k][cc];
         }
     }
-    // 5. S workgroup, wave 0: next diagonal tile = A - L U from the 32 critical rows / columns, then its LU
-    if (sblock && tid < 64) {
-        const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB;
+}
+
+// Tiled path, step k0: trailing update  A22 -= L21 * U12  on v_mfma_f64_16x16x4_f64 over the active
+// range [base, f + base)^2 minus the (unused) corner where both indices are >= f.
+// A 256-thread workgroup owns a 64 x 64 tile; each of its 4 waves owns 32 x 32 = 2 x 2 MFMA tiles.
+// The product is formed transposed (D = U^T L^T) so that a result register of 16 adjacent lanes
+// maps to 16 consecutive rows of one column: stores are 128-byte contiguous segments.
+// LDS layouts: Ls[kk][r] (ld 80) and Us[c][kk] (ld 34) make the fragment reads of ds_read_b64
+// conflict-free (banks = (dword address) mod 64) and both global->LDS copies conflict-free too.
+// Workgroup 0 of every front also moves the factorised diagonal tile of this step from dws into the front
+// and leaves the next diagonal tile to the look-ahead workgroup.
+// Look-ahead: one extra workgroup per front (t == nt * nt, while a next diagonal tile exists) forms the NEXT
+// diagonal tile  A - L U  from the 32 critical rows / columns with a single wavefront (lane r < 32 owns row r
+// for columns 0..15, lane r + 32 for columns 16..31), factorises it in registers (tile_lu32) and parks it in
+// dws (other buffer) with its row interchanges.  That 32 x 32 LU -- the longest serial piece of a tiled step --
+// runs beside the trailing update instead of in front of the next panel solve.
+__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
+                                                const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
+                                                double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
+                                                const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
+    __shared__ double Ls[NB * LS_LD];
+    __shared__ double Us[UPD_T * US_LD];
+    __shared__ __attribute__((aligned(16))) double UM[NB][NB + 2];
+    const int tid = threadIdx.x;
+    const int slot = find_slot(pfx, nactive, blockIdx.x);
+    const int t = blockIdx.x - pfx[slot];
+    FrontDesc fd = FD[list[slot]];
+    const int64_t ld = fd.ld;
+    const int f = fd.p + fd.m;
+    const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
+    const int base = k0 + nb, limit = f + base;
+    const int nt = (f + UPD_T - 1) / UPD_T;
+    const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
+    double *F = pool + fd.off;
+    if (t == nt * nt) {
+        // ---- look-ahead workgroup: only wave 0 works ----
+        if (tid >= 64) return;
+        const int r = tid & 31, half = tid >> 5; // row, column half (16 columns each)
+        // U block (rows k0.., columns base..base+32) -> LDS, 16 elements per lane
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int e = tid + 64 * u, kk = e & 31, c = e >> 5;
+            UM[kk][c] = (kk < nb && c < nb2) ? F[(k0 + kk) + (int64_t)(base + c) * ld] : 0.0;
+        }
+        double lrow[NB], acc[16];
+#pragma unroll
+        for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nb) ? F[(base + r) + (int64_t)(k0 + kk) * ld] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int cc = half * 16 + c;
+            acc[c] = (r < nb2 && cc < nb2) ? F[(base + r) + (int64_t)(base + cc) * ld] : (r == cc ? 1.0 : 0.0);
+        }
+        __syncthreads(); // (only wave 0 is left in this workgroup)
+#pragma unroll
+        for (int kk = 0; kk < NB; kk++) {
+            double u[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) u[c] = UM[kk][half * 16 + c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc[c] -= lrow[kk] * u[c];
+        }
+        // lanes 0..31 collect the other half of their row from lane + 32
         double a2[NB];
 #pragma unroll
-        for (int c = 0; c < NB; c++)
-            a2[c] = (tid < nb2 && c < nb2) ? F[(base + tid) + (int64_t)(base + c) * ld] : (tid == c ? 1.0 : 0.0);
-        if (tid < nb2) {
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-                const double lk = T[k][tid]; // L(row tid, k); rows k >= nb of T are zero
-                double u[NB];
-#pragma unroll
-                for (int c = 0; c < NB; c++) u[c] = UM[k][c];
-#pragma unroll
-                for (int c = 0; c < NB; c++) a2[c] -= lk * u[c];
-            }
-#pragma unroll
-            for (int c = 0; c < NB; c++)
-                if (c >= nb2) a2[c] = 0.0; // columns beyond the tile: identity padding (this row is a real row)
+        for (int c = 0; c < 16; c++) {
+            const double other = __shfl(acc[c], (tid + 32) & 63);
+            a2[c] = half == 0 ? acc[c] : other;
+            a2[16 + c] = half == 0 ? other : acc[c];
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32(a2, tid, eps, step, npert, nzero);
+        tile_lu32(a2, tid, eps, step, npert, nzero); // lanes >= 32 are not candidates and take no part
         if (tid < nb2) {
             double *dwo = dws + ((int64_t)(((k0 / NB) + 1) & 1) * dws_stride + slot) * NB * NB;
 #pragma unroll
@@ -361,35 +360,9 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
             atomicAdd(&info->n_perturbed, npert);
             if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
         }
+        return;
     }
-}
-
-// Tiled path, step k0: trailing update  A22 -= L21 * U12  on v_mfma_f64_16x16x4_f64 over the active
-// range [base, f + base)^2 minus the (unused) corner where both indices are >= f.
-// A 256-thread workgroup owns a 64 x 64 tile; each of its 4 waves owns 32 x 32 = 2 x 2 MFMA tiles.
-// The product is formed transposed (D = U^T L^T) so that a result register of 16 adjacent lanes
-// maps to 16 consecutive rows of one column: stores are 128-byte contiguous segments.
-// LDS layouts: Ls[kk][r] (ld 80) and Us[c][kk] (ld 34) make the fragment reads of ds_read_b64
-// conflict-free (banks = (dword address) mod 64) and both global->LDS copies conflict-free too.
-// Workgroup 0 of every front also moves the factorised diagonal tile of this step from dws into the front
-// and leaves the next diagonal tile (already formed and factorised by k_panel's S workgroup) alone.
-__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
-                                                const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
-                                                const double *__restrict__ dws, int32_t dws_stride) {
-    __shared__ double Ls[NB * LS_LD];
-    __shared__ double Us[UPD_T * US_LD];
-    const int tid = threadIdx.x;
-    const int slot = find_slot(pfx, nactive, blockIdx.x);
-    const int t = blockIdx.x - pfx[slot];
-    FrontDesc fd = FD[list[slot]];
-    const int64_t ld = fd.ld;
-    const int f = fd.p + fd.m;
-    const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
-    const int base = k0 + nb, limit = f + base;
-    const int nt = (f + UPD_T - 1) / UPD_T;
     const int r0 = base + (t % nt) * UPD_T, c0 = base + (t / nt) * UPD_T;
-    const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
-    double *F = pool + fd.off;
     if (t == 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];

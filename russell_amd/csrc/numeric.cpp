@@ -202,8 +202,7 @@ int32_t Solver::upload_plan() {
             int64_t acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
-                const bool la = S.npiv(big[a]) > k0 + NB; // a next diagonal tile exists: one S workgroup owns 32 rows + 32 columns
-                acc += (la ? 1 : 0) + 2 * ((S.fsize(big[a]) - (la ? NB : 0) + PANEL_T - 1) / PANEL_T);
+                acc += 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
             }
             tasks.push_back((int32_t)acc);
             st.n_panel = (int32_t)acc;
@@ -212,7 +211,7 @@ int32_t Solver::upload_plan() {
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
                 int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T;
-                acc += nt * nt;
+                acc += nt * nt + (S.npiv(big[a]) > k0 + NB ? 1 : 0); // + the look-ahead workgroup
             }
             tasks.push_back((int32_t)acc);
             if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
@@ -332,7 +331,7 @@ int32_t Solver::run_factor() {
             hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
                                d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info);
             hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
-                               d_pool, d_dws, dws_stride);
+                               d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info);
             launches += 2;
             k0 += NB;
         }
