@@ -1,5 +1,5 @@
 // kernels_solve.hpp -- level-set sparse triangular solves in multifrontal form (HBM-bound).
-//   small fronts (f <= SMALL_F): k_fwd / k_bwd, one workgroup per supernode, substitution against L11 / U11
+//   small fronts (f <= SMALL_F): k_fwd / k_bwd, one wavefront per supernode, panel staged in LDS, substitution by wave shuffles
 //   big fronts (augmented):      k_fwd_big / k_bwd_big, GEMVs against the inverse-based panels E / E'
 //                                split into 64-row slabs, one 256-thread workgroup per slab
 // Forward pass, leaves to root:   w = [b1; 0] + sum_children u_c;  y1 = L11^{-1} P w1;  u = w2 - L21 y1
@@ -11,94 +11,67 @@
 
 namespace hipmf {
 
-__global__ void k_fwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
-                      const int32_t *__restrict__ lperm, const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
-                      double *__restrict__ work, double *__restrict__ x) {
-    __shared__ double xb[NB];
-    const int tid = threadIdx.x, nt = blockDim.x;
+// Small fronts (f <= SMALL_F = 64), one wavefront per supernode.  The factor panel the step needs is copied
+// to LDS first with every load in flight at once (the substitution would otherwise pay one HBM round trip per
+// column); all arithmetic then runs out of LDS.  Dynamic LDS: ldp * pmax doubles (ldp = fmax | 1).
+__global__ void __launch_bounds__(64) k_fwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
+                                            const double *__restrict__ pool, const int32_t *__restrict__ lperm,
+                                            const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
+                                            double *__restrict__ work, double *__restrict__ x, int32_t ldp) {
+    HIPMF_DYN_SHARED(double, P); // P[i + j * ldp] = F(i, j), i < f, j < p  (L11 and L21)
+    __shared__ double w[SMALL_F];
+    __shared__ double y[SMALL_F];
+    const int tid = threadIdx.x;
     FrontDesc fd = FD[list[blockIdx.x]];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = fd.ld;
     const double *F = pool + fd.off;
     double *W = work + fd.woff;
     double *xs = x + fd.first;
-    for (int i = tid; i < f; i += nt) W[i] = (i < p) ? xs[i] : 0.0;
+    if (tid < f)
+        for (int j = 0; j < p; j++) P[tid + j * ldp] = F[tid + (int64_t)j * f];
+    w[tid] = (tid < p) ? xs[tid] : 0.0;
     __syncthreads();
     for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
         FrontDesc cd = FD[child_idx[ci]];
         const double *uc = work + cd.woff + cd.p;
         const int32_t *relc = rel + cd.rowptr;
-        for (int i = tid; i < cd.m; i += nt) W[relc[i]] += uc[i];
+        for (int i = tid; i < cd.m; i += 64) w[relc[i]] += uc[i];
         __syncthreads();
     }
-    // row interchanges of the pivot block: xs[r] = W[lperm[r]]
-    for (int i = tid; i < p; i += nt) xs[i] = W[lperm[fd.first + i]];
-    __syncthreads();
-    for (int j0 = 0; j0 < p; j0 += NB) {
-        const int jb = (p - j0) < NB ? (p - j0) : NB;
-        if (tid < 64) {
-            double v = (tid < jb) ? xs[j0 + tid] : 0.0;
-            for (int j = 0; j < jb; j++) {
-                double vj = __shfl(v, j);
-                if (tid > j && tid < jb) v -= F[(j0 + tid) + (int64_t)(j0 + j) * ld] * vj;
-            }
-            if (tid < jb) {
-                xb[tid] = v;
-                xs[j0 + tid] = v;
-            }
-        }
-        __syncthreads();
-        for (int i = j0 + jb + tid; i < f; i += nt) {
-            double acc = 0.0;
-            for (int j = 0; j < jb; j++) acc += F[i + (int64_t)(j0 + j) * ld] * xb[j];
-            if (i < p) xs[i] -= acc;
-            else W[i] -= acc;
-        }
-        __syncthreads();
+    // row interchanges of the pivot block, then y1 = L11^{-1} (P w1) column by column, u = w2 - L21 y1
+    double v = (tid < p) ? w[lperm[fd.first + tid]] : ((tid < f) ? w[tid] : 0.0);
+    for (int j = 0; j < p; j++) {
+        const double vj = __shfl(v, j);
+        if (tid > j && tid < f) v -= P[tid + j * ldp] * vj;
     }
+    if (tid < p) xs[tid] = v;
+    else if (tid < f) W[tid] = v;
 }
 
-__global__ void k_bwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
-                      const int32_t *__restrict__ rows, double *__restrict__ work, double *__restrict__ x) {
-    __shared__ double xb[NB];
-    const int tid = threadIdx.x, nt = blockDim.x;
+__global__ void __launch_bounds__(64) k_bwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
+                                            const double *__restrict__ pool, const int32_t *__restrict__ rows,
+                                            double *__restrict__ work, double *__restrict__ x, int32_t ldp) {
+    HIPMF_DYN_SHARED(double, P); // P[i + j * ldp] = F(i, j), i < p, j < f  (U11 and U12)
+    const int tid = threadIdx.x;
     FrontDesc fd = FD[list[blockIdx.x]];
-    const int p = fd.p, m = fd.m;
-    const int64_t ld = fd.ld;
+    const int p = fd.p, m = fd.m, f = fd.p + fd.m;
     const double *F = pool + fd.off;
-    double *W = work + fd.woff;
     double *xs = x + fd.first;
     const int32_t *rws = rows + fd.rowptr;
-    for (int i = tid; i < m; i += nt) W[p + i] = x[rws[i]];
+    if (tid < p)
+        for (int j = 0; j < f; j++) P[tid + j * ldp] = F[tid + (int64_t)j * f];
+    // lane j >= p holds x2[j - p] (gathered from the ancestors), lane i < p holds y1[i]
+    double v = (tid < p) ? xs[tid] : ((tid < f) ? x[rws[tid - p]] : 0.0);
     __syncthreads();
-    for (int i = tid; i < p; i += nt) {
-        double acc = 0.0;
-        for (int j = 0; j < m; j++) acc += F[i + (int64_t)(p + j) * ld] * W[p + j];
-        xs[i] -= acc;
+    // x1 = U11^{-1} (y1 - U12 x2): columns from right to left
+    for (int j = f - 1; j >= 0; j--) {
+        if (tid == j && j < p) v /= P[j + j * ldp];
+        const double vj = __shfl(v, j);
+        if (tid < j && tid < p) v -= P[tid + j * ldp] * vj;
     }
-    __syncthreads();
-    for (int j0 = ((p - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
-        const int jb = (p - j0) < NB ? (p - j0) : NB;
-        if (tid < 64) {
-            double v = (tid < jb) ? xs[j0 + tid] : 0.0;
-            for (int j = jb - 1; j >= 0; j--) {
-                if (tid == j) v /= F[(j0 + j) + (int64_t)(j0 + j) * ld];
-                double vj = __shfl(v, j);
-                if (tid < j) v -= F[(j0 + tid) + (int64_t)(j0 + j) * ld] * vj;
-            }
-            if (tid < jb) {
-                xb[tid] = v;
-                xs[j0 + tid] = v;
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < j0; i += nt) {
-            double acc = 0.0;
-            for (int j = 0; j < jb; j++) acc += F[i + (int64_t)(j0 + j) * ld] * xb[j];
-            xs[i] -= acc;
-        }
-        __syncthreads();
-    }
+    if (tid < p) xs[tid] = v;
+    (void)m;
+    (void)work;
 }
 
 // 8-way unrolled strided dot product: acc += sum_j col[j * ld] * w[j], j = j0, j0 + step, ... < j1.

@@ -179,6 +179,7 @@ int32_t Solver::upload_plan() {
             if (S.fsize(s) <= SMALL_F) {
                 small.push_back(s);
                 fmax_small = std::max(fmax_small, S.fsize(s));
+                L.small_pmax = std::max(L.small_pmax, S.npiv(s));
             } else {
                 big.push_back(s);
             }
@@ -363,8 +364,8 @@ int32_t Solver::run_triangular(double *xp) {
     HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
         if (L.small_cnt > 0) {
-            hipLaunchKernelGGL(k_fwd, dim3(L.small_cnt), dim3(64), 0, STREAM, d_lists + L.small_off, d_fd, d_pool, d_lperm, d_child,
-                               d_rel, d_work, xp);
+            hipLaunchKernelGGL(k_fwd, dim3(L.small_cnt), dim3(64), sizeof(double) * (size_t)L.small_ld * (size_t)L.small_pmax, STREAM,
+                               d_lists + L.small_off, d_fd, d_pool, d_lperm, d_child, d_rel, d_work, xp, L.small_ld);
             launches++;
         }
         if (L.fwd_cnt > 0) {
@@ -382,7 +383,8 @@ int32_t Solver::run_triangular(double *xp) {
             launches++;
         }
         if (L.small_cnt > 0) {
-            hipLaunchKernelGGL(k_bwd, dim3(L.small_cnt), dim3(64), 0, STREAM, d_lists + L.small_off, d_fd, d_pool, d_rows, d_work, xp);
+            hipLaunchKernelGGL(k_bwd, dim3(L.small_cnt), dim3(64), sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld, STREAM,
+                               d_lists + L.small_off, d_fd, d_pool, d_rows, d_work, xp, L.small_ld);
             launches++;
         }
     }

@@ -58,7 +58,7 @@ struct StepPlan {
     int32_t n_panel = 0, n_update = 0;
 };
 struct LevelPlan {
-    int32_t small_off = 0, small_cnt = 0, small_ld = 0; // fronts with f <= SMALL_F
+    int32_t small_off = 0, small_cnt = 0, small_ld = 0, small_pmax = 1; // fronts with f <= SMALL_F
     int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
     int32_t ea_off = 0, ea_cnt = 0;
     int32_t fwd_off = 0, fwd_cnt = 0, bwd_off = 0, bwd_cnt = 0; // SolveTask ranges of the big fronts
