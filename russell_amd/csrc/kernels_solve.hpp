@@ -58,8 +58,24 @@ __global__ void __launch_bounds__(64) k_bwd(const int32_t *__restrict__ list, co
     const double *F = pool + fd.off;
     double *xs = x + fd.first;
     const int32_t *rws = rows + fd.rowptr;
-    if (tid < p)
-        for (int j = 0; j < f; j++) P[tid + j * ldp] = F[tid + (int64_t)j * f];
+    {
+        // rows 0..p of all f columns, all 64 lanes busy: 64 / pw columns per pass (pw = p rounded up to 16 / 32 / 64)
+        const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
+        const int i = tid & ((1 << sh) - 1), jq = tid >> sh, step = 64 >> sh;
+        for (int j0 = 0; j0 < f; j0 += 4 * step) {
+            double v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u * step + jq;
+                v4[u] = (i < p && j < f) ? F[i + (int64_t)j * f] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u * step + jq;
+                if (i < p && j < f) P[i + j * ldp] = v4[u];
+            }
+        }
+    }
     // lane j >= p holds x2[j - p] (gathered from the ancestors), lane i < p holds y1[i]
     double v = (tid < p) ? xs[tid] : ((tid < f) ? x[rws[tid - p]] : 0.0);
     __syncthreads();
