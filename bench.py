@@ -64,7 +64,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -115,9 +115,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from russell_amd.distributed import max_over_ranks
+        elapsed = max_over_ranks(elapsed, dist, device=torch.device("cuda", local_rank))
     ms_per_step = elapsed * 1e3 / args.steps
 
     st = s.stats()
