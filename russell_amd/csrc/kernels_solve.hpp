@@ -51,42 +51,44 @@ __global__ void __launch_bounds__(64) k_fwd(const int32_t *__restrict__ list, co
 __global__ void __launch_bounds__(64) k_bwd(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
                                             const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                             double *__restrict__ work, double *__restrict__ x, int32_t ldp) {
-    HIPMF_DYN_SHARED(double, P); // P[i + j * ldp] = F(i, j), i < p, j < f  (U11 and U12)
+    HIPMF_DYN_SHARED(double, P); // P[i + j * ldp] = U11(i, j), i, j < p
+    __shared__ double xg[SMALL_F]; // x2 gathered from the ancestors
     const int tid = threadIdx.x;
     FrontDesc fd = FD[list[blockIdx.x]];
     const int p = fd.p, m = fd.m, f = fd.p + fd.m;
     const double *F = pool + fd.off;
     double *xs = x + fd.first;
     const int32_t *rws = rows + fd.rowptr;
-    {
-        // rows 0..p of all f columns, all 64 lanes busy: 64 / pw columns per pass (pw = p rounded up to 16 / 32 / 64)
-        const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
-        const int i = tid & ((1 << sh) - 1), jq = tid >> sh, step = 64 >> sh;
-        for (int j0 = 0; j0 < f; j0 += 4 * step) {
-            double v4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u * step + jq;
-                v4[u] = (i < p && j < f) ? F[i + (int64_t)j * f] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u * step + jq;
-                if (i < p && j < f) P[i + j * ldp] = v4[u];
-            }
-        }
-    }
-    // lane j >= p holds x2[j - p] (gathered from the ancestors), lane i < p holds y1[i]
-    double v = (tid < p) ? xs[tid] : ((tid < f) ? x[rws[tid - p]] : 0.0);
+    // lanes are arranged as (row i, column group jq): pw = p rounded up to 16 / 32 / 64 lanes per column
+    const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
+    const int i = tid & ((1 << sh) - 1), jq = tid >> sh, ng = 64 >> sh;
+    if (tid < m) xg[tid] = x[rws[tid]];
+    for (int j = jq; j < p; j += ng)
+        if (i < p) P[i + j * ldp] = F[i + (int64_t)j * f];
     __syncthreads();
-    // x1 = U11^{-1} (y1 - U12 x2): columns from right to left
-    for (int j = f - 1; j >= 0; j--) {
-        if (tid == j && j < p) v /= P[j + j * ldp];
+    // t = y1 - U12 x2: U12 is streamed from HBM exactly once, ng columns per pass, 4 passes in flight
+    double acc = 0.0;
+    if (i < p) {
+        const double *Ui = F + i + (int64_t)p * f;
+        int j = jq;
+        for (; j + 3 * ng < m; j += 4 * ng) {
+            const double e0 = Ui[(int64_t)j * f], e1 = Ui[(int64_t)(j + ng) * f], e2 = Ui[(int64_t)(j + 2 * ng) * f], e3 = Ui[(int64_t)(j + 3 * ng) * f];
+            acc += e0 * xg[j];
+            acc += e1 * xg[j + ng];
+            acc += e2 * xg[j + 2 * ng];
+            acc += e3 * xg[j + 3 * ng];
+        }
+        for (; j < m; j += ng) acc += Ui[(int64_t)j * f] * xg[j];
+    }
+    for (int off = 1 << sh; off < 64; off <<= 1) acc += __shfl_xor(acc, off); // sum over the column groups (fixed order)
+    double v = (tid < p) ? xs[tid] - acc : 0.0;
+    // x1 = U11^{-1} t: columns from right to left among lanes 0..p-1
+    for (int j = p - 1; j >= 0; j--) {
+        if (tid == j) v /= P[j + j * ldp];
         const double vj = __shfl(v, j);
-        if (tid < j && tid < p) v -= P[tid + j * ldp] * vj;
+        if (tid < j) v -= P[tid + j * ldp] * vj;
     }
     if (tid < p) xs[tid] = v;
-    (void)m;
     (void)work;
 }
 

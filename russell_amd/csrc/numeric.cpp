@@ -383,7 +383,7 @@ int32_t Solver::run_triangular(double *xp) {
             launches++;
         }
         if (L.small_cnt > 0) {
-            hipLaunchKernelGGL(k_bwd, dim3(L.small_cnt), dim3(64), sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld, STREAM,
+            hipLaunchKernelGGL(k_bwd, dim3(L.small_cnt), dim3(64), sizeof(double) * (size_t)L.small_ld * (size_t)L.small_pmax, STREAM,
                                d_lists + L.small_off, d_fd, d_pool, d_rows, d_work, xp, L.small_ld);
             launches++;
         }
