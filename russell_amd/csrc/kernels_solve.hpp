@@ -1,7 +1,9 @@
 // kernels_solve.hpp -- level-set sparse triangular solves in multifrontal form (HBM-bound).
 //   small fronts (f <= SMALL_F): k_fwd / k_bwd, one wavefront per supernode, panel staged in LDS, substitution by wave shuffles
 //   big fronts (augmented):      k_fwd_big / k_bwd_big, GEMVs against the inverse-based panels E / E'
-//                                split into 64-row slabs, one 256-thread workgroup per slab
+//                                split into row slabs, one workgroup per slab: 64 rows x 4 column groups (256 threads),
+//                                or 32 rows x 32 column groups (1024 threads) on the levels near the root, where
+//                                the fronts are few and large and the per-thread column chain sets the latency
 // Forward pass, leaves to root:   w = [b1; 0] + sum_children u_c;  y1 = L11^{-1} P w1;  u = w2 - L21 y1
 // Backward pass, root to leaves:  x1 = U11^{-1} (y1 - U12 x2),  x2 gathered from the ancestors
 // Every sum has a fixed order (children ascending, columns ascending, 4 fixed column groups), so the
@@ -20,7 +22,6 @@ __global__ void __launch_bounds__(64) k_fwd(const int32_t *__restrict__ list, co
                                             double *__restrict__ work, double *__restrict__ x, int32_t ldp) {
     HIPMF_DYN_SHARED(double, P); // P[i + j * ldp] = F(i, j), i < f, j < p  (L11 and L21)
     __shared__ double w[SMALL_F];
-    __shared__ double y[SMALL_F];
     const int tid = threadIdx.x;
     FrontDesc fd = FD[list[blockIdx.x]];
     const int p = fd.p, f = fd.p + fd.m;
@@ -111,17 +112,32 @@ __device__ __forceinline__ double strided_dot(const double *__restrict__ col, in
     return acc0 + acc1;
 }
 
+// Sum of the G column-group partial sums of row rr, pairwise in a fixed order.
+template <int SLAB, int G>
+__device__ __forceinline__ double group_sum(const double (*red)[SLAB], int rr) {
+    double t[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) t[g] = red[g][rr];
+#pragma unroll
+    for (int w = 1; w < G; w <<= 1)
+#pragma unroll
+        for (int g = 0; g + w < G; g += 2 * w) t[g] += t[g + w];
+    return t[0];
+}
+
 // Forward step of a big (augmented) front, rows [r0, r1) of its f-vector:
 //   [y1; -delta] = E * w1,  E(r, j) = F[r + (f + j) ld]   ->   work[r] = y1[r] (r < p),  work[r] = w2[r] + (E w1)[r] (r >= p)
 // Every workgroup of the front assembles w1 = b1 + (children's updates to the pivot rows) in LDS itself;
 // the children's entries are swept linearly (no searches), in child order.  Dynamic LDS: p doubles.
-__global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+template <int SLAB, int G>
+__global__ void __launch_bounds__(SLAB *G) k_fwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                  const double *__restrict__ pool, const int32_t *__restrict__ child_idx,
                                                  const int32_t *__restrict__ rel, double *__restrict__ work,
                                                  const double *__restrict__ x) {
     HIPMF_DYN_SHARED(double, w1);
-    __shared__ double wsl[SOLVE_SLAB];
-    __shared__ double red[4][SOLVE_SLAB];
+    __shared__ double wsl[SLAB];
+    __shared__ double red[G][SLAB];
+    constexpr int T = SLAB * G;
     const int tid = threadIdx.x;
     SolveTask tk = tasks[blockIdx.x];
     FrontDesc fd = FD[tk.s];
@@ -130,31 +146,31 @@ __global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ t
     const double *E = pool + fd.off + (int64_t)f * ld;
     double *W = work + fd.woff;
     const int r0 = tk.r0, r1 = tk.r1;
-    for (int i = tid; i < p; i += 256) w1[i] = x[fd.first + i];
-    if (tid < SOLVE_SLAB) wsl[tid] = 0.0;
+    for (int i = tid; i < p; i += T) w1[i] = x[fd.first + i];
+    if (tid < SLAB) wsl[tid] = 0.0;
     __syncthreads();
     for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
         FrontDesc cd = FD[child_idx[ci]];
         const double *uc = work + cd.woff + cd.p;
         const int32_t *relc = rel + cd.rowptr;
-        for (int i = tid; i < cd.m; i += 256) {
+        for (int i = tid; i < cd.m; i += T) {
             const int r = relc[i];
             if (r < p) w1[r] += uc[i];
             else if (r >= r0 && r < r1) wsl[r - r0] += uc[i];
         }
         __syncthreads();
     }
-    const int rr = tid & (SOLVE_SLAB - 1), g = tid >> 6;
+    const int rr = tid & (SLAB - 1), g = tid / SLAB;
     const int r = r0 + rr;
     // rows of inv(L11) P are zero right of their own 32-column block
     int jmax = p;
     if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
     double acc = 0.0;
-    if (r < r1) acc = strided_dot(E + r, ld, w1, g, jmax, 4);
+    if (r < r1) acc = strided_dot(E + r, ld, w1, g, jmax, G);
     red[g][rr] = acc;
     __syncthreads();
     if (g == 0 && r < r1) {
-        double tot = (red[0][rr] + red[1][rr]) + (red[2][rr] + red[3][rr]);
+        const double tot = group_sum<SLAB, G>(red, rr);
         W[r] = (r < p) ? tot : wsl[rr] + tot;
     }
 }
@@ -162,11 +178,13 @@ __global__ void __launch_bounds__(256) k_fwd_big(const SolveTask *__restrict__ t
 // Backward step of a big front, pivot rows [r0, r1):
 //   x1 = E' * [y1; x2],  E'(i, j) = F[(f + i) + j ld],  y1 = work[0..p),  x2 = x[rows]
 // Dynamic LDS: f doubles.
-__global__ void __launch_bounds__(256) k_bwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+template <int SLAB, int G>
+__global__ void __launch_bounds__(SLAB *G) k_bwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                  const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                  const double *__restrict__ work, double *__restrict__ x) {
     HIPMF_DYN_SHARED(double, v);
-    __shared__ double red[4][SOLVE_SLAB];
+    __shared__ double red[G][SLAB];
+    constexpr int T = SLAB * G;
     const int tid = threadIdx.x;
     SolveTask tk = tasks[blockIdx.x];
     FrontDesc fd = FD[tk.s];
@@ -178,15 +196,15 @@ __global__ void __launch_bounds__(256) k_bwd_big(const SolveTask *__restrict__ t
     const int r0 = tk.r0, r1 = tk.r1;
     // columns of inv(U11) left of the slab's first 32-column block are zero
     const int jmin = (r0 / NB) * NB;
-    for (int j = jmin + tid; j < f; j += 256) v[j] = (j < p) ? W[j] : x[rws[j - p]];
+    for (int j = jmin + tid; j < f; j += T) v[j] = (j < p) ? W[j] : x[rws[j - p]];
     __syncthreads();
-    const int rr = tid & (SOLVE_SLAB - 1), g = tid >> 6;
+    const int rr = tid & (SLAB - 1), g = tid / SLAB;
     const int i = r0 + rr;
     double acc = 0.0;
-    if (i < r1) acc = strided_dot(Ep + i, ld, v, jmin + g, f, 4);
+    if (i < r1) acc = strided_dot(Ep + i, ld, v, jmin + g, f, G);
     red[g][rr] = acc;
     __syncthreads();
-    if (g == 0 && i < r1) x[fd.first + i] = (red[0][rr] + red[1][rr]) + (red[2][rr] + red[3][rr]);
+    if (g == 0 && i < r1) x[fd.first + i] = group_sum<SLAB, G>(red, rr);
 }
 
 } // namespace hipmf

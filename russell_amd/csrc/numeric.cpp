@@ -247,17 +247,24 @@ int32_t Solver::upload_plan() {
         L.ea_cnt = (int32_t)ea.size() - L.ea_off;
         // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
         L.fwd_off = (int32_t)stasks.size();
+        int64_t nslab = 0;
+        for (int32_t s : big) {
+            L.big_pmax = std::max(L.big_pmax, S.npiv(s));
+            L.big_fmax = std::max(L.big_fmax, S.fsize(s));
+            nslab += (S.fsize(s) + SOLVE_SLAB - 1) / SOLVE_SLAB;
+        }
+        // few, large fronts (the levels near the root): narrow slabs and 32 column groups per workgroup
+        L.wide = nslab < 256 && L.big_pmax >= 128;
+        const int32_t slab = L.wide ? SOLVE_SLAB_WIDE : SOLVE_SLAB;
         for (int32_t s : big) {
             int32_t f = S.fsize(s);
-            L.big_pmax = std::max(L.big_pmax, S.npiv(s));
-            L.big_fmax = std::max(L.big_fmax, f);
-            for (int32_t r0 = 0; r0 < f; r0 += SOLVE_SLAB) stasks.push_back({s, r0, std::min(f, r0 + SOLVE_SLAB)});
+            for (int32_t r0 = 0; r0 < f; r0 += slab) stasks.push_back({s, r0, std::min(f, r0 + slab)});
         }
         L.fwd_cnt = (int32_t)stasks.size() - L.fwd_off;
         L.bwd_off = (int32_t)stasks.size();
         for (int32_t s : big) {
             int32_t p = S.npiv(s);
-            for (int32_t r0 = 0; r0 < p; r0 += SOLVE_SLAB) stasks.push_back({s, r0, std::min(p, r0 + SOLVE_SLAB)});
+            for (int32_t r0 = 0; r0 < p; r0 += slab) stasks.push_back({s, r0, std::min(p, r0 + slab)});
         }
         L.bwd_cnt = (int32_t)stasks.size() - L.bwd_off;
         if (L.big_pmax > MAX_LDS_DOUBLES || L.big_fmax > MAX_LDS_DOUBLES) {
@@ -369,8 +376,12 @@ int32_t Solver::run_triangular(double *xp) {
             launches++;
         }
         if (L.fwd_cnt > 0) {
-            hipLaunchKernelGGL(k_fwd_big, dim3(L.fwd_cnt), dim3(256), sizeof(double) * (size_t)L.big_pmax, STREAM, d_st + L.fwd_off, d_fd,
-                               d_pool, d_child, d_rel, d_work, xp);
+            if (L.wide)
+                hipLaunchKernelGGL((k_fwd_big<SOLVE_SLAB_WIDE, 32>), dim3(L.fwd_cnt), dim3(SOLVE_SLAB_WIDE * 32), sizeof(double) * (size_t)L.big_pmax,
+                                   STREAM, d_st + L.fwd_off, d_fd, d_pool, d_child, d_rel, d_work, xp);
+            else
+                hipLaunchKernelGGL((k_fwd_big<SOLVE_SLAB, 4>), dim3(L.fwd_cnt), dim3(SOLVE_SLAB * 4), sizeof(double) * (size_t)L.big_pmax, STREAM,
+                                   d_st + L.fwd_off, d_fd, d_pool, d_child, d_rel, d_work, xp);
             launches++;
         }
     }
@@ -378,8 +389,12 @@ int32_t Solver::run_triangular(double *xp) {
     for (auto it = levels.rbegin(); it != levels.rend(); ++it) {
         const LevelPlan &L = *it;
         if (L.bwd_cnt > 0) {
-            hipLaunchKernelGGL(k_bwd_big, dim3(L.bwd_cnt), dim3(256), sizeof(double) * (size_t)L.big_fmax, STREAM, d_st + L.bwd_off, d_fd,
-                               d_pool, d_rows, d_work, xp);
+            if (L.wide)
+                hipLaunchKernelGGL((k_bwd_big<SOLVE_SLAB_WIDE, 32>), dim3(L.bwd_cnt), dim3(SOLVE_SLAB_WIDE * 32), sizeof(double) * (size_t)L.big_fmax,
+                                   STREAM, d_st + L.bwd_off, d_fd, d_pool, d_rows, d_work, xp);
+            else
+                hipLaunchKernelGGL((k_bwd_big<SOLVE_SLAB, 4>), dim3(L.bwd_cnt), dim3(SOLVE_SLAB * 4), sizeof(double) * (size_t)L.big_fmax, STREAM,
+                                   d_st + L.bwd_off, d_fd, d_pool, d_rows, d_work, xp);
             launches++;
         }
         if (L.small_cnt > 0) {

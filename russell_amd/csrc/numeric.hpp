@@ -63,6 +63,7 @@ struct LevelPlan {
     int32_t ea_off = 0, ea_cnt = 0;
     int32_t fwd_off = 0, fwd_cnt = 0, bwd_off = 0, bwd_cnt = 0; // SolveTask ranges of the big fronts
     int32_t big_pmax = 0, big_fmax = 0;
+    bool wide = false; // solve with 32-row slabs x 32 column groups (few large fronts)
     std::vector<StepPlan> steps;
 };
 
