@@ -74,30 +74,52 @@ __global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc
 // tile of the parent front.  Children are visited in ascending order and a parent entry belongs to
 // exactly one task, so the floating-point summation order is fixed (bit-reproducible factors).
 // The sub-ranges of every child's (sorted) relative-index list that fall into the tile are precomputed on
-// the host (EaRange, one per task and child): no dependent binary searches on the device.
-__global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const FrontDesc *__restrict__ FD,
-                             const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
+// the host (EaRange, one per task and child that actually hits the tile, self-contained): no dependent
+// descriptor loads or binary searches on the device, and tiles no child touches have no task at all.
+__global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const int32_t *__restrict__ rel,
                              double *__restrict__ pool) {
-    EaTask t = tasks[blockIdx.x];
-    FrontDesc fd = FD[t.s];
-    const int64_t ld = fd.ld;
-    double *F = pool + fd.off;
-    for (int ci = fd.child_begin; ci < fd.child_end; ci++) {
-        FrontDesc cd = FD[child_idx[ci]];
-        const int mc = cd.m;
-        if (mc == 0) continue;
-        const int64_t ldc = cd.ld;
-        const double *CB = pool + cd.off + cd.p + (int64_t)cd.p * ldc;
-        const int32_t *relc = rel + cd.rowptr;
-        const EaRange rg = ranges[t.range_off + (ci - fd.child_begin)];
+    const EaTask t = tasks[blockIdx.x];
+    const int64_t ld = t.ld;
+    double *F = pool + t.f_off;
+    const int tid = threadIdx.x;
+    EaRange rg = ranges[t.piece_begin];
+    for (int pc = t.piece_begin; pc < t.piece_end; pc++) {
+        const EaRange nxt = ranges[pc + 1 < t.piece_end ? pc + 1 : pc]; // the next piece's descriptor travels with this one's data
+        const int64_t ldc = rg.ldc;
+        const double *CB = pool + rg.cb_off;
+        const int32_t *relc = rel + rg.rel_off;
         const int jlo = rg.jlo, jhi = rg.jhi, ilo = rg.ilo, ihi = rg.ihi;
+        // lane = row, sh = log2(rows per pass) chosen by the height of the piece; 256 >> sh column groups; eight
+        // columns are in flight per thread before the first store (within one child the targets are distinct:
+        // rel is strictly increasing)
         const int ni = ihi - ilo;
-        const int total = (jhi - jlo) * ni;
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            int j = jlo + e / ni, i = ilo + e % ni;
-            F[relc[i] + (int64_t)relc[j] * ld] += CB[i + (int64_t)j * ldc];
+        const int sh = ni <= 16 ? 4 : (ni <= 32 ? 5 : 6);
+        const int tx = tid & ((1 << sh) - 1), ty = tid >> sh, ng = (int)blockDim.x >> sh;
+        for (int i = ilo + tx; i < ihi; i += (1 << sh)) {
+            const int ri = relc[i];
+            for (int j0 = jlo + ty; j0 < jhi; j0 += 8 * ng) {
+                double cb[8], fo[8];
+                int64_t at[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int j = j0 + q * ng;
+                    at[q] = (j < jhi) ? ri + (int64_t)relc[j] * ld : -1;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int j = j0 + q * ng;
+                    if (at[q] >= 0) {
+                        cb[q] = CB[i + (int64_t)j * ldc];
+                        fo[q] = F[at[q]];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (at[q] >= 0) F[at[q]] = fo[q] + cb[q];
+            }
         }
         __syncthreads(); // the next child may hit the same parent entries from other threads
+        rg = nxt;
     }
 }
 

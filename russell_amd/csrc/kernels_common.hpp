@@ -44,12 +44,19 @@ struct FrontDesc {
 };
 
 struct EaTask {
-    int32_t s, c0, c1, r0, r1; // parent front, parent-column range [c0, c1), parent-row range [r0, r1)
-    int32_t range_off;         // first EaRange of this task (one per child of s, in child order)
+    int64_t f_off;                    // pool offset of the parent front
+    int32_t ld;                       // its leading dimension
+    int32_t piece_begin, piece_end;   // the EaRange pieces (children in ascending order) that hit this tile of the parent
+    int32_t pad;
 };
 
+// One child's contribution block restricted to one tile of the parent: everything the kernel needs in one load.
 struct EaRange {
-    int32_t jlo, jhi, ilo, ihi; // child entries whose relative index falls in [c0, c1) resp. [r0, r1)
+    int64_t cb_off;             // pool offset of the child's contribution block (entry p, p of its front)
+    int64_t rel_off;            // offset of the child's relative indices
+    int32_t ldc;                // leading dimension of the child front
+    int32_t jlo, jhi, ilo, ihi; // child entries whose relative index falls into the tile's column resp. row range
+    int32_t pad;
 };
 
 struct SolveTask {

@@ -27,8 +27,17 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     const int p = fd.p, f = fd.p + fd.m;
     double *F = pool + fd.off;
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
-    if (tid < f)
-        for (int c = 0; c < f; c++) sm[tid + c * ld] = F[tid + c * f];
+    if (tid < f) {
+        int c = 0;
+        for (; c + 7 < f; c += 8) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = F[tid + (c + q) * f];
+#pragma unroll
+            for (int q = 0; q < 8; q++) sm[tid + (c + q) * ld] = a[q];
+        }
+        for (; c < f; c++) sm[tid + c * ld] = F[tid + c * f];
+    }
     if (tid < p) lp[tid] = tid;
     __syncthreads();
     for (int c = 0; c < p; c++) {
@@ -71,12 +80,34 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
         if (below) {
             l = sm[tid + c * ld] / d;
             sm[tid + c * ld] = l;
-            for (int cc = c + 1; cc < f; cc++) sm[tid + cc * ld] -= l * sm[c + cc * ld];
+            // eight columns per pass, all LDS reads issued before the first write (the compiler cannot
+            // reorder them itself: it has to assume the writes alias the pivot row)
+            int cc = c + 1;
+            for (; cc + 7 < f; cc += 8) {
+                double u[8], a[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    u[q] = sm[c + (cc + q) * ld];
+                    a[q] = sm[tid + (cc + q) * ld];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) sm[tid + (cc + q) * ld] = a[q] - l * u[q];
+            }
+            for (; cc < f; cc++) sm[tid + cc * ld] -= l * sm[c + cc * ld];
         }
         __syncthreads();
     }
-    if (tid < f)
-        for (int c = 0; c < f; c++) F[tid + c * f] = sm[tid + c * ld];
+    if (tid < f) {
+        int c = 0;
+        for (; c + 7 < f; c += 8) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = sm[tid + (c + q) * ld];
+#pragma unroll
+            for (int q = 0; q < 8; q++) F[tid + (c + q) * f] = a[q];
+        }
+        for (; c < f; c++) F[tid + c * f] = sm[tid + c * ld];
+    }
     if (tid < p) lperm[fd.first + tid] = lp[tid];
 }
 
@@ -286,9 +317,17 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // maps to 16 consecutive rows of one column: stores are 128-byte contiguous segments.
 // LDS layouts: Ls[kk][r] (ld 80) and Us[c][kk] (ld 34) make the fragment reads of ds_read_b64
 // conflict-free (banks = (dword address) mod 64) and both global->LDS copies conflict-free too.
+//
+// Two-level blocking (the read-modify-write of the trailing matrix is what bounds the large fronts, so it
+// is done once per TWO 32-wide panels): the steps of a front come in pairs.
+//   first step of a pair  (k0 / 32 even, another step follows): NARROW update -- only the next panel's block
+//                         column and block row (width nb2) receive this panel's rank-32 update;
+//   second step of a pair (k0 / 32 odd):  the whole trailing matrix receives the rank-(32 + nb) update of both
+//                         panels, 32 columns of K at a time through the same LDS buffers;
+//   first step with nothing to follow:    plain rank-nb update of the whole trailing matrix.
 // Workgroup 0 of every front also moves the factorised diagonal tile of this step from dws into the front
 // and leaves the next diagonal tile to the look-ahead workgroup.
-// Look-ahead: one extra workgroup per front (t == nt * nt, while a next diagonal tile exists) forms the NEXT
+// Look-ahead: one extra workgroup per front (the last one, while a next diagonal tile exists) forms the NEXT
 // diagonal tile  A - L U  from the 32 critical rows / columns with a single wavefront (lane r < 32 owns row r
 // for columns 0..15, lane r + 32 for columns 16..31), factorises it in registers (tile_lu32) and parks it in
 // dws (other buffer) with its row interchanges.  That 32 x 32 LU -- the longest serial piece of a tiled step --
@@ -310,33 +349,43 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int base = k0 + nb, limit = f + base;
     const int nt = (f + UPD_T - 1) / UPD_T;
     const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
+    const bool second = ((k0 / NB) & 1) != 0;                // second step of a pair
+    const bool narrow = !second && nb2 > 0;                  // first step of a pair
+    const int nhalf = second ? 2 : 1;                        // 32-column slices of K
+    const int kfirst = second ? k0 - NB : k0;
+    const int ntiles = narrow ? 2 * nt : nt * nt;
     double *F = pool + fd.off;
-    if (t == nt * nt) {
+    if (t == ntiles) {
         // ---- look-ahead workgroup: only wave 0 works ----
         if (tid >= 64) return;
         const int r = tid & 31, half = tid >> 5; // row, column half (16 columns each)
-        // U block (rows k0.., columns base..base+32) -> LDS, 16 elements per lane
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const int e = tid + 64 * u, kk = e & 31, c = e >> 5;
-            UM[kk][c] = (kk < nb && c < nb2) ? F[(k0 + kk) + (int64_t)(base + c) * ld] : 0.0;
-        }
-        double lrow[NB], acc[16];
-#pragma unroll
-        for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nb) ? F[(base + r) + (int64_t)(k0 + kk) * ld] : 0.0;
+        double acc[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const int cc = half * 16 + c;
             acc[c] = (r < nb2 && cc < nb2) ? F[(base + r) + (int64_t)(base + cc) * ld] : (r == cc ? 1.0 : 0.0);
         }
-        __syncthreads(); // (only wave 0 is left in this workgroup)
+        for (int h = 0; h < nhalf; h++) {
+            const int kh = kfirst + h * NB, nbh = (h == nhalf - 1) ? nb : NB;
+            if (h > 0) __syncthreads();
+            // U block (rows kh.., columns base..base+32) -> LDS, 16 elements per lane
 #pragma unroll
-        for (int kk = 0; kk < NB; kk++) {
-            double u[16];
+            for (int u = 0; u < 16; u++) {
+                const int e = tid + 64 * u, kk = e & 31, c = e >> 5;
+                UM[kk][c] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * ld] : 0.0;
+            }
+            double lrow[NB];
 #pragma unroll
-            for (int c = 0; c < 16; c++) u[c] = UM[kk][half * 16 + c];
+            for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * ld] : 0.0;
+            __syncthreads(); // (only wave 0 is left in this workgroup)
 #pragma unroll
-            for (int c = 0; c < 16; c++) acc[c] -= lrow[kk] * u[c];
+            for (int kk = 0; kk < NB; kk++) {
+                double u[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) u[c] = UM[kk][half * 16 + c];
+#pragma unroll
+                for (int c = 0; c < 16; c++) acc[c] -= lrow[kk] * u[c];
+            }
         }
         // lanes 0..31 collect the other half of their row from lane + 32
         double a2[NB];
@@ -362,53 +411,52 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         }
         return;
     }
-    const int r0 = base + (t % nt) * UPD_T, c0 = base + (t / nt) * UPD_T;
+    // tile of this workgroup; a narrow step has the nt tiles of the block column, then the nt tiles of the block row
+    const bool rowstrip = narrow && t >= nt;
+    const int ti = narrow ? (rowstrip ? 0 : t) : t % nt;
+    const int tj = narrow ? (rowstrip ? t - nt : 0) : t / nt;
+    const int r0 = base + ti * UPD_T, c0 = base + tj * UPD_T;
     if (t == 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];
     }
     if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
-    for (int e = tid; e < NB * UPD_T; e += 256) {
-        int r = e % UPD_T, kk = e / UPD_T;
-        Ls[kk * LS_LD + r] = (r0 + r < limit && kk < nb) ? F[(r0 + r) + (int64_t)(k0 + kk) * ld] : 0.0;
-    }
-    for (int e = tid; e < NB * UPD_T; e += 256) {
-        int kk = e % NB, c = e / NB;
-        Us[c * US_LD + kk] = (c0 + c < limit && kk < nb) ? F[(k0 + kk) + (int64_t)(c0 + c) * ld] : 0.0;
-    }
-    __syncthreads();
+    // entries this step may touch: rows < rmax, columns in [cmin, cmax)
+    const int rmax = rowstrip ? base + nb2 : limit;
+    const int cmax = (narrow && !rowstrip) ? base + nb2 : limit;
+    const int cmin = rowstrip ? base + nb2 : 0;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // the 16 entries of the trailing matrix this lane updates are fetched while the MFMAs run
-    double cur[2][2][4];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                cur[a][b][g] = (r < limit && c < limit && !(r >= f && c >= f)) ? F[r + (int64_t)c * ld] : 0.0;
-            }
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk0 = 0; kk0 < NB; kk0 += 4) {
-        double ua[2], lb[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) ua[a] = Us[(wc + a * 16 + l15) * US_LD + kk0 + l4];
-#pragma unroll
-        for (int b = 0; b < 2; b++) lb[b] = Ls[(kk0 + l4) * LS_LD + wr + b * 16 + l15];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) acc[a][b] = mfma_f64_16x16x4(ua[a], lb[b], acc[a][b]);
+    double lreg[8], ureg[8];
+    // slice h of the two panels: global -> registers, registers -> LDS
+#define HIPMF_FETCH_SLICE(h)                                                                                           \
+    {                                                                                                                  \
+        const int kh = kfirst + (h) * NB, nbh = ((h) == nhalf - 1) ? nb : NB;                                          \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                \
+            const int e = tid + 256 * u;                                                                               \
+            const int r = e % UPD_T, kk = e / UPD_T;                                                                   \
+            lreg[u] = (r0 + r < limit && kk < nbh) ? F[(r0 + r) + (int64_t)(kh + kk) * ld] : 0.0;                      \
+            const int k2 = e % NB, c = e / NB;                                                                         \
+            ureg[u] = (c0 + c < limit && k2 < nbh) ? F[(kh + k2) + (int64_t)(c0 + c) * ld] : 0.0;                      \
+        }                                                                                                              \
     }
+#define HIPMF_STORE_SLICE()                                                                                            \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                \
+            const int e = tid + 256 * u;                                                                               \
+            Ls[(e / UPD_T) * LS_LD + e % UPD_T] = lreg[u];                                                             \
+            Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                                   \
+        }                                                                                                              \
+    }
+    HIPMF_FETCH_SLICE(0)
+    HIPMF_STORE_SLICE()
+    __syncthreads();
+    if (nhalf == 2) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
+    // the 16 entries of the trailing matrix this lane updates are fetched while the MFMAs run
     const bool owner0 = t == 0 && nb2 > 0 && wave == 0; // this wave's block holds the next diagonal tile
+    double cur[2][2][4];
+    bool live[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -417,7 +465,43 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
                 const bool corner = owner0 && (b * 16 + l15) < nb2 && (a * 16 + l4 + 4 * g) < nb2;
-                if (r < limit && c < limit && !(r >= f && c >= f) && !corner) F[r + (int64_t)c * ld] = cur[a][b][g] - acc[a][b][g];
+                live[a][b][g] = r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner;
+                cur[a][b][g] = live[a][b][g] ? F[r + (int64_t)c * ld] : 0.0;
+            }
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int h = 0; h < nhalf; h++) {
+        if (h > 0) {
+            __syncthreads();
+            HIPMF_STORE_SLICE()
+            __syncthreads();
+        }
+#pragma unroll
+        for (int kk0 = 0; kk0 < NB; kk0 += 4) {
+            double ua[2], lb[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++) ua[a] = Us[(wc + a * 16 + l15) * US_LD + kk0 + l4];
+#pragma unroll
+            for (int b = 0; b < 2; b++) lb[b] = Ls[(kk0 + l4) * LS_LD + wr + b * 16 + l15];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc[a][b] = mfma_f64_16x16x4(ua[a], lb[b], acc[a][b]);
+        }
+    }
+#undef HIPMF_FETCH_SLICE
+#undef HIPMF_STORE_SLICE
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
+                if (live[a][b][g]) F[r + (int64_t)c * ld] = cur[a][b][g] - acc[a][b][g];
             }
 }
 

@@ -212,7 +212,9 @@ int32_t Solver::upload_plan() {
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
                 int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T;
-                acc += nt * nt + (S.npiv(big[a]) > k0 + NB ? 1 : 0); // + the look-ahead workgroup
+                const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
+                const bool narrow = follow && ((k0 / NB) & 1) == 0; // first step of a pair: block column + block row only
+                acc += (narrow ? 2 * nt : nt * nt) + (follow ? 1 : 0);
             }
             tasks.push_back((int32_t)acc);
             if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
@@ -230,18 +232,29 @@ int32_t Solver::upload_plan() {
             const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
             for (int32_t c0 = 0; c0 < f; c0 += cstep)
                 for (int32_t r0 = 0; r0 < f; r0 += rstep) {
-                    EaTask tk = {s, c0, std::min(f, c0 + cstep), r0, std::min(f, r0 + rstep), (int32_t)ear.size()};
+                    EaTask tk;
+                    tk.f_off = S.front_off[s];
+                    tk.ld = S.front_ld[s];
+                    tk.piece_begin = (int32_t)ear.size();
+                    tk.pad = 0;
+                    const int32_t c1 = std::min(f, c0 + cstep), r1 = std::min(f, r0 + rstep);
                     for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
                         int32_t ch = S.child_idx[c];
                         const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
                         EaRange rg;
-                        rg.jlo = (int32_t)(std::lower_bound(rb, re, tk.c0) - rb);
-                        rg.jhi = (int32_t)(std::lower_bound(rb, re, tk.c1) - rb);
-                        rg.ilo = (int32_t)(std::lower_bound(rb, re, tk.r0) - rb);
-                        rg.ihi = (int32_t)(std::lower_bound(rb, re, tk.r1) - rb);
+                        rg.jlo = (int32_t)(std::lower_bound(rb, re, c0) - rb);
+                        rg.jhi = (int32_t)(std::lower_bound(rb, re, c1) - rb);
+                        rg.ilo = (int32_t)(std::lower_bound(rb, re, r0) - rb);
+                        rg.ihi = (int32_t)(std::lower_bound(rb, re, r1) - rb);
+                        if (rg.jlo >= rg.jhi || rg.ilo >= rg.ihi) continue;
+                        rg.ldc = S.front_ld[ch];
+                        rg.cb_off = S.front_off[ch] + S.npiv(ch) + (int64_t)S.npiv(ch) * rg.ldc;
+                        rg.rel_off = S.sn_rowptr[ch];
+                        rg.pad = 0;
                         ear.push_back(rg);
                     }
-                    ea.push_back(tk);
+                    tk.piece_end = (int32_t)ear.size();
+                    if (tk.piece_end > tk.piece_begin) ea.push_back(tk);
                 }
         }
         L.ea_cnt = (int32_t)ea.size() - L.ea_off;
@@ -324,7 +337,7 @@ int32_t Solver::run_factor() {
     HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
         if (L.ea_cnt > 0) {
-            hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_fd, d_child, d_rel, d_pool);
+            hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             launches++;
         }
         if (L.small_cnt > 0) {
