@@ -80,8 +80,15 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int v) {
     return lo;
 }
 
-// largest a in [0, n) with pfx[a] <= g  (pfx is an exclusive prefix sum with pfx[n] = total)
+// largest a in [0, n) with pfx[a] <= g  (pfx is an exclusive prefix sum with pfx[n] = total).
+// Called by whole wavefronts (g is workgroup-uniform): up to 64 slots are resolved with ONE load and a ballot
+// instead of log2(n) dependent loads, which sit at the head of every tiled kernel's critical path.
 __device__ __forceinline__ int find_slot(const int32_t *pfx, int n, int g) {
+    if (n <= 64) {
+        const int lane = threadIdx.x & 63;
+        const int v = lane < n ? pfx[lane] : 0x7fffffff;
+        return __popcll(__ballot(v <= g)) - 1;
+    }
     int lo = 0, hi = n;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;

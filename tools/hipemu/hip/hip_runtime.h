@@ -197,6 +197,7 @@ inline T __shfl_down(T v, unsigned delta, int width = 64) {
     if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
     return hipemu_shfl_abs(v, src);
 }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned long long __ballot(int pred) {
     unsigned long long mine = pred ? 1ull : 0ull, all = 0;
     int lin = hipemu::linear_tid(), lane = lin & 63, wave = lin >> 6;
