@@ -5,4 +5,5 @@
 #include "kernels_common.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_solve.hpp"
+#include "kernels_solve_fused.hpp"
 #include "kernels_vector.hpp"

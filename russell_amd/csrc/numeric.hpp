@@ -12,6 +12,7 @@ struct FrontDesc;
 struct EaTask;
 struct EaRange;
 struct SolveTask;
+struct SfTask;
 struct FactorInfo;
 
 // status codes shared with the reference's C shims (/root/reference/russell_sparse/c_code/constants.h:5-12)
@@ -113,6 +114,14 @@ class Solver {
     EaRange *d_ear = nullptr;
     double *d_dws = nullptr; // factorised diagonal tiles of the current tiled step, one per active big front
     SolveTask *d_st = nullptr;
+    // dependency-driven solve (kernels_solve_fused.hpp): one launch per direction
+    SfTask *d_sf = nullptr;
+    int32_t sf_fwd_cnt = 0, sf_bwd_cnt = 0; // forward tasks first, then the backward tasks
+    int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
+    int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
+    bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
+    bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
+    int32_t sf_err[2] = {0, 0};
     FactorInfo *d_info = nullptr;
     unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] |r|_inf bits, [2] omega bits
     double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_den = nullptr, *d_b = nullptr, *d_x = nullptr,

@@ -75,3 +75,27 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned key) {
     }
     return best;
 }
+
+// ---- in-launch hand-off between workgroups (dependency-driven solve kernels) ----
+// The 8 XCDs have private L2s and every CU a private L1, so data exchanged INSIDE a launch is written
+// write-through and read around the L1 with agent-scope (sc1) accesses; flags are agent-scope counters.
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int flag_add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every wave that stored hand-off data drains its stores before the flag is raised (inline asm: the compiler
+// must not drop or move this wait)
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void poll_nap() { __builtin_amdgcn_s_sleep(2); }
+// LDS written by some lanes of a wavefront becomes readable by its other lanes (single-wave phases of
+// multi-wave workgroups: no s_barrier, the wave's LDS operations complete in order)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

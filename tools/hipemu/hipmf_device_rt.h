@@ -50,3 +50,18 @@ inline unsigned __float_as_uint(float f) {
     memcpy(&u, &f, 4);
     return u;
 }
+
+// in-launch hand-off primitives (the emulator runs workgroups one after another in index order, so a
+// dependency is always satisfied before its consumer starts; these keep the protocol's code path alive)
+inline double ld_agent(const double *p) { return *(const volatile double *)p; }
+inline void st_agent(double *p, double v) { *(volatile double *)p = v; }
+inline int flag_load(const int *p) { return *(const volatile int *)p; }
+inline int flag_add(int *p, int v) {
+    int o = *p;
+    *p = o + v;
+    return o;
+}
+inline void flag_store(int *p, int v) { *(volatile int *)p = v; }
+inline void drain_stores() {}
+inline void poll_nap() {}
+inline void wave_sync() { hipemu::sync_wave(); }
