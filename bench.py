@@ -150,7 +150,9 @@ def main():
                                    "with values and rhs resident in HBM" % (args.grid, args.grid, n, int(rp[-1])),
                        "rhs_per_gpu": 1, "refinement_steps": st["refinement_steps"]},
             "sptrsv_gbs": round(achieved, 1),
-            "roofline": {"kernel": "level-set SpTRSV pass (k_fwd + k_bwd over %d levels, %d launches)" % (st["nlevels"], st["solve_launches"]),
+            "roofline": {"kernel": "multifrontal SpTRSV pass, forward + backward (%s, %d launches over %d tree levels)" %
+                                   ("dependency-driven k_fwd_fused + k_bwd_fused" if st["solve_launches"] <= 4 else "level-set k_fwd/k_bwd[_big]",
+                                    st["solve_launches"], st["nlevels"]),
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4)},

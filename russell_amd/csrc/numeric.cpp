@@ -317,9 +317,31 @@ int32_t Solver::upload_plan() {
                 sf.push_back(t);
             }
         };
-        for (int32_t l = 0; l < S.nlevels; l++) emit_level(l, true);
+        // the all-small band at the bottom of the tree (levels below the first one with a big front) runs in a lean
+        // instance of the kernels (fewer registers, more wavefronts per CU); it holds most of the tasks
+        int32_t band = 0;
+        while (band < S.nlevels) {
+            bool all_small = true;
+            for (int32_t k = S.level_ptr[band]; k < S.level_ptr[band + 1] && all_small; k++) all_small = S.fsize(S.level_sn[k]) <= SMALL_F;
+            if (!all_small) break;
+            band++;
+        }
+        int32_t fwd_limit = S.nlevels; // profiling knob: run the forward pass up to this level only (the result is then meaningless)
+        if (const char *e = getenv("HIPMF_SF_FWD_LEVELS")) fwd_limit = std::max(1, std::min(S.nlevels, atoi(e)));
+        sf_fwd_launch = 0;
+        sf_fwd_band = 0;
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            emit_level(l, true);
+            if (l + 1 == band) sf_fwd_band = (int32_t)sf.size();
+            if (l + 1 == fwd_limit) sf_fwd_launch = (int32_t)sf.size();
+        }
         sf_fwd_cnt = (int32_t)sf.size();
-        for (int32_t l = S.nlevels - 1; l >= 0; l--) emit_level(l, false);
+        sf_bwd_top = 0;
+        for (int32_t l = S.nlevels - 1; l >= 0; l--) {
+            if (l + 1 == band) sf_bwd_top = (int32_t)sf.size() - sf_fwd_cnt;
+            emit_level(l, false);
+        }
+        if (band == 0) sf_bwd_top = (int32_t)sf.size() - sf_fwd_cnt;
         sf_bwd_cnt = (int32_t)sf.size() - sf_fwd_cnt;
         HIPC(dev_upload(&d_sf, sf), ERROR_HIP_MALLOC);
         HIPC(dev_upload(&d_need, need), ERROR_HIP_MALLOC);
@@ -424,13 +446,23 @@ int32_t Solver::run_triangular(double *xp) {
         int32_t *sync_f = d_sync, *sync_b = d_sync + SF_SYNC_HEADER + ns, *sync_err = d_sync + 2 * (SF_SYNC_HEADER + ns);
         HIPC(hipMemsetAsync(d_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), STREAM), ERROR_HIP_MEMCPY);
         HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
-        hipLaunchKernelGGL(k_fwd_fused, dim3(sf_fwd_cnt), dim3(256), 0, STREAM, d_sf, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f,
-                           sync_err, d_work, xp);
+        const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
+        if (fa > 0)
+            hipLaunchKernelGGL(k_fwd_fused<true>, dim3(fa), dim3(256), 0, STREAM, d_sf, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f,
+                               sync_err, d_work, xp);
+        if (fb > 0)
+            hipLaunchKernelGGL(k_fwd_fused<false>, dim3(fb), dim3(256), 0, STREAM, d_sf + fa, d_fd, d_pool, d_lperm, d_child, d_rel, d_need,
+                               sync_f, sync_err, d_work, xp);
         HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
-        hipLaunchKernelGGL(k_bwd_fused, dim3(sf_bwd_cnt), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt, d_fd, d_pool, d_rows, d_need + ns, sync_b,
-                           sync_err, d_work, xp);
+        const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
+        if (bt > 0)
+            hipLaunchKernelGGL(k_bwd_fused<false>, dim3(bt), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt, d_fd, d_pool, d_rows, d_need + ns, sync_b,
+                               sync_err, d_work, xp);
+        if (bb > 0)
+            hipLaunchKernelGGL(k_bwd_fused<true>, dim3(bb), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt + bt, d_fd, d_pool, d_rows, d_need + ns,
+                               sync_b, sync_err, d_work, xp);
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
-        times.n_kernel_launches_solve = 2;
+        times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
         tri_pending = true;
         return SUCCESSFUL_EXIT;
     }

@@ -117,6 +117,8 @@ class Solver {
     // dependency-driven solve (kernels_solve_fused.hpp): one launch per direction
     SfTask *d_sf = nullptr;
     int32_t sf_fwd_cnt = 0, sf_bwd_cnt = 0; // forward tasks first, then the backward tasks
+    int32_t sf_fwd_band = 0, sf_bwd_top = 0; // tasks of the all-small bottom band (forward: first; backward: after sf_bwd_top)
+    int32_t sf_fwd_launch = 0;              // == sf_fwd_cnt unless the profiling knob HIPMF_SF_FWD_LEVELS cuts the pass short
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)

@@ -1,0 +1,71 @@
+"""Dependency-driven triangular solves (kernels_solve_fused.hpp, one launch per direction) against the
+level-set launches (kernels_solve.hpp): same factor, same right-hand side.  With identical slab shapes
+(HIPMF_SOLVE_SLAB64=1) the two paths add the same numbers in the same order, so a stale or torn hand-off
+between workgroups shows up as a bit difference; the test repeats the solve to catch intermittent ones."""
+import os
+
+import numpy as np
+import pytest
+
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(n, rp, ci, v, b, fused, slab64, reps=1, nrefine=0):
+    old = {k: os.environ.get(k) for k in ("HIPMF_FUSED_SOLVE", "HIPMF_SOLVE_SLAB64")}
+    os.environ["HIPMF_FUSED_SOLVE"] = "1" if fused else "0"
+    os.environ["HIPMF_SOLVE_SLAB64"] = "1" if slab64 else "0"
+    try:
+        s = Hipmf()
+        assert s.initialize(n, rp, ci, refinement_nstep=nrefine) == 0
+        assert s.factorize(v) == 0
+        outs = []
+        for _ in range(reps):
+            outs.append(s.solve(b))
+        st = s.stats()
+        s.close()
+        return outs, st
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+@pytest.mark.parametrize("grid", [37, 300, 1000])
+def test_fused_equals_level_set_bitwise(grid):
+    n, rp, ci, v = P.poisson2d(grid)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    (ref,), st_l = _solve(n, rp, ci, v, b, fused=False, slab64=True)
+    outs, st_f = _solve(n, rp, ci, v, b, fused=True, slab64=True, reps=8)
+    assert st_f["solve_launches"] <= 4 < st_l["solve_launches"] or grid < 64
+    for x in outs:
+        assert np.array_equal(ref, x)
+    assert np.max(np.abs(ref - xs)) < 1e-9
+
+
+def test_fused_default_slabs_unsymmetric():
+    # convection-diffusion (unsymmetric values, row interchanges inside the pivot blocks), default slab shapes
+    n, rp, ci, v = P.convection_diffusion2d(160, peclet=30.0, scale_decades=0.0)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    (ref,), _ = _solve(n, rp, ci, v, b, fused=False, slab64=False, nrefine=2)
+    outs, _ = _solve(n, rp, ci, v, b, fused=True, slab64=False, reps=4, nrefine=2)
+    for x in outs:
+        assert np.array_equal(outs[0], x)  # run-to-run reproducible
+        assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-10
+    assert np.max(np.abs(outs[0] - ref)) / np.max(np.abs(xs)) < 1e-12
+
+
+def test_fused_poisson3d():
+    n, rp, ci, v = P.poisson3d(22)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    (ref,), _ = _solve(n, rp, ci, v, b, fused=False, slab64=True)
+    outs, _ = _solve(n, rp, ci, v, b, fused=True, slab64=True, reps=4)
+    for x in outs:
+        assert np.array_equal(ref, x)

@@ -48,6 +48,6 @@ if __name__ == "__main__":
     fd, _, st_d, _ = run(grid, True, False, reps)
     print("fused(default slabs): max err %.2e, all runs identical: %s" %
           (max(np.max(np.abs(x - xs)) for x in fd), all(np.array_equal(fd[0], x) for x in fd)))
-    print("sptrsv ms: level %.4f fused64 %.4f fused %.4f" % tuple(
-        (st["acc_fwd_ms"] + st["acc_bwd_ms"]) / max(st["acc_tri_count"], 1) for st in (st_l, st_f, st_d)))
+    print("sptrsv ms (fwd + bwd): level %.4f + %.4f, fused64 %.4f + %.4f, fused %.4f + %.4f" % tuple(
+        v for st in (st_l, st_f, st_d) for v in (st["acc_fwd_ms"] / max(st["acc_tri_count"], 1), st["acc_bwd_ms"] / max(st["acc_tri_count"], 1))))
     sys.exit(1 if bad else 0)
