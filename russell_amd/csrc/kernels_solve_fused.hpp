@@ -229,7 +229,7 @@ template <bool SMALL_ONLY>
 __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
-                                                   const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x) {
+                                                   const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int warm) {
     __shared__ double wv[4][64];
     __shared__ double wc[SMALL_ONLY ? 1 : SF_CHUNK];
     __shared__ double wsl[SOLVE_SLAB];
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
                 const int ch = child_idx[fd.child_begin + c0 + lane];
                 sf_wait(done + ch, need[ch], err);
             }
-    } else if (r < r1) {
+    } else if (warm && r < r1) {
         sink = sf_warm(E + r, ld, g, jmax, G);
         if (wave == 1) sink += sf_warm(E + r, ld, g - (G >> 2), jmax, G); // the polling wave's columns
     }
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
 template <bool SMALL_ONLY>
 __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
-                                                   const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x) {
+                                                   const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int warm) {
     __shared__ double wv[4][64];
     __shared__ double wc[SMALL_ONLY ? 1 : SF_CHUNK];
     __shared__ double red[256];
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
     double sink = 0.0;
     if (wave == 0) {
         if (fd.parent >= 0 && tid == 0) sf_wait(done + fd.parent, need[fd.parent], err);
-    } else if (i < r1) {
+    } else if (warm && i < r1) {
         sink = sf_warm(Ep + i, ld, jmin + g, f, G);
         if (wave == 1) sink += sf_warm(Ep + i, ld, jmin + g - (G >> 2), f, G); // the polling wave's columns
     }

@@ -95,6 +95,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     }
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_SF_WARM")) sf_warm_flag = atoi(e) != 0;
     int rc = analyse(n, rp, ci, sym_lower, so, S);
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
@@ -449,18 +450,18 @@ int32_t Solver::run_triangular(double *xp) {
         const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
         if (fa > 0)
             hipLaunchKernelGGL(k_fwd_fused<true>, dim3(fa), dim3(256), 0, STREAM, d_sf, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f,
-                               sync_err, d_work, xp);
+                               sync_err, d_work, xp, sf_warm_flag);
         if (fb > 0)
             hipLaunchKernelGGL(k_fwd_fused<false>, dim3(fb), dim3(256), 0, STREAM, d_sf + fa, d_fd, d_pool, d_lperm, d_child, d_rel, d_need,
-                               sync_f, sync_err, d_work, xp);
+                               sync_f, sync_err, d_work, xp, sf_warm_flag);
         HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
         const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
         if (bt > 0)
             hipLaunchKernelGGL(k_bwd_fused<false>, dim3(bt), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt, d_fd, d_pool, d_rows, d_need + ns, sync_b,
-                               sync_err, d_work, xp);
+                               sync_err, d_work, xp, sf_warm_flag);
         if (bb > 0)
             hipLaunchKernelGGL(k_bwd_fused<true>, dim3(bb), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt + bt, d_fd, d_pool, d_rows, d_need + ns,
-                               sync_b, sync_err, d_work, xp);
+                               sync_b, sync_err, d_work, xp, sf_warm_flag);
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
         times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
         tri_pending = true;
