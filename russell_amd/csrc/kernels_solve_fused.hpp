@@ -27,12 +27,11 @@ namespace hipmf {
 
 constexpr int SF_SYNC_HEADER = 16;       // ints in front of the completion counters (reserved)
 constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
-constexpr int SF_NK = 2, SF_NE = 4;      // children per batch and entries per thread and child in the big fronts' child sweep
 constexpr int SF_CHUNK = 1024;           // doubles of the big fronts' vectors staged in LDS at a time
 
 struct SfTask {
     int32_t kind;       // 0: group of small fronts, one per wavefront (a, b, c, d; -1 = none)
-                        // 4, 5, 6: slab of a big front, kind = log2(rows per slab): a = front, rows [b, c)
+                        // 3..7: slab of a big front, kind = log2(rows per slab): a = front, rows [b, c)
     int32_t a, b, c, d;
     int32_t pad;
 };
@@ -177,7 +176,8 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double *xg, const 
 }
 
 // Strided dot product against an LDS vector chunk: acc += sum_j col[j * ld] * w[j - c0], j = j0, j0 + step, ... < j1.
-// Sixteen loads are in flight per lane (then eight, then one by one); the order of the additions is the one of
+// Sixteen unconditional loads are in flight per lane (then eight, then the last partial group of eight predicated:
+// a loop of predicated loads compiles to a wait per load); the order of the additions is the one of
 // kernels_solve.hpp's strided_dot: even positions into acc0, odd ones into acc1, the tail into acc0.
 __device__ __forceinline__ void sf_dot(double &acc0, double &acc1, const double *__restrict__ col, int64_t ld, const double *w, int c0, int j0,
                                        int j1, int step) {
@@ -204,7 +204,86 @@ __device__ __forceinline__ void sf_dot(double &acc0, double &acc1, const double 
             acc1 += e[u + 1] * w[j + (u + 1) * step - c0];
         }
     }
-    for (; j < j1; j += step) acc0 += col[(int64_t)j * ld] * w[j - c0];
+    // the last (partial) group of eight: all its loads at once (addresses clamped, not predicated), the additions in
+    // the same order (into acc0)
+    if (j < j1) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int jj = j + u * step < j1 ? j + u * step : j;
+            e[u] = col[(int64_t)jj * ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (j + u * step < j1) acc0 += e[u] * w[j + u * step - c0];
+    }
+}
+
+// The children's update vectors are added into the LDS copy of w1 (chunk [c0, c1)) and, on the first chunk, into the
+// slab's own rows wsl: NK children at a time, NE entries per thread and child fetched together (one round trip),
+// then added child by child in ascending order (the order fixes the floating-point sums).  Longer children finish
+// in a plain loop.
+template <int NK, int NE>
+__device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int64_t *cd_woff, const int64_t *cd_rel, const int32_t *cd_m,
+                                            const FrontDesc &fd, const FrontDesc *__restrict__ FD, const int32_t *__restrict__ child_idx,
+                                            const int32_t *__restrict__ rel, const double *work, double *wc, double *wsl, int c0, int c1, int p,
+                                            int r0, int r1) {
+    for (int cb = 0; cb < nch; cb += NK) {
+        int qv[NK][NE];
+        double uv[NK][NE];
+        int cm[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int c = cb + k;
+            cm[k] = 0;
+            if (c < nch) {
+                int64_t woff, relo;
+                if (c < ncd) {
+                    woff = cd_woff[c], relo = cd_rel[c], cm[k] = cd_m[c];
+                } else {
+                    const FrontDesc cd = FD[child_idx[fd.child_begin + c]];
+                    woff = cd.woff + cd.p, relo = cd.rowptr, cm[k] = cd.m;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const int i = tid + 256 * e;
+                    qv[k][e] = -1;
+                    if (i < cm[k]) {
+                        qv[k][e] = rel[relo + i];
+                        uv[k][e] = ld_agent(work + woff + i);
+                    }
+                }
+                if (cm[k] > 256 * NE) cm[k] = -cm[k]; // the rest of this child's list goes through the plain loop below
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            if (cb + k < nch) { // workgroup-uniform
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const int q = qv[k][e];
+                    if (q >= c0 && q < c1) wc[q - c0] += uv[k][e];
+                    else if (c0 == 0 && q >= p && q >= r0 && q < r1) wsl[q - r0] += uv[k][e];
+                }
+                if (cm[k] < 0) {
+                    const int c = cb + k;
+                    int64_t woff, relo;
+                    if (c < ncd) {
+                        woff = cd_woff[c], relo = cd_rel[c];
+                    } else {
+                        const FrontDesc cd = FD[child_idx[fd.child_begin + c]];
+                        woff = cd.woff + cd.p, relo = cd.rowptr;
+                    }
+                    for (int i = tid + 256 * NE; i < -cm[k]; i += 256) {
+                        const int q = rel[relo + i];
+                        if (q >= c0 && q < c1) wc[q - c0] += ld_agent(work + woff + i);
+                        else if (c0 == 0 && q >= p && q >= r0 && q < r1) wsl[q - r0] += ld_agent(work + woff + i);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
 }
 
 // Pulls the panel entries a thread is going to multiply into the XCD's L2 while the workgroup would otherwise only
@@ -229,13 +308,14 @@ template <bool SMALL_ONLY>
 __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
-                                                   const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int warm) {
+                                                   const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int warm, unsigned long long *trace) {
     __shared__ double wv[4][64];
     __shared__ double wc[SMALL_ONLY ? 1 : SF_CHUNK];
-    __shared__ double wsl[SOLVE_SLAB];
+    __shared__ double wsl[128];
     __shared__ double red[256];
     __shared__ int64_t cd_woff[SMALL_ONLY ? 1 : 64], cd_rel[SMALL_ONLY ? 1 : 64];
     __shared__ int32_t cd_m[SMALL_ONLY ? 1 : 64];
+    __shared__ int32_t cm_max_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *done = sync + SF_SYNC_HEADER;
     const SfTask t = tasks[blockIdx.x];
@@ -247,6 +327,8 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     }
     if (SMALL_ONLY) return; // (never reached: the small-only instance is launched on all-small bands)
     // ---- slab [r0, r1) of the big front t.a:  [y1; -delta] = E w1,  work[r] = y1[r] (r < p) or w2[r] + (E w1)[r] ----
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
     const int64_t ld = fd.ld;
@@ -255,7 +337,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     const int r0 = t.b, r1 = t.c, sh = t.kind;
     const int rr = tid & ((1 << sh) - 1), g = tid >> sh, G = 256 >> sh;
     const int r = r0 + rr;
-    if (tid < SOLVE_SLAB) wsl[tid] = 0.0;
+    if (tid < 128) wsl[tid] = 0.0;
     // rows of inv(L11) P are zero right of their own 32-column block
     int jmax = p;
     if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
@@ -268,12 +350,19 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     for (int i = tid; i < (jmax < SF_CHUNK ? jmax : SF_CHUNK); i += 256) wc[i] = ld_agent(x + fd.first + i);
     double sink = 0.0;
     if (wave == 0) {
+        int mym = 0;
         if (lane < ncd) {
             const int ch = child_idx[fd.child_begin + lane];
             const FrontDesc cd = FD[ch];
             cd_woff[lane] = cd.woff + cd.p;
             cd_rel[lane] = cd.rowptr;
             cd_m[lane] = cd.m;
+            mym = cd.m;
+        }
+        const int mx = (int)wave_max_u32((unsigned)mym);
+        if (lane == 0) cm_max_s = nch > 64 ? 0x7fffffff : mx;
+        if (lane < ncd) {
+            const int ch = child_idx[fd.child_begin + lane];
             sf_wait(done + ch, need[ch], err);
         }
         for (int c0 = 64; c0 < nch; c0 += 64)
@@ -287,7 +376,9 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     }
     if (sink == 1.2345e300) wsl[0] = sink; // never true: keeps the warm-up loads alive
     __syncthreads();
+    if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
+    const int cm_max = cm_max_s;
     double acc0 = 0.0, acc1 = 0.0;
     for (int c0 = 0; c0 < jmax; c0 += SF_CHUNK) {
         const int c1 = c0 + SF_CHUNK < jmax ? c0 + SF_CHUNK : jmax;
@@ -296,66 +387,8 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
             for (int i = c0 + tid; i < c1; i += 256) wc[i - c0] = ld_agent(x + fd.first + i);
             __syncthreads();
         }
-        for (int cb = 0; cb < nch; cb += SF_NK) {
-            // SF_NK children at a time: their entries (SF_NE per thread and child) are fetched together, then
-            // added child by child; longer children finish in a plain loop
-            int qv[SF_NK][SF_NE];
-            double uv[SF_NK][SF_NE];
-            int cm[SF_NK];
-#pragma unroll
-            for (int k = 0; k < SF_NK; k++) {
-                const int c = cb + k;
-                cm[k] = 0;
-                if (c < nch) {
-                    int64_t woff, relo;
-                    if (c < ncd) {
-                        woff = cd_woff[c], relo = cd_rel[c], cm[k] = cd_m[c];
-                    } else {
-                        const FrontDesc cd = FD[child_idx[fd.child_begin + c]];
-                        woff = cd.woff + cd.p, relo = cd.rowptr, cm[k] = cd.m;
-                    }
-#pragma unroll
-                    for (int e = 0; e < SF_NE; e++) {
-                        const int i = tid + 256 * e;
-                        qv[k][e] = -1;
-                        if (i < cm[k]) {
-                            qv[k][e] = rel[relo + i];
-                            uv[k][e] = ld_agent(work + woff + i);
-                        }
-                    }
-                    if (cm[k] > 256 * SF_NE) { // rare: spill the rest of this child's list into the generic loop below
-                        cm[k] = -cm[k];
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < SF_NK; k++) {
-                if (cb + k < nch) { // workgroup-uniform
-#pragma unroll
-                    for (int e = 0; e < SF_NE; e++) {
-                        const int q = qv[k][e];
-                        if (q >= c0 && q < c1) wc[q - c0] += uv[k][e];
-                        else if (c0 == 0 && q >= p && q >= r0 && q < r1) wsl[q - r0] += uv[k][e];
-                    }
-                    if (cm[k] < 0) {
-                        const int c = cb + k;
-                        int64_t woff, relo;
-                        if (c < ncd) {
-                            woff = cd_woff[c], relo = cd_rel[c];
-                        } else {
-                            const FrontDesc cd = FD[child_idx[fd.child_begin + c]];
-                            woff = cd.woff + cd.p, relo = cd.rowptr;
-                        }
-                        for (int i = tid + 256 * SF_NE; i < -cm[k]; i += 256) {
-                            const int q = rel[relo + i];
-                            if (q >= c0 && q < c1) wc[q - c0] += ld_agent(work + woff + i);
-                            else if (c0 == 0 && q >= p && q >= r0 && q < r1) wsl[q - r0] += ld_agent(work + woff + i);
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-        }
+        if (cm_max <= 256) sf_children<8, 1>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, wsl, c0, c1, p, r0, r1);
+        else sf_children<2, 4>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, wsl, c0, c1, p, r0, r1);
         if (nch == 0) __syncthreads();
         // the group's columns of this chunk: g, g + G, ... continue across chunks (SF_CHUNK is a multiple of every G)
         if (r < r1) sf_dot(acc0, acc1, E + r, ld, wc, c0, c0 + g, c1, G);
@@ -365,25 +398,30 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     __syncthreads();
     if (g == 0 && r < r1) {
         // pairwise sum over the G column groups in a fixed order
-        double tsum[16];
+        double tsum[32];
 #pragma unroll
-        for (int q = 0; q < 16; q++) tsum[q] = (q < G) ? red[q * (1 << sh) + rr] : 0.0;
+        for (int q = 0; q < 32; q++) tsum[q] = (q < G) ? red[q * (1 << sh) + rr] : 0.0;
 #pragma unroll
-        for (int wdt = 1; wdt < 16; wdt <<= 1)
+        for (int wdt = 1; wdt < 32; wdt <<= 1)
 #pragma unroll
-            for (int q = 0; q + wdt < 16; q += 2 * wdt) tsum[q] += tsum[q + wdt];
+            for (int q = 0; q + wdt < 32; q += 2 * wdt) tsum[q] += tsum[q + wdt];
         st_agent(W + r, (r < p) ? tsum[0] : wsl[rr] + tsum[0]);
     }
+    if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();
     __syncthreads();
     if (tid == 0) flag_add(done + t.a, 1);
+    if (trace && tid == 0) {
+        unsigned long long *tr = trace + 4 * (size_t)blockIdx.x;
+        tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock();
+    }
 }
 
 // Backward pass, one launch (tasks ordered root first).
 template <bool SMALL_ONLY>
 __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
-                                                   const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int warm) {
+                                                   const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int warm, unsigned long long *trace) {
     __shared__ double wv[4][64];
     __shared__ double wc[SMALL_ONLY ? 1 : SF_CHUNK];
     __shared__ double red[256];
@@ -397,6 +435,8 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
     }
     if (SMALL_ONLY) return;
     // ---- pivot rows [r0, r1) of the big front t.a:  x1 = E' [y1; x2] ----
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
     const int64_t ld = fd.ld;
@@ -429,6 +469,7 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
     }
     if (sink == 1.2345e300) red[0] = sink; // never true: keeps the warm-up loads alive
     __syncthreads();
+    if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -447,18 +488,23 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
     red[g * (1 << sh) + rr] = acc0 + acc1;
     __syncthreads();
     if (g == 0 && i < r1) {
-        double tsum[16];
+        double tsum[32];
 #pragma unroll
-        for (int q = 0; q < 16; q++) tsum[q] = (q < G) ? red[q * (1 << sh) + rr] : 0.0;
+        for (int q = 0; q < 32; q++) tsum[q] = (q < G) ? red[q * (1 << sh) + rr] : 0.0;
 #pragma unroll
-        for (int wdt = 1; wdt < 16; wdt <<= 1)
+        for (int wdt = 1; wdt < 32; wdt <<= 1)
 #pragma unroll
-            for (int q = 0; q + wdt < 16; q += 2 * wdt) tsum[q] += tsum[q + wdt];
+            for (int q = 0; q + wdt < 32; q += 2 * wdt) tsum[q] += tsum[q + wdt];
         st_agent(x + fd.first + i, tsum[0]);
     }
+    if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();
     __syncthreads();
     if (tid == 0) flag_add(done + t.a, 1);
+    if (trace && tid == 0) {
+        unsigned long long *tr = trace + 4 * (size_t)blockIdx.x;
+        tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock();
+    }
 }
 
 } // namespace hipmf

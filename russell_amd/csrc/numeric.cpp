@@ -44,13 +44,13 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+    void *ptrs[] = {d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d_dws = nullptr, d_ear = nullptr;
-    d_sf = nullptr, d_need = nullptr, d_sync = nullptr;
+    d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
@@ -297,7 +297,12 @@ int32_t Solver::upload_plan() {
     {
         std::vector<SfTask> sf;
         std::vector<int32_t> need((size_t)2 * ns, 1);
-        auto kind_of = [&](int32_t s) { return slab64 ? 6 : (S.npiv(s) >= 512 ? 4 : (S.npiv(s) >= 128 ? 5 : 6)); };
+        // rows per slab by the length of the dot products (forward: p columns, backward: f columns): long ones get
+        // narrow slabs, i.e. more column groups per workgroup and more workgroups per front
+        auto kind_of = [&](int32_t s, bool forward) {
+            const int32_t len = forward ? S.npiv(s) : S.fsize(s);
+            return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
+        };
         auto emit_level = [&](int32_t l, bool forward) {
             std::vector<int32_t> small;
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
@@ -306,7 +311,7 @@ int32_t Solver::upload_plan() {
                     small.push_back(s);
                     continue;
                 }
-                const int32_t kind = kind_of(s), rows = 1 << kind, ext = forward ? S.fsize(s) : S.npiv(s);
+                const int32_t kind = kind_of(s, forward), rows = 1 << kind, ext = forward ? S.fsize(s) : S.npiv(s);
                 need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows;
                 for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), 0, 0});
             }
@@ -344,6 +349,13 @@ int32_t Solver::upload_plan() {
         }
         if (band == 0) sf_bwd_top = (int32_t)sf.size() - sf_fwd_cnt;
         sf_bwd_cnt = (int32_t)sf.size() - sf_fwd_cnt;
+        if (getenv("HIPMF_SF_TRACE")) { // profiling aid: four device-clock stamps per task of the upper (mixed) launches
+            const size_t ntr = (size_t)(sf_fwd_cnt - sf_fwd_band) + (size_t)sf_bwd_top;
+            HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 4 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
+            HIPC(hipMemset(d_trace, 0, sizeof(unsigned long long) * 4 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
+            sf_host.clear();
+            for (const SfTask &t : sf) sf_host.push_back(t.kind), sf_host.push_back(t.a);
+        }
         HIPC(dev_upload(&d_sf, sf), ERROR_HIP_MALLOC);
         HIPC(dev_upload(&d_need, need), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
@@ -450,18 +462,18 @@ int32_t Solver::run_triangular(double *xp) {
         const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
         if (fa > 0)
             hipLaunchKernelGGL(k_fwd_fused<true>, dim3(fa), dim3(256), 0, STREAM, d_sf, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f,
-                               sync_err, d_work, xp, sf_warm_flag);
+                               sync_err, d_work, xp, sf_warm_flag, (unsigned long long *)nullptr);
         if (fb > 0)
             hipLaunchKernelGGL(k_fwd_fused<false>, dim3(fb), dim3(256), 0, STREAM, d_sf + fa, d_fd, d_pool, d_lperm, d_child, d_rel, d_need,
-                               sync_f, sync_err, d_work, xp, sf_warm_flag);
+                               sync_f, sync_err, d_work, xp, sf_warm_flag, d_trace);
         HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
         const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
         if (bt > 0)
             hipLaunchKernelGGL(k_bwd_fused<false>, dim3(bt), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt, d_fd, d_pool, d_rows, d_need + ns, sync_b,
-                               sync_err, d_work, xp, sf_warm_flag);
+                               sync_err, d_work, xp, sf_warm_flag, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
         if (bb > 0)
             hipLaunchKernelGGL(k_bwd_fused<true>, dim3(bb), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt + bt, d_fd, d_pool, d_rows, d_need + ns,
-                               sync_b, sync_err, d_work, xp, sf_warm_flag);
+                               sync_b, sync_err, d_work, xp, sf_warm_flag, (unsigned long long *)nullptr);
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
         times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
         tri_pending = true;
@@ -585,6 +597,21 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
     harvest_tri();
+    if (use_fused && d_trace) {
+        // dump: one line per task of the two upper launches: direction, level, front, kind, p, f, four stamps (10 ns units)
+        const size_t nf = (size_t)(sf_fwd_launch - std::min(sf_fwd_band, sf_fwd_launch)), nb = (size_t)sf_bwd_top;
+        std::vector<unsigned long long> tr(4 * (nf + nb));
+        (void)hipMemcpy(tr.data(), d_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost);
+        if (FILE *fp = fopen(getenv("HIPMF_SF_TRACE"), "w")) {
+            for (size_t k = 0; k < nf + nb; k++) {
+                const size_t ti = k < nf ? (size_t)sf_fwd_band + k : (size_t)sf_fwd_cnt + (k - nf);
+                const int32_t kind = sf_host[2 * ti], a = sf_host[2 * ti + 1];
+                fprintf(fp, "%c %d %d %d %d %d %llu %llu %llu %llu\n", k < nf ? 'F' : 'B', S.sn_level[a], a, kind, S.npiv(a), S.fsize(a),
+                        tr[4 * k], tr[4 * k + 1], tr[4 * k + 2], tr[4 * k + 3]);
+            }
+            fclose(fp);
+        }
+    }
     if (use_fused && sf_err[0] != 0) {
         // a hand-off wait timed out (never expected): the result is not trusted; redo with the level-set launches
         use_fused = false;

@@ -124,6 +124,8 @@ class Solver {
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
+    unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
+    std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
     int32_t sf_warm_flag = 0;               // HIPMF_SF_WARM=1: waiting workgroups pre-touch their panel (tuning knob; measured slower:
                                             // 0.674 vs 0.628 ms per pass pair and +35 % fetched bytes on the 1M-DOF Poisson factor)
     FactorInfo *d_info = nullptr;

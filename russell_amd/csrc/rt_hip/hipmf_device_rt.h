@@ -99,3 +99,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// constant-rate device clock (100 MHz), for the optional per-task trace of the dependency-driven solve
+__device__ __forceinline__ unsigned long long dev_clock() { return wall_clock64(); }

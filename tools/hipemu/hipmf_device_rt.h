@@ -65,3 +65,4 @@ inline void flag_store(int *p, int v) { *(volatile int *)p = v; }
 inline void drain_stores() {}
 inline void poll_nap() {}
 inline void wave_sync() { hipemu::sync_wave(); }
+inline unsigned long long dev_clock() { return 0; }
