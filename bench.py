@@ -32,6 +32,17 @@ def sptrsv_bytes(st, n, k=1):
     return (st["nnz_l"] + st["nnz_u"]) * 12 + 2 * (n + 1) * 4 + k * n * 8 * 4
 
 
+def measured_traffic(grid):
+    """HBM bytes per SpTRSV pass from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed
+    loop; the counters were collected with this same command on the same workload, see profiles/r01_v6_pmc_hbm.txt)."""
+    path = os.path.join(ROOT, "profiles", "r01_sptrsv_traffic.json")
+    if grid != 1000 or not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        t = json.load(fh)
+    return t["traffic_bytes_per_pass"], t["source"]
+
+
 def cpu_baseline(n, rp, ci, v, b, perm):
     """The CPU oracle (kind 'port') timed on this box's host cores, single thread, same matrix/ordering."""
     import oracle_lib as O
@@ -130,6 +141,7 @@ def main():
         tri = max(st["acc_tri_count"], 1.0)
         tri_ms = (st["acc_fwd_ms"] + st["acc_bwd_ms"]) / tri
         bytes_alg = sptrsv_bytes(st, n)
+        traffic, traffic_src = measured_traffic(args.grid)
         achieved = bytes_alg / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
         fact_ms = st["acc_factor_ms"] / max(st["acc_factor_count"], 1.0)
         asm_ms = st["acc_assemble_ms"] / max(st["acc_factor_count"], 1.0)
@@ -154,7 +166,7 @@ def main():
                                    ("dependency-driven k_fwd_fused + k_bwd_fused" if st["solve_launches"] <= 4 else "level-set k_fwd/k_bwd[_big]",
                                     st["solve_launches"], st["nlevels"]),
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4)},
             "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_diag, k_panel, k_update MFMA f64)",
                                 "bound": "mfma", "achieved": round(st["flops"] / (fact_ms * 1e-3) / 1e12, 3) if fact_ms > 0 else 0.0,
