@@ -75,7 +75,11 @@ void solver_hipmf_drop(struct InterfaceHIPMF *solver);
 /* Phase 1 (once): ordering + symbolic analysis on the host, device allocation, structure upload.
  * pivot_epsilon < 0 and refinement_nstep < 0 select the defaults (1e-13 relative, 2 steps).
  * general_symmetric: the CSR holds the LOWER triangle of a symmetric matrix (Sym::YesLower).
- * values may be NULL (they are not needed before solver_hipmf_factorize). */
+ * values may be NULL.  When given (the reference hands the numbers to the analysis phase as well:
+ * umfpack_di_symbolic(Ap, Ai, Ax) at interface_umfpack.c:109, cudssExecute(ANALYSIS) at interface_cudss.cu:361)
+ * and the diagonal is weak (missing, zero or < 1 % of the row's largest entry somewhere), general-storage matrices
+ * get a maximum-product matching + row/column scaling pre-permutation, which stays in force for every later
+ * factorisation with this handle. */
 int32_t solver_hipmf_initialize(struct InterfaceHIPMF *solver,
                                 int32_t ordering,
                                 int32_t scaling,
@@ -121,6 +125,13 @@ int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *solver, double *v, doubl
 
 /* perm[new] = old: the fill-reducing permutation applied to rows and columns (ndim entries) */
 int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *solver, int32_t *perm);
+
+/* Host-only helper (no device needed): the maximum-product matching + scaling of an n x n CSR matrix that
+ * solver_hipmf_initialize applies to weak-diagonal matrices.  matched_row[j] = row matched to column j;
+ * |row_scale[i] * a_ij * col_scale[j]| <= 1 with equality on the matched entries.  Returns 0, or
+ * ERROR_HIPMF_INVALID_MATRIX when the matrix is structurally singular. */
+int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values,
+                                   int32_t *matched_row, double *row_scale, double *col_scale);
 
 /* istats[16]: 0 ndim, 1 nnz(A), 2 nsuper, 3 nlevels, 4 nnz(L) strict, 5 nnz(U) incl. diag, 6 max front,
  *             7 max pivots, 8 perturbed pivots, 9 zero pivots, 10 refinement steps, 11 factor launches,

@@ -42,12 +42,19 @@ class Hipmf:
         return HipmfError(code, where, (self.lib.solver_hipmf_last_error(self.h) or b"").decode())
 
     def initialize(self, n, row_pointers, col_indices, ordering=0, scaling=1, pivot_epsilon=-1.0, refinement_nstep=-1,
-                   verbose=False, general_symmetric=False, positive_definite=False):
+                   verbose=False, general_symmetric=False, positive_definite=False, values=None):
+        """values (optional, as in the reference's shims, which hand the numbers to the analysis phase too): lets the
+        analysis apply the maximum-product matching + scaling when the diagonal is weak."""
         rp = np.ascontiguousarray(row_pointers, dtype=np.int32)
         ci = np.ascontiguousarray(col_indices, dtype=np.int32)
         self.n, self.nnz = int(n), int(rp[n])
+        vptr = None
+        if values is not None:
+            self._init_values = np.ascontiguousarray(values, dtype=np.float64)
+            assert self._init_values.size >= self.nnz
+            vptr = self._init_values.ctypes.data
         return self.lib.solver_hipmf_initialize(self.h, ordering, scaling, pivot_epsilon, refinement_nstep, int(verbose),
-                                                int(general_symmetric), int(positive_definite), n, rp, ci, None)
+                                                int(general_symmetric), int(positive_definite), n, rp, ci, vptr)
 
     def factorize(self, values, compute_determinant=False, verbose=False):
         v = np.ascontiguousarray(values, dtype=np.float64)

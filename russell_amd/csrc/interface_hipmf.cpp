@@ -9,6 +9,7 @@
 #include <new>
 
 #include "numeric.hpp"
+#include "matching.hpp"
 // the C header #defines the same status names as macros: it must come after numeric.hpp
 #include "../../include/russell_hipmf.h"
 
@@ -37,7 +38,6 @@ void solver_hipmf_drop(struct InterfaceHIPMF *h) {
 int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
                                 int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, C_BOOL positive_definite,
                                 int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
-    (void)values;
     (void)positive_definite; // accepted for API parity; the numeric phase is LU with static pivoting either way
     if (!h || !row_pointers || !col_indices) return ERROR_NULL_POINTER;
     if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
@@ -51,7 +51,7 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int3
     no.verbose = verbose == 1;
     h->ordering_requested = ordering;
     h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
-    int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, general_symmetric == 1, so, no);
+    int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, general_symmetric == 1, so, no, values);
     if (verbose == 1 && code == SUCCESSFUL_EXIT) {
         const Symbolic &S = h->solver.S;
         printf("solver_hipmf_initialize: n=%d nnz=%lld supernodes=%d levels=%d nnz(L)=%lld nnz(U)=%lld flops=%.3e "
@@ -124,6 +124,17 @@ int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *h, double *d_x, const d
 int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *h, double *v, double alpha, const double *u) {
     if (!h || !v || !u) return ERROR_NULL_POINTER;
     return h->solver.spmv(v, u, alpha, false);
+}
+
+int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values,
+                                   int32_t *matched_row, double *row_scale, double *col_scale) {
+    if (!row_pointers || !col_indices || !values || !matched_row || !row_scale || !col_scale) return ERROR_NULL_POINTER;
+    if (ndim < 1) return ERROR_HIPMF_INVALID_MATRIX;
+    std::vector<int32_t> mrow;
+    std::vector<double> dr, dc;
+    if (max_product_matching(ndim, row_pointers, col_indices, values, mrow, dr, dc) != 0) return ERROR_HIPMF_INVALID_MATRIX;
+    for (int32_t i = 0; i < ndim; i++) matched_row[i] = mrow[i], row_scale[i] = dr[i], col_scale[i] = dc[i];
+    return SUCCESSFUL_EXIT;
 }
 
 int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *h, int32_t *perm) {

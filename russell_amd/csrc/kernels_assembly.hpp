@@ -28,12 +28,13 @@ __global__ void k_row_scale(int32_t n, const int32_t *__restrict__ rp, const dou
 }
 
 // max |rs[row] * a| over the stored entries -> *out (as ordered bits of a non-negative double)
-__global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow,
-                         const double *__restrict__ rs, unsigned long long *out) {
+__global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow, const int32_t *__restrict__ acol,
+                         const double *__restrict__ rs, const double *__restrict__ cs, unsigned long long *out) {
     __shared__ double red[256];
     double m = 0.0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
         double a = fabs(vals[k] * rs[arow[k]]);
+        if (cs) a *= cs[acol[k]];
         m = a > m ? a : m;
     }
     red[threadIdx.x] = m;
@@ -45,13 +46,15 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
     if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
 }
 
-// pool[amap[k]] = rs[row(k)] * a_k  (the pool is zero-filled first; every position is hit once)
+// pool[amap[k]] = rs[row(k)] * a_k * cs[col(k)]  (the pool is zero-filled first; every position is hit once;
+// cs == nullptr: rows only)
 __global__ void k_scatter(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow,
                           const int64_t *__restrict__ amap, const int64_t *__restrict__ amap2,
-                          const double *__restrict__ rs, const int32_t *__restrict__ acol, double *__restrict__ pool) {
+                          const double *__restrict__ rs, const double *__restrict__ cs, const int32_t *__restrict__ acol,
+                          double *__restrict__ pool) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
         double v = vals[k];
-        pool[amap[k]] = v * rs[arow[k]];
+        pool[amap[k]] = cs ? v * rs[arow[k]] * cs[acol[k]] : v * rs[arow[k]];
         if (amap2) {
             int64_t q = amap2[k];
             if (q >= 0) pool[q] = v * rs[acol[k]]; // mirrored entry lives in row acol[k]

@@ -4,21 +4,23 @@
 
 namespace hipmf {
 
-// xp[i] = rs[perm[i]] * b[perm[i]]
+// xp[i] = rs[rperm[i]] * b[rperm[i]]   (rperm: the row of A that is row i of the permuted system)
 __global__ void k_perm_in(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ rs,
                           const double *__restrict__ b, double *__restrict__ xp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) xp[i] = rs[perm[i]] * b[perm[i]];
 }
 
-// out[perm[j]] = xp[j] (mode 0), += (mode 1), -= (mode 2)
-__global__ void k_perm_out(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ xp,
+// out[perm[j]] = cs[perm[j]] * xp[j] (mode 0), += (mode 1), -= (mode 2); cs == nullptr: no column scaling
+__global__ void k_perm_out(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ cs, const double *__restrict__ xp,
                            double *__restrict__ out, int32_t mode) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
-        if (mode == 1) out[perm[j]] += xp[j];
-        else if (mode == 2) out[perm[j]] -= xp[j];
-        else out[perm[j]] = xp[j];
+        const int q = perm[j];
+        const double v = cs ? cs[q] * xp[j] : xp[j];
+        if (mode == 1) out[q] += v;
+        else if (mode == 2) out[q] -= v;
+        else out[q] = v;
     }
 }
 

@@ -1,0 +1,17 @@
+// matching.hpp -- maximum-product matching + scaling pre-permutation (host, part of the "initialize" phase).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace hipmf {
+
+// true when some row's diagonal entry is missing, zero or smaller than threshold * (largest magnitude of the row)
+bool diagonal_is_weak(int32_t n, const int32_t *rp, const int32_t *ci, const double *v, double threshold);
+
+// n x n matrix in CSR.  On success (0): mrow[j] = row matched to column j (the row-permuted matrix B with
+// B(j, :) = A(mrow[j], :) has the matched entries on its diagonal), and scalings dr (rows of A), dc (columns) such that
+// |dr_i a_ij dc_j| <= 1 with equality on the matched entries.  -1: structurally singular (no perfect matching).
+int32_t max_product_matching(int32_t n, const int32_t *rp, const int32_t *ci, const double *v, std::vector<int32_t> &mrow,
+                             std::vector<double> &dr, std::vector<double> &dc);
+
+} // namespace hipmf

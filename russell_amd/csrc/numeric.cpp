@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "kernels.hpp"
+#include "matching.hpp"
 
 namespace hipmf {
 
@@ -44,13 +45,15 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+    void *ptrs[] = {d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d_dws = nullptr, d_ear = nullptr;
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
+    d_cs = nullptr, d_rperm = nullptr;
+    matched = false;
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
@@ -68,7 +71,7 @@ void Solver::release() {
 }
 
 int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
-                           const NumericOptions &nopt) {
+                           const NumericOptions &nopt, const double *values) {
     if (initialized) return ERROR_ALREADY_INITIALIZED;
     opt = nopt;
     int ndev = 0;
@@ -96,10 +99,36 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SF_WARM")) sf_warm_flag = atoi(e) != 0;
-    int rc = analyse(n, rp, ci, sym_lower, so, S);
+    if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
+    // Maximum-product matching + scaling (matching.cpp) when the numbers are known and the diagonal is weak: the
+    // analysis then runs on B = A(mrow, :), whose diagonal holds the matched entries (all 1 after scaling).
+    std::vector<int32_t> mrow, rpB, ciB;
+    std::vector<int64_t> kB; // position in B's CSR of every entry of A
+    std::vector<double> dr, dc;
+    matched = false;
+    if (values && !sym_lower && n > 1 && opt.matching > 0 && rp[0] == 0 && (opt.matching >= 2 || diagonal_is_weak(n, rp, ci, values, 0.01))) {
+        if (max_product_matching(n, rp, ci, values, mrow, dr, dc) == 0) {
+            matched = true;
+            rpB.assign((size_t)n + 1, 0);
+            for (int32_t j = 0; j < n; j++) rpB[j + 1] = rpB[j] + (rp[mrow[j] + 1] - rp[mrow[j]]);
+            ciB.resize((size_t)rp[n]);
+            kB.resize((size_t)rp[n]);
+            for (int32_t j = 0; j < n; j++)
+                for (int32_t p = rp[mrow[j]], q = rpB[j]; p < rp[mrow[j] + 1]; p++, q++) ciB[q] = ci[p], kB[p] = q;
+            if (opt.verbose) fprintf(stderr, "hipmf: initialize: maximum-product matching + scaling applied (weak diagonal)\n");
+        } else if (opt.verbose) {
+            fprintf(stderr, "hipmf: initialize: the matrix has no perfect matching (structurally singular); continuing without\n");
+        }
+    }
+    int rc = matched ? analyse(n, rpB.data(), ciB.data(), false, so, S) : analyse(n, rp, ci, sym_lower, so, S);
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
         return rc <= -30 || rc >= -2 ? ERROR_HIPMF_INVALID_MATRIX : ERROR_HIPMF_SYMBOLIC;
+    }
+    if (matched) { // the assembly map back in the order of A's entries
+        std::vector<int64_t> am((size_t)rp[n]);
+        for (int64_t k = 0; k < rp[n]; k++) am[k] = S.amap[kB[k]];
+        S.amap.swap(am);
     }
     int32_t code = upload_plan();
     if (code != SUCCESSFUL_EXIT) {
@@ -128,12 +157,29 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         HIPC(dev_upload(&d_tidx, tidx), ERROR_HIP_MALLOC);
     }
     HIPC(dev_upload(&d_perm, S.perm), ERROR_HIP_MALLOC);
+    d_rperm = d_perm;
+    if (matched) {
+        std::vector<int32_t> rperm((size_t)n);
+        for (int32_t k = 0; k < n; k++) rperm[k] = mrow[S.perm[k]];
+        HIPC(dev_upload(&d_rperm, rperm), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_cs, dc), ERROR_HIP_MALLOC);
+        // parity of the row permutation (determinant)
+        std::vector<char> seen((size_t)n, 0);
+        match_parity = 0;
+        for (int32_t i = 0; i < n; i++) {
+            if (seen[i]) continue;
+            int len = 0;
+            for (int32_t j = i; !seen[j]; j = mrow[j]) seen[j] = 1, len++;
+            if ((len & 1) == 0) match_parity ^= 1;
+        }
+    }
     HIPC(dev_upload(&d_amap, S.amap), ERROR_HIP_MALLOC);
     if (sym_lower) HIPC(dev_upload(&d_amap2, S.amap2), ERROR_HIP_MALLOC);
     std::vector<int64_t>().swap(S.amap);
     std::vector<int64_t>().swap(S.amap2);
     HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
+    if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_scalar, 4 * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
@@ -395,13 +441,14 @@ int32_t Solver::run_factor() {
     const int64_t nnz = S.nnz_a;
     int64_t launches = 0;
     HIPC(hipEventRecord((hipEvent_t)ev[0], STREAM), ERROR_HIP_SYNCHRONIZE);
-    hipLaunchKernelGGL(k_row_scale, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_vals, d_tptr, d_tidx, opt.scaling, d_rs);
+    // (with a matching in force the scalings dr, dc of initialize stay: the structure was chosen for them)
+    if (!matched) hipLaunchKernelGGL(k_row_scale, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_vals, d_tptr, d_tidx, opt.scaling, d_rs);
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
-    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_rs, d_scalar);
+    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_scalar);
     HIPC(hipMemsetAsync(d_pool, 0, sizeof(double) * pool_doubles, STREAM), ERROR_HIP_MEMCPY);
-    hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_amap, d_amap2, d_rs, d_ci, d_pool);
+    hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_amap, d_amap2, d_rs, d_cs, d_ci, d_pool);
     launches += 3;
     if (allbig_cnt > 0) {
         hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, STREAM, d_lists + allbig_off, d_fd, d_pool);
@@ -555,10 +602,10 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             bj = d_b;
             xj = d_x;
         }
-        hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_perm, d_rs, bj, d_xp);
+        hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, bj, d_xp);
         int32_t code = run_triangular(d_xp);
         if (code != SUCCESSFUL_EXIT) return code;
-        hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_xp, xj, 0);
+        hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, d_xp, xj, 0);
         // Iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229).
         // Stopping rule on the sparse backward error omega = max_i |r_i| / (|A||x| + |b|)_i: stop when omega <= eps,
         // when a step fails to halve it, or after refinement_nstep steps; a step that makes omega worse is taken back.
@@ -573,17 +620,17 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             harvest_tri();
             const double rn = nrm[0], omega = nrm[1];
             if (it > 0 && !(omega < prev)) {
-                hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_du, xj, 2); // take the last correction back
+                hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, d_du, xj, 2); // take the last correction back
                 break;
             }
             last_residual_inf = rn;
             last_omega = omega;
             if (omega <= EPS || it == opt.refinement_nstep || (it > 0 && omega > 0.5 * prev)) break;
             prev = omega;
-            hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_perm, d_rs, d_r, d_du);
+            hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, d_r, d_du);
             code = run_triangular(d_du);
             if (code != SUCCESSFUL_EXIT) return code;
-            hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_du, xj, 1);
+            hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, d_du, xj, 1);
             if (j == 0) refinement_steps_done++;
         }
         if (!on_device)
@@ -661,8 +708,12 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
     HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
     const int32_t n = S.n;
     hipLaunchKernelGGL(k_diag_gather, dim3(S.nsuper), dim3(64), 0, STREAM, S.nsuper, d_fd, d_pool, d_du);
-    std::vector<double> du((size_t)n), rs((size_t)n);
+    std::vector<double> du((size_t)n), rs((size_t)n), cs;
     std::vector<int32_t> lp((size_t)n);
+    if (matched) {
+        cs.resize((size_t)n);
+        HIPC(hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    }
     HIPC(hipMemcpyAsync(du.data(), d_du, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemcpyAsync(rs.data(), d_rs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemcpyAsync(lp.data(), d_lperm, sizeof(int32_t) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
@@ -672,7 +723,7 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
     double m = 1.0, e = 0.0, umin = INFINITY, umax = 0.0;
     bool zero = false;
     for (int32_t i = 0; i < n; i++) {
-        double d = du[i] / rs[i];
+        double d = matched ? du[i] / rs[i] / cs[i] : du[i] / rs[i]; // (any pairing: only the products matter)
         umin = std::min(umin, std::fabs(du[i]));
         umax = std::max(umax, std::fabs(du[i]));
         if (d == 0.0 || !std::isfinite(d)) {
@@ -698,6 +749,7 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
             if ((len & 1) == 0) parity ^= 1;
         }
     }
+    if (matched) parity ^= match_parity;
     if (parity) m = -m;
     if (zero || n_zero_pivot > 0) m = 0.0, e = 0.0;
     if (mantissa) *mantissa = m;

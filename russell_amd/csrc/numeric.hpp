@@ -42,6 +42,8 @@ struct NumericOptions {
     int32_t scaling = 1;            // 0 none, 1 sum (UMFPACK_SCALE_SUM), 2 max
     double pivot_epsilon = 1e-13;   // relative to max|scaled a_ij| (cuDSS documents 1e-13 as its f64 default)
     int32_t refinement_nstep = 2;   // UMFPACK's default UMFPACK_IRSTEP is 2
+    int32_t matching = 1;           // maximum-product matching + scaling at initialize: 0 never, 1 when the diagonal is weak, 2 always
+                                    // (needs the values at initialize; general storage only)
     bool verbose = false;
 };
 
@@ -73,7 +75,7 @@ class Solver {
     Solver();
     ~Solver();
     int32_t initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
-                       const NumericOptions &nopt);
+                       const NumericOptions &nopt, const double *values = nullptr);
     // values: nnz doubles in the CSR order given to initialize; on_device tells where they live
     int32_t factorize(const double *values, bool on_device);
     int32_t solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device);
@@ -98,6 +100,10 @@ class Solver {
     int64_t pool_doubles = 0;
     int32_t *d_lperm = nullptr;
     double *d_rs = nullptr;
+    double *d_cs = nullptr;       // column scaling of the matching (nullptr: none)
+    int32_t *d_rperm = nullptr;   // row of A that is row i of the permuted system (== d_perm without matching)
+    bool matched = false;         // a maximum-product matching pre-permutation is in force
+    int32_t match_parity = 0;     // parity of its row permutation (for the determinant)
 
   private:
     int32_t upload_plan();

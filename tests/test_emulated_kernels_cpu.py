@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "russell_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def emu_lib():
-    srcs = [os.path.join(CSRC, f) for f in ("symbolic.cpp", "numeric.cpp", "interface_hipmf.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("symbolic.cpp", "matching.cpp", "numeric.cpp", "interface_hipmf.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     deps += [os.path.join(ROOT, "tools", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "tools", "hipemu", "hipmf_device_rt.h")]
     if not os.path.exists(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):

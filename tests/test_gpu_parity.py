@@ -166,10 +166,10 @@ def test_random_unsymmetric_needs_pivoting():
     s.close()
 
 
-def test_random_unsymmetric_weak_diagonal_is_tracked():
+def test_random_unsymmetric_weak_diagonal_without_values_at_initialize_is_tracked():
     # Hard case for static pivoting + inverse-based solve panels (kappa ~ 2e6, diagonal 10x weaker than the
-    # off-diagonals, no matching pre-permutation yet): only the residual metric is asserted, loosely; the
-    # achieved accuracy is what later rounds must improve ("pivoting").
+    # off-diagonals).  WITHOUT the values at initialize no matching can be applied: only the residual metric is
+    # asserted, loosely (the reference-style call path hands the values over, next test).
     n = 400
     M, rng = _random_unsymmetric(n, 0.1, 3)
     xs = rng.standard_normal(n)
@@ -177,6 +177,44 @@ def test_random_unsymmetric_weak_diagonal_is_tracked():
     s, code, x = gpu_solve(n, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data, b)
     assert code in (0, 1)
     assert relative_error_metric(n, M.indptr, M.indices, M.data, x, b) <= 1e-6
+    s.close()
+
+
+def test_random_unsymmetric_weak_diagonal_with_matching():
+    # the same matrix with the values known at initialize (what LinSolver::factorize does, lin_solver.rs:38-46):
+    # maximum-product matching + scaling makes static pivoting safe; the oracle (threshold partial pivoting) agrees
+    n = 400
+    M, rng = _random_unsymmetric(n, 0.1, 3)
+    xs = rng.standard_normal(n)
+    b = M @ xs
+    rp, ci = M.indptr.astype(np.int32), M.indices.astype(np.int32)
+    s, code, x = gpu_solve(n, rp, ci, M.data, b, values=M.data)
+    assert code == 0 and s.num_perturbed == 0
+    xo, lu = oracle_solve(n, rp, ci, M.data, b)
+    assert np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo)))
+    assert relative_error_metric(n, M.indptr, M.indices, M.data, x, b) <= 1e-12
+    assert abs(s.det_coefficient - lu.determinant()[0]) < 1e-8 and s.det_exponent == lu.determinant()[1]
+    s.close()
+
+
+def test_zero_diagonal_row_shuffled_matrix_needs_the_matching():
+    # a diagonally dominant matrix with its rows shuffled: almost every diagonal entry is structurally zero
+    n = 500
+    rng = np.random.default_rng(21)
+    import scipy.sparse as sp
+    D = (sp.random(n, n, density=0.01, random_state=4, format="csr") + sp.diags(3.0 + rng.random(n))).tocsr()
+    Pm = sp.csr_matrix((np.ones(n), (rng.permutation(n), np.arange(n))), shape=(n, n))
+    M = (Pm @ D).tocsr()
+    M.sort_indices()
+    xs = rng.standard_normal(n)
+    b = M @ xs
+    rp, ci = M.indptr.astype(np.int32), M.indices.astype(np.int32)
+    s, code, x = gpu_solve(n, rp, ci, M.data, b, values=M.data)
+    assert code == 0
+    assert np.max(np.abs(x - xs)) <= 1e-11 * np.max(np.abs(xs))
+    sign, logdet = np.linalg.slogdet(M.toarray())
+    assert np.sign(s.det_coefficient) == sign
+    assert abs(np.log10(abs(s.det_coefficient)) + s.det_exponent - logdet / np.log(10.0)) < 1e-8
     s.close()
 
 
