@@ -331,8 +331,13 @@ int32_t Solver::upload_plan() {
         }
         L.bwd_cnt = (int32_t)stasks.size() - L.bwd_off;
         if (L.big_pmax > MAX_LDS_DOUBLES || L.big_fmax > MAX_LDS_DOUBLES) {
-            last_error = "a frontal matrix exceeds the LDS staging limit of this build (f = " + std::to_string(L.big_fmax) + ")";
-            return ERROR_NOT_AVAILABLE;
+            // the level-set solve kernels stage a whole p- / f-vector in LDS; the dependency-driven ones work in chunks
+            level_path_ok = false;
+            if (!use_fused) {
+                last_error = "a frontal matrix exceeds the LDS staging limit of the level-set solves (f = " + std::to_string(L.big_fmax) +
+                             "); enable the dependency-driven solves (HIPMF_FUSED_SOLVE=1)";
+                return ERROR_NOT_AVAILABLE;
+            }
         }
     }
     allbig_off = (int32_t)lists.size();
@@ -661,6 +666,10 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     }
     if (use_fused && sf_err[0] != 0) {
         // a hand-off wait timed out (never expected): the result is not trusted; redo with the level-set launches
+        if (!level_path_ok) {
+            last_error = "dependency-driven solve timed out and the fronts are too large for the level-set fallback";
+            return ERROR_NOT_AVAILABLE;
+        }
         use_fused = false;
         sf_err[0] = 0;
         (void)hipMemset(d_sync + 2 * (SF_SYNC_HEADER + S.nsuper), 0, sizeof(int32_t));

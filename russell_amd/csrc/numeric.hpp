@@ -127,6 +127,7 @@ class Solver {
     int32_t sf_fwd_launch = 0;              // == sf_fwd_cnt unless the profiling knob HIPMF_SF_FWD_LEVELS cuts the pass short
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
+    bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};

@@ -69,3 +69,18 @@ def test_fused_poisson3d():
     outs, _ = _solve(n, rp, ci, v, b, fused=True, slab64=True, reps=4)
     for x in outs:
         assert np.array_equal(ref, x)
+
+
+def test_poisson3d_fronts_beyond_the_lds_staging_limit():
+    # 88^3: the root front has > 7 936 rows, more than the level-set solve kernels can stage in LDS; the
+    # dependency-driven solves sweep such fronts in chunks (needs ~26 GB of HBM)
+    n, rp, ci, v = P.poisson3d(88)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.stats()["max_front"] > 7936
+    assert s.factorize(v) == 0
+    x = s.solve(b)
+    assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-11
+    s.close()
