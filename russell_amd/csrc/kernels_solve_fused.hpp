@@ -27,7 +27,8 @@ namespace hipmf {
 
 constexpr int SF_SYNC_HEADER = 16;       // ints in front of the completion counters (reserved)
 constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
-constexpr int SF_CHUNK = 1024;           // doubles of the big fronts' vectors staged in LDS at a time
+constexpr int SF_CHUNK = 1024;           // doubles of the big fronts' vectors staged in LDS at a time (per right-hand side: SF_CHUNK / K)
+constexpr int SF_KMAX = 4;               // right-hand sides solved together by the blocked instances (the factor is read once per block)
 
 struct SfTask {
     int32_t kind;       // 0: group of small fronts, one per wavefront (a, b, c, d; -1 = none)
@@ -51,17 +52,25 @@ __device__ __forceinline__ bool sf_wait(const int *cnt, int need, int *err) {
     return true;
 }
 
-// ---- forward step of one small front by one wavefront; w = 64 doubles of LDS owned by this wave ----
-__device__ __forceinline__ void sf_fwd_small(int s, int lane, double *w, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
+// All kernels are templates on K = the number of right-hand sides a launch carries (1: the instances the
+// benchmark path uses; SF_KMAX: the many-RHS instances, which read every factor entry ONCE for K columns -- the
+// solves are HBM-bound, so K columns cost little more than one).  Column c of x lives at x + c * xstr, its solve
+// workspace at work + c * wstr; nk <= K columns are live.  Per column the arithmetic and its order are those of K = 1.
+
+// ---- forward step of one small front by one wavefront; w = K x 64 doubles of LDS owned by this wave ----
+template <int K>
+__device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
                                              const int32_t *__restrict__ lperm, const int32_t *__restrict__ child_idx,
                                              const int32_t *__restrict__ rel, const int32_t *__restrict__ need, int *done, int *err,
-                                             double *work, double *x) {
+                                             double *work, double *x, int nk, int64_t xstr, int64_t wstr) {
     const FrontDesc fd = FD[s];
     const int p = fd.p, f = fd.p + fd.m;
     const double *F = pool + fd.off;
     double *W = work + fd.woff;
     double *xs = x + fd.first;
-    w[lane] = (lane < p) ? ld_agent(xs + lane) : 0.0;
+#pragma unroll
+    for (int c = 0; c < K; c++)
+        if (c < nk) w[c][lane] = (lane < p) ? ld_agent(xs + c * xstr + lane) : 0.0;
     const int lp = (lane < p) ? lperm[fd.first + lane] : 0;
     // the lane's row of [L11; L21], first 8 columns: on their way before the waits (the panel is read-only)
     constexpr int CH = 8;
@@ -90,11 +99,18 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double *w, const F
             const FrontDesc cd = FD[child_idx[fd.child_begin + ci]];
             woff = cd.woff, rowptr = cd.rowptr, cp = cd.p, cm = cd.m;
         }
-        if (lane < cm) w[rel[rowptr + lane]] += ld_agent(work + woff + cp + lane); // cm <= f <= 64
+        if (lane < cm) { // cm <= f <= 64
+            const int r = rel[rowptr + lane];
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk) w[c][r] += ld_agent(work + c * wstr + woff + cp + lane);
+        }
         wave_sync();
     }
     // row interchanges of the pivot block, then y1 = L11^{-1} (P w1) column by column, u = w2 - L21 y1;
-    double v = (lane < p) ? w[lp] : ((lane < f) ? w[lane] : 0.0);
+    double v[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) v[c] = (c < nk) ? ((lane < p) ? w[c][lp] : ((lane < f) ? w[c][lane] : 0.0)) : 0.0;
     for (int j0 = 0; j0 < p; j0 += CH) {
         double an[CH]; // next chunk: its loads fly while this chunk's substitution steps run
 #pragma unroll
@@ -102,29 +118,39 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double *w, const F
 #pragma unroll
         for (int q = 0; q < CH; q++) {
             const int j = j0 + q;
-            const double vj = __shfl(v, j & 63);
-            if (lane > j) v -= a[q] * vj; // a[q] == 0 for j >= p and for lanes >= f
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                const double vj = __shfl(v[c], j & 63);
+                if (lane > j) v[c] -= a[q] * vj; // a[q] == 0 for j >= p and for lanes >= f
+            }
         }
 #pragma unroll
         for (int q = 0; q < CH; q++) a[q] = an[q];
     }
-    if (lane < p) st_agent(xs + lane, v);
-    else if (lane < f) st_agent(W + lane, v);
+#pragma unroll
+    for (int c = 0; c < K; c++)
+        if (c < nk) {
+            if (lane < p) st_agent(xs + c * xstr + lane, v[c]);
+            else if (lane < f) st_agent(W + c * wstr + lane, v[c]);
+        }
     drain_stores();
     if (lane == 0) flag_add(done + s, 1);
 }
 
-// ---- backward step of one small front by one wavefront; xg = 64 doubles of LDS owned by this wave ----
-__device__ __forceinline__ void sf_bwd_small(int s, int lane, double *xg, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
+// ---- backward step of one small front by one wavefront; xg = K x 64 doubles of LDS owned by this wave ----
+template <int K>
+__device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
                                              const int32_t *__restrict__ rows, const int32_t *__restrict__ need, int *done, int *err,
-                                             double *x) {
+                                             double *x, int nk, int64_t xstr) {
     const FrontDesc fd = FD[s];
     const int p = fd.p, m = fd.m, f = fd.p + fd.m;
     const double *F = pool + fd.off;
     double *xs = x + fd.first;
     const int32_t *rws = rows + fd.rowptr;
     const int myrow = (lane < m) ? rws[lane] : 0;
-    const double y1 = (lane < p) ? ld_agent(xs + lane) : 0.0; // from the forward launch
+    double y1[K]; // from the forward launch
+#pragma unroll
+    for (int c = 0; c < K; c++) y1[c] = (c < nk && lane < p) ? ld_agent(xs + c * xstr + lane) : 0.0;
     const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
     const int i = lane & ((1 << sh) - 1), jq = lane >> sh, ng = 64 >> sh;
     // read-only factor data on their way before the wait: the first 8 of this lane's U12 entries and the
@@ -140,26 +166,48 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double *xg, const 
     }
     if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
     wave_sync();
-    if (lane < m) xg[lane] = ld_agent(x + myrow);
+    if (lane < m) {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+            if (c < nk) xg[c][lane] = ld_agent(x + c * xstr + myrow);
+    }
     wave_sync();
-    double acc = 0.0;
+    double acc[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) acc[c] = 0.0;
     if (i < p) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (jq + k * ng < m) acc += e[k] * xg[jq + k * ng];
-        for (int j = jq + 8 * ng; j < m; j += ng) acc += Ui[(int64_t)j * f] * xg[j];
+            if (jq + k * ng < m) {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) acc[c] += e[k] * xg[c][jq + k * ng];
+            }
+        for (int j = jq + 8 * ng; j < m; j += ng) {
+            const double u = Ui[(int64_t)j * f];
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk) acc[c] += u * xg[c][j];
+        }
     }
-    for (int off = 1 << sh; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-    double v = (lane < p) ? y1 - acc : 0.0;
+    double v[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        for (int off = 1 << sh; off < 64; off <<= 1) acc[c] += __shfl_xor(acc[c], off);
+        v[c] = (lane < p) ? y1[c] - acc[c] : 0.0;
+    }
     // x1 = U11^{-1} t, columns from right to left, the lane's row of U11 16 columns at a time
     for (int jhi = p; jhi > 0; jhi -= 16) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int j = jhi - 1 - q;
             if (j >= 0) { // wave-uniform
-                if (lane == j) v /= a[q];
-                const double vj = __shfl(v, j);
-                if (lane < j) v -= a[q] * vj;
+#pragma unroll
+                for (int c = 0; c < K; c++) {
+                    if (lane == j) v[c] /= a[q];
+                    const double vj = __shfl(v[c], j);
+                    if (lane < j) v[c] -= a[q] * vj;
+                }
             }
         }
         if (jhi > 16) {
@@ -170,17 +218,23 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double *xg, const 
             }
         }
     }
-    if (lane < p) st_agent(xs + lane, v);
+    if (lane < p) {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+            if (c < nk) st_agent(xs + c * xstr + lane, v[c]);
+    }
     drain_stores();
     if (lane == 0) flag_add(done + s, 1);
 }
 
-// Strided dot product against an LDS vector chunk: acc += sum_j col[j * ld] * w[j - c0], j = j0, j0 + step, ... < j1.
-// Sixteen unconditional loads are in flight per lane (then eight, then the last partial group of eight predicated:
-// a loop of predicated loads compiles to a wait per load); the order of the additions is the one of
+// Strided dot products against K LDS vector chunks (column c at w + c * wld):
+//   acc[c] += sum_j col[j * ld] * w[c * wld + j - c0],  j = j0, j0 + step, ... < j1.
+// Sixteen unconditional loads are in flight per lane (then eight, then the last partial group of eight with clamped
+// addresses: a loop of predicated loads compiles to a wait per load); the order of the additions is the one of
 // kernels_solve.hpp's strided_dot: even positions into acc0, odd ones into acc1, the tail into acc0.
-__device__ __forceinline__ void sf_dot(double &acc0, double &acc1, const double *__restrict__ col, int64_t ld, const double *w, int c0, int j0,
-                                       int j1, int step) {
+template <int K>
+__device__ __forceinline__ void sf_dot(double (&acc0)[K], double (&acc1)[K], const double *__restrict__ col, int64_t ld, const double *w, int wld,
+                                       int c0, int j0, int j1, int step) {
     int j = j0;
     const int nfull = (j1 - j0 + step - 1) / step / 8 * 8; // positions covered by whole groups of 8
     const int jend8 = j0 + nfull * step;
@@ -189,23 +243,25 @@ __device__ __forceinline__ void sf_dot(double &acc0, double &acc1, const double 
 #pragma unroll
         for (int u = 0; u < 16; u++) e[u] = col[(int64_t)(j + u * step) * ld];
 #pragma unroll
-        for (int u = 0; u < 16; u += 2) {
-            acc0 += e[u] * w[j + u * step - c0];
-            acc1 += e[u + 1] * w[j + (u + 1) * step - c0];
-        }
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                acc0[c] += e[u] * w[c * wld + j + u * step - c0];
+                acc1[c] += e[u + 1] * w[c * wld + j + (u + 1) * step - c0];
+            }
     }
     for (; j + 7 * step < j1; j += 8 * step) {
         double e[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) e[u] = col[(int64_t)(j + u * step) * ld];
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-            acc0 += e[u] * w[j + u * step - c0];
-            acc1 += e[u + 1] * w[j + (u + 1) * step - c0];
-        }
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0[c] += e[u] * w[c * wld + j + u * step - c0];
+                acc1[c] += e[u + 1] * w[c * wld + j + (u + 1) * step - c0];
+            }
     }
-    // the last (partial) group of eight: all its loads at once (addresses clamped, not predicated), the additions in
-    // the same order (into acc0)
     if (j < j1) {
         double e[8];
 #pragma unroll
@@ -214,23 +270,25 @@ __device__ __forceinline__ void sf_dot(double &acc0, double &acc1, const double 
             e[u] = col[(int64_t)jj * ld];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (j + u * step < j1) acc0 += e[u] * w[j + u * step - c0];
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j + u * step < j1) acc0[c] += e[u] * w[c * wld + j + u * step - c0];
     }
 }
 
-// The children's update vectors are added into the LDS copy of w1 (chunk [c0, c1)) and, on the first chunk, into the
-// slab's own rows wsl: NK children at a time, NE entries per thread and child fetched together (one round trip),
-// then added child by child in ascending order (the order fixes the floating-point sums).  Longer children finish
-// in a plain loop.
-template <int NK, int NE>
+// The children's update vectors are added into the LDS copies of w1 (chunk [c0, c1), column c at wc + c * wld) and, on
+// the first chunk, into the slab's own rows wsl (column c at wsl + c * 128): NK children at a time, NE entries per
+// thread and child fetched together (one round trip), then added child by child in ascending order (the order fixes
+// the floating-point sums).  Longer children finish in a plain loop.
+template <int NK, int NE, int K>
 __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int64_t *cd_woff, const int64_t *cd_rel, const int32_t *cd_m,
                                             const FrontDesc &fd, const FrontDesc *__restrict__ FD, const int32_t *__restrict__ child_idx,
-                                            const int32_t *__restrict__ rel, const double *work, double *wc, double *wsl, int c0, int c1, int p,
-                                            int r0, int r1) {
+                                            const int32_t *__restrict__ rel, const double *work, double *wc, int wld, double *wsl, int c0, int c1,
+                                            int p, int r0, int r1, int nk, int64_t wstr) {
     for (int cb = 0; cb < nch; cb += NK) {
         int qv[NK][NE];
-        double uv[NK][NE];
+        double uv[NK][NE][K];
         int cm[NK];
 #pragma unroll
         for (int k = 0; k < NK; k++) {
@@ -250,7 +308,9 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
                     qv[k][e] = -1;
                     if (i < cm[k]) {
                         qv[k][e] = rel[relo + i];
-                        uv[k][e] = ld_agent(work + woff + i);
+#pragma unroll
+                        for (int cc = 0; cc < K; cc++)
+                            if (cc < nk) uv[k][e][cc] = ld_agent(work + cc * wstr + woff + i);
                     }
                 }
                 if (cm[k] > 256 * NE) cm[k] = -cm[k]; // the rest of this child's list goes through the plain loop below
@@ -262,8 +322,15 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
                     const int q = qv[k][e];
-                    if (q >= c0 && q < c1) wc[q - c0] += uv[k][e];
-                    else if (c0 == 0 && q >= p && q >= r0 && q < r1) wsl[q - r0] += uv[k][e];
+                    if (q >= c0 && q < c1) {
+#pragma unroll
+                        for (int cc = 0; cc < K; cc++)
+                            if (cc < nk) wc[cc * wld + q - c0] += uv[k][e][cc];
+                    } else if (c0 == 0 && q >= p && q >= r0 && q < r1) {
+#pragma unroll
+                        for (int cc = 0; cc < K; cc++)
+                            if (cc < nk) wsl[cc * 128 + q - r0] += uv[k][e][cc];
+                    }
                 }
                 if (cm[k] < 0) {
                     const int c = cb + k;
@@ -276,8 +343,15 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
                     }
                     for (int i = tid + 256 * NE; i < -cm[k]; i += 256) {
                         const int q = rel[relo + i];
-                        if (q >= c0 && q < c1) wc[q - c0] += ld_agent(work + woff + i);
-                        else if (c0 == 0 && q >= p && q >= r0 && q < r1) wsl[q - r0] += ld_agent(work + woff + i);
+                        if (q >= c0 && q < c1) {
+#pragma unroll
+                            for (int cc = 0; cc < K; cc++)
+                                if (cc < nk) wc[cc * wld + q - c0] += ld_agent(work + cc * wstr + woff + i);
+                        } else if (c0 == 0 && q >= p && q >= r0 && q < r1) {
+#pragma unroll
+                            for (int cc = 0; cc < K; cc++)
+                                if (cc < nk) wsl[cc * 128 + q - r0] += ld_agent(work + cc * wstr + woff + i);
+                        }
                     }
                 }
                 __syncthreads();
@@ -286,32 +360,30 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
     }
 }
 
-// Pulls the panel entries a thread is going to multiply into the XCD's L2 while the workgroup would otherwise only
-// wait for its dependencies (the panel is read-only; the sum is returned so that the loads cannot be dropped).
-__device__ __forceinline__ double sf_warm(const double *__restrict__ col, int64_t ld, int j0, int j1, int step) {
-    double sink = 0.0;
-    int j = j0;
-    for (; j + 15 * step < j1; j += 16 * step) {
-        double e[16];
+// pairwise sum over the G <= 32 column groups of row rr in a fixed order
+__device__ __forceinline__ double sf_group_sum(const double *red, int rows, int rr, int G) {
+    double tsum[32];
 #pragma unroll
-        for (int u = 0; u < 16; u++) e[u] = col[(int64_t)(j + u * step) * ld];
+    for (int q = 0; q < 32; q++) tsum[q] = (q < G) ? red[q * rows + rr] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; u++) sink += e[u];
-    }
-    for (; j < j1; j += step) sink += col[(int64_t)j * ld];
-    return sink;
+    for (int wdt = 1; wdt < 32; wdt <<= 1)
+#pragma unroll
+        for (int q = 0; q + wdt < 32; q += 2 * wdt) tsum[q] += tsum[q + wdt];
+    return tsum[0];
 }
 
-// Forward pass, one launch.  sync[SF_SYNC_HEADER + s] = completed tasks of front s (zeroed before
+// Forward pass, one launch per band of levels.  sync[SF_SYNC_HEADER + s] = completed tasks of front s (zeroed before
 // every pass); *err is sticky: set when a wait timed out.
-template <bool SMALL_ONLY>
+template <bool SMALL_ONLY, int K>
 __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
-                                                   const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int warm, unsigned long long *trace) {
-    __shared__ double wv[4][64];
-    __shared__ double wc[SMALL_ONLY ? 1 : SF_CHUNK];
-    __shared__ double wsl[128];
+                                                   const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int nk,
+                                                   int64_t xstr, int64_t wstr, unsigned long long *trace) {
+    constexpr int CHK = SF_CHUNK / K; // chunk of w1 per right-hand side
+    __shared__ double wv[4][K][64];
+    __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
+    __shared__ double wsl[SMALL_ONLY ? 1 : K * 128];
     __shared__ double red[256];
     __shared__ int64_t cd_woff[SMALL_ONLY ? 1 : 64], cd_rel[SMALL_ONLY ? 1 : 64];
     __shared__ int32_t cd_m[SMALL_ONLY ? 1 : 64];
@@ -322,7 +394,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     if (SMALL_ONLY || t.kind == 0) {
         // (wave-uniform: the front's descriptor then lives in scalar registers and the panel loads use scalar bases)
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
-        if (s >= 0) sf_fwd_small(s, lane, wv[wave], FD, pool, lperm, child_idx, rel, need, done, err, work, x);
+        if (s >= 0) sf_fwd_small<K>(s, lane, wv[wave], FD, pool, lperm, child_idx, rel, need, done, err, work, x, nk, xstr, wstr);
         return;
     }
     if (SMALL_ONLY) return; // (never reached: the small-only instance is launched on all-small bands)
@@ -337,18 +409,19 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     const int r0 = t.b, r1 = t.c, sh = t.kind;
     const int rr = tid & ((1 << sh) - 1), g = tid >> sh, G = 256 >> sh;
     const int r = r0 + rr;
-    if (tid < 128) wsl[tid] = 0.0;
+    for (int i = tid; i < K * 128; i += 256) wsl[i] = 0.0;
     // rows of inv(L11) P are zero right of their own 32-column block
     int jmax = p;
     if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
     // ---- before the wait: everything that does not depend on the children ----
     //  * the children's descriptors, one child per lane of wave 0, parked in LDS for all waves
     //  * b1 = the first chunk of x (set before the launch; the children write `work`, not x)
-    //  * the other waves warm the L2 with the slab's panel and the children's relative indices
     const int nch = fd.child_end - fd.child_begin;
     const int ncd = nch < 64 ? nch : 64; // children with a parked descriptor
-    for (int i = tid; i < (jmax < SF_CHUNK ? jmax : SF_CHUNK); i += 256) wc[i] = ld_agent(x + fd.first + i);
-    double sink = 0.0;
+#pragma unroll
+    for (int c = 0; c < K; c++)
+        if (c < nk)
+            for (int i = tid; i < (jmax < CHK ? jmax : CHK); i += 256) wc[c * CHK + i] = ld_agent(x + c * xstr + fd.first + i);
     if (wave == 0) {
         int mym = 0;
         if (lane < ncd) {
@@ -370,42 +443,44 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
                 const int ch = child_idx[fd.child_begin + c0 + lane];
                 sf_wait(done + ch, need[ch], err);
             }
-    } else if (warm && r < r1) {
-        sink = sf_warm(E + r, ld, g, jmax, G);
-        if (wave == 1) sink += sf_warm(E + r, ld, g - (G >> 2), jmax, G); // the polling wave's columns
     }
-    if (sink == 1.2345e300) wsl[0] = sink; // never true: keeps the warm-up loads alive
     __syncthreads();
     if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
     const int cm_max = cm_max_s;
-    double acc0 = 0.0, acc1 = 0.0;
-    for (int c0 = 0; c0 < jmax; c0 += SF_CHUNK) {
-        const int c1 = c0 + SF_CHUNK < jmax ? c0 + SF_CHUNK : jmax;
+    double acc0[K], acc1[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) acc0[c] = acc1[c] = 0.0;
+    for (int c0 = 0; c0 < jmax; c0 += CHK) {
+        const int c1 = c0 + CHK < jmax ? c0 + CHK : jmax;
         // w1[c0, c1) = b1 + the children's updates to these pivot rows (children in ascending order)
         if (c0 > 0) {
-            for (int i = c0 + tid; i < c1; i += 256) wc[i - c0] = ld_agent(x + fd.first + i);
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk)
+                    for (int i = c0 + tid; i < c1; i += 256) wc[c * CHK + i - c0] = ld_agent(x + c * xstr + fd.first + i);
             __syncthreads();
         }
-        if (cm_max <= 256) sf_children<8, 1>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, wsl, c0, c1, p, r0, r1);
-        else sf_children<2, 4>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, wsl, c0, c1, p, r0, r1);
+        if (cm_max <= 256)
+            sf_children<(K == 1 ? 8 : 4), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+        else
+            sf_children<2, (K == 1 ? 4 : 2), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         if (nch == 0) __syncthreads();
-        // the group's columns of this chunk: g, g + G, ... continue across chunks (SF_CHUNK is a multiple of every G)
-        if (r < r1) sf_dot(acc0, acc1, E + r, ld, wc, c0, c0 + g, c1, G);
+        // the group's columns of this chunk: g, g + G, ... continue across chunks (CHK is a multiple of every G)
+        if (r < r1) sf_dot<K>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
-    red[g * (1 << sh) + rr] = acc0 + acc1;
-    __syncthreads();
-    if (g == 0 && r < r1) {
-        // pairwise sum over the G column groups in a fixed order
-        double tsum[32];
 #pragma unroll
-        for (int q = 0; q < 32; q++) tsum[q] = (q < G) ? red[q * (1 << sh) + rr] : 0.0;
-#pragma unroll
-        for (int wdt = 1; wdt < 32; wdt <<= 1)
-#pragma unroll
-            for (int q = 0; q + wdt < 32; q += 2 * wdt) tsum[q] += tsum[q + wdt];
-        st_agent(W + r, (r < p) ? tsum[0] : wsl[rr] + tsum[0]);
+    for (int c = 0; c < K; c++) {
+        if (c < nk) { // workgroup-uniform
+            red[g * (1 << sh) + rr] = acc0[c] + acc1[c];
+            __syncthreads();
+            if (g == 0 && r < r1) {
+                const double tot = sf_group_sum(red, 1 << sh, rr, G);
+                st_agent(W + c * wstr + r, (r < p) ? tot : wsl[c * 128 + rr] + tot);
+            }
+            if (K > 1) __syncthreads();
+        }
     }
     if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();
@@ -417,20 +492,22 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     }
 }
 
-// Backward pass, one launch (tasks ordered root first).
-template <bool SMALL_ONLY>
+// Backward pass, one launch per band of levels (tasks ordered root first).
+template <bool SMALL_ONLY, int K>
 __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
-                                                   const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int warm, unsigned long long *trace) {
-    __shared__ double wv[4][64];
-    __shared__ double wc[SMALL_ONLY ? 1 : SF_CHUNK];
+                                                   const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
+                                                   int64_t xstr, int64_t wstr, unsigned long long *trace) {
+    constexpr int CHK = SF_CHUNK / K;
+    __shared__ double wv[4][K][64];
+    __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
     __shared__ double red[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *done = sync + SF_SYNC_HEADER;
     const SfTask t = tasks[blockIdx.x];
     if (SMALL_ONLY || t.kind == 0) {
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
-        if (s >= 0) sf_bwd_small(s, lane, wv[wave], FD, pool, rows, need, done, err, x);
+        if (s >= 0) sf_bwd_small<K>(s, lane, wv[wave], FD, pool, rows, need, done, err, x, nk, xstr);
         return;
     }
     if (SMALL_ONLY) return;
@@ -448,54 +525,60 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
     const int i = r0 + rr;
     // columns of inv(U11) left of the slab's first 32-column block are zero
     const int jmin = (r0 / NB) * NB;
-    // ---- before the wait: y1 (forward launch) and the row numbers of x2 for the first chunk; panel warm-up ----
-    const int e1 = jmin + SF_CHUNK < f ? jmin + SF_CHUNK : f;
+    // ---- before the wait: y1 (forward launch) and the row numbers of x2 for the first chunk ----
+    const int e1 = jmin + CHK < f ? jmin + CHK : f;
     int xrow[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = jmin + tid + 256 * k;
         xrow[k] = -1;
         if (j < e1) {
-            if (j < p) wc[j - jmin] = W[j];
-            else xrow[k] = rws[j - p];
+            if (j < p) {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) wc[c * CHK + j - jmin] = W[c * wstr + j];
+            } else {
+                xrow[k] = rws[j - p];
+            }
         }
     }
-    double sink = 0.0;
-    if (wave == 0) {
-        if (fd.parent >= 0 && tid == 0) sf_wait(done + fd.parent, need[fd.parent], err);
-    } else if (warm && i < r1) {
-        sink = sf_warm(Ep + i, ld, jmin + g, f, G);
-        if (wave == 1) sink += sf_warm(Ep + i, ld, jmin + g - (G >> 2), f, G); // the polling wave's columns
-    }
-    if (sink == 1.2345e300) red[0] = sink; // never true: keeps the warm-up loads alive
+    if (fd.parent >= 0 && tid == 0) sf_wait(done + fd.parent, need[fd.parent], err);
     __syncthreads();
     if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        if (xrow[k] >= 0) wc[tid + 256 * k] = ld_agent(x + xrow[k]);
+        if (xrow[k] >= 0) {
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk) wc[c * CHK + tid + 256 * k] = ld_agent(x + c * xstr + xrow[k]);
+        }
     __syncthreads();
-    double acc0 = 0.0, acc1 = 0.0;
-    for (int c0 = jmin; c0 < f; c0 += SF_CHUNK) {
-        const int c1 = c0 + SF_CHUNK < f ? c0 + SF_CHUNK : f;
+    double acc0[K], acc1[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) acc0[c] = acc1[c] = 0.0;
+    for (int c0 = jmin; c0 < f; c0 += CHK) {
+        const int c1 = c0 + CHK < f ? c0 + CHK : f;
         if (c0 > jmin) {
-            for (int j = c0 + tid; j < c1; j += 256) wc[j - c0] = (j < p) ? W[j] : ld_agent(x + rws[j - p]);
+            for (int j = c0 + tid; j < c1; j += 256) {
+                const int row = (j < p) ? 0 : rws[j - p];
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) wc[c * CHK + j - c0] = (j < p) ? W[c * wstr + j] : ld_agent(x + c * xstr + row);
+            }
             __syncthreads();
         }
-        if (i < r1) sf_dot(acc0, acc1, Ep + i, ld, wc, c0, c0 + g, c1, G);
+        if (i < r1) sf_dot<K>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
-    red[g * (1 << sh) + rr] = acc0 + acc1;
-    __syncthreads();
-    if (g == 0 && i < r1) {
-        double tsum[32];
 #pragma unroll
-        for (int q = 0; q < 32; q++) tsum[q] = (q < G) ? red[q * (1 << sh) + rr] : 0.0;
-#pragma unroll
-        for (int wdt = 1; wdt < 32; wdt <<= 1)
-#pragma unroll
-            for (int q = 0; q + wdt < 32; q += 2 * wdt) tsum[q] += tsum[q + wdt];
-        st_agent(x + fd.first + i, tsum[0]);
+    for (int c = 0; c < K; c++) {
+        if (c < nk) {
+            red[g * (1 << sh) + rr] = acc0[c] + acc1[c];
+            __syncthreads();
+            if (g == 0 && i < r1) st_agent(x + c * xstr + fd.first + i, sf_group_sum(red, 1 << sh, rr, G));
+            if (K > 1) __syncthreads();
+        }
     }
     if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();

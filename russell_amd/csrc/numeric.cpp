@@ -45,7 +45,7 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+    void *ptrs[] = {d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
@@ -53,6 +53,7 @@ void Solver::release() {
     d_dws = nullptr, d_ear = nullptr;
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_cs = nullptr, d_rperm = nullptr;
+    d_blk = nullptr, d_work_blk = nullptr;
     matched = false;
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
@@ -182,7 +183,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_scalar, 4 * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_scalar, (4 + 2 * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     for (auto &e : ev) {
         hipEvent_t he;
         HIPC(hipEventCreate(&he), ERROR_HIP_MALLOC);
@@ -504,7 +505,7 @@ int32_t Solver::run_factor() {
     return SUCCESSFUL_EXIT;
 }
 
-int32_t Solver::run_triangular(double *xp) {
+int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr) {
     int64_t launches = 0;
     if (use_fused) {
         const int32_t ns = S.nsuper;
@@ -512,25 +513,37 @@ int32_t Solver::run_triangular(double *xp) {
         HIPC(hipMemsetAsync(d_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), STREAM), ERROR_HIP_MEMCPY);
         HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
         const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
-        if (fa > 0)
-            hipLaunchKernelGGL(k_fwd_fused<true>, dim3(fa), dim3(256), 0, STREAM, d_sf, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f,
-                               sync_err, d_work, xp, sf_warm_flag, (unsigned long long *)nullptr);
-        if (fb > 0)
-            hipLaunchKernelGGL(k_fwd_fused<false>, dim3(fb), dim3(256), 0, STREAM, d_sf + fa, d_fd, d_pool, d_lperm, d_child, d_rel, d_need,
-                               sync_f, sync_err, d_work, xp, sf_warm_flag, d_trace);
-        HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
         const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
-        if (bt > 0)
-            hipLaunchKernelGGL(k_bwd_fused<false>, dim3(bt), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt, d_fd, d_pool, d_rows, d_need + ns, sync_b,
-                               sync_err, d_work, xp, sf_warm_flag, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
-        if (bb > 0)
-            hipLaunchKernelGGL(k_bwd_fused<true>, dim3(bb), dim3(256), 0, STREAM, d_sf + sf_fwd_cnt + bt, d_fd, d_pool, d_rows, d_need + ns,
-                               sync_b, sync_err, d_work, xp, sf_warm_flag, (unsigned long long *)nullptr);
+        unsigned long long *no_trace = nullptr;
+#define HIPMF_FWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
+    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, STREAM, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f, \
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE)
+#define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
+    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, STREAM, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b, sync_err,  \
+                       wrk, xp, nk, xstr, wstr, TRACE)
+        if (nk == 1) {
+            if (fa > 0) HIPMF_FWD(true, 1, fa, d_sf, no_trace);
+            if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, d_trace);
+        } else {
+            if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, d_sf, no_trace);
+            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, no_trace);
+        }
+        HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
+        if (nk == 1) {
+            if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
+            if (bb > 0) HIPMF_BWD(true, 1, bb, d_sf + sf_fwd_cnt + bt, no_trace);
+        } else {
+            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, no_trace);
+            if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, d_sf + sf_fwd_cnt + bt, no_trace);
+        }
+#undef HIPMF_FWD
+#undef HIPMF_BWD
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
         times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
         tri_pending = true;
         return SUCCESSFUL_EXIT;
     }
+    if (nk != 1 || wrk != d_work) return ERROR_HIPMF_INVALID_VALUE; // the level-set launches carry one right-hand side
     HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
         if (L.small_cnt > 0) {
@@ -595,51 +608,90 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     const dim3 g((n + 255) / 256), b(256);
     const double EPS = 2.220446049250313e-16;
     refinement_steps_done = 0;
+    // Blocks of KB right-hand sides go through the triangular solves together (the dependency-driven kernels read each
+    // factor entry once per block); one right-hand side uses the single-column instances and buffers.
+    const int32_t KB = (use_fused && nrhs > 1) ? SF_KMAX : 1;
+    if (KB > 1 && !d_blk) {
+        // xp | du | r | den | b | x: six n x KB blocks, plus KB solve workspaces
+        HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
+    }
+    double *XP = KB > 1 ? d_blk : d_xp, *DU = KB > 1 ? d_blk + (size_t)n * KB : d_du, *RR = KB > 1 ? d_blk + 2 * (size_t)n * KB : d_r,
+           *DEN = KB > 1 ? d_blk + 3 * (size_t)n * KB : d_den, *BB = KB > 1 ? d_blk + 4 * (size_t)n * KB : d_b,
+           *XX = KB > 1 ? d_blk + 5 * (size_t)n * KB : d_x, *WRK = KB > 1 ? d_work_blk : d_work;
+    const int64_t wstr = work_doubles;
     HIPC(hipEventRecord((hipEvent_t)ev[6], STREAM), ERROR_HIP_SYNCHRONIZE);
-    for (int32_t j = 0; j < nrhs; j++) {
-        const double *bj;
-        double *xj;
-        if (on_device) {
-            bj = rhs + (int64_t)j * ldx;
-            xj = x + (int64_t)j * ldx;
-        } else {
-            HIPC(hipMemcpyAsync(d_b, rhs + (int64_t)j * ldx, sizeof(double) * n, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
-            bj = d_b;
-            xj = d_x;
+    for (int32_t j0 = 0; j0 < nrhs; j0 += KB) {
+        const int32_t nk = std::min(KB, nrhs - j0);
+        const double *bj[SF_KMAX];
+        double *xj[SF_KMAX];
+        for (int32_t c = 0; c < nk; c++) {
+            if (on_device) {
+                bj[c] = rhs + (int64_t)(j0 + c) * ldx;
+                xj[c] = x + (int64_t)(j0 + c) * ldx;
+            } else {
+                HIPC(hipMemcpyAsync(BB + (size_t)c * n, rhs + (int64_t)(j0 + c) * ldx, sizeof(double) * n, hipMemcpyHostToDevice, STREAM),
+                     ERROR_HIP_MEMCPY);
+                bj[c] = BB + (size_t)c * n;
+                xj[c] = XX + (size_t)c * n;
+            }
+            hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, bj[c], XP + (size_t)c * n);
         }
-        hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, bj, d_xp);
-        int32_t code = run_triangular(d_xp);
+        int32_t code = run_triangular(XP, nk, WRK, n, wstr);
         if (code != SUCCESSFUL_EXIT) return code;
-        hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, d_xp, xj, 0);
+        for (int32_t c = 0; c < nk; c++) hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, XP + (size_t)c * n, xj[c], 0);
         // Iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229).
-        // Stopping rule on the sparse backward error omega = max_i |r_i| / (|A||x| + |b|)_i: stop when omega <= eps,
-        // when a step fails to halve it, or after refinement_nstep steps; a step that makes omega worse is taken back.
-        double prev = INFINITY;
+        // Stopping rule per column on the sparse backward error omega = max_i |r_i| / (|A||x| + |b|)_i: stop when
+        // omega <= eps, when a step fails to halve it, or after refinement_nstep steps; a step that makes omega worse is
+        // taken back.  The correction solves of a block run together as long as any of its columns is still active.
+        double prev[SF_KMAX];
+        bool active[SF_KMAX];
+        for (int32_t c = 0; c < nk; c++) prev[c] = INFINITY, active[c] = true;
         for (int32_t it = 0; it <= opt.refinement_nstep && opt.refinement_nstep > 0; it++) {
-            hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj, bj, d_r, d_den);
-            HIPC(hipMemsetAsync(d_scalar + 1, 0, 2 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
-            hipLaunchKernelGGL(k_norms, dim3(std::min(1024, (n + 255) / 256)), b, 0, STREAM, n, d_r, d_den, d_scalar + 1);
-            double nrm[2] = {0.0, 0.0};
-            HIPC(hipMemcpyAsync(nrm, d_scalar + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+            HIPC(hipMemsetAsync(d_scalar + 1, 0, 2 * SF_KMAX * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
+            for (int32_t c = 0; c < nk; c++) {
+                if (!active[c]) continue;
+                hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj[c], bj[c], RR + (size_t)c * n,
+                                   DEN + (size_t)c * n);
+                hipLaunchKernelGGL(k_norms, dim3(std::min(1024, (n + 255) / 256)), b, 0, STREAM, n, RR + (size_t)c * n, DEN + (size_t)c * n,
+                                   d_scalar + 1 + 2 * c);
+            }
+            double nrm[2 * SF_KMAX] = {0.0};
+            HIPC(hipMemcpyAsync(nrm, d_scalar + 1, 2 * nk * sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
             HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
             harvest_tri();
-            const double rn = nrm[0], omega = nrm[1];
-            if (it > 0 && !(omega < prev)) {
-                hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, d_du, xj, 2); // take the last correction back
-                break;
+            bool any = false;
+            for (int32_t c = 0; c < nk; c++) {
+                if (!active[c]) continue;
+                const double rn = nrm[2 * c], omega = nrm[2 * c + 1];
+                if (it > 0 && !(omega < prev[c])) {
+                    hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, DU + (size_t)c * n, xj[c], 2); // take the last correction back
+                    active[c] = false;
+                    continue;
+                }
+                if (j0 + c == 0) last_residual_inf = rn, last_omega = omega;
+                if (omega <= EPS || it == opt.refinement_nstep || (it > 0 && omega > 0.5 * prev[c])) {
+                    active[c] = false;
+                    continue;
+                }
+                prev[c] = omega;
+                any = true;
             }
-            last_residual_inf = rn;
-            last_omega = omega;
-            if (omega <= EPS || it == opt.refinement_nstep || (it > 0 && omega > 0.5 * prev)) break;
-            prev = omega;
-            hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, d_r, d_du);
-            code = run_triangular(d_du);
+            if (!any) break;
+            for (int32_t c = 0; c < nk; c++) {
+                if (active[c]) hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, RR + (size_t)c * n, DU + (size_t)c * n);
+                else HIPC(hipMemsetAsync(DU + (size_t)c * n, 0, sizeof(double) * n, STREAM), ERROR_HIP_MEMCPY); // finished columns ride along as zeros
+            }
+            code = run_triangular(DU, nk, WRK, n, wstr);
             if (code != SUCCESSFUL_EXIT) return code;
-            hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, d_du, xj, 1);
-            if (j == 0) refinement_steps_done++;
+            for (int32_t c = 0; c < nk; c++)
+                if (active[c]) hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, DU + (size_t)c * n, xj[c], 1);
+            if (j0 == 0 && active[0]) refinement_steps_done++;
         }
         if (!on_device)
-            HIPC(hipMemcpyAsync(x + (int64_t)j * ldx, d_x, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+            for (int32_t c = 0; c < nk; c++)
+                HIPC(hipMemcpyAsync(x + (int64_t)(j0 + c) * ldx, XX + (size_t)c * n, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM),
+                     ERROR_HIP_MEMCPY);
     }
     HIPC(hipEventRecord((hipEvent_t)ev[7], STREAM), ERROR_HIP_SYNCHRONIZE);
     if (use_fused) {

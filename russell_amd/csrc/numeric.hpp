@@ -108,7 +108,8 @@ class Solver {
   private:
     int32_t upload_plan();
     int32_t run_factor();
-    int32_t run_triangular(double *d_xp); // forward + backward on a permuted, scaled vector
+    // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)
+    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr);
     void harvest_tri();
     bool tri_pending = false;
     std::vector<LevelPlan> levels;
@@ -131,6 +132,7 @@ class Solver {
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
+    double *d_blk = nullptr, *d_work_blk = nullptr; // many-RHS blocks (allocated at the first multi-column solve)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
     int32_t sf_warm_flag = 0;               // HIPMF_SF_WARM=1: waiting workgroups pre-touch their panel (tuning knob; measured slower:

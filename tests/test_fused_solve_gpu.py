@@ -84,3 +84,21 @@ def test_poisson3d_fronts_beyond_the_lds_staging_limit():
     x = s.solve(b)
     assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-11
     s.close()
+
+
+@pytest.mark.parametrize("grid,nrhs", [(60, 6), (300, 9)])
+def test_many_rhs_blocks_equal_single_solves_bitwise(grid, nrhs):
+    # solve_many sends blocks of 4 right-hand sides through the dependency-driven kernels together (the factor is read
+    # once per block); per column the arithmetic is the single-column one
+    n, rp, ci, v = P.poisson2d(grid)
+    rng = np.random.default_rng(grid)
+    XS = rng.standard_normal((nrhs, n))
+    B = np.array([P.csr_matvec(n, rp, ci, v, XS[j]) for j in range(nrhs)])
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    X = s.solve_many(B)
+    for j in range(nrhs):
+        assert np.array_equal(X[j], s.solve(B[j]))
+    assert np.max(np.abs(X - XS)) / np.max(np.abs(XS)) < 1e-10
+    s.close()
