@@ -68,6 +68,15 @@ void Solver::release() {
         (void)hipStreamDestroy(STREAM);
         stream = nullptr;
     }
+    if (stream2) {
+        (void)hipStreamDestroy((hipStream_t)stream2);
+        stream2 = nullptr;
+    }
+    for (void **e : {&ev_fork, &ev_join})
+        if (*e) {
+            (void)hipEventDestroy((hipEvent_t)*e);
+            *e = nullptr;
+        }
     initialized = factorized = false;
 }
 
@@ -85,6 +94,12 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         hipStream_t st;
         HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
         stream = st;
+        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+        stream2 = st;
+        hipEvent_t e1, e2;
+        HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+        HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+        ev_fork = e1, ev_join = e2;
     }
     SymbolicOptions so = sopt;
     so.augment_above = SMALL_F;
@@ -98,6 +113,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SF_WARM")) sf_warm_flag = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -466,10 +482,20 @@ int32_t Solver::run_factor() {
             hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             launches++;
         }
+        // a level's small fronts and its big fronts are independent of each other (both only need the level's extend-add):
+        // when the level has both, the small ones are factorised on a second stream beside the tiled steps
+        const bool forked = L.small_cnt > 0 && !L.steps.empty() && overlap_small;
         if (L.small_cnt > 0) {
             size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
-            hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt), dim3(64), shmem, STREAM, d_lists + L.small_off, d_fd, d_pool,
-                               d_lperm, d_scalar, opt.pivot_epsilon, d_info, L.small_ld);
+            hipStream_t sst = STREAM;
+            if (forked) {
+                HIPC(hipEventRecord((hipEvent_t)ev_fork, STREAM), ERROR_HIP_SYNCHRONIZE);
+                HIPC(hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
+                sst = (hipStream_t)stream2;
+            }
+            hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt), dim3(64), shmem, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
+                               d_scalar, opt.pivot_epsilon, d_info, L.small_ld);
+            if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
             launches++;
         }
         int32_t k0 = 0;
@@ -482,6 +508,7 @@ int32_t Solver::run_factor() {
             launches += 2;
             k0 += NB;
         }
+        if (forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
     }
     HIPC(hipEventRecord((hipEvent_t)ev[2], STREAM), ERROR_HIP_SYNCHRONIZE);
     FactorInfo hinfo;

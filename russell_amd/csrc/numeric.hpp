@@ -93,6 +93,8 @@ class Solver {
     double last_residual_inf = 0.0, last_omega = 0.0;
     int device = 0;
     void *stream = nullptr;
+    void *stream2 = nullptr;          // the small fronts of a level are factorised beside its tiled steps
+    void *ev_fork = nullptr, *ev_join = nullptr;
     std::string last_error;
 
     // exported for the many-RHS / multi-GPU paths: the factor lives in [d_pool, d_pool + pool_doubles)
@@ -128,6 +130,7 @@ class Solver {
     int32_t sf_fwd_launch = 0;              // == sf_fwd_cnt unless the profiling knob HIPMF_SF_FWD_LEVELS cuts the pass short
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
+    bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
