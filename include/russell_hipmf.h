@@ -124,6 +124,21 @@ int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *solver, double *d_x, co
 int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *solver, double *v, double alpha, const double *u);
 
 /* perm[new] = old: the fill-reducing permutation applied to rows and columns (ndim entries) */
+/* Value refresh through a map (extension for the repeat-factorise callers, SURVEY.md 8f-2: Radau5 / Newton iterations call
+ * LinSolTrait::factorize with the same structure and new values every step, radau5.rs:264-303; the reference converts
+ * COO -> CSC/CSR on the host each time, csc_matrix.rs:365-505).  After solver_hipmf_initialize:
+ *   solver_hipmf_set_value_map: CSR entry j (the order given to initialize) is the sum of the caller's entries
+ *     input[seg_idx[q]], seg_ptr[j] <= q < seg_ptr[j+1]  (seg_ptr has nnz+1 entries, seg_ptr[nnz] = nnz_in; e.g. the COO
+ *     triplets with their duplicates);
+ *   solver_hipmf_factorize_mapped / _device: numeric factorisation from nnz_in caller-ordered values (host / device pointer):
+ *     one gather kernel replaces the host conversion. */
+int32_t solver_hipmf_set_value_map(struct InterfaceHIPMF *solver, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx);
+int32_t solver_hipmf_factorize_mapped(struct InterfaceHIPMF *solver, int32_t *effective_ordering, int32_t *effective_scaling,
+                                      int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
+                                      double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose,
+                                      const double *input_values);
+int32_t solver_hipmf_factorize_mapped_device(struct InterfaceHIPMF *solver, const double *d_input_values);
+
 int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *solver, int32_t *perm);
 
 /* Host-only helper (no device needed): the maximum-product matching + scaling of an n x n CSR matrix that

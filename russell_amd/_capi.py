@@ -31,6 +31,11 @@ SYMBOLS = {
     "solver_hipmf_solve_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "solver_hipmf_mat_vec_mul": (C.c_int32, [C.c_void_p, f64p, C.c_double, f64p]),
     "solver_hipmf_get_permutation": (C.c_int32, [C.c_void_p, i32p]),
+    "solver_hipmf_set_value_map": (C.c_int32, [C.c_void_p, C.c_int32, i32p, i32p]),
+    "solver_hipmf_factorize_mapped": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
+                                                  C.c_int32, f64p]),
+    "solver_hipmf_factorize_mapped_device": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "hipmf_max_product_matching": (C.c_int32, [C.c_int32, i32p, i32p, f64p, i32p, f64p, f64p]),
     "solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
     "solver_hipmf_reset_timers": (C.c_int32, [C.c_void_p]),

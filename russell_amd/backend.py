@@ -67,6 +67,24 @@ class Hipmf:
         self.rcond, self.det_coefficient, self.det_exponent = rc.value, dc.value, de.value
         return code
 
+    def set_value_map(self, seg_ptr, seg_idx):
+        """CSR entry j <- sum of input[seg_idx[seg_ptr[j]:seg_ptr[j+1]]] (e.g. COO triplets with duplicates)."""
+        sp = np.ascontiguousarray(seg_ptr, dtype=np.int32)
+        si = np.ascontiguousarray(seg_idx, dtype=np.int32)
+        self.nnz_in = int(si.size)
+        return self.lib.solver_hipmf_set_value_map(self.h, self.nnz_in, sp, si)
+
+    def factorize_mapped(self, input_values, compute_determinant=False, verbose=False):
+        v = np.ascontiguousarray(input_values, dtype=np.float64)
+        assert v.size >= self.nnz_in
+        eo, es, npv = C.c_int32(), C.c_int32(), C.c_int32()
+        rc, dc, de = C.c_double(), C.c_double(), C.c_double()
+        code = self.lib.solver_hipmf_factorize_mapped(self.h, C.byref(eo), C.byref(es), C.byref(npv), C.byref(rc), C.byref(dc),
+                                                      C.byref(de), int(compute_determinant), int(verbose), v)
+        self.effective_ordering, self.effective_scaling, self.num_perturbed = eo.value, es.value, npv.value
+        self.rcond, self.det_coefficient, self.det_exponent = rc.value, dc.value, de.value
+        return code
+
     def solve(self, rhs, verbose=False):
         b = np.ascontiguousarray(rhs, dtype=np.float64)
         x = np.zeros(self.n)

@@ -346,6 +346,8 @@ struct Backend {
     decltype(&solver_hipmf_factorize) factorize = nullptr;
     decltype(&solver_hipmf_solve) solve = nullptr;
     decltype(&solver_hipmf_solve_many) solve_many = nullptr;
+    decltype(&solver_hipmf_set_value_map) set_value_map = nullptr;
+    decltype(&solver_hipmf_factorize_mapped) factorize_mapped = nullptr;
     bool tried = false;
 };
 Backend g_backend;
@@ -381,6 +383,8 @@ bool load_backend() {
     BIND(factorize, "solver_hipmf_factorize")
     BIND(solve, "solver_hipmf_solve")
     BIND(solve_many, "solver_hipmf_solve_many")
+    BIND(set_value_map, "solver_hipmf_set_value_map")
+    BIND(factorize_mapped, "solver_hipmf_factorize_mapped")
 #undef BIND
     g_backend.dl = dl;
     return true;
@@ -447,8 +451,10 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
         if (mat.nrow != initialized_ndim) return "subsequent factorizations must use the same matrix (ndim differs)";
         if (mat.nnz != initialized_nnz) return "subsequent factorizations must use the same matrix (nnz differs)";
         if (params) return "subsequent factorizations must not change LinSolParams";
-        StrError e = csr.update_from_coo(mat);
-        if (e) return e;
+        if (!value_map_set) { // (the device refreshes the values through the map otherwise: no host conversion per call)
+            StrError e = csr.update_from_coo(mat);
+            if (e) return e;
+        }
     } else {
         if (mat.nrow != mat.ncol) return "the matrix must be square";
         if (mat.nnz < 1) return "the COO matrix must have at least one non-zero value";
@@ -470,12 +476,35 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
                                               mat.symmetric == Sym::YesLower ? 1 : 0, par.positive_definite ? 1 : 0, (int32_t)csr.nrow,
                                               csr.row_pointers.data(), csr.col_indices.data(), csr.values.data());
         if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+        // value map for the repeat calls: CSR entry <- the COO triplets (duplicates in COO order) that sum into it
+        {
+            const size_t nz = (size_t)csr.row_pointers[csr.nrow];
+            std::vector<int32_t> seg_ptr(nz + 1, 0), seg_idx(mat.nnz), pos(mat.nnz);
+            for (size_t k = 0; k < mat.nnz; k++) {
+                const int32_t i = mat.indices_i[k], j = mat.indices_j[k];
+                const int32_t *b = csr.col_indices.data() + csr.row_pointers[i], *e = csr.col_indices.data() + csr.row_pointers[i + 1];
+                pos[k] = (int32_t)(std::lower_bound(b, e, j) - csr.col_indices.data());
+                seg_ptr[(size_t)pos[k] + 1]++;
+            }
+            for (size_t q = 0; q < nz; q++) seg_ptr[q + 1] += seg_ptr[q];
+            std::vector<int32_t> w(seg_ptr.begin(), seg_ptr.end() - 1);
+            for (size_t k = 0; k < mat.nnz; k++) seg_idx[(size_t)w[pos[k]]++] = (int32_t)k;
+            value_map_set = g_backend.set_value_map((InterfaceHIPMF *)solver, (int32_t)mat.nnz, seg_ptr.data(), seg_idx.data()) == SUCCESSFUL_EXIT;
+        }
         time_initialize_ns = now_ns() - t0;
         initialized = true;
+        first_call = true;
     }
     uint64_t t0 = now_ns();
-    int32_t status = g_backend.factorize((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
+    int32_t status;
+    if (value_map_set && !first_call)
+        status = g_backend.factorize_mapped((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
+                                            &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose,
+                                            mat.values.data());
+    else
+        status = g_backend.factorize((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
                                          &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose, csr.values.data());
+    first_call = false;
     if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
     time_factorize_ns = now_ns() - t0;
     factorized = true;

@@ -131,6 +131,7 @@ class SolverHIPMF : public LinSolTrait {
     StrError solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs);
 
     bool factorized = false;
+    bool value_map_set = false, first_call = false; // repeat factorizations refresh the values on the device through a map
     int32_t effective_ordering = -1, effective_scaling = -1, perturbed_pivots = 0;
     double rcond_estimate = 0.0, determinant_coefficient = 0.0, determinant_exponent = 0.0;
 

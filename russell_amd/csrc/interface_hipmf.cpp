@@ -91,6 +91,28 @@ int32_t solver_hipmf_factorize(struct InterfaceHIPMF *h, int32_t *effective_orde
                             determinant_coefficient, determinant_exponent, compute_determinant);
 }
 
+int32_t solver_hipmf_set_value_map(struct InterfaceHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
+    if (!h) return ERROR_NULL_POINTER;
+    return h->solver.set_value_map(nnz_in, seg_ptr, seg_idx);
+}
+
+int32_t solver_hipmf_factorize_mapped(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+                                      int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
+                                      double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *input_values) {
+    if (!h || !input_values) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    h->solver.opt.verbose = verbose == 1;
+    int32_t code = h->solver.factorize_mapped(input_values, false);
+    return finish_factorize(h, code, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, determinant_coefficient,
+                            determinant_exponent, compute_determinant);
+}
+
+int32_t solver_hipmf_factorize_mapped_device(struct InterfaceHIPMF *h, const double *d_input_values) {
+    if (!h || !d_input_values) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    return h->solver.factorize_mapped(d_input_values, true);
+}
+
 int32_t solver_hipmf_factorize_device(struct InterfaceHIPMF *h, const double *d_values) {
     if (!h || !d_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;

@@ -45,7 +45,7 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+    void *ptrs[] = {d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
@@ -54,6 +54,7 @@ void Solver::release() {
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_cs = nullptr, d_rperm = nullptr;
     d_blk = nullptr, d_work_blk = nullptr;
+    d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr, nnz_in = 0;
     matched = false;
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
@@ -452,6 +453,47 @@ int32_t Solver::factorize(const double *values, bool on_device) {
     const int64_t nnz = S.nnz_a;
     HIPC(hipMemcpyAsync(d_vals, values, sizeof(double) * nnz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, STREAM),
          ERROR_HIP_MEMCPY);
+    int32_t code = run_factor();
+    if (code != SUCCESSFUL_EXIT) return code;
+    factorized = true;
+    return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::set_value_map(int64_t nin, const int32_t *seg_ptr, const int32_t *seg_idx) {
+    if (!initialized) return ERROR_NEED_INITIALIZATION;
+    if (!seg_ptr || !seg_idx) return ERROR_NULL_POINTER;
+    const int64_t nnz = S.nnz_a;
+    if (nin < 1 || nin > 0x7fffffffLL || seg_ptr[0] != 0 || seg_ptr[nnz] != nin) return ERROR_HIPMF_INVALID_VALUE;
+    for (int64_t j = 0; j < nnz; j++)
+        if (seg_ptr[j + 1] < seg_ptr[j]) return ERROR_HIPMF_INVALID_VALUE;
+    for (int64_t q = 0; q < nin; q++)
+        if (seg_idx[q] < 0 || seg_idx[q] >= nin) return ERROR_HIPMF_INVALID_VALUE;
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    for (void *p : {(void *)d_seg_ptr, (void *)d_seg_idx, (void *)d_vin})
+        if (p) (void)hipFree(p);
+    d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr;
+    HIPC(hipMalloc((void **)&d_seg_ptr, sizeof(int32_t) * (nnz + 1)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_seg_idx, sizeof(int32_t) * nin), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_vin, sizeof(double) * nin), ERROR_HIP_MALLOC);
+    HIPC(hipMemcpy(d_seg_ptr, seg_ptr, sizeof(int32_t) * (nnz + 1), hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpy(d_seg_idx, seg_idx, sizeof(int32_t) * nin, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
+    nnz_in = nin;
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::factorize_mapped(const double *input, bool on_device) {
+    if (!initialized) return ERROR_NEED_INITIALIZATION;
+    if (!input) return ERROR_NULL_POINTER;
+    if (nnz_in < 1) return ERROR_HIPMF_INVALID_VALUE; // no map set
+    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    const double *src = input;
+    if (!on_device) {
+        HIPC(hipMemcpyAsync(d_vin, input, sizeof(double) * nnz_in, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
+        src = d_vin;
+    }
+    const int64_t nnz = S.nnz_a;
+    hipLaunchKernelGGL(k_gather_values, dim3((unsigned)std::min<int64_t>(4096, (nnz + 255) / 256)), dim3(256), 0, STREAM, nnz, d_seg_ptr, d_seg_idx,
+                       src, d_vals);
     int32_t code = run_factor();
     if (code != SUCCESSFUL_EXIT) return code;
     factorized = true;

@@ -78,6 +78,9 @@ class Solver {
                        const NumericOptions &nopt, const double *values = nullptr);
     // values: nnz doubles in the CSR order given to initialize; on_device tells where they live
     int32_t factorize(const double *values, bool on_device);
+    // value refresh through a map: CSR entry j = sum of input[seg_idx[seg_ptr[j] .. seg_ptr[j + 1])]
+    int32_t set_value_map(int64_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx);
+    int32_t factorize_mapped(const double *input, bool on_device);
     int32_t solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device);
     int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
     int32_t determinant(double *mantissa, double *exponent, double *rcond);
@@ -135,6 +138,9 @@ class Solver {
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
+    int32_t *d_seg_ptr = nullptr, *d_seg_idx = nullptr; // value map (set_value_map)
+    double *d_vin = nullptr;
+    int64_t nnz_in = 0;
     double *d_blk = nullptr, *d_work_blk = nullptr; // many-RHS blocks (allocated at the first multi-column solve)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing

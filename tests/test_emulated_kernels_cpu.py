@@ -64,3 +64,41 @@ def test_emulated_pivoting_and_determinant(emu_lib):
     assert code == 0 and np.max(np.abs(x - np.arange(1, 6))) < 1e-13
     assert abs(s.det_coefficient * 10.0 ** s.det_exponent - 114.0) < 1e-10
     s.close()
+
+
+def test_emulated_value_map_refresh_with_duplicates(emu_lib):
+    # COO triplets with duplicates -> CSR values on the "device": same factor as handing over the summed CSR values
+    n, rp, ci, v = P.poisson2d(10, 8)
+    rng = np.random.default_rng(5)
+    nnz = int(rp[-1])
+    # every CSR entry is split into 1..3 triplets, shuffled
+    owner = np.concatenate([np.full(rng.integers(1, 4), j) for j in range(nnz)])
+    rng.shuffle(owner)
+    order = np.argsort(owner, kind="stable")
+    seg_ptr = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=nnz))]).astype(np.int32)
+    seg_idx = order.astype(np.int32)
+    xs = P.manufactured_solution(n)
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci) == 0
+    assert s.set_value_map(seg_ptr, seg_idx) == 0
+    for step in range(3):
+        vals = v * (1.0 + 0.1 * step) + (step > 0) * 0.01 * rng.standard_normal(nnz) * (ci == np.repeat(np.arange(n), np.diff(rp)))
+        parts = rng.standard_normal(owner.size)
+        # make the triplets of every entry sum to its value (last triplet of each segment takes the remainder)
+        trip = parts.copy()
+        for j in range(nnz):
+            idx = seg_idx[seg_ptr[j]:seg_ptr[j + 1]]
+            trip[idx[-1]] = vals[j] - np.sum(trip[idx[:-1]])
+        summed = np.array([np.sum(np.concatenate([[0.0], trip[seg_idx[seg_ptr[j]:seg_ptr[j + 1]]]])) for j in range(nnz)])
+        b = P.csr_matvec(n, rp, ci, summed, xs)
+        assert s.factorize_mapped(trip) == 0
+        x1 = s.solve(b)
+        assert s.factorize(summed) == 0
+        x2 = s.solve(b)
+        assert np.max(np.abs(x1 - xs)) < 1e-9
+        assert np.max(np.abs(x1 - x2)) < 1e-12
+    # invalid maps are refused
+    bad = seg_ptr.copy()
+    bad[-1] += 1
+    assert s.set_value_map(bad, seg_idx) == 803
+    s.close()

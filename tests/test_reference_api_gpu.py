@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from helpers import BY_NAME, GOLD, triplets
+from russell_amd import problems as P
 from russell_amd.sparse import (CooMatrix, Genie, LinSolParams, LinSolver, MMsym, Ordering, Scaling, StrError, Sym, VerifyLinSys,
                                 read_matrix_market)
 
@@ -187,3 +188,32 @@ def test_many_rhs_through_host_layer():
     B = np.vstack([np.array(c["rhs"]), 2.0 * np.array(c["rhs"]), np.ones(5)])
     X = solver.actual.solve_many(B)
     assert np.max(np.abs(X[0] - np.array(c["x"]))) <= 1e-12 and np.max(np.abs(X[1] - 2.0 * np.array(c["x"]))) <= 1e-12
+
+
+def test_repeat_factorize_refreshes_values_on_device():
+    # the Radau5 / Newton pattern (radau5.rs:264-303): same structure, new values every step, factorize(coo, None).
+    # After the first call the backend refreshes the CSR values on the device through a map built once
+    # (solver_hipmf_set_value_map): triplets incl. duplicates, no host COO -> CSR conversion per step.
+    npoint = 12
+    n, rp, ci, v0 = P.brusselator_pattern(npoint)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    rng = np.random.default_rng(17)
+    dup = rng.choice(len(v0), size=len(v0) // 10, replace=False)  # 10 % of the entries arrive as two triplets
+    solver = LinSolver(Genie.Hipmf)
+    coo = CooMatrix(n, n, len(v0) + len(dup), Sym.No)
+    xs = 1.0 + (np.arange(n) % 7) / 7.0
+    for step in range(6):
+        v = v0 * (1.0 + 0.05 * step) + 0.3 * step * (rows == ci)
+        coo.reset()
+        isdup = np.zeros(len(v), bool)
+        isdup[dup] = True
+        for k in range(len(v)):
+            if isdup[k]:
+                coo.put(int(rows[k]), int(ci[k]), 0.25 * v[k])
+                coo.put(int(rows[k]), int(ci[k]), 0.75 * v[k])
+            else:
+                coo.put(int(rows[k]), int(ci[k]), v[k])
+        solver.actual.factorize(coo, None)
+        b = P.csr_matvec(n, rp, ci, v, xs)
+        x = solver.actual.solve(b)
+        assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-10, step
