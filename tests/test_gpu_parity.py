@@ -309,3 +309,37 @@ def test_full_size_c2_properties():
     st = s.stats()
     assert st["n_perturbed"] == 0 and st["n_zero_pivot"] == 0
     s.close()
+
+
+def test_distinct_handles_from_concurrent_threads():
+    # LinSolTrait is Send and Radau5 drives its real and complex solvers from two scoped threads
+    # (radau5.rs:270-296, russell_ode/tests/test_multithreaded.rs): distinct handles, own streams, used concurrently.
+    import threading
+
+    results = {}
+
+    def work(tag, grid, seed):
+        n, rp, ci, v = P.poisson2d(grid)
+        rng = np.random.default_rng(seed)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci) == 0
+        out = []
+        for rep in range(4):
+            vv = v * (1.0 + 0.1 * rep)
+            xs = rng.standard_normal(n)
+            b = P.csr_matvec(n, rp, ci, vv, xs)
+            assert s.factorize(vv) == 0
+            x = s.solve(b)
+            out.append(float(np.max(np.abs(x - xs)) / np.max(np.abs(xs))))
+        s.close()
+        results[tag] = out
+
+    ts = [threading.Thread(target=work, args=("a", 220, 1)), threading.Thread(target=work, args=("b", 301, 2)),
+          threading.Thread(target=work, args=("c", 150, 3))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert sorted(results) == ["a", "b", "c"]
+    for tag, errs in results.items():
+        assert max(errs) < 1e-10, (tag, errs)
