@@ -52,6 +52,18 @@ void rh_csr_free(void *csr);
 const char *rh_verify(void *coo, const double *x, int64_t nx, const double *rhs, int64_t nr, double *out4);
 void *rh_read_matrix_market(const char *path, int32_t mmsym, const char **err);
 
+/* complex twin (ComplexCooMatrix, ComplexLinSolTrait): complex numbers are (re, im) pairs of doubles, vectors interleaved;
+ * solved through the real-equivalent system on the same device path (complex_lin_solver.rs:12-104) */
+void *rh_ccoo_new(int64_t nrow, int64_t ncol, int64_t max_nnz, int32_t sym, const char **err);
+void rh_ccoo_free(void *ccoo);
+const char *rh_ccoo_put(void *ccoo, int64_t i, int64_t j, double re, double im);
+void rh_ccoo_reset(void *ccoo);
+const char *rh_ccoo_mat_vec_mul(void *ccoo, double *v, int64_t nv, double alpha_re, double alpha_im, const double *u, int64_t nu);
+void *rh_clinsolver_new(const char **err);
+void rh_clinsolver_free(void *solver);
+const char *rh_clinsolver_factorize(void *solver, void *ccoo, const struct RhParams *params_or_null);
+const char *rh_clinsolver_solve(void *solver, double *x, int64_t nx, const double *rhs, int64_t nr, int32_t verbose);
+
 void *rh_linsolver_new(int32_t genie, const char **err);
 void rh_linsolver_free(void *solver);
 const char *rh_linsolver_factorize(void *solver, void *coo, const struct RhParams *params_or_null);

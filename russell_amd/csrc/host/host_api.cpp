@@ -522,6 +522,106 @@ StrError SolverHIPMF::solve(std::vector<double> &x, const std::vector<double> &r
     return nullptr;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// complex twin through the real-equivalent system
+StrError ComplexCooMatrix::create(ComplexCooMatrix &out, size_t nrow, size_t ncol, size_t max_nnz, Sym symmetric) {
+    if (nrow < 1) return "nrow must be ≥ 1";
+    if (ncol < 1) return "ncol must be ≥ 1";
+    if (max_nnz < 1) return "max_nnz must be ≥ 1";
+    out.symmetric = symmetric;
+    out.nrow = nrow, out.ncol = ncol, out.nnz = 0, out.max_nnz = max_nnz;
+    out.indices_i.assign(max_nnz, 0);
+    out.indices_j.assign(max_nnz, 0);
+    out.values.assign(2 * max_nnz, 0.0);
+    return nullptr;
+}
+
+StrError ComplexCooMatrix::put(size_t i, size_t j, double re, double im) {
+    // coo_matrix.rs:324-352 (same checks for the complex instantiation)
+    if (i >= nrow) return "COO matrix: index of row is outside range";
+    if (j >= ncol) return "COO matrix: index of column is outside range";
+    if (nnz >= max_nnz) return "COO matrix: max number of items has been reached";
+    if (symmetric == Sym::YesLower && j > i) return "COO matrix: j > i is incorrect for lower triangular storage";
+    if (symmetric == Sym::YesUpper && j < i) return "COO matrix: j < i is incorrect for upper triangular storage";
+    indices_i[nnz] = (int32_t)i, indices_j[nnz] = (int32_t)j;
+    values[2 * nnz] = re, values[2 * nnz + 1] = im;
+    nnz++;
+    return nullptr;
+}
+
+StrError ComplexCooMatrix::mat_vec_mul(std::vector<double> &v, double ar, double ai, const std::vector<double> &u) const {
+    if (u.size() != 2 * ncol) return "u.ndim must equal ncol";
+    if (v.size() != 2 * nrow) return "v.ndim must equal nrow";
+    std::fill(v.begin(), v.end(), 0.0);
+    const bool mirror = symmetric == Sym::YesLower || symmetric == Sym::YesUpper;
+    for (size_t k = 0; k < nnz; k++) {
+        const size_t i = (size_t)indices_i[k], j = (size_t)indices_j[k];
+        // alpha * a_ij
+        const double cr = ar * values[2 * k] - ai * values[2 * k + 1], ci = ar * values[2 * k + 1] + ai * values[2 * k];
+        v[2 * i] += cr * u[2 * j] - ci * u[2 * j + 1];
+        v[2 * i + 1] += cr * u[2 * j + 1] + ci * u[2 * j];
+        if (mirror && i != j) {
+            v[2 * j] += cr * u[2 * i] - ci * u[2 * i + 1];
+            v[2 * j + 1] += cr * u[2 * i + 1] + ci * u[2 * i];
+        }
+    }
+    return nullptr;
+}
+
+StrError ComplexSolverHIPMF::create(std::unique_ptr<ComplexSolverHIPMF> &out) {
+    std::unique_ptr<ComplexSolverHIPMF> s(new ComplexSolverHIPMF());
+    StrError e = SolverHIPMF::create(s->real);
+    if (e) return e;
+    out = std::move(s);
+    return nullptr;
+}
+
+StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSolParams *params) {
+    if (initialized) {
+        if (mat.symmetric != initialized_sym) return "subsequent factorizations must use the same matrix (symmetric differs)";
+        if (mat.nrow != initialized_ndim) return "subsequent factorizations must use the same matrix (ndim differs)";
+        if (mat.nnz != initialized_nnz) return "subsequent factorizations must use the same matrix (nnz differs)";
+        if (params) return "subsequent factorizations must not change LinSolParams";
+    } else {
+        if (mat.nrow != mat.ncol) return "the matrix must be square";
+        if (mat.nnz < 1) return "the COO matrix must have at least one non-zero value";
+        if (mat.symmetric == Sym::YesFull || mat.symmetric == Sym::YesUpper) return "HIPMF requires Sym::YesLower for symmetric matrices";
+        if (params && params->compute_determinant) return "the complex twin of HIPMF does not compute the determinant";
+        initialized_sym = mat.symmetric;
+        initialized_ndim = mat.nrow;
+        initialized_nnz = mat.nnz;
+        // a complex SYMMETRIC matrix has an unsymmetric real-equivalent form: mirrored entries are written out
+        size_t nz = 0;
+        for (size_t k = 0; k < mat.nnz; k++) nz += (mat.symmetric == Sym::YesLower && mat.indices_i[k] != mat.indices_j[k]) ? 8 : 4;
+        StrError e = CooMatrix::create(requiv, 2 * mat.nrow, 2 * mat.nrow, nz, Sym::No);
+        if (e) return e;
+    }
+    requiv.reset();
+    for (size_t k = 0; k < mat.nnz; k++) {
+        const size_t i = (size_t)mat.indices_i[k], j = (size_t)mat.indices_j[k];
+        const double a = mat.values[2 * k], b = mat.values[2 * k + 1];
+        for (int t = 0; t < ((mat.symmetric == Sym::YesLower && i != j) ? 2 : 1); t++) {
+            const size_t r = t ? j : i, c = t ? i : j;
+            requiv.put(2 * r, 2 * c, a);
+            requiv.put(2 * r, 2 * c + 1, -b);
+            requiv.put(2 * r + 1, 2 * c, b);
+            requiv.put(2 * r + 1, 2 * c + 1, a);
+        }
+    }
+    StrError e = real->factorize(requiv, initialized ? nullptr : params);
+    if (e) return e;
+    initialized = true;
+    factorized = true;
+    return nullptr;
+}
+
+StrError ComplexSolverHIPMF::solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) {
+    if (!factorized) return "the function factorize must be called before solve";
+    if (x.size() != 2 * initialized_ndim) return "the dimension of the vector of unknown values x is incorrect";
+    if (rhs.size() != 2 * initialized_ndim) return "the dimension of the right-hand side vector is incorrect";
+    return real->solve(x, rhs, verbose); // (re, im) interleaving of the vectors is the ordering of the real-equivalent unknowns
+}
+
 StrError SolverHIPMF::solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs) {
     if (!factorized) return "the function factorize must be called before solve";
     if (nrhs < 1 || x.size() != initialized_ndim * nrhs) return "the dimension of the vector of unknown values x is incorrect";
@@ -804,6 +904,56 @@ struct RhSolver {
     StatsLinSol stats;
     std::string json;
 };
+
+void *rh_ccoo_new(int64_t nrow, int64_t ncol, int64_t max_nnz, int32_t sym, const char **err) {
+    ComplexCooMatrix *c = new ComplexCooMatrix();
+    *err = ComplexCooMatrix::create(*c, (size_t)std::max<int64_t>(nrow, 0), (size_t)std::max<int64_t>(ncol, 0), (size_t)std::max<int64_t>(max_nnz, 0), (Sym)sym);
+    if (*err) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+void rh_ccoo_free(void *c) { delete (ComplexCooMatrix *)c; }
+const char *rh_ccoo_put(void *c, int64_t i, int64_t j, double re, double im) {
+    if (i < 0 || j < 0) return "COO matrix: index of row is outside range";
+    return ((ComplexCooMatrix *)c)->put((size_t)i, (size_t)j, re, im);
+}
+void rh_ccoo_reset(void *c) { ((ComplexCooMatrix *)c)->reset(); }
+const char *rh_ccoo_mat_vec_mul(void *c, double *v, int64_t nv, double alpha_re, double alpha_im, const double *u, int64_t nu) {
+    std::vector<double> vv((size_t)nv), uu(u, u + nu);
+    StrError e = ((ComplexCooMatrix *)c)->mat_vec_mul(vv, alpha_re, alpha_im, uu);
+    if (!e) std::copy(vv.begin(), vv.end(), v);
+    return e;
+}
+struct RhComplexSolver {
+    std::unique_ptr<ComplexSolverHIPMF> s;
+};
+void *rh_clinsolver_new(const char **err) {
+    RhComplexSolver *h = new RhComplexSolver();
+    *err = ComplexSolverHIPMF::create(h->s);
+    if (*err) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void rh_clinsolver_free(void *h) { delete (RhComplexSolver *)h; }
+const char *rh_clinsolver_factorize(void *h, void *ccoo, const RhParams *params) {
+    RhComplexSolver *s = (RhComplexSolver *)h;
+    if (params) {
+        LinSolParams p = to_params(params);
+        return s->s->factorize(*(ComplexCooMatrix *)ccoo, &p);
+    }
+    return s->s->factorize(*(ComplexCooMatrix *)ccoo, nullptr);
+}
+const char *rh_clinsolver_solve(void *h, double *x, int64_t nx, const double *rhs, int64_t nr, int32_t verbose) {
+    RhComplexSolver *s = (RhComplexSolver *)h;
+    std::vector<double> xx((size_t)nx), rr(rhs, rhs + nr);
+    StrError e = s->s->solve(xx, rr, verbose != 0);
+    if (!e) std::copy(xx.begin(), xx.end(), x);
+    return e;
+}
 
 void *rh_linsolver_new(int32_t genie, const char **err) {
     RhSolver *s = new RhSolver();

@@ -146,6 +146,44 @@ class SolverHIPMF : public LinSolTrait {
     bool compute_determinant = false;
 };
 
+// ---- complex twin (ComplexLinSolTrait, complex_lin_solver.rs:12-104; ComplexCooMatrix, complex_coo_matrix.rs) ----
+// Values are interleaved (re, im) pairs like the reference's Complex64 arrays (constants.h:18).  The backend solves the
+// REAL-EQUIVALENT system of order 2n with unknowns (Re z_k, Im z_k) interleaved,
+//     a + ib at (i, j)   ->   [ a  -b ; b  a ] at rows 2i, 2i+1 / columns 2j, 2j+1,
+// on the same device path as the real solver (a native complex kernel set is a "next" row of DESIGN.md).
+struct ComplexCooMatrix {
+    Sym symmetric = Sym::No;
+    size_t nrow = 0, ncol = 0, nnz = 0, max_nnz = 0;
+    std::vector<int32_t> indices_i, indices_j;
+    std::vector<double> values; // 2 * max_nnz: re, im
+    static StrError create(ComplexCooMatrix &out, size_t nrow, size_t ncol, size_t max_nnz, Sym symmetric);
+    StrError put(size_t i, size_t j, double re, double im);
+    void reset() { nnz = 0; }
+    // v := alpha * A * u with interleaved complex vectors (complex_coo_matrix.rs mat_vec_mul; symmetric storage mirrored)
+    StrError mat_vec_mul(std::vector<double> &v, double alpha_re, double alpha_im, const std::vector<double> &u) const;
+};
+
+class ComplexSolverHIPMF {
+  public:
+    static StrError create(std::unique_ptr<ComplexSolverHIPMF> &out);
+    // complex_solver_umfpack.rs:232-329 with this backend's symmetry rule (Sym::No or Sym::YesLower)
+    StrError factorize(const ComplexCooMatrix &mat, const LinSolParams *params);
+    // x, rhs: interleaved complex vectors of length 2 n
+    StrError solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose);
+    bool factorized = false;
+    uint64_t get_ns_init() const { return real ? real->get_ns_init() : 0; }
+    uint64_t get_ns_fact() const { return real ? real->get_ns_fact() : 0; }
+    uint64_t get_ns_solve() const { return real ? real->get_ns_solve() : 0; }
+
+  private:
+    ComplexSolverHIPMF() {}
+    std::unique_ptr<SolverHIPMF> real;
+    CooMatrix requiv; // the real-equivalent matrix, rebuilt (same triplet order) at every factorize
+    bool initialized = false;
+    Sym initialized_sym = Sym::No;
+    size_t initialized_ndim = 0, initialized_nnz = 0;
+};
+
 class LinSolver {
   public:
     std::unique_ptr<LinSolTrait> actual;

@@ -146,6 +146,15 @@ def _L():
         "rh_linsolver_times": (None, [vp, pp(C.c_uint64)]),
         "rh_linsolver_outputs": (None, [vp, pp(f64), pp(f64), pp(f64), pp(i32), pp(i32), pp(i32)]),
         "rh_linsolver_stats_json": (cp, [vp, vp, cp, vp, vp]),
+        "rh_ccoo_new": (vp, [i64, i64, i64, i32, pp(cp)]),
+        "rh_ccoo_free": (None, [vp]),
+        "rh_ccoo_put": (cp, [vp, i64, i64, f64, f64]),
+        "rh_ccoo_reset": (None, [vp]),
+        "rh_ccoo_mat_vec_mul": (cp, [vp, vp, i64, f64, f64, vp, i64]),
+        "rh_clinsolver_new": (vp, [pp(cp)]),
+        "rh_clinsolver_free": (None, [vp]),
+        "rh_clinsolver_factorize": (cp, [vp, vp, pp(_RhParams)]),
+        "rh_clinsolver_solve": (cp, [vp, vp, i64, vp, i64, i32]),
         "rh_error_string": (cp, [i32]),
         "rh_enum_name": (cp, [i32, i32]),
         "rh_genie_get_sym": (i32, [i32, i32]),
@@ -366,6 +375,74 @@ class LinSolver:
         s = LinSolver(genie)
         s.actual.factorize(mat, params)
         return s, s.actual.solve(rhs)
+
+
+class ComplexCooMatrix:
+    """complex_coo_matrix.rs: COO triplets with Complex64 values (duplicates allowed, summed at conversion)."""
+
+    def __init__(self, nrow, ncol, max_nnz, symmetric=Sym.No):
+        err = C.c_char_p()
+        self._h = _L().rh_ccoo_new(int(nrow), int(ncol), int(max_nnz), int(symmetric), C.byref(err))
+        _check(err.value)
+        self.nrow, self.ncol = int(nrow), int(ncol)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rh_ccoo_free(self._h)
+            self._h = None
+
+    def put(self, i, j, aij):
+        aij = complex(aij)
+        _check(_L().rh_ccoo_put(self._h, int(i), int(j), aij.real, aij.imag))
+
+    def reset(self):
+        _L().rh_ccoo_reset(self._h)
+
+    def mat_vec_mul(self, u, alpha=1.0):
+        """v = alpha * A * u (complex vectors)."""
+        uu = np.ascontiguousarray(np.asarray(u, dtype=np.complex128)).view(np.float64)
+        v = np.zeros(2 * self.nrow)
+        alpha = complex(alpha)
+        _check(_L().rh_ccoo_mat_vec_mul(self._h, _ptr(v), v.size, alpha.real, alpha.imag, _ptr(uu), uu.size))
+        return v.view(np.complex128)
+
+
+class _ComplexActual:
+    """ComplexLinSolTrait (complex_lin_solver.rs:12-64)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rh_clinsolver_free(self._h)
+            self._h = None
+
+    def factorize(self, mat, params=None):
+        p = C.byref(params._c()) if params is not None else None
+        _check(_L().rh_clinsolver_factorize(self._h, mat._h, p))
+
+    def solve(self, rhs, x=None, verbose=False):
+        r = np.ascontiguousarray(np.asarray(rhs, dtype=np.complex128)).view(np.float64)
+        nx = r.size if x is None else 2 * len(x)
+        out = np.zeros(nx)
+        _check(_L().rh_clinsolver_solve(self._h, _ptr(out), out.size, _ptr(r), r.size, int(verbose)))
+        z = out.view(np.complex128)
+        if x is not None:
+            x[:] = z
+        return z
+
+
+class ComplexLinSolver:
+    """complex_lin_solver.rs:105-142 for Genie::Hipmf: the complex system is solved through its real-equivalent form."""
+
+    def __init__(self, genie=Genie.Hipmf):
+        if genie != Genie.Hipmf:
+            raise StrError("only Genie::Hipmf is available in this build")
+        err = C.c_char_p()
+        h = _L().rh_clinsolver_new(C.byref(err))
+        _check(err.value)
+        self.actual = _ComplexActual(h)
 
 
 def handle_hipmf_error_code(code):
