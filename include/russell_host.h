@@ -54,6 +54,8 @@ void *rh_read_matrix_market(const char *path, int32_t mmsym, const char **err);
 
 /* complex twin (ComplexCooMatrix, ComplexLinSolTrait): complex numbers are (re, im) pairs of doubles, vectors interleaved;
  * solved through the real-equivalent system on the same device path (complex_lin_solver.rs:12-104) */
+const char *rh_coo_put_many(void *coo, int64_t n, const int32_t *i, const int32_t *j, const double *aij);
+const char *rh_ccoo_put_many(void *ccoo, int64_t n, const int32_t *i, const int32_t *j, const double *re_im);
 void *rh_ccoo_new(int64_t nrow, int64_t ncol, int64_t max_nnz, int32_t sym, const char **err);
 void rh_ccoo_free(void *ccoo);
 const char *rh_ccoo_put(void *ccoo, int64_t i, int64_t j, double re, double im);

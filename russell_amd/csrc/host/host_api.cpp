@@ -905,6 +905,25 @@ struct RhSolver {
     std::string json;
 };
 
+// bulk put (host-side convenience of the test / bench drivers: same checks as put, stops at the first error)
+const char *rh_coo_put_many(void *c, int64_t n, const int32_t *ii, const int32_t *jj, const double *aa) {
+    CooMatrix *m = (CooMatrix *)c;
+    for (int64_t k = 0; k < n; k++) {
+        if (ii[k] < 0 || jj[k] < 0) return "COO matrix: index of row is outside range";
+        StrError e = m->put((size_t)ii[k], (size_t)jj[k], aa[k]);
+        if (e) return e;
+    }
+    return nullptr;
+}
+const char *rh_ccoo_put_many(void *c, int64_t n, const int32_t *ii, const int32_t *jj, const double *reim) {
+    ComplexCooMatrix *m = (ComplexCooMatrix *)c;
+    for (int64_t k = 0; k < n; k++) {
+        if (ii[k] < 0 || jj[k] < 0) return "COO matrix: index of row is outside range";
+        StrError e = m->put((size_t)ii[k], (size_t)jj[k], reim[2 * k], reim[2 * k + 1]);
+        if (e) return e;
+    }
+    return nullptr;
+}
 void *rh_ccoo_new(int64_t nrow, int64_t ncol, int64_t max_nnz, int32_t sym, const char **err) {
     ComplexCooMatrix *c = new ComplexCooMatrix();
     *err = ComplexCooMatrix::create(*c, (size_t)std::max<int64_t>(nrow, 0), (size_t)std::max<int64_t>(ncol, 0), (size_t)std::max<int64_t>(max_nnz, 0), (Sym)sym);

@@ -146,6 +146,8 @@ def _L():
         "rh_linsolver_times": (None, [vp, pp(C.c_uint64)]),
         "rh_linsolver_outputs": (None, [vp, pp(f64), pp(f64), pp(f64), pp(i32), pp(i32), pp(i32)]),
         "rh_linsolver_stats_json": (cp, [vp, vp, cp, vp, vp]),
+        "rh_coo_put_many": (cp, [vp, i64, vp, vp, vp]),
+        "rh_ccoo_put_many": (cp, [vp, i64, vp, vp, vp]),
         "rh_ccoo_new": (vp, [i64, i64, i64, i32, pp(cp)]),
         "rh_ccoo_free": (None, [vp]),
         "rh_ccoo_put": (cp, [vp, i64, i64, f64, f64]),
@@ -198,6 +200,11 @@ class CooMatrix:
 
     def put(self, i, j, aij):
         _check(_L().rh_coo_put(self._h, int(i), int(j), float(aij)))
+
+    def put_many(self, i, j, aij):
+        ii, jj = np.ascontiguousarray(i, dtype=np.int32), np.ascontiguousarray(j, dtype=np.int32)
+        aa = np.ascontiguousarray(aij, dtype=np.float64)
+        _check(_L().rh_coo_put_many(self._h, ii.size, _ptr(ii), _ptr(jj), _ptr(aa)))
 
     def reset(self):
         _L().rh_coo_reset(self._h)
@@ -394,6 +401,11 @@ class ComplexCooMatrix:
     def put(self, i, j, aij):
         aij = complex(aij)
         _check(_L().rh_ccoo_put(self._h, int(i), int(j), aij.real, aij.imag))
+
+    def put_many(self, i, j, aij):
+        ii, jj = np.ascontiguousarray(i, dtype=np.int32), np.ascontiguousarray(j, dtype=np.int32)
+        aa = np.ascontiguousarray(np.asarray(aij, dtype=np.complex128)).view(np.float64)
+        _check(_L().rh_ccoo_put_many(self._h, ii.size, _ptr(ii), _ptr(jj), _ptr(aa)))
 
     def reset(self):
         _L().rh_ccoo_reset(self._h)
