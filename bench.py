@@ -191,12 +191,24 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(n2, rp2, ci2, v2, P.csr_matvec(n2, rp2, ci2, v2, P.manufactured_solution(n2)), perm2)
             else:
                 out["cpu_baseline"] = cpu_baseline(n, rp, ci, v, b, s.permutation())
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     s.dev_free(d_vals), s.dev_free(d_b), s.dev_free(d_x)
     s.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line goes out LAST and unbuffered: RCCL prints its banner through C stdio, which would otherwise
+        # land after Python's buffered print
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.write(1, (line + "\n").encode())
 
 
 if __name__ == "__main__":
