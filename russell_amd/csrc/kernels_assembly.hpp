@@ -39,14 +39,20 @@ __global__ void k_gather_values(int64_t nnz, const int32_t *__restrict__ seg_ptr
     }
 }
 
-// max |rs[row] * a| over the stored entries -> *out (as ordered bits of a non-negative double)
+// Scaled values vs[k] = rs[row(k)] * a_k * cs[col(k)] (and, for symmetric-lower storage, the mirrored entry's
+// vs2[k] = rs[col(k)] * a_k) for the assembly kernels, and max |vs| -> *out (as ordered bits of a non-negative double).
 __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow, const int32_t *__restrict__ acol,
-                         const double *__restrict__ rs, const double *__restrict__ cs, unsigned long long *out) {
+                         const double *__restrict__ rs, const double *__restrict__ cs, double *__restrict__ vs, double *__restrict__ vs2,
+                         unsigned long long *out) {
     __shared__ double red[256];
     double m = 0.0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
-        double a = fabs(vals[k] * rs[arow[k]]);
-        if (cs) a *= cs[acol[k]];
+        const double v = vals[k];
+        double sv = v * rs[arow[k]];
+        if (cs) sv *= cs[acol[k]];
+        vs[k] = sv;
+        if (vs2) vs2[k] = v * rs[acol[k]];
+        const double a = fabs(sv);
         m = a > m ? a : m;
     }
     red[threadIdx.x] = m;
@@ -58,20 +64,30 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
     if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
 }
 
-// pool[amap[k]] = rs[row(k)] * a_k * cs[col(k)]  (the pool is zero-filled first; every position is hit once;
-// cs == nullptr: rows only)
-__global__ void k_scatter(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow,
-                          const int64_t *__restrict__ amap, const int64_t *__restrict__ amap2,
-                          const double *__restrict__ rs, const double *__restrict__ cs, const int32_t *__restrict__ acol,
-                          double *__restrict__ pool) {
+// pool[amap[k]] = vs[k] (scaled values, k_absmax) for the entries of the big fronts (the pool regions of the big fronts are
+// zero-filled first; every position is hit once; amap < 0: entry of a small front, assembled by k_small_factor)
+__global__ void k_scatter(int64_t nnz, const double *__restrict__ vs, const double *__restrict__ vs2, const int64_t *__restrict__ amap,
+                          const int64_t *__restrict__ amap2, double *__restrict__ pool) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
-        double v = vals[k];
-        pool[amap[k]] = cs ? v * rs[arow[k]] * cs[acol[k]] : v * rs[arow[k]];
+        const int64_t q = amap[k];
+        if (q >= 0) pool[q] = vs[k];
         if (amap2) {
-            int64_t q = amap2[k];
-            if (q >= 0) pool[q] = v * rs[acol[k]]; // mirrored entry lives in row acol[k]
+            const int64_t q2 = amap2[k];
+            if (q2 >= 0) pool[q2] = vs2[k];
         }
     }
+}
+
+// zero-fill of the big fronts only (the small ones are written whole by k_small_factor): one workgroup per chunk
+struct ZeroTask {
+    int64_t off; // pool offset (doubles)
+    int32_t len; // doubles
+    int32_t pad;
+};
+__global__ void __launch_bounds__(256) k_zero(const ZeroTask *__restrict__ tasks, double *__restrict__ pool) {
+    const ZeroTask t = tasks[blockIdx.x];
+    double *p = pool + t.off;
+    for (int i = threadIdx.x; i < t.len; i += 256) p[i] = 0.0;
 }
 
 // identity blocks of the augmented big fronts: E(i, f+i) = 1 and E'(f+i, i) = 1 (the pool is zero-filled first)

@@ -13,30 +13,86 @@
 
 namespace hipmf {
 
-// One wavefront factorises one small front (f <= SMALL_F = 64) held entirely in LDS: lane r owns row r.
-// Partial pivoting searches the whole remaining pivot block (rows c..p-1) with one 32-bit DPP max-reduction.
+// Everything a small front needs to ASSEMBLE itself (fused into k_small_factor: no memset, scatter or extend-add
+// traffic for the small fronts, which hold most of the fronts and half of the pool).
+struct SmallAsm {
+    const int32_t *sa_ptr;  // per supernode: its range in sa_k / sa_pos
+    const int32_t *sa_k;    // input entry k (>= 0), or ~k for the mirrored copy of a symmetric-lower entry
+    const uint16_t *sa_pos; // row | column << 8 inside the front
+    const double *vs, *vs2; // scaled values (k_absmax): vs2 = the mirrored entries of symmetric-lower storage
+    const int32_t *child_idx, *rel;
+};
+
+// One wavefront assembles and factorises one small front (f <= SMALL_F = 64) held entirely in LDS: lane r owns row r.
+//   assembly:  F = (scaled entries of A that belong to this front) + sum over the children of their contribution
+//              blocks (children in ascending order, read from the pool where their own factorisation left them)
+//   LU:        partial pivoting searches the whole remaining pivot block (rows c..p-1) with one 32-bit DPP max-reduction.
 // No integer divisions and no per-element index arithmetic: every loop runs over columns with lane = row.
 __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
                                                      double *__restrict__ pool, int32_t *__restrict__ lperm,
                                                      const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
-                                                     FactorInfo *info, int32_t ld) {
+                                                     FactorInfo *info, int32_t ld, SmallAsm A) {
     HIPMF_DYN_SHARED(double, sm);
     __shared__ int32_t lp[SMALL_F];
     const int tid = threadIdx.x;
-    FrontDesc fd = FD[list[blockIdx.x]];
+    const int s = list[blockIdx.x];
+    FrontDesc fd = FD[s];
     const int p = fd.p, f = fd.p + fd.m;
     double *F = pool + fd.off;
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
-    if (tid < f) {
-        int c = 0;
-        for (; c + 7 < f; c += 8) {
-            double a[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) a[q] = F[tid + (c + q) * f];
-#pragma unroll
-            for (int q = 0; q < 8; q++) sm[tid + (c + q) * ld] = a[q];
+    // descriptors of up to 64 children, one lane each (on their way while the front is zeroed and A's entries come in)
+    const int nch = fd.child_end - fd.child_begin;
+    int64_t d_cb = 0, d_ldc = 0, d_rel = 0;
+    int d_m = 0;
+    if (tid < nch) { // (nch > 64: the tail is read per child below)
+        const FrontDesc cd = FD[A.child_idx[fd.child_begin + tid]];
+        d_ldc = cd.ld;
+        d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
+        d_rel = cd.rowptr;
+        d_m = cd.m;
+    }
+    const int e0 = A.sa_ptr[s], e1 = A.sa_ptr[s + 1];
+    for (int e = tid; e < f * ld; e += 64) sm[e] = 0.0;
+    __syncthreads();
+    // entries of A, already scaled (LDS atomics: a caller's CSR may hold duplicates)
+    for (int e = e0 + tid; e < e1; e += 64) {
+        const int kk = A.sa_k[e];
+        const int pos = A.sa_pos[e];
+        const double v = kk < 0 ? A.vs2[~kk] : A.vs[kk];
+        atomicAdd(&sm[(pos & 255) + (pos >> 8) * ld], v);
+    }
+    __syncthreads();
+    // children's contribution blocks.  Per child the lanes are (row i, column group g) with 16 / 32 / 64 rows per pass by
+    // the block's size, sixteen columns in flight per lane; rel of column j comes from the lane that holds it as a row.
+    for (int ci = 0; ci < nch; ci++) {
+        int64_t cbo, ldc, relo;
+        int mc;
+        if (ci < 64) {
+            cbo = __shfl(d_cb, ci), ldc = __shfl(d_ldc, ci), relo = __shfl(d_rel, ci), mc = __shfl(d_m, ci);
+        } else {
+            const FrontDesc cd = FD[A.child_idx[fd.child_begin + ci]];
+            ldc = cd.ld, cbo = cd.off + cd.p + (int64_t)cd.p * cd.ld, relo = cd.rowptr, mc = cd.m;
         }
-        for (; c < f; c++) sm[tid + c * ld] = F[tid + c * f];
+        if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
+        const double *CB = pool + cbo;
+        const int sh = mc <= 16 ? 4 : (mc <= 32 ? 5 : 6);
+        const int i = tid & ((1 << sh) - 1), g = tid >> sh, G = 64 >> sh;
+        const int myrel = i < mc ? A.rel[relo + i] : 0; // lanes 0 .. mc-1 hold rel of rows (= columns) 0 .. mc-1
+        for (int jb = 0; jb < mc; jb += 16 * G) { // (wave-uniform trip count: the shuffles below need every lane)
+            double cb[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int j = jb + g + q * G;
+                cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int j = jb + g + q * G;
+                const int rj = __shfl(myrel, j & 63);
+                if (i < mc && j < mc) sm[myrel + rj * ld] += cb[q];
+            }
+        }
+        __syncthreads(); // the next child may hit the same entries from other lanes
     }
     if (tid < p) lp[tid] = tid;
     __syncthreads();

@@ -45,7 +45,7 @@ Solver::~Solver() { release(); }
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+    void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
@@ -55,6 +55,8 @@ void Solver::release() {
     d_cs = nullptr, d_rperm = nullptr;
     d_blk = nullptr, d_work_blk = nullptr;
     d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr, nnz_in = 0;
+    d_sa_ptr = d_sa_k = nullptr, d_sa_pos = nullptr, d_zero = nullptr, zero_cnt = 0;
+    d_vs = d_vs2 = nullptr;
     matched = false;
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
@@ -191,11 +193,72 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
             if ((len & 1) == 0) match_parity ^= 1;
         }
     }
+    {
+        // The entries of A that land in small fronts are gathered by k_small_factor itself (per-front lists: entry index,
+        // position inside the front); only the big fronts are zero-filled and scattered into.
+        const int32_t ns = S.nsuper;
+        // owner front of a pool offset: bucket table (4 Ki doubles per bucket -> first front that ends beyond the bucket's start)
+        const int SHIFT = 12;
+        std::vector<int32_t> bucket((size_t)(S.front_off[ns] >> SHIFT) + 2, 0);
+        {
+            int32_t sf = 0;
+            for (size_t b = 0; b < bucket.size(); b++) {
+                while (sf + 1 < ns && S.front_off[sf + 1] <= (int64_t)(b << SHIFT)) sf++;
+                bucket[b] = sf;
+            }
+        }
+        auto owner = [&](int64_t off) {
+            int32_t sf = bucket[(size_t)(off >> SHIFT)];
+            while (S.front_off[sf + 1] <= off) sf++;
+            return sf;
+        };
+        std::vector<int32_t> sa_ptr((size_t)ns + 1, 0);
+        const int64_t nz = S.nnz_a;
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
+            for (int64_t k = 0; k < (int64_t)am.size(); k++)
+                if (am[k] >= 0) {
+                    const int32_t s = owner(am[k]);
+                    if (S.fsize(s) <= SMALL_F) sa_ptr[(size_t)s + 1]++;
+                }
+        }
+        for (int32_t s = 0; s < ns; s++) sa_ptr[(size_t)s + 1] += sa_ptr[s];
+        std::vector<int32_t> sa_k((size_t)sa_ptr[ns]), w(sa_ptr.begin(), sa_ptr.end() - 1);
+        std::vector<uint16_t> sa_pos((size_t)sa_ptr[ns]);
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
+            for (int64_t k = 0; k < (int64_t)am.size(); k++)
+                if (am[k] >= 0) {
+                    const int32_t s = owner(am[k]);
+                    if (S.fsize(s) > SMALL_F) continue;
+                    const int64_t off = am[k] - S.front_off[s], f = S.fsize(s);
+                    const size_t q = (size_t)w[s]++;
+                    sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
+                    sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
+                    am[k] = -1; // not scattered
+                }
+        }
+        (void)nz;
+        HIPC(dev_upload(&d_sa_ptr, sa_ptr), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sa_k, sa_k), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sa_pos, sa_pos), ERROR_HIP_MALLOC);
+        // zero-fill tasks: 16 Ki doubles per workgroup over the big fronts
+        std::vector<ZeroTask> zt;
+        for (int32_t s = 0; s < ns; s++) {
+            if (S.fsize(s) <= SMALL_F) continue;
+            for (int64_t o = S.front_off[s]; o < S.front_off[s + 1]; o += 16384)
+                zt.push_back({o, (int32_t)std::min<int64_t>(16384, S.front_off[s + 1] - o), 0});
+        }
+        zero_cnt = (int32_t)zt.size();
+        HIPC(dev_upload(&d_zero, zt), ERROR_HIP_MALLOC);
+    }
     HIPC(dev_upload(&d_amap, S.amap), ERROR_HIP_MALLOC);
     if (sym_lower) HIPC(dev_upload(&d_amap2, S.amap2), ERROR_HIP_MALLOC);
     std::vector<int64_t>().swap(S.amap);
     std::vector<int64_t>().swap(S.amap2);
     HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_vs, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+    if (sym_lower) HIPC(hipMalloc((void **)&d_vs2, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
     if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
@@ -296,6 +359,7 @@ int32_t Solver::upload_plan() {
             bool any = false;
             for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
             if (!any) continue;
+            if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
             int32_t f = S.fsize(s);
             const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
             for (int32_t c0 = 0; c0 < f; c0 += cstep)
@@ -510,9 +574,9 @@ int32_t Solver::run_factor() {
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
-    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_scalar);
-    HIPC(hipMemsetAsync(d_pool, 0, sizeof(double) * pool_doubles, STREAM), ERROR_HIP_MEMCPY);
-    hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_amap, d_amap2, d_rs, d_cs, d_ci, d_pool);
+    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar);
+    if (zero_cnt > 0) hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, STREAM, d_zero, d_pool);
+    hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vs, d_vs2, d_amap, d_amap2, d_pool);
     launches += 3;
     if (allbig_cnt > 0) {
         hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, STREAM, d_lists + allbig_off, d_fd, d_pool);
@@ -535,8 +599,9 @@ int32_t Solver::run_factor() {
                 HIPC(hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
                 sst = (hipStream_t)stream2;
             }
+            const SmallAsm sasm = {d_sa_ptr, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel};
             hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt), dim3(64), shmem, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
-                               d_scalar, opt.pivot_epsilon, d_info, L.small_ld);
+                               d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
             if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
             launches++;
         }

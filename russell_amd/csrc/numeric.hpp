@@ -13,6 +13,7 @@ struct EaTask;
 struct EaRange;
 struct SolveTask;
 struct SfTask;
+struct ZeroTask;
 struct FactorInfo;
 
 // status codes shared with the reference's C shims (/root/reference/russell_sparse/c_code/constants.h:5-12)
@@ -138,6 +139,12 @@ class Solver {
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
+    // fused assembly of the small fronts (k_small_factor) and zero-fill of the big ones only
+    int32_t *d_sa_ptr = nullptr, *d_sa_k = nullptr;
+    uint16_t *d_sa_pos = nullptr;
+    ZeroTask *d_zero = nullptr;
+    double *d_vs = nullptr, *d_vs2 = nullptr; // scaled values (and the mirrored ones of symmetric-lower storage)
+    int32_t zero_cnt = 0;
     int32_t *d_seg_ptr = nullptr, *d_seg_idx = nullptr; // value map (set_value_map)
     double *d_vin = nullptr;
     int64_t nnz_in = 0;
