@@ -140,6 +140,10 @@ def main():
     if rank == 0:
         tri = max(st["acc_tri_count"], 1.0)
         tri_ms = (st["acc_fwd_ms"] + st["acc_bwd_ms"]) / tri
+        import ctypes
+        copy_gbs = ctypes.c_double(0.0)
+        if s.lib.hipmf_device_copy_bandwidth(1 << 30, 3, ctypes.byref(copy_gbs)) != 0:
+            copy_gbs.value = 0.0
         bytes_alg = sptrsv_bytes(st, n)
         traffic, traffic_src = measured_traffic(args.grid)
         achieved = bytes_alg / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
@@ -167,7 +171,9 @@ def main():
                                     st["solve_launches"], st["nlevels"]),
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4)},
+                         "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4),
+                         "measured_copy_gbs": round(copy_gbs.value, 1),
+                         "frac_of_measured_copy": round(achieved / copy_gbs.value, 4) if copy_gbs.value > 0 else None},
             "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_diag, k_panel, k_update MFMA f64)",
                                 "bound": "mfma", "achieved": round(st["flops"] / (fact_ms * 1e-3) / 1e12, 3) if fact_ms > 0 else 0.0,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

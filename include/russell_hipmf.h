@@ -173,6 +173,9 @@ int32_t hipmf_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int32_t hipmf_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int32_t hipmf_device_synchronize(void);
 int32_t hipmf_device_count(void);
+/* Measured device-to-device copy rate in GB/s (read + written bytes over HIP-event time, `bytes` per copy, best of `reps`):
+ * the achievable-HBM denominator bench.py reports beside the 8 TB/s spec. */
+int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_s);
 int32_t hipmf_set_device(int32_t device); /* selects the device later solver_hipmf_new() calls of this thread bind to */
 
 #ifdef __cplusplus

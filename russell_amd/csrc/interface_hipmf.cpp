@@ -5,6 +5,7 @@
 // blocking (stream-synchronised) on return (interface_cudss.cu:383,449,536).
 #include <hipmf_device_rt.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <new>
 
@@ -230,6 +231,36 @@ int32_t hipmf_memcpy_d2h(void *dst, const void *src, size_t bytes) {
 }
 int32_t hipmf_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_SYNCHRONIZE; }
 int32_t hipmf_set_device(int32_t device) { return hipSetDevice(device) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIPMF_NO_DEVICE; }
+int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_s) {
+    if (!gb_per_s || bytes < 1 || reps < 1) return ERROR_NULL_POINTER;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0, e1;
+    if (hipMalloc(&a, (size_t)bytes) != hipSuccess) return ERROR_HIP_MALLOC;
+    if (hipMalloc(&b, (size_t)bytes) != hipSuccess) {
+        (void)hipFree(a);
+        return ERROR_HIP_MALLOC;
+    }
+    (void)hipMemset(a, 1, (size_t)bytes);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    double best = 0.0;
+    for (int32_t r = 0; r <= reps; r++) { // first copy = warm-up
+        (void)hipEventRecord(e0, nullptr);
+        (void)hipMemcpyAsync(b, a, (size_t)bytes, hipMemcpyDeviceToDevice, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms > 0.0f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *gb_per_s = best;
+    return SUCCESSFUL_EXIT;
+}
+
 int32_t hipmf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
