@@ -43,9 +43,10 @@ __global__ void k_gather_values(int64_t nnz, const int32_t *__restrict__ seg_ptr
 // vs2[k] = rs[col(k)] * a_k) for the assembly kernels, and max |vs| -> *out (as ordered bits of a non-negative double).
 __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow, const int32_t *__restrict__ acol,
                          const double *__restrict__ rs, const double *__restrict__ cs, double *__restrict__ vs, double *__restrict__ vs2,
-                         unsigned long long *out) {
+                         unsigned long long *out, FactorInfo *info) {
     __shared__ double red[256];
     double m = 0.0;
+    bool bad = false;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
         const double v = vals[k];
         double sv = v * rs[arow[k]];
@@ -53,8 +54,10 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
         vs[k] = sv;
         if (vs2) vs2[k] = v * rs[acol[k]];
         const double a = fabs(sv);
+        bad |= !(a <= 1.7976931348623157e308); // NaN or Inf
         m = a > m ? a : m;
     }
+    if (bad) atomicAdd(&info->n_nonfinite, 1);
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {

@@ -67,7 +67,8 @@ struct SolveTask {
 struct FactorInfo {
     int32_t n_perturbed;  // pivots replaced by +-eps (cf. CUDSS_DATA_NPIVOTS, interface_cudss.cu:466-475)
     int32_t n_zero_pivot; // exactly-zero pivots met (singular in the UMFPACK sense, solver_umfpack.rs:492)
-    int32_t pad0, pad1;
+    int32_t n_nonfinite;  // NaN / Inf among the scaled input values (the factorisation is refused)
+    int32_t pad1;
 };
 
 __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int v) {

@@ -574,7 +574,7 @@ int32_t Solver::run_factor() {
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
-    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar);
+    hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar, d_info);
     if (zero_cnt > 0) hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, STREAM, d_zero, d_pool);
     hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vs, d_vs2, d_amap, d_amap2, d_pool);
     launches += 3;
@@ -624,6 +624,11 @@ int32_t Solver::run_factor() {
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
     n_perturbed = hinfo.n_perturbed;
     n_zero_pivot = hinfo.n_zero_pivot;
+    if (hinfo.n_nonfinite > 0) {
+        last_error = "the matrix values contain NaN or Inf";
+        factorized = false;
+        return ERROR_HIPMF_INVALID_VALUE;
+    }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, (hipEvent_t)ev[0], (hipEvent_t)ev[1]);
     times.scale_assemble_ms = ms;

@@ -343,3 +343,18 @@ def test_distinct_handles_from_concurrent_threads():
     assert sorted(results) == ["a", "b", "c"]
     for tag, errs in results.items():
         assert max(errs) < 1e-10, (tag, errs)
+
+
+def test_nan_in_the_values_is_refused():
+    n, rp, ci, v = P.poisson2d(20, 15)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    bad = v.copy()
+    bad[37] = np.nan
+    assert s.factorize(bad) == 803  # ERROR_HIPMF_INVALID_VALUE
+    with pytest.raises(Exception):
+        s.solve(np.ones(n))  # not factorized
+    assert s.factorize(v) == 0  # the handle stays usable
+    x = s.solve(P.csr_matvec(n, rp, ci, v, np.ones(n)))
+    assert np.max(np.abs(x - 1.0)) < 1e-12
+    s.close()
