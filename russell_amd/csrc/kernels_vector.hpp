@@ -24,29 +24,50 @@ __global__ void k_perm_out(int32_t n, const int32_t *__restrict__ perm, const do
     }
 }
 
-// r = b - A x and den_i = (|A| |x| + |b|)_i  (CSR; for symmetric-lower storage the mirrored entries come
-// from tptr/tidx/arow).  den feeds the componentwise backward error omega = max_i |r_i| / den_i that
-// decides, as in UMFPACK's / LAPACK's refinement, whether another step can still help.
-__global__ void k_residual(int32_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                           const double *__restrict__ vals, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx,
-                           const int32_t *__restrict__ arow, const double *__restrict__ x, const double *__restrict__ b,
-                           double *__restrict__ r, double *__restrict__ den) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double acc = b[i], d = fabs(b[i]);
-    for (int p = rp[i]; p < rp[i + 1]; p++) {
-        double t = vals[p] * x[ci[p]];
-        acc -= t;
-        d += fabs(t);
-    }
-    if (tptr)
-        for (int q = tptr[i]; q < tptr[i + 1]; q++) {
-            double t = vals[tidx[q]] * x[arow[tidx[q]]];
+// r = b - A x and, fused, the two norms the refinement needs: nrm[0] = max_i |r_i|, nrm[1] = omega = max_i |r_i| / den_i
+// with den_i = (|A| |x| + |b|)_i (ordered bits of non-negative doubles, atomicMax; nrm is zeroed before the launch).
+// CSR; for symmetric-lower storage the mirrored entries come from tptr/tidx/arow.  omega, the componentwise backward
+// error, decides as in UMFPACK's / LAPACK's refinement whether another step can still help.
+__global__ void __launch_bounds__(256) k_residual(int32_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                  const double *__restrict__ vals, const int32_t *__restrict__ tptr,
+                                                  const int32_t *__restrict__ tidx, const int32_t *__restrict__ arow,
+                                                  const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ r,
+                                                  unsigned long long *nrm) {
+    __shared__ double red[256], red2[256];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double a = 0.0, q = 0.0;
+    if (i < n) {
+        double acc = b[i], d = fabs(b[i]);
+        for (int p = rp[i]; p < rp[i + 1]; p++) {
+            double t = vals[p] * x[ci[p]];
             acc -= t;
             d += fabs(t);
         }
-    r[i] = acc;
-    den[i] = d;
+        if (tptr)
+            for (int k = tptr[i]; k < tptr[i + 1]; k++) {
+                double t = vals[tidx[k]] * x[arow[tidx[k]]];
+                acc -= t;
+                d += fabs(t);
+            }
+        r[i] = acc;
+        a = fabs(acc);
+        q = (d > 0.0) ? a / d : (a > 0.0 ? 1.0 : 0.0);
+    }
+    // a NaN never wins a maximum: a NaN residual ends the refinement through the "no progress" test
+    red[threadIdx.x] = a > 0.0 ? a : 0.0;
+    red2[threadIdx.x] = q > 0.0 ? q : 0.0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            if (red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+            if (red2[threadIdx.x + s] > red2[threadIdx.x]) red2[threadIdx.x] = red2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(nrm, (unsigned long long)__double_as_longlong(red[0]));
+        atomicMax(nrm + 1, (unsigned long long)__double_as_longlong(red2[0]));
+    }
 }
 
 // y = alpha * A x  (CSR SpMV, the mat_vec_mul of csr_matrix.rs:709-729), one thread per row
@@ -60,34 +81,6 @@ __global__ void k_spmv(int32_t n, const int32_t *__restrict__ rp, const int32_t 
     if (tptr)
         for (int q = tptr[i]; q < tptr[i + 1]; q++) acc += vals[tidx[q]] * x[arow[tidx[q]]];
     y[i] = alpha * acc;
-}
-
-// out[0] = max_i |v_i| ; out[1] = max_i |v_i| / den_i  (ordered bits; den may be NULL)
-__global__ void k_norms(int32_t n, const double *__restrict__ v, const double *__restrict__ den, unsigned long long *out) {
-    __shared__ double red[256], red2[256];
-    double m = 0.0, w = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        double a = fabs(v[i]);
-        m = a > m ? a : m; // a NaN never wins: a NaN residual ends the refinement through the "no progress" test
-        if (den) {
-            double q = (den[i] > 0.0) ? a / den[i] : (a > 0.0 ? 1.0 : 0.0);
-            w = q > w ? q : w;
-        }
-    }
-    red[threadIdx.x] = m;
-    red2[threadIdx.x] = w;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            if (red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
-            if (red2[threadIdx.x + s] > red2[threadIdx.x]) red2[threadIdx.x] = red2[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
-        atomicMax(out + 1, (unsigned long long)__double_as_longlong(red2[0]));
-    }
 }
 
 // diagonal of U in pivot order (for the determinant / rcond estimate)

@@ -791,8 +791,6 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             for (int32_t c = 0; c < nk; c++) {
                 if (!active[c]) continue;
                 hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj[c], bj[c], RR + (size_t)c * n,
-                                   DEN + (size_t)c * n);
-                hipLaunchKernelGGL(k_norms, dim3(std::min(1024, (n + 255) / 256)), b, 0, STREAM, n, RR + (size_t)c * n, DEN + (size_t)c * n,
                                    d_scalar + 1 + 2 * c);
             }
             double nrm[2 * SF_KMAX] = {0.0};
@@ -826,6 +824,14 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             for (int32_t c = 0; c < nk; c++)
                 if (active[c]) hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, DU + (size_t)c * n, xj[c], 1);
             if (j0 == 0 && active[0]) refinement_steps_done++;
+            // a column whose backward error was already within 64 eps is done after this correction: no further residual /
+            // norm / host round trip just to confirm it
+            bool again = false;
+            for (int32_t c = 0; c < nk; c++) {
+                if (active[c] && prev[c] <= 64.0 * EPS) active[c] = false;
+                again |= active[c];
+            }
+            if (!again) break;
         }
         if (!on_device)
             for (int32_t c = 0; c < nk; c++)
