@@ -76,6 +76,15 @@ void rh_linsolver_outputs(void *solver, double *det_coef, double *det_exp, doubl
 const char *rh_linsolver_stats_json(void *solver, void *coo, const char *name, const double *x, const double *rhs);
 
 const char *rh_error_string(int32_t code);
+/* russell_lab formatters.rs:60-95 ("2.5ms", "1h2m3s"); writes at most len-1 bytes + NUL into buf */
+void rh_format_nanoseconds(uint64_t nanoseconds, char *buf, int32_t len);
+/* stats_lin_sol.rs:334-340 */
+int32_t rh_is_memory_error(const char *message);
+/* read_matrix_market.rs:346-475 for real AND complex files: exactly one of *coo / *ccoo is set (the other is NULL);
+ * the handles are those of rh_coo_* / rh_ccoo_* */
+void rh_ccoo_info(void *ccoo, int64_t *nrow, int64_t *ncol, int64_t *nnz, int64_t *max_nnz, int32_t *sym);
+void rh_ccoo_arrays(void *ccoo, const int32_t **ai, const int32_t **aj, const double **ax_interleaved);
+const char *rh_read_matrix_market_any(const char *path, int32_t mmsym, void **coo, void **ccoo);
 const char *rh_enum_name(int32_t which, int32_t value);
 int32_t rh_genie_get_sym(int32_t genie, int32_t symmetric);
 

@@ -294,12 +294,117 @@ StrError VerifyLinSys::from(VerifyLinSys &out, const CooMatrix &mat, const std::
     return nullptr;
 }
 
+StrError VerifyLinSys::from_complex(VerifyLinSys &out, const ComplexCooMatrix &mat, const std::vector<double> &x, const std::vector<double> &rhs) {
+    if (x.size() != 2 * mat.ncol) return "x.dim() must be equal to ncol";
+    if (rhs.size() != 2 * mat.nrow) return "rhs.dim() must be equal to nrow";
+    if (mat.nnz < 1) return "matrix is empty";
+    double max_abs_a = 0.0;
+    for (size_t p = 0; p < mat.nnz; p++) max_abs_a = std::max(max_abs_a, std::hypot(mat.values[2 * p], mat.values[2 * p + 1]));
+    std::vector<double> ax(2 * mat.nrow, 0.0);
+    mat.mat_vec_mul(ax, 1.0, 0.0, x);
+    double max_abs_ax = 0.0, max_abs_diff = 0.0;
+    for (size_t i = 0; i < mat.nrow; i++) {
+        max_abs_ax = std::max(max_abs_ax, std::hypot(ax[2 * i], ax[2 * i + 1]));
+        max_abs_diff = std::max(max_abs_diff, std::hypot(ax[2 * i] - rhs[2 * i], ax[2 * i + 1] - rhs[2 * i + 1]));
+    }
+    out.max_abs_a = max_abs_a;
+    out.max_abs_ax = max_abs_ax;
+    out.max_abs_diff = max_abs_diff;
+    out.relative_error = max_abs_diff / (max_abs_a + 1.0);
+    return nullptr;
+}
+
 // ---- stats -------------------------------------------------------------------------------------------
+// shortest decimal form that reads back to the same double (what Rust's `{}` prints for an f64)
+static std::string shortest(double v) {
+    char num[64];
+    for (int prec = 1; prec <= 17; prec++) {
+        snprintf(num, sizeof num, "%.*g", prec, v);
+        if (strtod(num, nullptr) == v) break;
+    }
+    std::string t(num);
+    // %g may switch to exponent form; the values printed here (< 1000 of a unit, or seconds < 60) never need it,
+    // except tiny fractions, which are re-printed in fixed form
+    if (t.find('e') != std::string::npos) {
+        snprintf(num, sizeof num, "%.12f", v);
+        t = num;
+        while (!t.empty() && t.back() == '0') t.pop_back();
+        if (!t.empty() && t.back() == '.') t.pop_back();
+    }
+    return t;
+}
+
+static void format_below_one_second(std::string &buf, uint64_t value) {
+    if (value < 1000ull) buf += std::to_string(value) + "ns";
+    else if (value < 1000000ull) buf += shortest((double)value / 1e3) + "\xC2\xB5s"; // U+00B5 MICRO SIGN, as the reference prints
+    else buf += shortest((double)value / 1e6) + "ms";
+}
+
+std::string format_nanoseconds(uint64_t nanoseconds) {
+    if (nanoseconds == 0) return "0ns";
+    const uint64_t second = 1000000000ull, minute = 60 * second, hour = 60 * minute;
+    uint64_t value = nanoseconds;
+    std::string buf;
+    if (value < second) {
+        format_below_one_second(buf, value);
+        return buf;
+    }
+    if (value >= hour) {
+        buf += std::to_string(value / hour) + "h";
+        value %= hour;
+    }
+    if (value >= minute) {
+        buf += std::to_string(value / minute) + "m";
+        value %= minute;
+    }
+    if (value > 0) {
+        if (value < second) format_below_one_second(buf, value);
+        else buf += shortest((double)value / 1e9) + "s";
+    }
+    return buf;
+}
+
+bool is_memory_error(const char *e) {
+    if (!e) return false;
+    const std::string m(e);
+    for (const char *key : {"MALLOC", "Not enough memory", "ALLOC_FAILED", "cudaMalloc", "memory is too small", "hipMalloc"})
+        if (m.find(key) != std::string::npos) return true;
+    return false;
+}
+
+void StatsLinSol::set_matrix_name_from_path(const std::string &filepath) {
+    size_t slash = filepath.find_last_of("/\\");
+    std::string base = slash == std::string::npos ? filepath : filepath.substr(slash + 1);
+    size_t dot = base.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) base = base.substr(0, dot);
+    matrix_name = base.empty() ? "Unknown" : base;
+}
+
+// coo_matrix.rs:872-887 (get_actual_nnz): off-diagonal entries of triangular storage count twice
+template <typename Coo> static size_t actual_nnz(const Coo &coo) {
+    if (coo.symmetric != Sym::YesLower && coo.symmetric != Sym::YesUpper) return coo.nnz;
+    size_t actual = 0;
+    for (size_t p = 0; p < coo.nnz; p++) actual += coo.indices_i[p] != coo.indices_j[p] ? 2 : 1;
+    return actual;
+}
+
+void StatsLinSol::set_matrix_info_from_coo(const CooMatrix &coo) {
+    nrow = coo.nrow, ncol = coo.ncol, nnz = coo.nnz, nnz_actual = actual_nnz(coo);
+    complex = false;
+    symmetric = sym_name(coo.symmetric);
+}
+
+void StatsLinSol::set_matrix_info_from_coo(const ComplexCooMatrix &coo) {
+    nrow = coo.nrow, ncol = coo.ncol, nnz = coo.nnz, nnz_actual = actual_nnz(coo);
+    complex = true;
+    symmetric = sym_name(coo.symmetric);
+}
+
 static uint64_t avg(const std::vector<uint64_t> &v) {
     if (v.empty()) return 0;
-    uint64_t s = 0;
-    for (auto x : v) s += x;
-    return s / v.size();
+    double s = 0;
+    for (auto x : v) s += (double)x;
+    return (uint64_t)(s / (double)v.size());
 }
 static std::string arr(const std::vector<uint64_t> &v) {
     std::ostringstream o;
@@ -308,7 +413,65 @@ static std::string arr(const std::vector<uint64_t> &v) {
     o << "]";
     return o.str();
 }
-std::string StatsLinSol::to_json() const {
+static std::string human_arr(const std::vector<uint64_t> &v) {
+    std::ostringstream o;
+    o << "[";
+    for (size_t i = 0; i < v.size(); i++) o << (i ? "," : "") << "\"" << format_nanoseconds(v[i]) << "\"";
+    o << "]";
+    return o.str();
+}
+static std::string json_escape(const std::string &t) {
+    std::string r;
+    for (char c : t) {
+        if (c == '"' || c == '\\') r += '\\';
+        r += c;
+    }
+    return r;
+}
+// two-space indentation of a compact JSON text (what serde_json::to_string_pretty prints)
+static std::string json_pretty(const std::string &compact) {
+    std::string out;
+    int depth = 0;
+    bool in_string = false;
+    auto newline = [&]() {
+        out += '\n';
+        out.append(2 * (size_t)depth, ' ');
+    };
+    for (size_t i = 0; i < compact.size(); i++) {
+        const char c = compact[i];
+        if (in_string) {
+            out += c;
+            if (c == '\\' && i + 1 < compact.size()) out += compact[++i];
+            else if (c == '"') in_string = false;
+            continue;
+        }
+        if (c == '"') {
+            in_string = true;
+            out += c;
+        } else if (c == '{' || c == '[') {
+            out += c;
+            if (i + 1 < compact.size() && (compact[i + 1] == '}' || compact[i + 1] == ']')) {
+                out += compact[++i]; // empty container stays on one line
+            } else {
+                depth++;
+                newline();
+            }
+        } else if (c == '}' || c == ']') {
+            depth--;
+            newline();
+            out += c;
+        } else if (c == ',') {
+            out += c;
+            newline();
+        } else if (c == ':') {
+            out += ": ";
+        } else
+            out += c;
+    }
+    return out;
+}
+
+std::string StatsLinSol::to_json(bool pretty) const {
     std::vector<uint64_t> total;
     for (size_t i = 0; i < std::min(initialize_ns.size(), std::min(factorize_ns.size(), solve_ns.size())); i++)
         total.push_back(initialize_ns[i] + factorize_ns[i] + solve_ns[i]);
@@ -316,24 +479,34 @@ std::string StatsLinSol::to_json() const {
     std::ostringstream o;
     auto f = [&](double v) {
         snprintf(num, sizeof num, "%.17g", v);
-        return std::string(num);
+        std::string t(num);
+        if (t.find_first_of(".enai") == std::string::npos) t += ".0"; // floats stay floats in the JSON text
+        return t;
     };
-    o << "{\"main\":{\"platform\":\"MI355X gfx950\",\"blas_lib\":\"none (hand-written HIP kernels)\",\"solver\":\"" << solver
-      << "\",\"out_of_memory\":false},"
-      << "\"matrix\":{\"name\":\"" << matrix_name << "\",\"nrow\":" << nrow << ",\"ncol\":" << ncol << ",\"nnz\":" << nnz
-      << ",\"nnz_actual\":" << nnz_actual << ",\"complex\":false,\"symmetric\":\"" << symmetric << "\"},"
-      << "\"requests\":{\"ordering\":\"" << ordering << "\",\"scaling\":\"" << scaling
-      << "\",\"positive_definite\":" << (positive_definite ? "true" : "false") << "},"
-      << "\"output\":{\"effective_ordering\":\"" << effective_ordering << "\",\"effective_scaling\":\"" << effective_scaling
-      << "\",\"rcond_estimate\":" << f(rcond_estimate) << ",\"perturbed_pivots\":" << perturbed_pivots << "},"
-      << "\"determinant\":{\"mantissa_real\":" << f(det_mantissa) << ",\"mantissa_imag\":0.0,\"base\":" << f(det_base)
+    auto q = [&](const std::string &t) { return "\"" + json_escape(t) + "\""; };
+    o << "{\"main\":{\"platform\":\"MI355X gfx950\",\"blas_lib\":\"none (hand-written HIP kernels)\",\"solver\":" << q(solver)
+      << ",\"local_sparse\":false,\"out_of_memory\":" << (out_of_memory ? "true" : "false") << "},"
+      << "\"matrix\":{\"name\":" << q(matrix_name) << ",\"nrow\":" << nrow << ",\"ncol\":" << ncol << ",\"nnz\":" << nnz
+      << ",\"nnz_actual\":" << nnz_actual << ",\"complex\":" << (complex ? "true" : "false") << ",\"symmetric\":" << q(symmetric) << "},"
+      << "\"requests\":{\"ordering\":" << q(ordering) << ",\"scaling\":" << q(scaling) << ",\"matching\":" << q(matching)
+      << ",\"positive_definite\":" << (positive_definite ? "true" : "false") << "},"
+      << "\"output\":{\"effective_ordering\":" << q(effective_ordering) << ",\"effective_scaling\":" << q(effective_scaling)
+      << ",\"effective_matching\":" << q(effective_matching) << ",\"rcond_estimate\":" << f(rcond_estimate)
+      << ",\"perturbed_pivots\":" << perturbed_pivots << "},"
+      << "\"determinant\":{\"mantissa_real\":" << f(det_mantissa) << ",\"mantissa_imag\":" << f(det_mantissa_imag) << ",\"base\":" << f(det_base)
       << ",\"exponent\":" << f(det_exponent) << "},"
       << "\"verify\":{\"max_abs_a\":" << f(verify.max_abs_a) << ",\"max_abs_ax\":" << f(verify.max_abs_ax)
       << ",\"max_abs_diff\":" << f(verify.max_abs_diff) << ",\"relative_error\":" << f(verify.relative_error) << "},"
-      << "\"time_nanoseconds\":{\"initialize_array\":" << arr(initialize_ns) << ",\"initialize\":" << avg(initialize_ns)
-      << ",\"factorize_array\":" << arr(factorize_ns) << ",\"factorize\":" << avg(factorize_ns) << ",\"solve_array\":" << arr(solve_ns)
-      << ",\"solve\":" << avg(solve_ns) << ",\"total_ifs_array\":" << arr(total) << ",\"total_ifs\":" << avg(total) << "}}";
-    return o.str();
+      << "\"time_human\":{\"read_matrix\":" << q(format_nanoseconds(read_matrix_ns)) << ",\"initialize_array\":" << human_arr(initialize_ns)
+      << ",\"initialize\":" << q(format_nanoseconds(avg(initialize_ns))) << ",\"factorize_array\":" << human_arr(factorize_ns)
+      << ",\"factorize\":" << q(format_nanoseconds(avg(factorize_ns))) << ",\"solve_array\":" << human_arr(solve_ns)
+      << ",\"solve\":" << q(format_nanoseconds(avg(solve_ns))) << ",\"total_ifs_array\":" << human_arr(total)
+      << ",\"total_ifs\":" << q(format_nanoseconds(avg(total))) << ",\"verify\":" << q(format_nanoseconds(verify_ns)) << "},"
+      << "\"time_nanoseconds\":{\"read_matrix\":" << read_matrix_ns << ",\"initialize_array\":" << arr(initialize_ns)
+      << ",\"initialize\":" << avg(initialize_ns) << ",\"factorize_array\":" << arr(factorize_ns) << ",\"factorize\":" << avg(factorize_ns)
+      << ",\"solve_array\":" << arr(solve_ns) << ",\"solve\":" << avg(solve_ns) << ",\"total_ifs_array\":" << arr(total)
+      << ",\"total_ifs\":" << avg(total) << ",\"verify\":" << verify_ns << "}}";
+    return pretty ? json_pretty(o.str()) : o.str();
 }
 
 // ---- the HIP backend, loaded at run time ---------------------------------------------------------------------
@@ -348,6 +521,7 @@ struct Backend {
     decltype(&solver_hipmf_solve_many) solve_many = nullptr;
     decltype(&solver_hipmf_set_value_map) set_value_map = nullptr;
     decltype(&solver_hipmf_factorize_mapped) factorize_mapped = nullptr;
+    decltype(&solver_hipmf_get_stats) get_stats = nullptr;
     bool tried = false;
 };
 Backend g_backend;
@@ -385,6 +559,7 @@ bool load_backend() {
     BIND(solve_many, "solver_hipmf_solve_many")
     BIND(set_value_map, "solver_hipmf_set_value_map")
     BIND(factorize_mapped, "solver_hipmf_factorize_mapped")
+    BIND(get_stats, "solver_hipmf_get_stats")
 #undef BIND
     g_backend.dl = dl;
     return true;
@@ -508,6 +683,9 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
     if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
     time_factorize_ns = now_ns() - t0;
     factorized = true;
+    int64_t istats[16];
+    double dstats[16];
+    if (g_backend.get_stats((InterfaceHIPMF *)solver, istats, dstats) == SUCCESSFUL_EXIT) effective_matching = istats[14] != 0;
     return nullptr;
 }
 
@@ -645,6 +823,12 @@ void SolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.det_base = 10.0;
     stats.det_exponent = determinant_exponent;
     stats.perturbed_pivots = perturbed_pivots;
+    stats.effective_matching = effective_matching ? "MaxProdScaled" : "None";
+}
+
+void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
+    if (real) real->update_stats(stats); // the real-equivalent solver did the work; the determinant is not available (see determinant note)
+    stats.det_mantissa = 0.0, stats.det_base = 0.0, stats.det_exponent = 0.0;
 }
 
 StrError LinSolver::create(LinSolver &out, Genie genie) {
@@ -673,7 +857,10 @@ StrError LinSolver::compute(Genie genie, std::vector<double> &x, const CooMatrix
 }
 
 // ---- MatrixMarket (read_matrix_market.rs:44-184,346-475) -------------------------------------------------------
-StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym handling) {
+StrError read_matrix_market(MatrixMarketData &data, const std::string &full_path, MMsym handling) {
+    CooMatrix &out = data.real;
+    ComplexCooMatrix &zout = data.complex_matrix;
+    data.complex = false;
     std::ifstream in(full_path);
     if (!in) return "cannot open file";
     std::string line;
@@ -730,8 +917,15 @@ StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym 
     }
     size_t max = (size_t)nnz;
     if (symmetric && handling == MMsym::MakeItFull) max = 2 * (size_t)nnz;
-    StrError e = CooMatrix::create(out, (size_t)m, (size_t)n, max, sym);
+    data.complex = complex;
+    StrError e = complex ? ComplexCooMatrix::create(zout, (size_t)m, (size_t)n, max, sym) : CooMatrix::create(out, (size_t)m, (size_t)n, max, sym);
     if (e) return e;
+    // one "put" for both value types (Hermitian files are mirrored WITHOUT conjugation, as read_matrix_market.rs:400-436 does)
+    double bij = 0.0;
+    auto put = [&](size_t i, size_t j, double aij) {
+        if (complex) zout.put(i, j, aij, bij);
+        else out.put(i, j, aij);
+    };
     long pos = 0;
     while (std::getline(in, line)) {
         size_t b = line.find_first_not_of(" \t\r");
@@ -752,25 +946,34 @@ StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym 
         if (complex) {
             std::string sb;
             if (!(vs >> sb)) return "cannot read bij";
-            strtod(sb.c_str(), &end);
+            bij = strtod(sb.c_str(), &end);
             if (*end) return "cannot parse bij";
         }
         i -= 1, j -= 1; // MatrixMarket is one-based
         if (i < 0 || i >= m || j < 0 || j >= n) return "found an invalid index";
         pos++;
         if (symmetric) {
-            if (handling == MMsym::LeaveAsLower) out.put((size_t)i, (size_t)j, aij);
-            else if (handling == MMsym::SwapToUpper) out.put((size_t)j, (size_t)i, aij);
+            if (handling == MMsym::LeaveAsLower) put((size_t)i, (size_t)j, aij);
+            else if (handling == MMsym::SwapToUpper) put((size_t)j, (size_t)i, aij);
             else {
-                out.put((size_t)i, (size_t)j, aij);
-                if (i != j) out.put((size_t)j, (size_t)i, aij);
+                put((size_t)i, (size_t)j, aij);
+                if (i != j) put((size_t)j, (size_t)i, aij);
             }
         } else {
-            out.put((size_t)i, (size_t)j, aij);
+            put((size_t)i, (size_t)j, aij);
         }
     }
     if (pos != nnz) return "not all values have been found";
-    if (complex) return "complex MatrixMarket files are not supported by this backend yet";
+    return nullptr;
+}
+
+// real files only (the form the flat C API and the older callers use)
+StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym handling) {
+    MatrixMarketData data;
+    StrError e = read_matrix_market(data, full_path, handling);
+    if (e) return e;
+    if (data.complex) return "the file holds a complex matrix: use the MatrixMarketData form";
+    out = std::move(data.real);
     return nullptr;
 }
 
@@ -1034,6 +1237,29 @@ const char *rh_linsolver_stats_json(void *h, void *coo, const char *name, const 
     return s->json.c_str();
 }
 const char *rh_error_string(int32_t code) { return handle_hipmf_error_code(code); }
+void rh_format_nanoseconds(uint64_t nanoseconds, char *buf, int32_t len) {
+    if (!buf || len < 1) return;
+    const std::string t = format_nanoseconds(nanoseconds);
+    snprintf(buf, (size_t)len, "%s", t.c_str());
+}
+int32_t rh_is_memory_error(const char *message) { return is_memory_error(message) ? 1 : 0; }
+void rh_ccoo_info(void *h, int64_t *nrow, int64_t *ncol, int64_t *nnz, int64_t *max_nnz, int32_t *sym) {
+    ComplexCooMatrix *c = (ComplexCooMatrix *)h;
+    *nrow = (int64_t)c->nrow, *ncol = (int64_t)c->ncol, *nnz = (int64_t)c->nnz, *max_nnz = (int64_t)c->max_nnz, *sym = (int32_t)c->symmetric;
+}
+void rh_ccoo_arrays(void *h, const int32_t **ai, const int32_t **aj, const double **ax) {
+    ComplexCooMatrix *c = (ComplexCooMatrix *)h;
+    *ai = c->indices_i.data(), *aj = c->indices_j.data(), *ax = c->values.data();
+}
+const char *rh_read_matrix_market_any(const char *path, int32_t mmsym, void **coo, void **ccoo) {
+    *coo = nullptr, *ccoo = nullptr;
+    MatrixMarketData data;
+    StrError e = read_matrix_market(data, path, (MMsym)mmsym);
+    if (e) return e;
+    if (data.complex) *ccoo = new ComplexCooMatrix(std::move(data.complex_matrix));
+    else *coo = new CooMatrix(std::move(data.real));
+    return nullptr;
+}
 const char *rh_enum_name(int32_t which, int32_t value) {
     if (which == 0 && value >= 0 && value < 12) return ORDERING_NAMES[value];
     if (which == 1 && value >= 0 && value < 9) return SCALING_NAMES[value];

@@ -11,7 +11,7 @@
 //   LinSolTrait, LinSolver::new / compute     .../lin_solver.rs:12-64,116-142,212-224
 //   SolverHIPMF (the new backend)             modelled on .../solver_cudss.rs:92-131,194-360,501-558
 //   VerifyLinSys::from                        .../verify_lin_sys.rs:60-96
-//   StatsLinSol (subset, JSON)                .../stats_lin_sol.rs:14-113
+//   StatsLinSol (JSON)                        .../stats_lin_sol.rs:14-113,212-340
 //   read_matrix_market                        .../read_matrix_market.rs:44-184,346-475
 // Errors are `StrError` = static C strings (nullptr means Ok), the analogue of Result<(), &'static str>.
 #pragma once
@@ -89,20 +89,40 @@ struct CsrMatrix {
     std::vector<size_t> temp_rc;
 };
 
+struct ComplexCooMatrix;
+
 struct VerifyLinSys {
     double max_abs_a = 0, max_abs_ax = 0, max_abs_diff = 0, relative_error = 0;
     static StrError from(VerifyLinSys &out, const CooMatrix &mat, const std::vector<double> &x, const std::vector<double> &rhs);
+    // verify_lin_sys.rs:103-143: x, rhs interleaved complex vectors; absolute values are complex moduli
+    static StrError from_complex(VerifyLinSys &out, const ComplexCooMatrix &mat, const std::vector<double> &x, const std::vector<double> &rhs);
+    // verify_lin_sys.rs:146-152
+    VerifyLinSys max_relative_error(const VerifyLinSys &other) const { return other.relative_error > relative_error ? other : *this; }
 };
 
+// russell_lab base/formatters.rs:60-95: "250ns", "2.5µs", "25ms", "2.5s", "4m10s", "1h2m3s", "1h100.001µs"
+std::string format_nanoseconds(uint64_t nanoseconds);
+
+// stats_lin_sol.rs:334-340: does the error message indicate an out-of-memory condition?
+bool is_memory_error(const char *message);
+
 struct StatsLinSol {
-    std::string solver, matrix_name, symmetric, ordering, scaling, effective_ordering, effective_scaling;
+    std::string solver = "Unknown", matrix_name = "Unknown", symmetric = "Unknown", ordering = "Unknown", scaling = "Unknown",
+                matching = "Unknown", effective_ordering = "Unknown", effective_scaling = "Unknown", effective_matching = "Unknown";
     size_t nrow = 0, ncol = 0, nnz = 0, nnz_actual = 0;
-    bool positive_definite = false;
-    double rcond_estimate = 0.0, det_mantissa = 0.0, det_base = 10.0, det_exponent = 0.0;
+    bool complex = false, positive_definite = false, out_of_memory = false;
+    double rcond_estimate = 0.0, det_mantissa = 0.0, det_mantissa_imag = 0.0, det_base = 0.0, det_exponent = 0.0;
     int32_t perturbed_pivots = 0;
     VerifyLinSys verify;
+    uint64_t read_matrix_ns = 0, verify_ns = 0;
     std::vector<uint64_t> initialize_ns, factorize_ns, solve_ns;
-    std::string to_json() const; // field names follow stats_lin_sol.rs (time_nanoseconds.*, total_ifs, verify, determinant)
+    // stats_lin_sol.rs:212-233
+    void set_matrix_name_from_path(const std::string &filepath);
+    void set_matrix_info_from_coo(const CooMatrix &coo);
+    void set_matrix_info_from_coo(const ComplexCooMatrix &coo);
+    // field names follow stats_lin_sol.rs:14-113 (main, matrix, requests, output, determinant, verify, time_human,
+    // time_nanoseconds); averages and total_ifs as compute_derived_values does (:277-326)
+    std::string to_json(bool pretty = false) const;
 };
 
 class LinSolTrait {
@@ -133,6 +153,7 @@ class SolverHIPMF : public LinSolTrait {
     bool factorized = false;
     bool value_map_set = false, first_call = false; // repeat factorizations refresh the values on the device through a map
     int32_t effective_ordering = -1, effective_scaling = -1, perturbed_pivots = 0;
+    bool effective_matching = false; // a maximum-product matching pre-permutation is in force (weak diagonal at initialize)
     double rcond_estimate = 0.0, determinant_coefficient = 0.0, determinant_exponent = 0.0;
 
   private:
@@ -171,6 +192,7 @@ class ComplexSolverHIPMF {
     // x, rhs: interleaved complex vectors of length 2 n
     StrError solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose);
     bool factorized = false;
+    void update_stats(StatsLinSol &stats) const; // complex_lin_solver.rs:12-104 (ComplexLinSolTrait::update_stats)
     uint64_t get_ns_init() const { return real ? real->get_ns_init() : 0; }
     uint64_t get_ns_fact() const { return real ? real->get_ns_fact() : 0; }
     uint64_t get_ns_solve() const { return real ? real->get_ns_solve() : 0; }
@@ -193,7 +215,14 @@ class LinSolver {
                             const LinSolParams *params);
 };
 
-StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym symmetric_handling);
+// read_matrix_market.rs:346-475 returns (Option<CooMatrix>, Option<ComplexCooMatrix>): exactly one of the two is filled
+struct MatrixMarketData {
+    bool complex = false;
+    CooMatrix real;
+    ComplexCooMatrix complex_matrix;
+};
+StrError read_matrix_market(MatrixMarketData &out, const std::string &full_path, MMsym symmetric_handling);
+StrError read_matrix_market(CooMatrix &out, const std::string &full_path, MMsym symmetric_handling); // real files only
 
 StrError handle_hipmf_error_code(int32_t err);
 

@@ -158,6 +158,11 @@ def _L():
         "rh_clinsolver_factorize": (cp, [vp, vp, pp(_RhParams)]),
         "rh_clinsolver_solve": (cp, [vp, vp, i64, vp, i64, i32]),
         "rh_error_string": (cp, [i32]),
+        "rh_format_nanoseconds": (None, [C.c_uint64, C.c_char_p, i32]),
+        "rh_is_memory_error": (i32, [cp]),
+        "rh_ccoo_info": (None, [vp, pp(i64), pp(i64), pp(i64), pp(i64), pp(i32)]),
+        "rh_ccoo_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64))]),
+        "rh_read_matrix_market_any": (cp, [cp, i32, pp(vp), pp(vp)]),
         "rh_enum_name": (cp, [i32, i32]),
         "rh_genie_get_sym": (i32, [i32, i32]),
     }
@@ -306,6 +311,27 @@ def read_matrix_market(full_path, symmetric_handling=MMsym.LeaveAsLower):
     return CooMatrix(0, 0, 0, _handle=h)
 
 
+def read_matrix_market_any(full_path, symmetric_handling=MMsym.LeaveAsLower):
+    """read_matrix_market.rs:346-475: returns (CooMatrix | None, ComplexCooMatrix | None), exactly one of them set."""
+    coo, ccoo = C.c_void_p(), C.c_void_p()
+    _check(_L().rh_read_matrix_market_any(os.fspath(full_path).encode(), int(symmetric_handling), C.byref(coo), C.byref(ccoo)))
+    if ccoo.value:
+        return None, ComplexCooMatrix(0, 0, 0, _handle=ccoo.value)
+    return CooMatrix(0, 0, 0, _handle=coo.value), None
+
+
+def format_nanoseconds(nanoseconds):
+    """russell_lab base/formatters.rs:60-95."""
+    buf = C.create_string_buffer(96)
+    _L().rh_format_nanoseconds(int(nanoseconds), buf, 96)
+    return buf.value.decode()
+
+
+def is_memory_error(message):
+    """stats_lin_sol.rs:334-340."""
+    return bool(_L().rh_is_memory_error(message.encode()))
+
+
 class _Actual:
     """What `solver.actual` exposes: the LinSolTrait methods (lin_solver.rs:12-64)."""
 
@@ -387,11 +413,27 @@ class LinSolver:
 class ComplexCooMatrix:
     """complex_coo_matrix.rs: COO triplets with Complex64 values (duplicates allowed, summed at conversion)."""
 
-    def __init__(self, nrow, ncol, max_nnz, symmetric=Sym.No):
+    def __init__(self, nrow, ncol, max_nnz, symmetric=Sym.No, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            self.nrow, self.ncol = self.get_info()[:2]
+            return
         err = C.c_char_p()
         self._h = _L().rh_ccoo_new(int(nrow), int(ncol), int(max_nnz), int(symmetric), C.byref(err))
         _check(err.value)
         self.nrow, self.ncol = int(nrow), int(ncol)
+
+    def get_info(self):
+        a, b, c, d, s = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        _L().rh_ccoo_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(s))
+        return a.value, b.value, c.value, Sym(s.value)
+
+    def triplets(self):
+        ai, aj, ax = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        _L().rh_ccoo_arrays(self._h, C.byref(ai), C.byref(aj), C.byref(ax))
+        n = self.get_info()[2]
+        vals = np.ctypeslib.as_array(ax, (2 * n,)).copy().view(np.complex128)
+        return np.ctypeslib.as_array(ai, (n,)).copy(), np.ctypeslib.as_array(aj, (n,)).copy(), vals
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

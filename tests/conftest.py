@@ -10,3 +10,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+EMU = os.path.join(ROOT, "tests", "emu", "libhipmf_emu.so")
+CSRC = os.path.join(ROOT, "russell_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """The HIP kernels compiled against tools/hipemu (development-only CPU emulator) behind the same C-ABI.
+
+    Used by the CPU tests of kernel logic and of the host layers above the C-ABI; never part of the product."""
+    import subprocess
+
+    srcs = [os.path.join(CSRC, f) for f in ("symbolic.cpp", "matching.cpp", "numeric.cpp", "interface_hipmf.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps += [os.path.join(ROOT, "tools", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "tools", "hipemu", "hipmf_device_rt.h")]
+    if not os.path.exists(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
+        os.makedirs(os.path.dirname(EMU), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-w", "-I", os.path.join(ROOT, "tools", "hipemu"), "-I", CSRC,
+                               "-x", "c++"] + srcs + ["-o", EMU])
+    return EMU

@@ -3,30 +3,10 @@ fibers for __syncthreads, wave shuffles, the MFMA lane maps) and driven through 
 
 This is NOT parity evidence (parity is measured on a real MI355X by the -m gpu tests) and the emulated library is never
 part of the product; it catches indexing / barrier / assembly-map mistakes before a GPU run."""
-import os
-import subprocess
-
 import numpy as np
-import pytest
 
 from russell_amd import problems as P
 from russell_amd.backend import Hipmf
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, "tests", "emu", "libhipmf_emu.so")
-CSRC = os.path.join(ROOT, "russell_amd", "csrc")
-
-
-@pytest.fixture(scope="module")
-def emu_lib():
-    srcs = [os.path.join(CSRC, f) for f in ("symbolic.cpp", "matching.cpp", "numeric.cpp", "interface_hipmf.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    deps += [os.path.join(ROOT, "tools", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "tools", "hipemu", "hipmf_device_rt.h")]
-    if not os.path.exists(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
-        os.makedirs(os.path.dirname(EMU), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-w", "-I", os.path.join(ROOT, "tools", "hipemu"), "-I", CSRC,
-                               "-x", "c++"] + srcs + ["-o", EMU])
-    return EMU
 
 
 def _solve(lib, n, rp, ci, v, b, **kw):

@@ -217,3 +217,26 @@ def test_repeat_factorize_refreshes_values_on_device():
         b = P.csr_matvec(n, rp, ci, v, xs)
         x = solver.actual.solve(b)
         assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-10, step
+
+
+@pytest.mark.gpu
+def test_solve_matrix_market_harness_on_device():
+    # bin/solve_matrix_market.rs:97-305 against the real HIP library: bfwb62 golden solution (1e-10), JSON record, nrun
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    harness = os.path.join(root, "russell_amd", "lib", "solve_matrix_market")
+    env = {k: v for k, v in os.environ.items() if k != "RUSSELL_HIPMF_LIB"}
+    p = subprocess.run([harness, "-d", "-r", "3", os.path.join(root, "tests", "golden", "mtx", "bfwb62.mtx")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "BFWB62 FAILED" not in p.stdout
+    d = json.loads(p.stdout)
+    assert d["matrix"]["nnz_actual"] == 342 and d["verify"]["relative_error"] < 1e-12
+    assert len(d["time_nanoseconds"]["total_ifs_array"]) == 3
+    p = subprocess.run([harness, os.path.join(root, "tests", "golden", "mtx", "ok_complex_general.mtx")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr
+    d = json.loads(p.stdout)
+    assert d["matrix"]["complex"] is True and d["verify"]["relative_error"] < 1e-13
