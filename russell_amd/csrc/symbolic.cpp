@@ -3,9 +3,14 @@
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 namespace hipmf {
 namespace {
@@ -77,54 +82,74 @@ static void permute_graph(const Graph &g, const std::vector<int32_t> &perm, cons
 // BFS from a pseudo-peripheral vertex that balances the two sides with the fewest vertices; the
 // separator is numbered last.  Regions of <= 64 vertices are numbered by minimum degree on a
 // one-word-per-row bitset elimination graph.
+//
+// The regions of the dissection tree are independent once their parent has been split, so they are
+// processed by a small pool of host threads (the first splits are serial, the rest of the tree is wide).
+// The result does not depend on the number of threads or on the schedule: a region's outcome is a function
+// of its own vertex list only; region ids and visit stamps are merely unique, never compared for order.
 // ------------------------------------------------------------------------------------------------
-struct NDWork {
+struct NDShared {
     const Graph &g;
-    std::vector<int32_t> part;   // region id per vertex, -1 once numbered
-    std::vector<int32_t> verts;  // region vertex lists (segments)
-    std::vector<int32_t> queue;  // BFS queue / scratch
-    std::vector<int32_t> lev;    // BFS level
-    std::vector<int32_t> stamp;  // visit stamps
-    std::vector<int32_t> tmp;
-    std::vector<int32_t> lvl_ptr;
-    int32_t cur_stamp = 0;
-    explicit NDWork(const Graph &gr) : g(gr) {}
+    std::unique_ptr<std::atomic<int32_t>[]> part; // region id per vertex, -1 once numbered (read across regions: atomic, relaxed)
+    std::vector<int32_t> verts;                   // region vertex lists (disjoint segments)
+    std::vector<int32_t> lev;                     // BFS level / local index (vertices of the own region only)
+    std::vector<int32_t> stamp;                   // visit stamps (vertices of the own region only)
+    std::atomic<int32_t> cur_stamp{0}, next_id{1};
+    explicit NDShared(const Graph &gr) : g(gr) {}
+    int32_t region_of(int32_t v) const { return part[v].load(std::memory_order_relaxed); }
+    void set_region(int32_t v, int32_t id) { part[v].store(id, std::memory_order_relaxed); }
 };
 
-// BFS inside region `id` from `root`; fills w.queue[0..count) in visit order, w.lev, w.lvl_ptr.
+// per-thread scratch, sized by the largest region the thread has seen
+struct NDScratch {
+    std::vector<int32_t> queue, tmp, lvl_ptr, comp_ptr;
+    void reserve(int32_t size) {
+        if ((int32_t)queue.size() < size) {
+            queue.resize((size_t)size);
+            tmp.resize((size_t)size);
+        }
+    }
+};
+
+struct NDRegion {
+    int32_t begin, end, pos, id;
+    bool connected;
+};
+
+// BFS inside region `id` from `root`; fills t.queue[0..count) in visit order, w.lev, t.lvl_ptr.
 // Returns the eccentricity (number of levels - 1).
-static int32_t bfs_region(NDWork &w, int32_t root, int32_t id, int32_t &count) {
+static int32_t bfs_region(NDShared &w, NDScratch &t, int32_t root, int32_t id, int32_t &count) {
     const Graph &g = w.g;
-    int32_t st = ++w.cur_stamp;
+    const int32_t st = w.cur_stamp.fetch_add(1, std::memory_order_relaxed) + 1;
     int32_t head = 0, tail = 0;
-    w.queue[tail++] = root;
+    t.queue[tail++] = root;
     w.stamp[root] = st;
     w.lev[root] = 0;
-    w.lvl_ptr.clear();
-    w.lvl_ptr.push_back(0);
+    t.lvl_ptr.clear();
+    t.lvl_ptr.push_back(0);
     int32_t curlev = 0;
     while (head < tail) {
-        int32_t v = w.queue[head];
+        int32_t v = t.queue[head];
         if (w.lev[v] != curlev) {
             curlev = w.lev[v];
-            w.lvl_ptr.push_back(head);
+            t.lvl_ptr.push_back(head);
         }
         head++;
         for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
             int32_t u = g.adj[p];
-            if (w.part[u] == id && w.stamp[u] != st) {
+            if (w.region_of(u) == id && w.stamp[u] != st) {
                 w.stamp[u] = st;
                 w.lev[u] = curlev + 1;
-                w.queue[tail++] = u;
+                t.queue[tail++] = u;
             }
         }
     }
-    w.lvl_ptr.push_back(tail);
+    t.lvl_ptr.push_back(tail);
     count = tail;
-    return (int32_t)w.lvl_ptr.size() - 2;
+    return (int32_t)t.lvl_ptr.size() - 2;
 }
 
-static void leaf_min_degree(NDWork &w, int32_t begin, int32_t end, int32_t id, int32_t pos, std::vector<int32_t> &perm) {
+static void leaf_min_degree(NDShared &w, int32_t begin, int32_t end, int32_t id, int32_t pos, std::vector<int32_t> &perm) {
     const Graph &g = w.g;
     int32_t s = end - begin;
     uint64_t a[64];
@@ -136,7 +161,7 @@ static void leaf_min_degree(NDWork &w, int32_t begin, int32_t end, int32_t id, i
         ext[i] = 0;
         for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
             int32_t u = g.adj[p];
-            if (w.part[u] == id) a[i] |= (uint64_t)1 << w.lev[u];
+            if (w.region_of(u) == id) a[i] |= (uint64_t)1 << w.lev[u];
             else ext[i]++;
         }
     }
@@ -153,7 +178,7 @@ static void leaf_min_degree(NDWork &w, int32_t begin, int32_t end, int32_t id, i
         }
         int32_t v = w.verts[begin + best];
         perm[pos + step] = v;
-        w.part[v] = -1;
+        w.set_region(v, -1);
         alive &= ~((uint64_t)1 << best);
         uint64_t nb = a[best] & alive;
         for (uint64_t m = nb; m; m &= m - 1) {
@@ -165,169 +190,212 @@ static void leaf_min_degree(NDWork &w, int32_t begin, int32_t end, int32_t id, i
     }
 }
 
+// One region: number it (leaf / clique) or split it; the sub-regions are appended to `out` (last = to be processed first
+// by a serial driver, which reproduces the depth-first order; any order gives the same permutation).
+static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, int32_t leaf, NDRegion R, std::vector<int32_t> &perm,
+                       std::vector<int32_t> &leaf_of, std::vector<NDRegion> &out) {
+    const Graph &g = w.g;
+    const int32_t size = R.end - R.begin;
+    if (size <= 0) return;
+    t.reserve(size);
+    if (!R.connected) {
+        // connected components of the region (discovery order, deterministic)
+        const int32_t st = w.cur_stamp.fetch_add(1, std::memory_order_relaxed) + 1;
+        int32_t outn = 0;
+        t.comp_ptr.clear();
+        t.comp_ptr.push_back(0);
+        for (int32_t k = R.begin; k < R.end; k++) {
+            int32_t r = w.verts[k];
+            if (w.stamp[r] == st) continue;
+            int32_t head = outn;
+            t.tmp[outn++] = r;
+            w.stamp[r] = st;
+            while (head < outn) {
+                int32_t v = t.tmp[head++];
+                for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
+                    int32_t u = g.adj[p];
+                    if (w.region_of(u) == R.id && w.stamp[u] != st) {
+                        w.stamp[u] = st;
+                        t.tmp[outn++] = u;
+                    }
+                }
+            }
+            t.comp_ptr.push_back(outn);
+        }
+        std::copy(t.tmp.begin(), t.tmp.begin() + size, w.verts.begin() + R.begin);
+        int32_t ncomp = (int32_t)t.comp_ptr.size() - 1;
+        if (ncomp > 1) {
+            // independent subtrees: number them one after the other
+            for (int32_t c = ncomp - 1; c >= 0; c--) {
+                int32_t b = R.begin + t.comp_ptr[c], e = R.begin + t.comp_ptr[c + 1];
+                int32_t id = w.next_id.fetch_add(1, std::memory_order_relaxed);
+                for (int32_t k = b; k < e; k++) w.set_region(w.verts[k], id);
+                out.push_back({b, e, R.pos + t.comp_ptr[c], id, true});
+            }
+            return;
+        }
+    }
+    if (size <= leaf) {
+        if (opt.dense_leaves && size > 1)
+            for (int32_t k = R.begin; k < R.end; k++) leaf_of[w.verts[k]] = R.pos; // leaf label: its first position (unique)
+        leaf_min_degree(w, R.begin, R.end, R.id, R.pos, perm);
+        return;
+    }
+    // pseudo-peripheral vertex: repeat BFS from a minimum-degree vertex of the last level
+    int32_t root = w.verts[R.begin], count = 0;
+    int32_t ecc = bfs_region(w, t, root, R.id, count);
+    for (int32_t it = 0; it < 4; it++) {
+        int32_t lb = t.lvl_ptr[t.lvl_ptr.size() - 2], le = t.lvl_ptr.back();
+        int32_t cand = t.queue[lb];
+        int64_t cdeg = g.ptr[cand + 1] - g.ptr[cand];
+        for (int32_t k = lb + 1; k < le; k++) {
+            int32_t v = t.queue[k];
+            int64_t d = g.ptr[v + 1] - g.ptr[v];
+            if (d < cdeg || (d == cdeg && v < cand)) {
+                cand = v;
+                cdeg = d;
+            }
+        }
+        if (cand == root) break;
+        int32_t e2 = bfs_region(w, t, cand, R.id, count);
+        // the structure rooted at `cand` is kept in both cases (same or larger eccentricity, valid structure)
+        const bool grew = e2 > ecc;
+        ecc = e2;
+        root = cand;
+        if (!grew) break;
+    }
+    if (ecc < 2) {
+        // (nearly) a clique: cannot be dissected; number in BFS order
+        for (int32_t k = 0; k < size; k++) {
+            perm[R.pos + k] = t.queue[k];
+            w.set_region(t.queue[k], -1);
+        }
+        return;
+    }
+    // choose the separating level
+    int32_t best = -1;
+    int64_t best_sz = 0, best_diff = 0;
+    bool best_ok = false;
+    for (int32_t l = 1; l < ecc; l++) {
+        int64_t a = t.lvl_ptr[l], s = t.lvl_ptr[l + 1] - t.lvl_ptr[l], b = size - a - s;
+        bool ok = std::min(a, b) * 20 >= (int64_t)size * 7; // both sides >= 35 %
+        int64_t diff = a > b ? a - b : b - a;
+        bool better;
+        if (best < 0) better = true;
+        else if (ok != best_ok) better = ok;
+        else if (ok) better = (s < best_sz) || (s == best_sz && diff < best_diff);
+        else better = (diff < best_diff) || (diff == best_diff && s < best_sz);
+        if (better) {
+            best = l;
+            best_sz = s;
+            best_diff = diff;
+            best_ok = ok;
+        }
+    }
+    int32_t lb = t.lvl_ptr[best], le = t.lvl_ptr[best + 1];
+    // queue layout: [0,lb) = side A, [lb,le) = separator level, [le,size) = side B.
+    // thin the separator: a vertex with no neighbour in level best+1 can join side A
+    int32_t idA = w.next_id.fetch_add(2, std::memory_order_relaxed), idB = idA + 1;
+    int32_t nA = 0, nS = 0;
+    for (int32_t k = 0; k < lb; k++) t.tmp[nA++] = t.queue[k];
+    int32_t sep_begin = size; // separator collected at the back of tmp (reverse)
+    for (int32_t k = lb; k < le; k++) {
+        int32_t v = t.queue[k];
+        bool up = false;
+        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1] && !up; p++) {
+            int32_t u = g.adj[p];
+            up = (w.region_of(u) == R.id && w.lev[u] == best + 1);
+        }
+        if (up) {
+            t.tmp[--sep_begin] = v;
+            nS++;
+        } else {
+            t.tmp[nA++] = v;
+        }
+    }
+    int32_t nB = size - le;
+    // tmp: [0,nA) = A ; B goes to [nA, nA+nB) ; separator currently at [sep_begin,size) == [nA+nB,size)
+    for (int32_t k = 0; k < nB; k++) t.tmp[nA + k] = t.queue[le + k];
+    for (int32_t k = 0; k < nA; k++) w.set_region(t.tmp[k], idA);
+    for (int32_t k = nA; k < nA + nB; k++) w.set_region(t.tmp[k], idB);
+    // separator numbered last, in ascending BFS order
+    for (int32_t k = 0; k < nS; k++) {
+        int32_t v = t.tmp[size - 1 - k];
+        perm[R.pos + nA + nB + k] = v;
+        w.set_region(v, -1);
+    }
+    std::copy(t.tmp.begin(), t.tmp.begin() + nA + nB, w.verts.begin() + R.begin);
+    out.push_back({R.begin + nA, R.begin + nA + nB, R.pos + nA, idB, false});
+    out.push_back({R.begin, R.begin + nA, R.pos, idA, false});
+}
+
 static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm, std::vector<int32_t> &leaf_of) {
     int32_t n = g.n;
     perm.assign((size_t)n, -1);
     leaf_of.assign((size_t)n, -1);
-    int32_t next_leaf = 0;
-    NDWork w(g);
-    w.part.assign((size_t)n, 0);
+    NDShared w(g);
+    w.part.reset(new std::atomic<int32_t>[(size_t)n]);
+    for (int32_t v = 0; v < n; v++) w.part[v].store(0, std::memory_order_relaxed);
     w.verts.resize((size_t)n);
     std::iota(w.verts.begin(), w.verts.end(), 0);
-    w.queue.resize((size_t)n);
     w.lev.assign((size_t)n, 0);
     w.stamp.assign((size_t)n, 0);
-    w.tmp.resize((size_t)n);
-    struct Region {
-        int32_t begin, end, pos, id;
-        bool connected;
-    };
-    std::vector<Region> stack;
-    int32_t next_id = 1;
-    stack.push_back({0, n, 0, 0, false});
     const int32_t leaf = std::min<int32_t>(64, std::max<int32_t>(1, opt.nd_leaf));
-    std::vector<int32_t> comp_ptr;
-    while (!stack.empty()) {
-        Region R = stack.back();
-        stack.pop_back();
-        int32_t size = R.end - R.begin;
-        if (size <= 0) continue;
-        if (!R.connected) {
-            // connected components of the region (discovery order, deterministic)
-            int32_t st = ++w.cur_stamp;
-            int32_t out = 0;
-            comp_ptr.clear();
-            comp_ptr.push_back(0);
-            for (int32_t k = R.begin; k < R.end; k++) {
-                int32_t r = w.verts[k];
-                if (w.stamp[r] == st) continue;
-                int32_t head = out;
-                w.tmp[out++] = r;
-                w.stamp[r] = st;
-                while (head < out) {
-                    int32_t v = w.tmp[head++];
-                    for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
-                        int32_t u = g.adj[p];
-                        if (w.part[u] == R.id && w.stamp[u] != st) {
-                            w.stamp[u] = st;
-                            w.tmp[out++] = u;
-                        }
-                    }
+
+    int nthreads = opt.nd_threads > 0 ? opt.nd_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 20000) nthreads = 1;
+    // shared LIFO of regions; a region below `serial_size` vertices is finished by the thread that took it
+    const int32_t serial_size = std::max<int32_t>(2048, n / (64 * nthreads));
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<NDRegion> shared;
+    int busy = 0;
+    shared.push_back({0, n, 0, 0, false});
+    auto worker = [&]() {
+        NDScratch t;
+        std::vector<NDRegion> local, out;
+        for (;;) {
+            NDRegion R;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !shared.empty() || busy == 0; });
+                if (shared.empty()) return; // nothing queued and nobody can produce more
+                R = shared.back();
+                shared.pop_back();
+                busy++;
+            }
+            local.clear();
+            local.push_back(R);
+            while (!local.empty()) {
+                NDRegion Q = local.back();
+                local.pop_back();
+                out.clear();
+                nd_process(w, t, opt, leaf, Q, perm, leaf_of, out);
+                bool gave = false;
+                for (const NDRegion &c : out) {
+                    if (nthreads > 1 && c.end - c.begin >= serial_size && (!local.empty() || &c != &out.back())) {
+                        // keep the last (first-to-process) child, hand the other large ones to the pool
+                        std::lock_guard<std::mutex> lk(mu);
+                        shared.push_back(c);
+                        gave = true;
+                    } else
+                        local.push_back(c);
                 }
-                comp_ptr.push_back(out);
+                if (gave) cv.notify_all();
             }
-            std::copy(w.tmp.begin(), w.tmp.begin() + size, w.verts.begin() + R.begin);
-            int32_t ncomp = (int32_t)comp_ptr.size() - 1;
-            if (ncomp > 1) {
-                // independent subtrees: number them one after the other
-                for (int32_t c = ncomp - 1; c >= 0; c--) {
-                    int32_t b = R.begin + comp_ptr[c], e = R.begin + comp_ptr[c + 1];
-                    int32_t id = next_id++;
-                    for (int32_t k = b; k < e; k++) w.part[w.verts[k]] = id;
-                    stack.push_back({b, e, R.pos + comp_ptr[c], id, true});
-                }
-                continue;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                busy--;
             }
+            cv.notify_all();
         }
-        if (size <= leaf) {
-            if (opt.dense_leaves && size > 1) {
-                for (int32_t k = R.begin; k < R.end; k++) leaf_of[w.verts[k]] = next_leaf;
-                next_leaf++;
-            }
-            leaf_min_degree(w, R.begin, R.end, R.id, R.pos, perm);
-            continue;
-        }
-        // pseudo-peripheral vertex: repeat BFS from a minimum-degree vertex of the last level
-        int32_t root = w.verts[R.begin], count = 0;
-        int32_t ecc = bfs_region(w, root, R.id, count);
-        for (int32_t it = 0; it < 4; it++) {
-            int32_t lb = w.lvl_ptr[w.lvl_ptr.size() - 2], le = w.lvl_ptr.back();
-            int32_t cand = w.queue[lb];
-            int64_t cdeg = g.ptr[cand + 1] - g.ptr[cand];
-            for (int32_t k = lb + 1; k < le; k++) {
-                int32_t v = w.queue[k];
-                int64_t d = g.ptr[v + 1] - g.ptr[v];
-                if (d < cdeg || (d == cdeg && v < cand)) {
-                    cand = v;
-                    cdeg = d;
-                }
-            }
-            if (cand == root) break;
-            int32_t e2 = bfs_region(w, cand, R.id, count);
-            if (e2 > ecc) {
-                ecc = e2;
-                root = cand;
-            } else {
-                // keep the structure rooted at `cand` anyway (same eccentricity, valid structure)
-                ecc = e2;
-                root = cand;
-                break;
-            }
-        }
-        if (ecc < 2) {
-            // (nearly) a clique: cannot be dissected; number in BFS order
-            for (int32_t k = 0; k < size; k++) {
-                perm[R.pos + k] = w.queue[k];
-                w.part[w.queue[k]] = -1;
-            }
-            continue;
-        }
-        // choose the separating level
-        int32_t best = -1;
-        int64_t best_sz = 0, best_diff = 0;
-        bool best_ok = false;
-        for (int32_t l = 1; l < ecc; l++) {
-            int64_t a = w.lvl_ptr[l], s = w.lvl_ptr[l + 1] - w.lvl_ptr[l], b = size - a - s;
-            bool ok = std::min(a, b) * 20 >= (int64_t)size * 7; // both sides >= 35 %
-            int64_t diff = a > b ? a - b : b - a;
-            bool better;
-            if (best < 0) better = true;
-            else if (ok != best_ok) better = ok;
-            else if (ok) better = (s < best_sz) || (s == best_sz && diff < best_diff);
-            else better = (diff < best_diff) || (diff == best_diff && s < best_sz);
-            if (better) {
-                best = l;
-                best_sz = s;
-                best_diff = diff;
-                best_ok = ok;
-            }
-        }
-        int32_t lb = w.lvl_ptr[best], le = w.lvl_ptr[best + 1];
-        // queue layout: [0,lb) = side A, [lb,le) = separator level, [le,size) = side B.
-        // thin the separator: a vertex with no neighbour in level best+1 can join side A
-        int32_t idA = next_id++, idB = next_id++;
-        int32_t nA = 0, nS = 0;
-        // write A
-        for (int32_t k = 0; k < lb; k++) w.tmp[nA++] = w.queue[k];
-        int32_t sep_begin = size; // separator collected at the back of tmp (reverse)
-        for (int32_t k = lb; k < le; k++) {
-            int32_t v = w.queue[k];
-            bool up = false;
-            for (int64_t p = g.ptr[v]; p < g.ptr[v + 1] && !up; p++) {
-                int32_t u = g.adj[p];
-                up = (w.part[u] == R.id && w.lev[u] == best + 1);
-            }
-            if (up) {
-                w.tmp[--sep_begin] = v;
-                nS++;
-            } else {
-                w.tmp[nA++] = v;
-            }
-        }
-        int32_t nB = size - le;
-        // tmp: [0,nA) = A ; B goes to [nA, nA+nB) ; separator currently at [sep_begin,size) == [nA+nB,size)
-        for (int32_t k = 0; k < nB; k++) w.tmp[nA + k] = w.queue[le + k];
-        for (int32_t k = 0; k < nA; k++) w.part[w.tmp[k]] = idA;
-        for (int32_t k = nA; k < nA + nB; k++) w.part[w.tmp[k]] = idB;
-        // separator numbered last, in ascending BFS order
-        for (int32_t k = 0; k < nS; k++) {
-            int32_t v = w.tmp[size - 1 - k];
-            perm[R.pos + nA + nB + k] = v;
-            w.part[v] = -1;
-        }
-        std::copy(w.tmp.begin(), w.tmp.begin() + nA + nB, w.verts.begin() + R.begin);
-        stack.push_back({R.begin + nA, R.begin + nA + nB, R.pos + nA, idB, false});
-        stack.push_back({R.begin, R.begin + nA, R.pos, idA, false});
+    };
+    if (nthreads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < nthreads; i++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
     }
 }
 

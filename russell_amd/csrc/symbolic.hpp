@@ -22,6 +22,7 @@ struct SymbolicOptions {
     int32_t ordering = ORDERING_NESTED_DISSECTION;
     int32_t nd_leaf = 64;         // leaf regions are ordered by bitset minimum degree (<= 64 vertices)
     bool dense_leaves = false;    // every nested-dissection leaf region becomes one dense supernode
+    int32_t nd_threads = 0;       // host threads of the nested dissection (0: min(16, hardware threads)); the result does not depend on it
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
     int32_t augment_above = 64;   // fronts with f > this are stored augmented (must equal kernels.hpp SMALL_F)
     int32_t relax_ncol[3] = {4, 16, 48};
