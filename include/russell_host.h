@@ -37,6 +37,19 @@ void rh_coo_info(void *coo, int64_t *nrow, int64_t *ncol, int64_t *nnz, int64_t 
 void rh_coo_arrays(void *coo, const int32_t **ai, const int32_t **aj, const double **ax);
 const char *rh_coo_mat_vec_mul(void *coo, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
 
+/* coo_matrix.rs:629 (v += alpha A u), :708 (v = alpha A^T u), :738 assign, :779 add, :823 put_lagrange_block, :468 to_dense
+ * (row-major nrow x ncol), :872 get_actual_nnz */
+const char *rh_coo_mat_vec_mul_update(void *coo, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
+const char *rh_coo_mat_t_vec_mul(void *coo, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
+const char *rh_coo_assign(void *coo, double alpha, void *other);
+const char *rh_coo_add(void *coo, double alpha, void *other);
+const char *rh_coo_put_lagrange_block(void *coo, void *bb);
+const char *rh_coo_to_dense(void *coo, double *a_row_major, int64_t len);
+int64_t rh_coo_actual_nnz(void *coo);
+/* csc_matrix.rs:508-584 / csr_matrix.rs:483-558 */
+void *rh_csc_from_csr(void *csr, const char **err);
+void *rh_csr_from_csc(void *csc, const char **err);
+
 void *rh_csc_from_coo(void *coo, const char **err);
 const char *rh_csc_update_from_coo(void *csc, void *coo);
 void rh_csc_arrays(void *csc, const int32_t **col_pointers, const int32_t **row_indices, const double **values, int64_t *ncol, int64_t *nnz);

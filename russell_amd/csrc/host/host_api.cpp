@@ -98,6 +98,130 @@ StrError CooMatrix::mat_vec_mul(std::vector<double> &v, double alpha, const std:
     return nullptr;
 }
 
+StrError CooMatrix::mat_vec_mul_update(std::vector<double> &v, double alpha, const std::vector<double> &u) const {
+    if (u.size() < ncol) return "u.dim() must be ≥ the number of columns of the matrix";
+    if (v.size() < nrow) return "v.dim() must be ≥ the number of rows of the matrix";
+    const bool mirror = triangular(symmetric);
+    for (size_t p = 0; p < nnz; p++) {
+        size_t i = (size_t)indices_i[p], j = (size_t)indices_j[p];
+        v[i] += alpha * values[p] * u[j];
+        if (mirror && i != j) v[j] += alpha * values[p] * u[i];
+    }
+    return nullptr;
+}
+
+StrError CooMatrix::mat_t_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const {
+    if (u.size() < nrow) return "u.dim() must be ≥ the number of rows of the matrix";
+    if (v.size() < ncol) return "v.dim() must be ≥ the number of columns of the matrix";
+    std::fill(v.begin(), v.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t p = 0; p < nnz; p++) {
+        size_t j = (size_t)indices_i[p], i = (size_t)indices_j[p]; // transposed roles
+        v[i] += alpha * values[p] * u[j];
+        if (mirror && i != j) v[j] += alpha * values[p] * u[i];
+    }
+    return nullptr;
+}
+
+StrError CooMatrix::assign(double alpha, const CooMatrix &other) {
+    if (other.nrow != nrow) return "matrices must have the same nrow";
+    if (other.ncol != ncol) return "matrices must have the same ncol";
+    if (other.symmetric != symmetric) return "matrices must have the same symmetric type";
+    reset();
+    for (size_t p = 0; p < other.nnz; p++)
+        if (StrError e = put((size_t)other.indices_i[p], (size_t)other.indices_j[p], alpha * other.values[p])) return e;
+    return nullptr;
+}
+
+StrError CooMatrix::add(double alpha, const CooMatrix &other) {
+    if (other.nrow > nrow) return "other.nrow must be ≤ this.nrow";
+    if (other.ncol > ncol) return "other.ncol must be ≤ this.ncol";
+    if (other.symmetric != symmetric) return "matrices must have the same symmetric type";
+    for (size_t p = 0; p < other.nnz; p++)
+        if (StrError e = put((size_t)other.indices_i[p], (size_t)other.indices_j[p], alpha * other.values[p])) return e;
+    return nullptr;
+}
+
+StrError CooMatrix::put_lagrange_block(const CooMatrix &bb) {
+    if (bb.symmetric != Sym::No) return "the Lagrange block must not be symmetric";
+    if (bb.ncol + bb.nrow > nrow) return "ncol(B) + nrow(B) must be ≤ nrow(A)";
+    if (bb.ncol + bb.nrow > ncol) return "ncol(B) + nrow(B) must be ≤ ncol(A)";
+    for (size_t p = 0; p < bb.nnz; p++) {
+        const size_t i = (size_t)bb.indices_i[p], j = (size_t)bb.indices_j[p];
+        const double x = bb.values[p];
+        StrError e = nullptr;
+        if (symmetric == Sym::YesLower) e = put(bb.ncol + i, j, x); // B only
+        else if (symmetric == Sym::YesUpper) e = put(j, bb.ncol + i, x); // B^T only
+        else {
+            e = put(bb.ncol + i, j, x);
+            if (!e) e = put(j, bb.ncol + i, x);
+        }
+        if (e) return e;
+    }
+    return nullptr;
+}
+
+StrError CooMatrix::to_dense(std::vector<double> &a) const {
+    if (a.size() != nrow * ncol) return "wrong matrix dimensions";
+    std::fill(a.begin(), a.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t p = 0; p < nnz; p++) {
+        size_t i = (size_t)indices_i[p], j = (size_t)indices_j[p];
+        a[i * ncol + j] += values[p];
+        if (mirror && i != j) a[j * ncol + i] += values[p];
+    }
+    return nullptr;
+}
+
+size_t CooMatrix::get_actual_nnz() const {
+    if (!triangular(symmetric)) return nnz;
+    size_t actual = 0;
+    for (size_t p = 0; p < nnz; p++) actual += indices_i[p] != indices_j[p] ? 2 : 1;
+    return actual;
+}
+
+// ---- CSC <-> CSR (csc_matrix.rs:508-584, csr_matrix.rs:483-558): counting transposition, entries of a column (row) come out in
+// ascending row (column) order because the source is swept row by row (column by column) ----------------------------------
+StrError CscMatrix::from_csr(CscMatrix &out, const CsrMatrix &csr) {
+    const size_t nnz = csr.nnz_final();
+    out.symmetric = csr.symmetric;
+    out.nrow = csr.nrow, out.ncol = csr.ncol;
+    out.col_pointers.assign(csr.ncol + 1, 0);
+    out.row_indices.assign(nnz, 0);
+    out.values.assign(nnz, 0.0);
+    out.temp_w.clear();
+    for (size_t p = 0; p < nnz; p++) out.col_pointers[(size_t)csr.col_indices[p] + 1]++;
+    for (size_t j = 0; j < csr.ncol; j++) out.col_pointers[j + 1] += out.col_pointers[j];
+    std::vector<int32_t> next(out.col_pointers.begin(), out.col_pointers.end() - 1);
+    for (size_t i = 0; i < csr.nrow; i++)
+        for (int32_t p = csr.row_pointers[i]; p < csr.row_pointers[i + 1]; p++) {
+            const int32_t dest = next[(size_t)csr.col_indices[p]]++;
+            out.row_indices[(size_t)dest] = (int32_t)i;
+            out.values[(size_t)dest] = csr.values[(size_t)p];
+        }
+    return nullptr;
+}
+
+StrError CsrMatrix::from_csc(CsrMatrix &out, const CscMatrix &csc) {
+    const size_t nnz = csc.nnz_final();
+    out.symmetric = csc.symmetric;
+    out.nrow = csc.nrow, out.ncol = csc.ncol;
+    out.row_pointers.assign(csc.nrow + 1, 0);
+    out.col_indices.assign(nnz, 0);
+    out.values.assign(nnz, 0.0);
+    out.temp_w.clear();
+    for (size_t p = 0; p < nnz; p++) out.row_pointers[(size_t)csc.row_indices[p] + 1]++;
+    for (size_t i = 0; i < csc.nrow; i++) out.row_pointers[i + 1] += out.row_pointers[i];
+    std::vector<int32_t> next(out.row_pointers.begin(), out.row_pointers.end() - 1);
+    for (size_t j = 0; j < csc.ncol; j++)
+        for (int32_t p = csc.col_pointers[j]; p < csc.col_pointers[j + 1]; p++) {
+            const int32_t dest = next[(size_t)csc.row_indices[p]]++;
+            out.col_indices[(size_t)dest] = (int32_t)j;
+            out.values[(size_t)dest] = csc.values[(size_t)p];
+        }
+    return nullptr;
+}
+
 // ---- CSC (csc_matrix.rs:337-505) -------------------------------------------------------------------------
 StrError CscMatrix::from_coo(CscMatrix &out, const CooMatrix &coo) {
     if (coo.nnz < 1) return "COO to CSC requires nnz > 0";
@@ -1039,6 +1163,47 @@ const char *rh_coo_mat_vec_mul(void *h, double *v, int64_t nv, double alpha, con
     StrError e = ((CooMatrix *)h)->mat_vec_mul(vv, alpha, uu);
     if (!e) std::copy(vv.begin(), vv.end(), v);
     return e;
+}
+
+const char *rh_coo_mat_vec_mul_update(void *h, double *v, int64_t nv, double alpha, const double *u, int64_t nu) {
+    std::vector<double> vv(v, v + nv), uu(u, u + nu);
+    StrError e = ((CooMatrix *)h)->mat_vec_mul_update(vv, alpha, uu);
+    if (!e) std::copy(vv.begin(), vv.end(), v);
+    return e;
+}
+const char *rh_coo_mat_t_vec_mul(void *h, double *v, int64_t nv, double alpha, const double *u, int64_t nu) {
+    std::vector<double> vv((size_t)nv), uu(u, u + nu);
+    StrError e = ((CooMatrix *)h)->mat_t_vec_mul(vv, alpha, uu);
+    if (!e) std::copy(vv.begin(), vv.end(), v);
+    return e;
+}
+const char *rh_coo_assign(void *h, double alpha, void *other) { return ((CooMatrix *)h)->assign(alpha, *(CooMatrix *)other); }
+const char *rh_coo_add(void *h, double alpha, void *other) { return ((CooMatrix *)h)->add(alpha, *(CooMatrix *)other); }
+const char *rh_coo_put_lagrange_block(void *h, void *bb) { return ((CooMatrix *)h)->put_lagrange_block(*(CooMatrix *)bb); }
+const char *rh_coo_to_dense(void *h, double *a, int64_t len) {
+    std::vector<double> aa((size_t)std::max<int64_t>(len, 0));
+    StrError e = ((CooMatrix *)h)->to_dense(aa);
+    if (!e) std::copy(aa.begin(), aa.end(), a);
+    return e;
+}
+int64_t rh_coo_actual_nnz(void *h) { return (int64_t)((CooMatrix *)h)->get_actual_nnz(); }
+void *rh_csc_from_csr(void *csr, const char **err) {
+    CscMatrix *m = new CscMatrix();
+    *err = CscMatrix::from_csr(*m, *(CsrMatrix *)csr);
+    if (*err) {
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+void *rh_csr_from_csc(void *csc, const char **err) {
+    CsrMatrix *m = new CsrMatrix();
+    *err = CsrMatrix::from_csc(*m, *(CscMatrix *)csc);
+    if (*err) {
+        delete m;
+        return nullptr;
+    }
+    return m;
 }
 
 void *rh_csc_from_coo(void *coo, const char **err) {

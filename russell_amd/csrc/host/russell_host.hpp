@@ -55,7 +55,20 @@ struct CooMatrix {
     StrError put(size_t i, size_t j, double aij);
     void reset() { nnz = 0; }
     StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
+    // coo_matrix.rs:629-652 (v += alpha A u), :708-730 (v = alpha A^T u)
+    StrError mat_vec_mul_update(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
+    StrError mat_t_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
+    // coo_matrix.rs:738-757 (this = alpha other, triplets replaced), :779-797 (this += alpha other: triplets appended, as Radau5 /
+    // BwEuler build K = gamma M - J on a fixed structure), :823-857 (Lagrange-multiplier block B / B^T)
+    StrError assign(double alpha, const CooMatrix &other);
+    StrError add(double alpha, const CooMatrix &other);
+    StrError put_lagrange_block(const CooMatrix &bb);
+    // coo_matrix.rs:468-497: dense row-major nrow x ncol copy (duplicates summed, triangular storage mirrored)
+    StrError to_dense(std::vector<double> &a) const;
+    size_t get_actual_nnz() const; // coo_matrix.rs:872-887
 };
+
+struct CsrMatrix;
 
 struct CscMatrix {
     Sym symmetric = Sym::No;
@@ -63,6 +76,7 @@ struct CscMatrix {
     std::vector<int32_t> col_pointers, row_indices;
     std::vector<double> values;
     static StrError from_coo(CscMatrix &out, const CooMatrix &coo);
+    static StrError from_csr(CscMatrix &out, const CsrMatrix &csr); // csc_matrix.rs:508-584
     StrError update_from_coo(const CooMatrix &coo);
     StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
     size_t nnz_final() const { return col_pointers.empty() ? 0 : (size_t)col_pointers[ncol]; }
@@ -79,6 +93,7 @@ struct CsrMatrix {
     std::vector<int32_t> row_pointers, col_indices;
     std::vector<double> values;
     static StrError from_coo(CsrMatrix &out, const CooMatrix &coo);
+    static StrError from_csc(CsrMatrix &out, const CscMatrix &csc); // csr_matrix.rs:483-558
     StrError update_from_coo(const CooMatrix &coo);
     StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;
     size_t nnz_final() const { return row_pointers.empty() ? 0 : (size_t)row_pointers[nrow]; }

@@ -126,6 +126,15 @@ def _L():
         "rh_coo_info": (None, [vp, pp(i64), pp(i64), pp(i64), pp(i64), pp(i32)]),
         "rh_coo_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64))]),
         "rh_coo_mat_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_coo_mat_vec_mul_update": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_coo_mat_t_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_coo_assign": (cp, [vp, f64, vp]),
+        "rh_coo_add": (cp, [vp, f64, vp]),
+        "rh_coo_put_lagrange_block": (cp, [vp, vp]),
+        "rh_coo_to_dense": (cp, [vp, vp, i64]),
+        "rh_coo_actual_nnz": (i64, [vp]),
+        "rh_csc_from_csr": (vp, [vp, pp(cp)]),
+        "rh_csr_from_csc": (vp, [vp, pp(cp)]),
         "rh_csc_from_coo": (vp, [vp, pp(cp)]),
         "rh_csc_update_from_coo": (cp, [vp, vp]),
         "rh_csc_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64)), pp(i64), pp(i64)]),
@@ -247,6 +256,43 @@ class CooMatrix:
         _check(_L().rh_coo_mat_vec_mul(self._h, _ptr(v), v.size, float(alpha), _ptr(u), u.size))
         return v
 
+    def mat_vec_mul_update(self, v, u, alpha=1.0):
+        """v += alpha * A * u in place (coo_matrix.rs:629)."""
+        u = _vec(u)
+        if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.c_contiguous):
+            raise TypeError("v must be a contiguous float64 array (updated in place)")
+        _check(_L().rh_coo_mat_vec_mul_update(self._h, _ptr(v), v.size, float(alpha), _ptr(u), u.size))
+        return v
+
+    def mat_t_vec_mul(self, u, alpha=1.0, nv=None):
+        """v = alpha * A^T * u (coo_matrix.rs:708)."""
+        u = _vec(u)
+        v = np.zeros(self.ncol if nv is None else nv)
+        _check(_L().rh_coo_mat_t_vec_mul(self._h, _ptr(v), v.size, float(alpha), _ptr(u), u.size))
+        return v
+
+    def assign(self, alpha, other):
+        """this = alpha * other, triplet by triplet (coo_matrix.rs:738)."""
+        _check(_L().rh_coo_assign(self._h, float(alpha), other._h))
+
+    def add(self, alpha, other):
+        """this += alpha * other: the triplets of other are appended (coo_matrix.rs:779)."""
+        _check(_L().rh_coo_add(self._h, float(alpha), other._h))
+
+    def put_lagrange_block(self, bb):
+        """Appends B (and B^T for full storage) below / right of the leading ncol(B) block (coo_matrix.rs:823)."""
+        _check(_L().rh_coo_put_lagrange_block(self._h, bb._h))
+
+    def to_dense(self):
+        a = np.zeros((self.nrow, self.ncol))
+        _check(_L().rh_coo_to_dense(self._h, _ptr(a), a.size))
+        return a
+
+    as_dense = to_dense
+
+    def get_actual_nnz(self):
+        return int(_L().rh_coo_actual_nnz(self._h))
+
 
 class _Compressed:
     _kind = ""
@@ -258,6 +304,13 @@ class _Compressed:
     def from_coo(cls, coo):
         err = C.c_char_p()
         h = getattr(_L(), "rh_%s_from_coo" % cls._kind)(coo._h, C.byref(err))
+        _check(err.value)
+        return cls(h)
+
+    @classmethod
+    def _from_other(cls, fn, other):
+        err = C.c_char_p()
+        h = fn(other._h, C.byref(err))
         _check(err.value)
         return cls(h)
 
@@ -287,10 +340,20 @@ class CscMatrix(_Compressed):
     """csc_matrix.rs:337-505 (col_pointers, row_indices, values)."""
     _kind = "csc"
 
+    @classmethod
+    def from_csr(cls, csr):
+        """csc_matrix.rs:508-584."""
+        return cls._from_other(_L().rh_csc_from_csr, csr)
+
 
 class CsrMatrix(_Compressed):
     """csr_matrix.rs:332-480 (row_pointers, col_indices, values)."""
     _kind = "csr"
+
+    @classmethod
+    def from_csc(cls, csc):
+        """csr_matrix.rs:483-558."""
+        return cls._from_other(_L().rh_csr_from_csc, csc)
 
 
 class VerifyLinSys:

@@ -154,3 +154,80 @@ def test_no_gpu_means_no_solver():
         pytest.skip("a GPU is visible here")
     with pytest.raises(StrError):
         LinSolver(Genie.Hipmf)
+
+
+def test_csc_csr_transposition_round_trips():
+    # csc_matrix.rs:1048-1100 (from_csr_works), csr_matrix.rs:1036-1090 (from_csc_works): the converted arrays are those of the
+    # direct COO conversion, for every sample matrix (duplicates already summed, triangular storage kept as stored)
+    from russell_amd.sparse import CscMatrix
+
+    for c in GOLD:
+        if "triplets" not in c or not c["triplets"]:
+            continue
+        coo = coo_from_case(c)
+        csc, csr = CscMatrix.from_coo(coo), CsrMatrix.from_coo(coo)
+        for got, want in ((CscMatrix.from_csr(csr), csc), (CsrMatrix.from_csc(csc), csr), (CsrMatrix.from_csc(CscMatrix.from_csr(csr)), csr)):
+            for a, b in zip(got.arrays(), want.arrays()):
+                assert np.array_equal(a, b), c["name"]
+    # rectangular 1 x 2 (csc_matrix.rs:1086-1089: [10 20])
+    coo = CooMatrix(1, 2, 2, Sym.No)
+    coo.put(0, 0, 10.0)
+    coo.put(0, 1, 20.0)
+    cp, ri, vx = CscMatrix.from_csr(CsrMatrix.from_coo(coo)).arrays()
+    assert cp.tolist() == [0, 1, 2] and ri.tolist() == [0, 0] and vx.tolist() == [10.0, 20.0]
+
+
+def test_coo_update_transpose_assign_add():
+    # coo_matrix.rs:590-627 (doc example of mat_vec_mul_update): lower-triangular storage, v = [1000, 2000, 3000] + A [1, 1, 1]
+    coo = CooMatrix(3, 3, 6, Sym.No)
+    for i, j, a in [(0, 0, 1.0), (1, 0, 2.0), (1, 1, 3.0), (2, 0, 4.0), (2, 1, 5.0), (2, 2, 6.0)]:
+        coo.put(i, j, a)
+    assert coo.as_dense().tolist() == [[1, 0, 0], [2, 3, 0], [4, 5, 6]]
+    v = np.array([1000.0, 2000.0, 3000.0])
+    coo.mat_vec_mul_update(v, np.ones(3))
+    assert v.tolist() == [1001.0, 2005.0, 3015.0]
+    assert coo.mat_t_vec_mul(np.ones(3)).tolist() == [7.0, 8.0, 6.0]
+    assert coo.get_actual_nnz() == 6
+    # triangular storage mirrors in every product and counts off-diagonals twice (coo_matrix.rs:1160-1170)
+    low = CooMatrix(3, 3, 5, Sym.YesLower)
+    for i, j, a in [(0, 0, 1.0), (1, 0, 2.0), (1, 1, 3.0), (2, 0, 4.0), (2, 2, 5.0)]:
+        low.put(i, j, a)
+    assert low.get_actual_nnz() == 7
+    dense = low.to_dense()
+    assert np.array_equal(dense, dense.T) and dense[0].tolist() == [1.0, 2.0, 4.0]
+    u = np.array([1.0, -2.0, 0.5])
+    assert np.allclose(low.mat_t_vec_mul(u), dense.T @ u, atol=0) and np.allclose(low.mat_vec_mul(u), dense @ u, atol=0)
+    # assign / add: K = gamma M - J on triplets (how radau5.rs / euler_backward.rs build their matrices)
+    mm, jj, kk = CooMatrix(2, 2, 2, Sym.No), CooMatrix(2, 2, 3, Sym.No), CooMatrix(2, 2, 5, Sym.No)
+    mm.put(0, 0, 1.0), mm.put(1, 1, 1.0)
+    jj.put(0, 0, 0.5), jj.put(0, 1, 2.0), jj.put(1, 0, -3.0)
+    kk.assign(10.0, mm)
+    kk.add(-1.0, jj)
+    assert kk.nnz == 5 and kk.to_dense().tolist() == [[9.5, -2.0], [3.0, 10.0]]
+    kk.assign(2.0, mm)  # assign resets the triplets first
+    assert kk.nnz == 2 and kk.to_dense().tolist() == [[2.0, 0.0], [0.0, 2.0]]
+    with pytest.raises(StrError, match="matrices must have the same nrow"):
+        kk.assign(1.0, CooMatrix(3, 2, 1, Sym.No))
+    with pytest.raises(StrError, match="matrices must have the same symmetric type"):
+        kk.add(1.0, CooMatrix(2, 2, 1, Sym.YesLower))
+    with pytest.raises(StrError, match="other.ncol must be ≤ this.ncol"):
+        kk.add(1.0, CooMatrix(2, 3, 1, Sym.No))
+    with pytest.raises(StrError, match="COO matrix: max number of items has been reached"):
+        small = CooMatrix(2, 2, 1, Sym.No)
+        small.add(1.0, jj)
+
+
+def test_coo_put_lagrange_block():
+    # coo_matrix.rs:823-857: [A B^T; B 0] for full storage, B only for lower, B^T only for upper
+    bb = CooMatrix(1, 2, 2, Sym.No)
+    bb.put(0, 0, 7.0), bb.put(0, 1, 8.0)
+    for sym, want in ((Sym.No, [[1, 0, 7], [0, 2, 8], [7, 8, 0]]), (Sym.YesLower, [[1, 0, 7], [0, 2, 8], [7, 8, 0]])):
+        aa = CooMatrix(3, 3, 6, sym)
+        aa.put(0, 0, 1.0), aa.put(1, 1, 2.0)
+        aa.put_lagrange_block(bb)
+        assert aa.nnz == (6 if sym == Sym.No else 4)
+        assert aa.to_dense().tolist() == want
+    with pytest.raises(StrError, match="the Lagrange block must not be symmetric"):
+        CooMatrix(3, 3, 6, Sym.No).put_lagrange_block(CooMatrix(1, 1, 1, Sym.YesLower))
+    with pytest.raises(StrError, match="ncol\\(B\\) \\+ nrow\\(B\\) must be ≤ nrow\\(A\\)"):
+        CooMatrix(2, 2, 6, Sym.No).put_lagrange_block(bb)
