@@ -40,7 +40,7 @@ struct FrontDesc {
     int32_t child_begin, child_end;
     int32_t parent;
     int32_t ld;     // leading dimension: f (small fronts) or f + p (augmented big fronts)
-    int32_t pad;
+    int32_t ugroup; // tiled path: 32-pivot panels per read-modify-write pass over the trailing matrix (2, 4, 8 or 16)
 };
 
 struct EaTask {

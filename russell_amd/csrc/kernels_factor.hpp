@@ -375,12 +375,13 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // conflict-free (banks = (dword address) mod 64) and both global->LDS copies conflict-free too.
 //
 // Two-level blocking (the read-modify-write of the trailing matrix is what bounds the large fronts, so it
-// is done once per TWO 32-wide panels): the steps of a front come in pairs.
-//   first step of a pair  (k0 / 32 even, another step follows): NARROW update -- only the next panel's block
-//                         column and block row (width nb2) receive this panel's rank-32 update;
-//   second step of a pair (k0 / 32 odd):  the whole trailing matrix receives the rank-(32 + nb) update of both
-//                         panels, 32 columns of K at a time through the same LDS buffers;
-//   first step with nothing to follow:    plain rank-nb update of the whole trailing matrix.
+// is done once per GROUP of G = fd.ugroup 32-wide panels; G = 2, or 4 / 8 for the largest fronts): step k0 is
+// at position g = (k0 / 32) mod G of its group.
+//   g < G - 1 and another step follows: NARROW update -- only the next panel's block column and block row
+//                         (width nb2) receive the rank-32(g + 1) update of the group's panels so far;
+//   g = G - 1:            the whole trailing matrix receives the update of all G panels, 32 columns of K at a
+//                         time through the same LDS buffers;
+//   g < G - 1 with nothing to follow: plain update of the whole trailing matrix with the panels so far.
 // Workgroup 0 of every front also moves the factorised diagonal tile of this step from dws into the front
 // and leaves the next diagonal tile to the look-ahead workgroup.
 // Look-ahead: one extra workgroup per front (the last one, while a next diagonal tile exists) forms the NEXT
@@ -405,10 +406,10 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int base = k0 + nb, limit = f + base;
     const int nt = (f + UPD_T - 1) / UPD_T;
     const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
-    const bool second = ((k0 / NB) & 1) != 0;                // second step of a pair
-    const bool narrow = !second && nb2 > 0;                  // first step of a pair
-    const int nhalf = second ? 2 : 1;                        // 32-column slices of K
-    const int kfirst = second ? k0 - NB : k0;
+    const int gpos = (k0 / NB) % fd.ugroup;                  // position of this step in its group of panels
+    const bool narrow = gpos < fd.ugroup - 1 && nb2 > 0;     // not the last step of the group and another step follows
+    const int nhalf = gpos + 1;                              // 32-column slices of K: every panel of the group so far
+    const int kfirst = k0 - gpos * NB;
     const int ntiles = narrow ? 2 * nt : nt * nt;
     double *F = pool + fd.off;
     if (t == ntiles) {
@@ -508,7 +509,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     HIPMF_FETCH_SLICE(0)
     HIPMF_STORE_SLICE()
     __syncthreads();
-    if (nhalf == 2) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
+    if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
     // the 16 entries of the trailing matrix this lane updates are fetched while the MFMAs run
     const bool owner0 = t == 0 && nb2 > 0 && wave == 0; // this wave's block holds the next diagonal tile
     double cur[2][2][4];
@@ -534,6 +535,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             __syncthreads();
             HIPMF_STORE_SLICE()
             __syncthreads();
+            if (h + 1 < nhalf) HIPMF_FETCH_SLICE(h + 1) // the next slice, in flight while this one is multiplied
         }
 #pragma unroll
         for (int kk0 = 0; kk0 < NB; kk0 += 4) {

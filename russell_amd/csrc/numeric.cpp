@@ -115,6 +115,10 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         so.dense_leaves = v > 0;
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
+    if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
+    if (const char *e = getenv("HIPMF_UPD_G8")) upd_g8 = std::max(upd_g4, atoi(e));
+    if (const char *e = getenv("HIPMF_UPD_G16")) upd_g16 = std::max(upd_g8, atoi(e));
+    if (const char *e = getenv("HIPMF_SPLIT_PIVOTS")) so.split_pivots = std::max(0, atoi(e)); // tuning knob: chain links of the big supernodes
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
@@ -291,7 +295,7 @@ int32_t Solver::upload_plan() {
         d.child_end = S.child_ptr[s + 1];
         d.parent = S.sn_parent[s];
         d.ld = S.front_ld[s];
-        d.pad = 0;
+        d.ugroup = update_group(S.fsize(s));
         work_doubles += d.p + d.m;
     }
     pool_doubles = S.front_off[ns];
@@ -345,7 +349,8 @@ int32_t Solver::upload_plan() {
                 tasks.push_back((int32_t)acc);
                 int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T;
                 const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
-                const bool narrow = follow && ((k0 / NB) & 1) == 0; // first step of a pair: block column + block row only
+                const int32_t G = update_group(S.fsize(big[a]));
+                const bool narrow = follow && ((k0 / NB) % G) != G - 1; // not the last step of a group: block column + block row only
                 acc += (narrow ? 2 * nt : nt * nt) + (follow ? 1 : 0);
             }
             tasks.push_back((int32_t)acc);

@@ -137,6 +137,10 @@ class Solver {
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
+    // Tiled path: fronts with at least upd_g4 (upd_g8, upd_g16) rows apply 4 (8, 16) panels per pass over the trailing matrix instead of 2:
+    // the read-modify-write of the trailing matrix bounds the large fronts (HIPMF_UPD_G4 / HIPMF_UPD_G8 / HIPMF_UPD_G16)
+    int32_t upd_g4 = 2048, upd_g8 = 4096, upd_g16 = 1 << 30;
+    int32_t update_group(int32_t f) const { return f >= upd_g16 ? 16 : (f >= upd_g8 ? 8 : (f >= upd_g4 ? 4 : 2)); }
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
     // fused assembly of the small fronts (k_small_factor) and zero-fill of the big ones only

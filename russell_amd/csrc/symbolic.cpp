@@ -597,9 +597,31 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.sn_first.clear();
     for (int32_t s = 0; s < nfs; s++)
         if (alive[s]) S.sn_first.push_back(s_first[s]);
+    std::sort(S.sn_first.begin(), S.sn_first.end());
+    // A supernode with more than opt.split_pivots pivots becomes a CHAIN of supernodes of (nearly) equal width, a multiple
+    // of 32 columns each: link k owns the next block of pivot columns and has the rest of the original front as its rows, so
+    // its contribution block is the next link's whole front.  The arithmetic is that of a blocked right-looking LU of the
+    // original front; what changes is the cost of the augmentation (section "front pool layout" below): an augmented front
+    // of p pivots and f rows does 2 p f^2 flops instead of 2/3 p^3 + 2 p^2 m + 2 p m^2, i.e. three times the work for a root
+    // separator -- with links of b pivots the overhead drops to about 3 b / (2 p).  (3D problems: the top separators hold
+    // most of the flops.)  Parents, children and row structures below follow from the column elimination tree as for any
+    // other supernode partition.
+    if (opt.split_pivots > 0 && !single_front) {
+        const int32_t nsn = (int32_t)S.sn_first.size();
+        std::vector<int32_t> extra;
+        for (int32_t s = 0; s < nsn; s++) {
+            const int32_t first = S.sn_first[s], next = s + 1 < nsn ? S.sn_first[s + 1] : n;
+            const int32_t np = next - first;
+            if (np <= opt.split_pivots) continue;
+            const int32_t nlinks = (np + opt.split_pivots - 1) / opt.split_pivots;
+            const int32_t width = ((np + nlinks - 1) / nlinks + 31) / 32 * 32;
+            for (int32_t c = first + width; c < next; c += width) extra.push_back(c);
+        }
+        S.sn_first.insert(S.sn_first.end(), extra.begin(), extra.end());
+        std::sort(S.sn_first.begin(), S.sn_first.end());
+    }
     S.nsuper = (int32_t)S.sn_first.size();
     S.sn_first.push_back(n);
-    std::sort(S.sn_first.begin(), S.sn_first.end());
     S.sn_of.resize((size_t)n);
     for (int32_t s = 0; s < S.nsuper; s++)
         for (int32_t j = S.sn_first[s]; j < S.sn_first[s + 1]; j++) S.sn_of[j] = s;

@@ -24,6 +24,7 @@ struct SymbolicOptions {
     bool dense_leaves = false;    // every nested-dissection leaf region becomes one dense supernode
     int32_t nd_threads = 0;       // host threads of the nested dissection (0: min(16, hardware threads)); the result does not depend on it
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
+    int32_t split_pivots = 4096;  // supernodes with more pivots are split into a chain of supernodes (0: never); see symbolic.cpp
     int32_t augment_above = 64;   // fronts with f > this are stored augmented (must equal kernels.hpp SMALL_F)
     int32_t relax_ncol[3] = {4, 16, 48};
     double relax_zeros[3] = {0.8, 0.1, 0.05};

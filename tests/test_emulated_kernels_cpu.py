@@ -82,3 +82,28 @@ def test_emulated_value_map_refresh_with_duplicates(emu_lib):
     bad[-1] += 1
     assert s.set_value_map(bad, seg_idx) == 803
     s.close()
+
+
+def test_emulated_grouped_updates_and_chain_split(emu_lib, monkeypatch):
+    # tiled path with 4 / 8 / 16 panels per pass over the trailing matrix, and big supernodes split into chains: same solution
+    # (to rounding) and same determinant as the default two-panel schedule
+    n, rp, ci, v = P.poisson3d(13)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s0, code, x0, st0 = _solve(emu_lib, n, rp, ci, v, b)
+    assert code == 0 and st0["max_pivots"] > 128
+    det0 = (s0.det_coefficient, s0.det_exponent)
+    s0.close()
+    for env in ({"HIPMF_UPD_G4": "65", "HIPMF_UPD_G8": "100", "HIPMF_UPD_G16": "150"},
+                {"HIPMF_SPLIT_PIVOTS": "64", "HIPMF_UPD_G4": "65", "HIPMF_UPD_G8": "65"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s, code, x, st = _solve(emu_lib, n, rp, ci, v, b)
+        assert code == 0
+        if "HIPMF_SPLIT_PIVOTS" in env:
+            assert st["nsuper"] > st0["nsuper"] and st["max_pivots"] <= 64
+        assert np.max(np.abs(x - xs)) < 1e-12 and np.max(np.abs(x - x0)) < 1e-13
+        assert s.det_exponent == det0[1] and abs(s.det_coefficient - det0[0]) < 1e-10
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)

@@ -358,3 +358,31 @@ def test_nan_in_the_values_is_refused():
     x = s.solve(P.csr_matvec(n, rp, ci, v, np.ones(n)))
     assert np.max(np.abs(x - 1.0)) < 1e-12
     s.close()
+
+
+@pytest.mark.gpu
+def test_grouped_updates_and_chain_split_match_the_oracle(monkeypatch):
+    # the schedules the large 3D fronts use (4 / 8 panels per pass over the trailing matrix, supernodes split into chains),
+    # forced on a problem the oracle finishes in seconds
+    n, rp, ci, v = P.poisson3d(22)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    ref = None
+    for env in ({}, {"HIPMF_UPD_G4": "128", "HIPMF_UPD_G8": "256"}, {"HIPMF_UPD_G4": "65", "HIPMF_UPD_G8": "65", "HIPMF_UPD_G16": "200"},
+                {"HIPMF_SPLIT_PIVOTS": "96"}, {"HIPMF_SPLIT_PIVOTS": "64", "HIPMF_UPD_G4": "100", "HIPMF_UPD_G8": "300"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci) == 0
+        assert s.factorize(v, compute_determinant=True) == 0
+        x = s.solve(b)
+        if ref is None:
+            rows = np.repeat(np.arange(n), np.diff(rp)).astype(np.int32)
+            cp, ri, vx = O.coo_to_csc(n, n, rows, ci, v)
+            lu = O.OracleLU(n, cp, ri, vx, q=s.permutation())
+            ref = (lu.solve(b), s.det_coefficient, s.det_exponent)
+        assert np.max(np.abs(x - ref[0])) < 1e-12 and np.max(np.abs(x - xs)) < 1e-12
+        assert s.det_exponent == ref[2] and abs(s.det_coefficient - ref[1]) < 1e-9
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
