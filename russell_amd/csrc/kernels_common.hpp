@@ -26,8 +26,7 @@ constexpr int NB = 32;         // pivot-block width of the tiled path
 constexpr int PANEL_T = 128;   // rows (L) / columns (U) handled by one panel workgroup
 constexpr int UPD_T = 64;      // trailing-update tile edge (one 256-thread workgroup, 4 waves of 32x32)
 constexpr int SMALL_F = 64;    // fronts with f <= SMALL_F are factorised by one wavefront in LDS
-constexpr int LS_LD = 80;      // LDS leading dimensions of the update kernel (bank-conflict free, see k_update)
-constexpr int US_LD = 34;
+constexpr int US_LD = 34;      // LDS leading dimension of the U slice in the update kernel (bank-conflict free, see k_update)
 constexpr int SOLVE_SLAB_WIDE = 32; // rows per 1024-thread workgroup on the levels near the root (32 rows x 32 column groups)
 constexpr int SOLVE_SLAB = 64; // rows of a solve panel per 256-thread workgroup (64 rows x 4 column groups)
 

@@ -389,13 +389,21 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // for columns 0..15, lane r + 32 for columns 16..31), factorises it in registers (tile_lu32) and parks it in
 // dws (other buffer) with its row interchanges.  That 32 x 32 LU -- the longest serial piece of a tiled step --
 // runs beside the trailing update instead of in front of the next panel solve.
+// (Tried and rejected: 128 x 128 tiles, four 64 x 64 waves -- 204 VGPRs + 128 AGPRs, one workgroup per CU: 962 ms instead of
+// 924 ms for the 128^3 Poisson factorisation.)
 __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                 const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
-    __shared__ double Ls[NB * LS_LD];
-    __shared__ double Us[UPD_T * US_LD];
-    __shared__ __attribute__((aligned(16))) double UM[NB][NB + 2];
+    constexpr int TS = UPD_T;
+    constexpr int LSLD = TS + 16;  // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
+    constexpr int MT = TS / 32;    // MFMA tiles per wave and dimension
+    constexpr int NE = TS / 8;     // panel entries per thread and 32-column slice (L and U each)
+    // the look-ahead workgroup's tile buffer shares the space of Ls (it never touches Ls / Us)
+    __shared__ __attribute__((aligned(16))) double LsUM[(NB * LSLD > NB * (NB + 2)) ? NB * LSLD : NB * (NB + 2)];
+    __shared__ double Us[TS * US_LD];
+    double *Ls = LsUM;
+    double(*UM)[NB + 2] = reinterpret_cast<double(*)[NB + 2]>(LsUM);
     const int tid = threadIdx.x;
     const int slot = find_slot(pfx, nactive, blockIdx.x);
     const int t = blockIdx.x - pfx[slot];
@@ -404,7 +412,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
-    const int nt = (f + UPD_T - 1) / UPD_T;
+    const int nt = (f + TS - 1) / TS;
     const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
     const int gpos = (k0 / NB) % fd.ugroup;                  // position of this step in its group of panels
     const bool narrow = gpos < fd.ugroup - 1 && nb2 > 0;     // not the last step of the group and another step follows
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const bool rowstrip = narrow && t >= nt;
     const int ti = narrow ? (rowstrip ? 0 : t) : t % nt;
     const int tj = narrow ? (rowstrip ? t - nt : 0) : t / nt;
-    const int r0 = base + ti * UPD_T, c0 = base + tj * UPD_T;
+    const int r0 = base + ti * TS, c0 = base + tj * TS;
     if (t == 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];
@@ -483,16 +491,16 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int cmax = (narrow && !rowstrip) ? base + nb2 : limit;
     const int cmin = rowstrip ? base + nb2 : 0;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    const int wr = (wave & 1) * (TS / 2), wc = (wave >> 1) * (TS / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
-    double lreg[8], ureg[8];
-    // slice h of the two panels: global -> registers, registers -> LDS
+    double lreg[NE], ureg[NE];
+    // slice h of the panels: global -> registers, registers -> LDS
 #define HIPMF_FETCH_SLICE(h)                                                                                           \
     {                                                                                                                  \
         const int kh = kfirst + (h) * NB, nbh = ((h) == nhalf - 1) ? nb : NB;                                          \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                \
+        _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
-            const int r = e % UPD_T, kk = e / UPD_T;                                                                   \
+            const int r = e % TS, kk = e / TS;                                                                         \
             lreg[u] = (r0 + r < limit && kk < nbh) ? F[(r0 + r) + (int64_t)(kh + kk) * ld] : 0.0;                      \
             const int k2 = e % NB, c = e / NB;                                                                         \
             ureg[u] = (c0 + c < limit && k2 < nbh) ? F[(kh + k2) + (int64_t)(c0 + c) * ld] : 0.0;                      \
@@ -500,9 +508,9 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     }
 #define HIPMF_STORE_SLICE()                                                                                            \
     {                                                                                                                  \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                \
+        _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
-            Ls[(e / UPD_T) * LS_LD + e % UPD_T] = lreg[u];                                                             \
+            Ls[(e / TS) * LSLD + e % TS] = lreg[u];                                                                    \
             Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                                   \
         }                                                                                                              \
     }
@@ -510,26 +518,31 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     HIPMF_STORE_SLICE()
     __syncthreads();
     if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
-    // the 16 entries of the trailing matrix this lane updates are fetched while the MFMAs run
     const bool owner0 = t == 0 && nb2 > 0 && wave == 0; // this wave's block holds the next diagonal tile
-    double cur[2][2][4];
-    bool live[2][2][4];
+    // is entry (sub-tile a, b; register g) of this lane updated by this step?
+    auto is_live = [&](int a, int b, int g) {
+        const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
+        const bool corner = owner0 && (b * 16 + l15) < nb2 && (a * 16 + l4 + 4 * g) < nb2;
+        return r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner;
+    };
+    // the 16 entries of the trailing matrix this lane updates are fetched while the MFMAs run
+    double cur[MT][MT][4];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < MT; b++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                const bool corner = owner0 && (b * 16 + l15) < nb2 && (a * 16 + l4 + 4 * g) < nb2;
-                live[a][b][g] = r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner;
-                cur[a][b][g] = live[a][b][g] ? F[r + (int64_t)c * ld] : 0.0;
+                cur[a][b][g] = is_live(a, b, g) ? F[r + (int64_t)c * ld] : 0.0;
             }
-    f64x4 acc[2][2];
+    // strips of a narrow step: a wave whose quarter of the tile holds no live entry has nothing to multiply
+    const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + TS / 2 <= cmin) || (r0 + wr >= rmax);
+    f64x4 acc[MT][MT];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < MT; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int h = 0; h < nhalf; h++) {
         if (h > 0) {
             __syncthreads();
@@ -537,29 +550,32 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             __syncthreads();
             if (h + 1 < nhalf) HIPMF_FETCH_SLICE(h + 1) // the next slice, in flight while this one is multiplied
         }
+        if (!wave_idle) {
 #pragma unroll
-        for (int kk0 = 0; kk0 < NB; kk0 += 4) {
-            double ua[2], lb[2];
+            for (int kk0 = 0; kk0 < NB; kk0 += 4) {
+                double ua[MT], lb[MT];
 #pragma unroll
-            for (int a = 0; a < 2; a++) ua[a] = Us[(wc + a * 16 + l15) * US_LD + kk0 + l4];
+                for (int a = 0; a < MT; a++) ua[a] = Us[(wc + a * 16 + l15) * US_LD + kk0 + l4];
 #pragma unroll
-            for (int b = 0; b < 2; b++) lb[b] = Ls[(kk0 + l4) * LS_LD + wr + b * 16 + l15];
+                for (int b = 0; b < MT; b++) lb[b] = Ls[(kk0 + l4) * LSLD + wr + b * 16 + l15];
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+                for (int a = 0; a < MT; a++)
 #pragma unroll
-                for (int b = 0; b < 2; b++) acc[a][b] = mfma_f64_16x16x4(ua[a], lb[b], acc[a][b]);
+                    for (int b = 0; b < MT; b++) acc[a][b] = mfma_f64_16x16x4(ua[a], lb[b], acc[a][b]);
+            }
         }
     }
 #undef HIPMF_FETCH_SLICE
 #undef HIPMF_STORE_SLICE
+    if (wave_idle) return;
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < MT; b++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                if (live[a][b][g]) F[r + (int64_t)c * ld] = cur[a][b][g] - acc[a][b][g];
+                if (is_live(a, b, g)) F[r + (int64_t)c * ld] = cur[a][b][g] - acc[a][b][g];
             }
 }
 
