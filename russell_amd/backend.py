@@ -154,6 +154,21 @@ class Hipmf:
     def factorize_device(self, d_values):
         return self.lib.solver_hipmf_factorize_device(self.h, d_values)
 
+    def factor_buffers(self):
+        """(pointer, bytes) of the three device buffers that hold the numeric factor: front pool, local row interchanges, row
+        scaling.  A peer that ran `initialize` on the same structure can be handed their contents and then `adopt_factor`."""
+        ptrs = [C.c_void_p() for _ in range(3)]
+        sizes = [C.c_int64() for _ in range(3)]
+        code = self.lib.solver_hipmf_factor_buffers(self.h, C.byref(ptrs[0]), C.byref(sizes[0]), C.byref(ptrs[1]), C.byref(sizes[1]),
+                                                    C.byref(ptrs[2]), C.byref(sizes[2]))
+        if code != 0:
+            raise self._err(code, "solver_hipmf_factor_buffers")
+        return [(int(p.value), int(n.value)) for p, n in zip(ptrs, sizes)]
+
+    def adopt_factor(self, d_values):
+        """Declare the factor buffers (filled by a peer) valid; d_values: the matrix values on the device (refinement SpMV)."""
+        return self.lib.solver_hipmf_adopt_factor(self.h, d_values)
+
     def solve_device(self, d_x, d_rhs, nrhs=1, ld=None):
         code = self.lib.solver_hipmf_solve_device(self.h, d_x, d_rhs, nrhs, ld or self.n)
         if code != 0:

@@ -1,7 +1,47 @@
 """Many-RHS sharding across the GPUs of one node: one process per GPU, columns of B split into
 contiguous blocks, no data-path collective for the solves themselves.  torch.distributed (RCCL on GPUs, gloo in the CPU
-tests) is used only for barriers, the max-over-ranks timing reduction and, optionally, gathering X on rank 0."""
+tests) is used for barriers, the max-over-ranks timing reduction, optionally gathering X on rank 0, and -- when the
+factorisation is done once instead of on every rank -- for the broadcast of the numeric factor over xGMI."""
+import ctypes
+
 import numpy as np
+
+
+class _DeviceBytes:
+    """A raw device allocation seen as a 1-D uint8 array through __cuda_array_interface__ (torch wraps it without a copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _as_tensor(ptr, nbytes, device):
+    import torch
+    if device is None or str(device) == "cpu":  # emulated library / host buffers: the "device" pointers are host pointers
+        buf = (ctypes.c_uint8 * nbytes).from_address(ptr)
+        return torch.from_numpy(np.ctypeslib.as_array(buf))
+    return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
+
+
+def broadcast_factor(solver, d_values, dist, src=0, device=None, chunk_bytes=256 << 20):
+    """Numeric factor of `solver` (rank `src` has factorised; every rank has run `initialize` on the same structure, which
+    is deterministic) -> all ranks, in place, straight between the solvers' own device buffers: the front pool, the local
+    row interchanges and the row scaling, in chunks of `chunk_bytes` (ring collectives over xGMI are per-link bound, large
+    messages keep the links busy).  Afterwards the other ranks adopt the factor; `d_values` = device pointer of the matrix
+    values of the calling rank (for the refinement SpMV).  Returns the number of bytes broadcast."""
+    total = 0
+    for ptr, nbytes in solver.factor_buffers():
+        for off in range(0, nbytes, chunk_bytes):
+            n = min(chunk_bytes, nbytes - off)
+            dist.broadcast(_as_tensor(ptr + off, n, device), src=src)
+            total += n
+    if device is not None and str(device) != "cpu":
+        import torch
+        torch.cuda.synchronize(device)
+    if dist.get_rank() != src:
+        code = solver.adopt_factor(d_values)
+        if code != 0:
+            raise RuntimeError("solver_hipmf_adopt_factor failed with code %d" % code)
+    return total
 
 
 def rhs_block(nrhs_total, world_size, rank):

@@ -56,3 +56,52 @@ def test_sharded_many_rhs_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     err, tmax = np.load(out)
     assert err == 0.0 and tmax == 2.0
+
+
+def _bcast_worker(rank, world, port, out, emu):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from russell_amd import problems as P
+    from russell_amd.backend import Hipmf
+    from russell_amd.distributed import broadcast_factor, rhs_block
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, rp, ci, v = P.poisson2d(30, 26)
+    B = np.random.default_rng(7).standard_normal((6, n))
+    s = Hipmf(emu)
+    assert s.initialize(n, rp, ci) == 0
+    d_v = s.dev_alloc(v.nbytes)
+    s.h2d(d_v, v)
+    if rank == 0:
+        assert s.factorize_device(d_v) == 0  # only the source rank factorises
+    nbytes = broadcast_factor(s, d_v, dist, src=0, device=None, chunk_bytes=1 << 16)
+    start, count = rhs_block(B.shape[0], world, rank)
+    X = np.array([s.solve(B[j]) for j in range(start, start + count)])
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((start, X), parts, dst=0)
+    if rank == 0:
+        full = np.zeros_like(B)
+        for st, xb in parts:
+            full[st:st + xb.shape[0]] = xb
+        ref = np.array([s.solve(b) for b in B])  # rank 0 solves everything with its own factor
+        resid = max(float(np.max(np.abs(P.csr_matvec(n, rp, ci, v, full[j]) - B[j]))) for j in range(B.shape[0]))
+        np.save(out, np.array([float(np.max(np.abs(full - ref))), resid, float(nbytes), float(s.stats()["pool_bytes"])]))
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+def test_factor_broadcast_and_adopt_gloo(tmp_path, emu_lib):
+    # factorise on one rank, broadcast the packed factor, every rank solves its block of right-hand sides.
+    # Two processes over gloo with the emulated backend (its "device" buffers are host memory): the adopting rank must produce
+    # bit-identical solutions to the rank that factorised.
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "bcast.npy")
+    mp.spawn(_bcast_worker, args=(2, port, out, emu_lib), nprocs=2, join=True)
+    diff, resid, nbytes, pool = np.load(out)
+    assert diff == 0.0 and resid < 1e-11
+    assert nbytes > pool  # pool + interchanges + row scaling
