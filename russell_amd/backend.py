@@ -96,6 +96,8 @@ class Hipmf:
     def solve_many(self, rhs_colmajor):
         """rhs_colmajor: array of shape (nrhs, n) whose rows are the right-hand sides (= column-major n x nrhs)."""
         b = np.ascontiguousarray(rhs_colmajor, dtype=np.float64)
+        if b.ndim != 2 or b.shape[1] != self.n:
+            raise ValueError("solve_many expects an array of shape (nrhs, n) with n = %d, got %r" % (self.n, b.shape))
         nrhs = b.shape[0]
         x = np.zeros_like(b)
         code = self.lib.solver_hipmf_solve_many(self.h, x, b, nrhs, self.n, 0)

@@ -671,14 +671,14 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, d_trace);
         } else {
             if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, d_sf, no_trace);
-            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, no_trace);
+            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, d_trace);
         }
         HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
         if (nk == 1) {
             if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, 1, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         } else {
-            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, no_trace);
+            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         }
 #undef HIPMF_FWD

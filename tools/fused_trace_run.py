@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+"""usage: fused_trace_run.py TRACE_FILE [GRID [NRHS]]  -- writes the HIPMF_SF_TRACE stamps of the last solve (NRHS columns in one block)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +11,8 @@ b = P.csr_matvec(n, rp, ci, v, P.manufactured_solution(n))
 s = Hipmf()
 assert s.initialize(n, rp, ci, refinement_nstep=0) == 0
 assert s.factorize(v) == 0
+nrhs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+import numpy as np
 for _ in range(3):
-    x = s.solve(b)
+    x = s.solve(b) if nrhs == 1 else s.solve_many(np.tile(b[None, :], (nrhs, 1)))
 s.close()
