@@ -144,6 +144,9 @@ def main():
         copy_gbs = ctypes.c_double(0.0)
         if s.lib.hipmf_device_copy_bandwidth(1 << 30, 3, ctypes.byref(copy_gbs)) != 0:
             copy_gbs.value = 0.0
+        mfma_tfs = ctypes.c_double(0.0)
+        if s.lib.hipmf_device_mfma_rate(1024, 4000, ctypes.byref(mfma_tfs)) != 0:
+            mfma_tfs.value = 0.0
         bytes_alg = sptrsv_bytes(st, n)
         traffic, traffic_src = measured_traffic(args.grid)
         achieved = bytes_alg / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
@@ -178,7 +181,8 @@ def main():
                                 "bound": "mfma", "achieved": round(st["flops"] / (fact_ms * 1e-3) / 1e12, 3) if fact_ms > 0 else 0.0,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(st["flops"] / (fact_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if fact_ms > 0 else 0.0,
-                                "flops": st["flops"], "avg_ms": round(fact_ms, 3), "assemble_ms": round(asm_ms, 3)},
+                                "flops": st["flops"], "avg_ms": round(fact_ms, 3), "assemble_ms": round(asm_ms, 3),
+                                "measured_mfma_tflops": round(mfma_tfs.value, 1)},
             "phases_ms": {"initialize_once": round(t_init * 1e3, 1), "ordering_s": st["ordering_s"], "symbolic_s": st["symbolic_s"],
                           "assemble": round(asm_ms, 3), "factor": round(fact_ms, 3), "sptrsv_pair": round(tri_ms, 4),
                           "solve_total_last": round(st["solve_total_ms"], 3)},

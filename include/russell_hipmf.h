@@ -176,6 +176,10 @@ int32_t hipmf_device_count(void);
 /* Measured device-to-device copy rate in GB/s (read + written bytes over HIP-event time, `bytes` per copy, best of `reps`):
  * the achievable-HBM denominator bench.py reports beside the 8 TB/s spec. */
 int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_s);
+/* Measured rate of v_mfma_f64_16x16x4_f64 in TFLOP/s (back-to-back MFMAs on four independent accumulators per wave, operands in
+ * registers, `workgroups` x 256 threads, best of two timed launches): the achievable-MFMA denominator bench.py reports beside the
+ * 78.6 TFLOP/s spec. */
+int32_t hipmf_device_mfma_rate(int32_t workgroups, int32_t iters, double *tflops);
 int32_t hipmf_set_device(int32_t device); /* selects the device later solver_hipmf_new() calls of this thread bind to */
 
 #ifdef __cplusplus

@@ -50,6 +50,7 @@ SYMBOLS = {
     "hipmf_device_synchronize": (C.c_int32, []),
     "hipmf_device_count": (C.c_int32, []),
     "hipmf_device_copy_bandwidth": (C.c_int32, [C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
+    "hipmf_device_mfma_rate": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "hipmf_set_device": (C.c_int32, [C.c_int32]),
 }
 

@@ -262,6 +262,47 @@ int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_
     return SUCCESSFUL_EXIT;
 }
 
+namespace {
+// back-to-back v_mfma_f64_16x16x4_f64 on four independent accumulators per wave, operands in registers
+__global__ void __launch_bounds__(256) k_mfma_probe(double *out, int32_t iters, double a0, double b0) {
+    f64x4 acc[4];
+    for (int i = 0; i < 4; i++) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const double a = a0 + threadIdx.x * 1e-9, b = b0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = mfma_f64_16x16x4(a, b, acc[i]);
+    }
+    double sum = 0.0;
+    for (int i = 0; i < 4; i++) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+} // namespace
+
+int32_t hipmf_device_mfma_rate(int32_t workgroups, int32_t iters, double *tflops) {
+    if (!tflops || workgroups < 1 || iters < 1) return ERROR_NULL_POINTER;
+    double *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(double) * 256 * (size_t)workgroups) != hipSuccess) return ERROR_HIP_MALLOC;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; r < 3; r++) { // first launch = warm-up
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(k_mfma_probe, dim3(workgroups), dim3(256), 0, nullptr, d, iters, 1.0, 1.0);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        // 4 waves x 4 accumulators x 2048 flops per MFMA and iteration
+        if (r > 0 && ms > 0.0f) best = std::max(best, (double)workgroups * 4.0 * 4.0 * 2048.0 * (double)iters / (ms * 1e-3) / 1e12);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    *tflops = best;
+    return hipGetLastError() == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_LAUNCH;
+}
+
 int32_t hipmf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
