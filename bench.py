@@ -177,7 +177,7 @@ def main():
                          "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4),
                          "measured_copy_gbs": round(copy_gbs.value, 1),
                          "frac_of_measured_copy": round(achieved / copy_gbs.value, 4) if copy_gbs.value > 0 else None},
-            "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_diag, k_panel, k_update MFMA f64)",
+            "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_panel, k_update MFMA f64, k_extend_add)",
                                 "bound": "mfma", "achieved": round(st["flops"] / (fact_ms * 1e-3) / 1e12, 3) if fact_ms > 0 else 0.0,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(st["flops"] / (fact_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if fact_ms > 0 else 0.0,
