@@ -115,6 +115,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         so.dense_leaves = v > 0;
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
+    if (const char *e = getenv("HIPMF_SMALL_SPLIT")) small_split = atoi(e);
     if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_UPD_G8")) upd_g8 = std::max(upd_g4, atoi(e));
     if (const char *e = getenv("HIPMF_UPD_G16")) upd_g16 = std::max(upd_g8, atoi(e));
@@ -321,6 +322,15 @@ int32_t Solver::upload_plan() {
             }
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
+        // the small fronts of a level go in two launches by size: the LDS a workgroup reserves is that of the largest front of
+        // its launch, and the assembly phases of k_small_factor are latency-bound, i.e. they live on the number of resident waves
+        std::stable_partition(small.begin(), small.end(), [&](int32_t a) { return S.fsize(a) <= small_split; });
+        L.small_cnt_a = 0;
+        int32_t fmax_a = 1;
+        for (int32_t a : small)
+            if (S.fsize(a) <= small_split) L.small_cnt_a++, fmax_a = std::max(fmax_a, S.fsize(a));
+        if (L.small_cnt_a < 2048 || (int32_t)small.size() - L.small_cnt_a < 2048) L.small_cnt_a = 0; // not worth a second launch
+        L.small_ld_a = fmax_a | 1;
         L.small_off = (int32_t)lists.size();
         L.small_cnt = (int32_t)small.size();
         L.small_ld = fmax_small | 1;
@@ -606,8 +616,14 @@ int32_t Solver::run_factor() {
                 sst = (hipStream_t)stream2;
             }
             const SmallAsm sasm = {d_sa_ptr, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel};
-            hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt), dim3(64), shmem, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
-                               d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
+            if (L.small_cnt_a > 0) {
+                const size_t shmem_a = sizeof(double) * (size_t)L.small_ld_a * (size_t)L.small_ld_a;
+                hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
+                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld_a, sasm);
+                launches++;
+            }
+            hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt - L.small_cnt_a), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd,
+                               d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
             if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
             launches++;
         }

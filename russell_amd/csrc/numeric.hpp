@@ -63,6 +63,7 @@ struct StepPlan {
 };
 struct LevelPlan {
     int32_t small_off = 0, small_cnt = 0, small_ld = 0, small_pmax = 1; // fronts with f <= SMALL_F
+    int32_t small_cnt_a = 0, small_ld_a = 1;                              // ... the first small_cnt_a of them have f <= small_split
     int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
     int32_t ea_off = 0, ea_cnt = 0;
     int32_t fwd_off = 0, fwd_cnt = 0, bwd_off = 0, bwd_cnt = 0; // SolveTask ranges of the big fronts
@@ -141,6 +142,7 @@ class Solver {
     // the read-modify-write of the trailing matrix bounds the large fronts (HIPMF_UPD_G4 / HIPMF_UPD_G8 / HIPMF_UPD_G16)
     int32_t upd_g4 = 2048, upd_g8 = 4096, upd_g16 = 1 << 30;
     int32_t update_group(int32_t f) const { return f >= upd_g16 ? 16 : (f >= upd_g8 ? 8 : (f >= upd_g4 ? 4 : 2)); }
+    int32_t small_split = 28; // small fronts up to this size get their own launch per level (HIPMF_SMALL_SPLIT, 0: one launch)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
     // fused assembly of the small fronts (k_small_factor) and zero-fill of the big ones only
