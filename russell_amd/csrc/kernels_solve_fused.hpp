@@ -239,7 +239,8 @@ __device__ __forceinline__ void sf_dot(double (&acc0)[K], double (&acc1)[K], con
     int j = j0;
     const int nfull = (j1 - j0 + step - 1) / step / 8 * 8; // positions covered by whole groups of 8
     const int jend8 = j0 + nfull * step;
-    for (; j + 15 * step < jend8; j += 16 * step) {
+    // (K > 1: eight in flight -- the blocked instances sit at the edge of a register-occupancy step)
+    for (; K == 1 && j + 15 * step < jend8; j += 16 * step) {
         double e[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) e[u] = col[(int64_t)(j + u * step) * ld];
