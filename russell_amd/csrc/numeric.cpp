@@ -124,7 +124,6 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
-    if (const char *e = getenv("HIPMF_SF_WARM")) sf_warm_flag = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
     // Maximum-product matching + scaling (matching.cpp) when the numbers are known and the diagonal is weak: the
     // analysis then runs on B = A(mrow, :), whose diagonal holds the matched entries (all 1 after scaling).

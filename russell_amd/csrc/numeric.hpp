@@ -157,8 +157,6 @@ class Solver {
     double *d_blk = nullptr, *d_work_blk = nullptr; // many-RHS blocks (allocated at the first multi-column solve)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
-    int32_t sf_warm_flag = 0;               // HIPMF_SF_WARM=1: waiting workgroups pre-touch their panel (tuning knob; measured slower:
-                                            // 0.674 vs 0.628 ms per pass pair and +35 % fetched bytes on the 1M-DOF Poisson factor)
     FactorInfo *d_info = nullptr;
     unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] |r|_inf bits, [2] omega bits
     double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_den = nullptr, *d_b = nullptr, *d_x = nullptr,
