@@ -50,6 +50,10 @@ void Solver::release() {
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *p : {(void *)d_blk2, (void *)d_work_blk2, (void *)d_sync2, (void *)d_norms2})
+        if (p) (void)hipFree(p);
+    if (h_nrm) (void)hipHostFree(h_nrm);
+    d_blk2 = d_work_blk2 = h_nrm = nullptr, d_sync2 = nullptr, d_norms2 = nullptr;
     d_dws = nullptr, d_ear = nullptr;
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_cs = nullptr, d_rperm = nullptr;
@@ -115,6 +119,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         so.dense_leaves = v > 0;
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
+    if (const char *e = getenv("HIPMF_SOLVE_LANES")) two_lanes = atoi(e) >= 2;
     if (const char *e = getenv("HIPMF_SMALL_SPLIT")) small_split = atoi(e);
     if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_UPD_G8")) upd_g8 = std::max(upd_g4, atoi(e));
@@ -665,42 +670,43 @@ int32_t Solver::run_factor() {
     return SUCCESSFUL_EXIT;
 }
 
-int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr) {
+int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed) {
     int64_t launches = 0;
     if (use_fused) {
         const int32_t ns = S.nsuper;
-        int32_t *sync_f = d_sync, *sync_b = d_sync + SF_SYNC_HEADER + ns, *sync_err = d_sync + 2 * (SF_SYNC_HEADER + ns);
-        HIPC(hipMemsetAsync(d_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), STREAM), ERROR_HIP_MEMCPY);
-        HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
+        const hipStream_t LST = (hipStream_t)lane_stream;
+        int32_t *sync_f = lane_sync, *sync_b = lane_sync + SF_SYNC_HEADER + ns, *sync_err = lane_sync + 2 * (SF_SYNC_HEADER + ns);
+        HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
+        if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
         const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
         const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
         unsigned long long *no_trace = nullptr;
 #define HIPMF_FWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
-    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, STREAM, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f, \
+    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f, \
                        sync_err, wrk, xp, nk, xstr, wstr, TRACE)
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
-    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, STREAM, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b, sync_err,  \
+    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b, sync_err,  \
                        wrk, xp, nk, xstr, wstr, TRACE)
         if (nk == 1) {
             if (fa > 0) HIPMF_FWD(true, 1, fa, d_sf, no_trace);
-            if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, d_trace);
+            if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, timed ? d_trace : no_trace);
         } else {
             if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, d_sf, no_trace);
-            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, d_trace);
+            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, timed ? d_trace : no_trace);
         }
-        HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
+        if (timed) HIPC(hipEventRecord((hipEvent_t)ev[4], LST), ERROR_HIP_SYNCHRONIZE);
         if (nk == 1) {
-            if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
+            if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 4 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, 1, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         } else {
-            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, d_trace ? d_trace + 4 * (size_t)fb : nullptr);
+            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 4 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         }
 #undef HIPMF_FWD
 #undef HIPMF_BWD
-        HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
+        if (timed) HIPC(hipEventRecord((hipEvent_t)ev[5], LST), ERROR_HIP_SYNCHRONIZE);
         times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
-        tri_pending = true;
+        if (timed) tri_pending = true;
         return SUCCESSFUL_EXIT;
     }
     if (nk != 1 || wrk != d_work) return ERROR_HIPMF_INVALID_VALUE; // the level-set launches carry one right-hand side
@@ -759,6 +765,25 @@ void Solver::harvest_tri() {
     times.acc_tri_count++;
 }
 
+// One lane of the solve driver: a stream with its own block buffers and hand-off words.  A single right-hand side (or a single
+// block) uses lane 0 = the solver's own stream and buffers; several blocks alternate between two lanes so that the
+// latency-bound upper levels of one block's triangular passes overlap with the bandwidth-bound leaf band of the other's.
+struct Solver::SolveLane {
+    hipStream_t st = nullptr;
+    double *XP = nullptr, *DU = nullptr, *RR = nullptr, *BB = nullptr, *XX = nullptr, *WRK = nullptr;
+    int32_t *sync = nullptr;             // completion counters + error word of the dependency-driven kernels
+    unsigned long long *norms = nullptr; // 2 words per column: |r|_inf bits, omega bits
+    double *h_nrm = nullptr;             // pinned host copy of the norms (a pageable target would make the copy synchronous)
+    bool timed = false;                  // records the forward / backward event pair (lane 0 only)
+    // the block in flight
+    bool busy = false;
+    int32_t j0 = 0, nk = 0, it = 0;
+    double prev[SF_KMAX];
+    bool active[SF_KMAX];
+    const double *bj[SF_KMAX];
+    double *xj[SF_KMAX];
+};
+
 int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device) {
     if (!factorized) return ERROR_NEED_FACTORIZATION;
     if (!x || !rhs) return ERROR_NULL_POINTER;
@@ -771,98 +796,160 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     // Blocks of KB right-hand sides go through the triangular solves together (the dependency-driven kernels read each
     // factor entry once per block); one right-hand side uses the single-column instances and buffers.
     const int32_t KB = (use_fused && nrhs > 1) ? SF_KMAX : 1;
+    const int32_t nblocks = (nrhs + KB - 1) / KB;
+    const int32_t nlanes = (KB > 1 && nblocks > 1 && two_lanes) ? 2 : 1;
+    const size_t sync_words = 2 * (size_t)(SF_SYNC_HEADER + S.nsuper) + 1;
     if (KB > 1 && !d_blk) {
         // xp | du | r | den | b | x: six n x KB blocks, plus KB solve workspaces
         HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
     }
-    double *XP = KB > 1 ? d_blk : d_xp, *DU = KB > 1 ? d_blk + (size_t)n * KB : d_du, *RR = KB > 1 ? d_blk + 2 * (size_t)n * KB : d_r,
-           *DEN = KB > 1 ? d_blk + 3 * (size_t)n * KB : d_den, *BB = KB > 1 ? d_blk + 4 * (size_t)n * KB : d_b,
-           *XX = KB > 1 ? d_blk + 5 * (size_t)n * KB : d_x, *WRK = KB > 1 ? d_work_blk : d_work;
+    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * 4 * SF_KMAX), ERROR_HIP_MALLOC);
+    if (nlanes > 1 && !d_blk2) {
+        HIPC(hipMalloc((void **)&d_blk2, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_work_blk2, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_sync2, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
+        HIPC(hipMemset(d_sync2, 0, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_norms2, 2 * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+    }
+    SolveLane lanes[2];
+    {
+        SolveLane &L = lanes[0];
+        L.st = STREAM;
+        L.XP = KB > 1 ? d_blk : d_xp, L.DU = KB > 1 ? d_blk + (size_t)n * KB : d_du, L.RR = KB > 1 ? d_blk + 2 * (size_t)n * KB : d_r;
+        L.BB = KB > 1 ? d_blk + 4 * (size_t)n * KB : d_b, L.XX = KB > 1 ? d_blk + 5 * (size_t)n * KB : d_x, L.WRK = KB > 1 ? d_work_blk : d_work;
+        L.sync = d_sync, L.norms = d_scalar + 1, L.h_nrm = h_nrm, L.timed = true;
+    }
+    if (nlanes > 1) {
+        SolveLane &L = lanes[1];
+        L.st = (hipStream_t)stream2;
+        L.XP = d_blk2, L.DU = d_blk2 + (size_t)n * KB, L.RR = d_blk2 + 2 * (size_t)n * KB, L.BB = d_blk2 + 4 * (size_t)n * KB;
+        L.XX = d_blk2 + 5 * (size_t)n * KB, L.WRK = d_work_blk2;
+        L.sync = d_sync2, L.norms = d_norms2, L.h_nrm = h_nrm + 2 * SF_KMAX, L.timed = false;
+    }
     const int64_t wstr = work_doubles;
     HIPC(hipEventRecord((hipEvent_t)ev[6], STREAM), ERROR_HIP_SYNCHRONIZE);
-    for (int32_t j0 = 0; j0 < nrhs; j0 += KB) {
-        const int32_t nk = std::min(KB, nrhs - j0);
-        const double *bj[SF_KMAX];
-        double *xj[SF_KMAX];
-        for (int32_t c = 0; c < nk; c++) {
-            if (on_device) {
-                bj[c] = rhs + (int64_t)(j0 + c) * ldx;
-                xj[c] = x + (int64_t)(j0 + c) * ldx;
-            } else {
-                HIPC(hipMemcpyAsync(BB + (size_t)c * n, rhs + (int64_t)(j0 + c) * ldx, sizeof(double) * n, hipMemcpyHostToDevice, STREAM),
-                     ERROR_HIP_MEMCPY);
-                bj[c] = BB + (size_t)c * n;
-                xj[c] = XX + (size_t)c * n;
-            }
-            hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, bj[c], XP + (size_t)c * n);
+    if (nlanes > 1) {
+        // the second lane starts after whatever the caller queued on the solver's stream (e.g. the factorisation)
+        HIPC(hipEventRecord((hipEvent_t)ev_fork, STREAM), ERROR_HIP_SYNCHRONIZE);
+        HIPC(hipStreamWaitEvent(lanes[1].st, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
+    }
+
+    // residual + norms of the active columns of the lane's block, and their way to the host
+    auto enqueue_norms = [&](SolveLane &L) -> int32_t {
+        HIPC(hipMemsetAsync(L.norms, 0, 2 * SF_KMAX * sizeof(unsigned long long), L.st), ERROR_HIP_MEMCPY);
+        for (int32_t c = 0; c < L.nk; c++) {
+            if (!L.active[c]) continue;
+            hipLaunchKernelGGL(k_residual, g, b, 0, L.st, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, L.xj[c], L.bj[c], L.RR + (size_t)c * n,
+                               L.norms + 2 * c);
         }
-        int32_t code = run_triangular(XP, nk, WRK, n, wstr);
-        if (code != SUCCESSFUL_EXIT) return code;
-        for (int32_t c = 0; c < nk; c++) hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, XP + (size_t)c * n, xj[c], 0);
-        // Iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229).
-        // Stopping rule per column on the sparse backward error omega = max_i |r_i| / (|A||x| + |b|)_i: stop when
-        // omega <= eps, when a step fails to halve it, or after refinement_nstep steps; a step that makes omega worse is
-        // taken back.  The correction solves of a block run together as long as any of its columns is still active.
-        double prev[SF_KMAX];
-        bool active[SF_KMAX];
-        for (int32_t c = 0; c < nk; c++) prev[c] = INFINITY, active[c] = true;
-        for (int32_t it = 0; it <= opt.refinement_nstep && opt.refinement_nstep > 0; it++) {
-            HIPC(hipMemsetAsync(d_scalar + 1, 0, 2 * SF_KMAX * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
-            for (int32_t c = 0; c < nk; c++) {
-                if (!active[c]) continue;
-                hipLaunchKernelGGL(k_residual, g, b, 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, xj[c], bj[c], RR + (size_t)c * n,
-                                   d_scalar + 1 + 2 * c);
-            }
-            double nrm[2 * SF_KMAX] = {0.0};
-            HIPC(hipMemcpyAsync(nrm, d_scalar + 1, 2 * nk * sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
-            HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
-            harvest_tri();
-            bool any = false;
-            for (int32_t c = 0; c < nk; c++) {
-                if (!active[c]) continue;
-                const double rn = nrm[2 * c], omega = nrm[2 * c + 1];
-                if (it > 0 && !(omega < prev[c])) {
-                    hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, DU + (size_t)c * n, xj[c], 2); // take the last correction back
-                    active[c] = false;
-                    continue;
-                }
-                if (j0 + c == 0) last_residual_inf = rn, last_omega = omega;
-                if (omega <= EPS || it == opt.refinement_nstep || (it > 0 && omega > 0.5 * prev[c])) {
-                    active[c] = false;
-                    continue;
-                }
-                prev[c] = omega;
-                any = true;
-            }
-            if (!any) break;
-            for (int32_t c = 0; c < nk; c++) {
-                if (active[c]) hipLaunchKernelGGL(k_perm_in, g, b, 0, STREAM, n, d_rperm, d_rs, RR + (size_t)c * n, DU + (size_t)c * n);
-                else HIPC(hipMemsetAsync(DU + (size_t)c * n, 0, sizeof(double) * n, STREAM), ERROR_HIP_MEMCPY); // finished columns ride along as zeros
-            }
-            code = run_triangular(DU, nk, WRK, n, wstr);
-            if (code != SUCCESSFUL_EXIT) return code;
-            for (int32_t c = 0; c < nk; c++)
-                if (active[c]) hipLaunchKernelGGL(k_perm_out, g, b, 0, STREAM, n, d_perm, d_cs, DU + (size_t)c * n, xj[c], 1);
-            if (j0 == 0 && active[0]) refinement_steps_done++;
-            // a column whose backward error was already within 64 eps is done after this correction: no further residual /
-            // norm / host round trip just to confirm it
-            bool again = false;
-            for (int32_t c = 0; c < nk; c++) {
-                if (active[c] && prev[c] <= 64.0 * EPS) active[c] = false;
-                again |= active[c];
-            }
-            if (!again) break;
-        }
+        HIPC(hipMemcpyAsync(L.h_nrm, L.norms, 2 * L.nk * sizeof(double), hipMemcpyDeviceToHost, L.st), ERROR_HIP_MEMCPY);
+        return SUCCESSFUL_EXIT;
+    };
+    auto finish = [&](SolveLane &L) -> int32_t {
         if (!on_device)
-            for (int32_t c = 0; c < nk; c++)
-                HIPC(hipMemcpyAsync(x + (int64_t)(j0 + c) * ldx, XX + (size_t)c * n, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM),
+            for (int32_t c = 0; c < L.nk; c++)
+                HIPC(hipMemcpyAsync(x + (int64_t)(L.j0 + c) * ldx, L.XX + (size_t)c * n, sizeof(double) * n, hipMemcpyDeviceToHost, L.st),
                      ERROR_HIP_MEMCPY);
+        L.busy = false;
+        return SUCCESSFUL_EXIT;
+    };
+    // first solve of the block that starts at column j0
+    auto start = [&](SolveLane &L, int32_t j0) -> int32_t {
+        L.j0 = j0, L.nk = std::min(KB, nrhs - j0), L.it = 0, L.busy = true;
+        for (int32_t c = 0; c < L.nk; c++) {
+            if (on_device) {
+                L.bj[c] = rhs + (int64_t)(j0 + c) * ldx;
+                L.xj[c] = x + (int64_t)(j0 + c) * ldx;
+            } else {
+                HIPC(hipMemcpyAsync(L.BB + (size_t)c * n, rhs + (int64_t)(j0 + c) * ldx, sizeof(double) * n, hipMemcpyHostToDevice, L.st),
+                     ERROR_HIP_MEMCPY);
+                L.bj[c] = L.BB + (size_t)c * n;
+                L.xj[c] = L.XX + (size_t)c * n;
+            }
+            hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.bj[c], L.XP + (size_t)c * n);
+        }
+        int32_t code = run_triangular(L.XP, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed);
+        if (code != SUCCESSFUL_EXIT) return code;
+        for (int32_t c = 0; c < L.nk; c++) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.XP + (size_t)c * n, L.xj[c], 0);
+        for (int32_t c = 0; c < L.nk; c++) L.prev[c] = INFINITY, L.active[c] = true;
+        if (opt.refinement_nstep <= 0) return finish(L);
+        return enqueue_norms(L);
+    };
+    // Iterative refinement on A x = b (UMFPACK refines inside umfpack_di_solve, interface_umfpack.c:229), one step of the
+    // lane's block; called when the norms of its last residual have arrived.
+    // Stopping rule per column on the sparse backward error omega = max_i |r_i| / (|A||x| + |b|)_i: stop when
+    // omega <= eps, when a step fails to halve it, or after refinement_nstep steps; a step that makes omega worse is
+    // taken back.  The correction solves of a block run together as long as any of its columns is still active.
+    auto advance = [&](SolveLane &L) -> int32_t {
+        if (L.timed) harvest_tri();
+        bool any = false;
+        for (int32_t c = 0; c < L.nk; c++) {
+            if (!L.active[c]) continue;
+            const double rn = L.h_nrm[2 * c], omega = L.h_nrm[2 * c + 1];
+            if (L.it > 0 && !(omega < L.prev[c])) {
+                hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 2); // take the last correction back
+                L.active[c] = false;
+                continue;
+            }
+            if (L.j0 + c == 0) last_residual_inf = rn, last_omega = omega;
+            if (omega <= EPS || L.it == opt.refinement_nstep || (L.it > 0 && omega > 0.5 * L.prev[c])) {
+                L.active[c] = false;
+                continue;
+            }
+            L.prev[c] = omega;
+            any = true;
+        }
+        if (!any) return finish(L);
+        for (int32_t c = 0; c < L.nk; c++) {
+            if (L.active[c]) hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.RR + (size_t)c * n, L.DU + (size_t)c * n);
+            else HIPC(hipMemsetAsync(L.DU + (size_t)c * n, 0, sizeof(double) * n, L.st), ERROR_HIP_MEMCPY); // finished columns ride along as zeros
+        }
+        int32_t code = run_triangular(L.DU, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed);
+        if (code != SUCCESSFUL_EXIT) return code;
+        for (int32_t c = 0; c < L.nk; c++)
+            if (L.active[c]) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 1);
+        if (L.j0 == 0 && L.active[0]) refinement_steps_done++;
+        // a column whose backward error was already within 64 eps is done after this correction: no further residual /
+        // norm / host round trip just to confirm it
+        bool again = false;
+        for (int32_t c = 0; c < L.nk; c++) {
+            if (L.active[c] && L.prev[c] <= 64.0 * EPS) L.active[c] = false;
+            again |= L.active[c];
+        }
+        L.it++;
+        if (!again || L.it > opt.refinement_nstep) return finish(L);
+        return enqueue_norms(L);
+    };
+
+    int32_t next = 0;
+    for (;;) {
+        bool progressed = false;
+        for (int32_t l = 0; l < nlanes; l++)
+            if (!lanes[l].busy && next < nblocks) {
+                int32_t code = start(lanes[l], next * KB);
+                if (code != SUCCESSFUL_EXIT) return code;
+                next++;
+                progressed = true;
+            }
+        for (int32_t l = 0; l < nlanes; l++)
+            if (lanes[l].busy) {
+                HIPC(hipStreamSynchronize(lanes[l].st), ERROR_HIP_SYNCHRONIZE);
+                int32_t code = advance(lanes[l]);
+                if (code != SUCCESSFUL_EXIT) return code;
+                progressed = true;
+            }
+        if (!progressed) break;
+    }
+    if (nlanes > 1) {
+        HIPC(hipEventRecord((hipEvent_t)ev_join, lanes[1].st), ERROR_HIP_SYNCHRONIZE);
+        HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
     }
     HIPC(hipEventRecord((hipEvent_t)ev[7], STREAM), ERROR_HIP_SYNCHRONIZE);
     if (use_fused) {
-        int32_t *sync_err = d_sync + 2 * (SF_SYNC_HEADER + S.nsuper);
-        HIPC(hipMemcpyAsync(&sf_err[0], sync_err, sizeof(int32_t), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+        HIPC(hipMemcpyAsync(&sf_err[0], d_sync + sync_words - 1, sizeof(int32_t), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+        sf_err[1] = 0;
+        if (nlanes > 1) HIPC(hipMemcpyAsync(&sf_err[1], d_sync2 + sync_words - 1, sizeof(int32_t), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     }
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
@@ -882,15 +969,16 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             fclose(fp);
         }
     }
-    if (use_fused && sf_err[0] != 0) {
+    if (use_fused && (sf_err[0] != 0 || sf_err[1] != 0)) {
         // a hand-off wait timed out (never expected): the result is not trusted; redo with the level-set launches
         if (!level_path_ok) {
             last_error = "dependency-driven solve timed out and the fronts are too large for the level-set fallback";
             return ERROR_NOT_AVAILABLE;
         }
         use_fused = false;
-        sf_err[0] = 0;
-        (void)hipMemset(d_sync + 2 * (SF_SYNC_HEADER + S.nsuper), 0, sizeof(int32_t));
+        sf_err[0] = sf_err[1] = 0;
+        (void)hipMemset(d_sync + sync_words - 1, 0, sizeof(int32_t));
+        if (d_sync2) (void)hipMemset(d_sync2 + sync_words - 1, 0, sizeof(int32_t));
         last_error = "dependency-driven solve timed out; level-set path used instead";
         if (opt.verbose) fprintf(stderr, "hipmf: %s\n", last_error.c_str());
         return solve(x, rhs, nrhs, ldx, on_device);

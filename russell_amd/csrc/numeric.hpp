@@ -116,7 +116,8 @@ class Solver {
     int32_t upload_plan();
     int32_t run_factor();
     // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)
-    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr);
+    struct SolveLane;
+    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed);
     void harvest_tri();
     bool tri_pending = false;
     std::vector<LevelPlan> levels;
@@ -155,6 +156,11 @@ class Solver {
     double *d_vin = nullptr;
     int64_t nnz_in = 0;
     double *d_blk = nullptr, *d_work_blk = nullptr; // many-RHS blocks (allocated at the first multi-column solve)
+    // second lane of the solve driver (allocated at the first solve with more than one block): buffers, hand-off words, norms
+    double *d_blk2 = nullptr, *d_work_blk2 = nullptr, *h_nrm = nullptr;
+    int32_t *d_sync2 = nullptr;
+    unsigned long long *d_norms2 = nullptr;
+    bool two_lanes = true; // HIPMF_SOLVE_LANES=1: one lane only
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
     FactorInfo *d_info = nullptr;
