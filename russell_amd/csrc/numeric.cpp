@@ -50,10 +50,14 @@ void Solver::release() {
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (void *p : {(void *)d_blk2, (void *)d_work_blk2, (void *)d_sync2, (void *)d_norms2})
-        if (p) (void)hipFree(p);
+    for (LaneBuffers &lb : extra_lanes) {
+        for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
+            if (p) (void)hipFree(p);
+        if (lb.stream) (void)hipStreamDestroy((hipStream_t)lb.stream);
+    }
+    extra_lanes.clear();
     if (h_nrm) (void)hipHostFree(h_nrm);
-    d_blk2 = d_work_blk2 = h_nrm = nullptr, d_sync2 = nullptr, d_norms2 = nullptr;
+    h_nrm = nullptr;
     d_dws = nullptr, d_ear = nullptr;
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_cs = nullptr, d_rperm = nullptr;
@@ -119,7 +123,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         so.dense_leaves = v > 0;
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
-    if (const char *e = getenv("HIPMF_SOLVE_LANES")) two_lanes = atoi(e) >= 2;
+    if (const char *e = getenv("HIPMF_SOLVE_LANES")) solve_lanes = std::max(1, std::min(MAX_SOLVE_LANES, atoi(e)));
     if (const char *e = getenv("HIPMF_SMALL_SPLIT")) small_split = atoi(e);
     if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_UPD_G8")) upd_g8 = std::max(upd_g4, atoi(e));
@@ -797,22 +801,28 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     // factor entry once per block); one right-hand side uses the single-column instances and buffers.
     const int32_t KB = (use_fused && nrhs > 1) ? SF_KMAX : 1;
     const int32_t nblocks = (nrhs + KB - 1) / KB;
-    const int32_t nlanes = (KB > 1 && nblocks > 1 && two_lanes) ? 2 : 1;
+    const int32_t nlanes = KB > 1 ? std::max(1, std::min(solve_lanes, nblocks)) : 1;
     const size_t sync_words = 2 * (size_t)(SF_SYNC_HEADER + S.nsuper) + 1;
     if (KB > 1 && !d_blk) {
         // xp | du | r | den | b | x: six n x KB blocks, plus KB solve workspaces
         HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
     }
-    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * 4 * SF_KMAX), ERROR_HIP_MALLOC);
-    if (nlanes > 1 && !d_blk2) {
-        HIPC(hipMalloc((void **)&d_blk2, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&d_work_blk2, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&d_sync2, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
-        HIPC(hipMemset(d_sync2, 0, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&d_norms2, 2 * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * 2 * SF_KMAX * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
+    while ((int32_t)extra_lanes.size() < nlanes - 1) {
+        LaneBuffers lb;
+        hipStream_t st = nullptr;
+        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+        lb.stream = st;
+        extra_lanes.push_back(lb); // (registered first: release() frees whatever a failed allocation leaves behind)
+        LaneBuffers &r = extra_lanes.back();
+        HIPC(hipMalloc((void **)&r.blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.work, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.sync, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
+        HIPC(hipMemset(r.sync, 0, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.norms, 2 * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     }
-    SolveLane lanes[2];
+    SolveLane lanes[MAX_SOLVE_LANES];
     {
         SolveLane &L = lanes[0];
         L.st = STREAM;
@@ -820,19 +830,20 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         L.BB = KB > 1 ? d_blk + 4 * (size_t)n * KB : d_b, L.XX = KB > 1 ? d_blk + 5 * (size_t)n * KB : d_x, L.WRK = KB > 1 ? d_work_blk : d_work;
         L.sync = d_sync, L.norms = d_scalar + 1, L.h_nrm = h_nrm, L.timed = true;
     }
-    if (nlanes > 1) {
-        SolveLane &L = lanes[1];
-        L.st = (hipStream_t)stream2;
-        L.XP = d_blk2, L.DU = d_blk2 + (size_t)n * KB, L.RR = d_blk2 + 2 * (size_t)n * KB, L.BB = d_blk2 + 4 * (size_t)n * KB;
-        L.XX = d_blk2 + 5 * (size_t)n * KB, L.WRK = d_work_blk2;
-        L.sync = d_sync2, L.norms = d_norms2, L.h_nrm = h_nrm + 2 * SF_KMAX, L.timed = false;
+    for (int32_t l = 1; l < nlanes; l++) {
+        SolveLane &L = lanes[l];
+        const LaneBuffers &r = extra_lanes[(size_t)l - 1];
+        L.st = (hipStream_t)r.stream;
+        L.XP = r.blk, L.DU = r.blk + (size_t)n * KB, L.RR = r.blk + 2 * (size_t)n * KB, L.BB = r.blk + 4 * (size_t)n * KB;
+        L.XX = r.blk + 5 * (size_t)n * KB, L.WRK = r.work;
+        L.sync = r.sync, L.norms = r.norms, L.h_nrm = h_nrm + 2 * SF_KMAX * l, L.timed = false;
     }
     const int64_t wstr = work_doubles;
     HIPC(hipEventRecord((hipEvent_t)ev[6], STREAM), ERROR_HIP_SYNCHRONIZE);
     if (nlanes > 1) {
-        // the second lane starts after whatever the caller queued on the solver's stream (e.g. the factorisation)
+        // the other lanes start after whatever the caller queued on the solver's stream (e.g. the factorisation)
         HIPC(hipEventRecord((hipEvent_t)ev_fork, STREAM), ERROR_HIP_SYNCHRONIZE);
-        HIPC(hipStreamWaitEvent(lanes[1].st, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
+        for (int32_t l = 1; l < nlanes; l++) HIPC(hipStreamWaitEvent(lanes[l].st, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
     }
 
     // residual + norms of the active columns of the lane's block, and their way to the host
@@ -941,15 +952,16 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             }
         if (!progressed) break;
     }
-    if (nlanes > 1) {
-        HIPC(hipEventRecord((hipEvent_t)ev_join, lanes[1].st), ERROR_HIP_SYNCHRONIZE);
-        HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
-    }
+    for (int32_t l = 1; l < nlanes; l++) HIPC(hipStreamSynchronize(lanes[l].st), ERROR_HIP_SYNCHRONIZE); // (idle by now: every block is finished)
     HIPC(hipEventRecord((hipEvent_t)ev[7], STREAM), ERROR_HIP_SYNCHRONIZE);
     if (use_fused) {
         HIPC(hipMemcpyAsync(&sf_err[0], d_sync + sync_words - 1, sizeof(int32_t), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
         sf_err[1] = 0;
-        if (nlanes > 1) HIPC(hipMemcpyAsync(&sf_err[1], d_sync2 + sync_words - 1, sizeof(int32_t), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+        for (int32_t l = 1; l < nlanes; l++) {
+            int32_t e = 0;
+            HIPC(hipMemcpy(&e, lanes[l].sync + sync_words - 1, sizeof(int32_t), hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
+            sf_err[1] |= e;
+        }
     }
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
@@ -978,7 +990,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         use_fused = false;
         sf_err[0] = sf_err[1] = 0;
         (void)hipMemset(d_sync + sync_words - 1, 0, sizeof(int32_t));
-        if (d_sync2) (void)hipMemset(d_sync2 + sync_words - 1, 0, sizeof(int32_t));
+        for (LaneBuffers &lb : extra_lanes) (void)hipMemset(lb.sync + sync_words - 1, 0, sizeof(int32_t));
         last_error = "dependency-driven solve timed out; level-set path used instead";
         if (opt.verbose) fprintf(stderr, "hipmf: %s\n", last_error.c_str());
         return solve(x, rhs, nrhs, ldx, on_device);

@@ -156,11 +156,18 @@ class Solver {
     double *d_vin = nullptr;
     int64_t nnz_in = 0;
     double *d_blk = nullptr, *d_work_blk = nullptr; // many-RHS blocks (allocated at the first multi-column solve)
-    // second lane of the solve driver (allocated at the first solve with more than one block): buffers, hand-off words, norms
-    double *d_blk2 = nullptr, *d_work_blk2 = nullptr, *h_nrm = nullptr;
-    int32_t *d_sync2 = nullptr;
-    unsigned long long *d_norms2 = nullptr;
-    bool two_lanes = true; // HIPMF_SOLVE_LANES=1: one lane only
+    // further lanes of the solve driver (allocated at the first solve with more than one block): stream, block buffers, hand-off
+    // words, norms; lane 0 is the solver's own stream and buffers
+    static constexpr int32_t MAX_SOLVE_LANES = 4;
+    struct LaneBuffers {
+        void *stream = nullptr;
+        double *blk = nullptr, *work = nullptr;
+        int32_t *sync = nullptr;
+        unsigned long long *norms = nullptr;
+    };
+    std::vector<LaneBuffers> extra_lanes;
+    double *h_nrm = nullptr;   // pinned: norms of every lane
+    int32_t solve_lanes = 2;   // HIPMF_SOLVE_LANES (1..4)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
     FactorInfo *d_info = nullptr;
