@@ -1055,23 +1055,30 @@ StrError read_matrix_market(MatrixMarketData &data, const std::string &full_path
         size_t b = line.find_first_not_of(" \t\r");
         if (b == std::string::npos || line[b] == '%') continue;
         if (pos == nnz) return "there are more values than specified";
-        std::istringstream vs(line);
-        std::string si, sj, sa;
-        if (!(vs >> si)) continue;
+        // tokens are parsed in place (strtol / strtod on the line buffer: the data section is millions of lines long)
+        const char *q = line.c_str() + b;
+        auto token = [&](const char *&tb, const char *&te) {
+            while (*q == ' ' || *q == '\t' || *q == '\r') q++;
+            tb = q;
+            while (*q && *q != ' ' && *q != '\t' && *q != '\r' && *q != '\n') q++;
+            te = q;
+            return te > tb;
+        };
+        const char *tb, *te;
         char *end;
-        long i = strtol(si.c_str(), &end, 10);
-        if (*end) return "cannot parse i";
-        if (!(vs >> sj)) return "cannot read j";
-        long j = strtol(sj.c_str(), &end, 10);
-        if (*end) return "cannot parse j";
-        if (!(vs >> sa)) return "cannot read aij";
-        double aij = strtod(sa.c_str(), &end);
-        if (*end) return "cannot parse aij";
+        if (!token(tb, te)) continue;
+        long i = strtol(tb, &end, 10);
+        if (end != te) return "cannot parse i";
+        if (!token(tb, te)) return "cannot read j";
+        long j = strtol(tb, &end, 10);
+        if (end != te) return "cannot parse j";
+        if (!token(tb, te)) return "cannot read aij";
+        double aij = strtod(tb, &end);
+        if (end != te) return "cannot parse aij";
         if (complex) {
-            std::string sb;
-            if (!(vs >> sb)) return "cannot read bij";
-            bij = strtod(sb.c_str(), &end);
-            if (*end) return "cannot parse bij";
+            if (!token(tb, te)) return "cannot read bij";
+            bij = strtod(tb, &end);
+            if (end != te) return "cannot parse bij";
         }
         i -= 1, j -= 1; // MatrixMarket is one-based
         if (i < 0 || i >= m || j < 0 || j >= n) return "found an invalid index";
