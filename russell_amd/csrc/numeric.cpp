@@ -277,7 +277,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_scalar, (4 + 2 * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     for (auto &e : ev) {
         hipEvent_t he;
         HIPC(hipEventCreate(&he), ERROR_HIP_MALLOC);
@@ -808,7 +808,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
     }
-    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * 2 * SF_KMAX * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
+    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * RES_NORM_WORDS * SF_KMAX * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
     while ((int32_t)extra_lanes.size() < nlanes - 1) {
         LaneBuffers lb;
         hipStream_t st = nullptr;
@@ -820,7 +820,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         HIPC(hipMalloc((void **)&r.work, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&r.sync, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
         HIPC(hipMemset(r.sync, 0, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&r.norms, 2 * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.norms, (size_t)RES_NORM_WORDS * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     }
     SolveLane lanes[MAX_SOLVE_LANES];
     {
@@ -828,7 +828,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         L.st = STREAM;
         L.XP = KB > 1 ? d_blk : d_xp, L.DU = KB > 1 ? d_blk + (size_t)n * KB : d_du, L.RR = KB > 1 ? d_blk + 2 * (size_t)n * KB : d_r;
         L.BB = KB > 1 ? d_blk + 4 * (size_t)n * KB : d_b, L.XX = KB > 1 ? d_blk + 5 * (size_t)n * KB : d_x, L.WRK = KB > 1 ? d_work_blk : d_work;
-        L.sync = d_sync, L.norms = d_scalar + 1, L.h_nrm = h_nrm, L.timed = true;
+        L.sync = d_sync, L.norms = d_scalar + 4, L.h_nrm = h_nrm, L.timed = true;
     }
     for (int32_t l = 1; l < nlanes; l++) {
         SolveLane &L = lanes[l];
@@ -836,7 +836,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         L.st = (hipStream_t)r.stream;
         L.XP = r.blk, L.DU = r.blk + (size_t)n * KB, L.RR = r.blk + 2 * (size_t)n * KB, L.BB = r.blk + 4 * (size_t)n * KB;
         L.XX = r.blk + 5 * (size_t)n * KB, L.WRK = r.work;
-        L.sync = r.sync, L.norms = r.norms, L.h_nrm = h_nrm + 2 * SF_KMAX * l, L.timed = false;
+        L.sync = r.sync, L.norms = r.norms, L.h_nrm = h_nrm + (size_t)RES_NORM_WORDS * SF_KMAX * l, L.timed = false;
     }
     const int64_t wstr = work_doubles;
     HIPC(hipEventRecord((hipEvent_t)ev[6], STREAM), ERROR_HIP_SYNCHRONIZE);
@@ -848,13 +848,13 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
 
     // residual + norms of the active columns of the lane's block, and their way to the host
     auto enqueue_norms = [&](SolveLane &L) -> int32_t {
-        HIPC(hipMemsetAsync(L.norms, 0, 2 * SF_KMAX * sizeof(unsigned long long), L.st), ERROR_HIP_MEMCPY);
+        HIPC(hipMemsetAsync(L.norms, 0, (size_t)RES_NORM_WORDS * L.nk * sizeof(unsigned long long), L.st), ERROR_HIP_MEMCPY);
         for (int32_t c = 0; c < L.nk; c++) {
             if (!L.active[c]) continue;
-            hipLaunchKernelGGL(k_residual, g, b, 0, L.st, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, L.xj[c], L.bj[c], L.RR + (size_t)c * n,
-                               L.norms + 2 * c);
+            hipLaunchKernelGGL(k_residual, dim3((n + 256 / RES_LANES - 1) / (256 / RES_LANES)), b, 0, L.st, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, L.xj[c], L.bj[c], L.RR + (size_t)c * n,
+                               L.norms + (size_t)RES_NORM_WORDS * c);
         }
-        HIPC(hipMemcpyAsync(L.h_nrm, L.norms, 2 * L.nk * sizeof(double), hipMemcpyDeviceToHost, L.st), ERROR_HIP_MEMCPY);
+        HIPC(hipMemcpyAsync(L.h_nrm, L.norms, (size_t)RES_NORM_WORDS * L.nk * sizeof(double), hipMemcpyDeviceToHost, L.st), ERROR_HIP_MEMCPY);
         return SUCCESSFUL_EXIT;
     };
     auto finish = [&](SolveLane &L) -> int32_t {
@@ -897,13 +897,18 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         bool any = false;
         for (int32_t c = 0; c < L.nk; c++) {
             if (!L.active[c]) continue;
-            const double rn = L.h_nrm[2 * c], omega = L.h_nrm[2 * c + 1];
+            double rn = 0.0, omega = 0.0; // maxima over the slots of k_residual (non-negative doubles)
+            for (int32_t sl = 0; sl < RES_SLOTS; sl++) {
+                rn = std::max(rn, L.h_nrm[(size_t)RES_NORM_WORDS * c + (size_t)sl * RES_SLOT_WORDS]);
+                omega = std::max(omega, L.h_nrm[(size_t)RES_NORM_WORDS * c + (size_t)sl * RES_SLOT_WORDS + 1]);
+            }
             if (L.it > 0 && !(omega < L.prev[c])) {
                 hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 2); // take the last correction back
                 L.active[c] = false;
                 continue;
             }
             if (L.j0 + c == 0) last_residual_inf = rn, last_omega = omega;
+            if (opt.verbose && L.j0 + c == 0) fprintf(stderr, "hipmf: refinement step %d: |r|_inf = %.3e, omega = %.3e\n", L.it, rn, omega);
             if (omega <= EPS || L.it == opt.refinement_nstep || (L.it > 0 && omega > 0.5 * L.prev[c])) {
                 L.active[c] = false;
                 continue;

@@ -171,7 +171,7 @@ class Solver {
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
     FactorInfo *d_info = nullptr;
-    unsigned long long *d_scalar = nullptr; // [0] anorm bits, [1] |r|_inf bits, [2] omega bits
+    unsigned long long *d_scalar = nullptr; // [0] anorm bits, [4 ...] the norm slots of k_residual (lane 0)
     double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_den = nullptr, *d_b = nullptr, *d_x = nullptr,
            *d_du = nullptr;
     int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
