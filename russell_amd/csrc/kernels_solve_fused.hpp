@@ -29,7 +29,7 @@ constexpr int SF_SYNC_HEADER = 16;       // ints in front of the completion coun
 constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
 constexpr int SF_CHUNK = 1024;           // doubles of a big front's vector staged in LDS at a time, per right-hand side (the children are
                                          // re-scanned for every chunk, so the chunk does not shrink with K: 32 KB of LDS at K = 4)
-constexpr int SF_KMAX = 4;               // right-hand sides solved together by the blocked instances (the factor is read once per block)
+constexpr int SF_KMAX = 8;               // right-hand sides solved together by the blocked instances (the factor is read once per block)
 
 struct SfTask {
     int32_t kind;       // 0: group of small fronts, one per wavefront (a, b, c, d; -1 = none)
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
                                                    const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace) {
-    constexpr int CHK = SF_CHUNK; // chunk of w1 per right-hand side
+    constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK; // chunk of w1 per right-hand side
     __shared__ double wv[4][K][64];
     __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
     __shared__ double wsl[SMALL_ONLY ? 1 : K * 128];
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace) {
-    constexpr int CHK = SF_CHUNK;
+    constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK;
     __shared__ double wv[4][K][64];
     __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
     __shared__ double red[256];
