@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Many right-hand sides on one GPU: solve_device with nrhs columns resident in HBM (blocks of SF_KMAX = 4 columns share
+"""Many right-hand sides on one GPU: solve_device with nrhs columns resident in HBM (blocks of SF_KMAX = 8 columns share
 one read of the factor) against nrhs single solves.  usage: many_rhs.py 2d|3d N nrhs [refinement_nstep]"""
 import os, sys, time
 import numpy as np
