@@ -28,7 +28,7 @@ namespace hipmf {
 constexpr int SF_SYNC_HEADER = 16;       // ints in front of the completion counters (reserved)
 constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
 constexpr int SF_CHUNK = 1024;           // doubles of a big front's vector staged in LDS at a time, per right-hand side (the children are
-                                         // re-scanned for every chunk, so the chunk does not shrink with K: 32 KB of LDS at K = 4)
+                                         // re-scanned for every chunk; 1024 doubles per right-hand side up to K = 4, 512 at K = 8: 32 KB of LDS)
 constexpr int SF_KMAX = 8;               // right-hand sides solved together by the blocked instances (the factor is read once per block)
 
 struct SfTask {

@@ -86,9 +86,9 @@ def test_poisson3d_fronts_beyond_the_lds_staging_limit():
     s.close()
 
 
-@pytest.mark.parametrize("grid,nrhs", [(60, 6), (300, 9)])
+@pytest.mark.parametrize("grid,nrhs", [(60, 6), (300, 9), (200, 20)])
 def test_many_rhs_blocks_equal_single_solves_bitwise(grid, nrhs):
-    # solve_many sends blocks of 4 right-hand sides through the dependency-driven kernels together (the factor is read
+    # solve_many sends blocks of SF_KMAX (8) right-hand sides through the dependency-driven kernels together (the factor is read
     # once per block); per column the arithmetic is the single-column one
     n, rp, ci, v = P.poisson2d(grid)
     rng = np.random.default_rng(grid)
