@@ -6,6 +6,7 @@
 #include "numeric.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -164,11 +165,18 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         for (int64_t k = 0; k < rp[n]; k++) am[k] = S.amap[kB[k]];
         S.amap.swap(am);
     }
+    const auto t_plan = std::chrono::steady_clock::now();
     int32_t code = upload_plan();
     if (code != SUCCESSFUL_EXIT) {
         release();
         return code;
     }
+    if (opt.verbose)
+        fprintf(stderr,
+                "hipmf: initialize: graph %.3f s, ordering %.3f s, etree %.3f s, supernodes %.3f s, row structures %.3f s, layout %.3f s, "
+                "assembly map %.3f s; plan + device allocation + upload %.3f s\n",
+                S.seconds_phase[0], S.seconds_phase[1], S.seconds_phase[2], S.seconds_phase[3], S.seconds_phase[4], S.seconds_phase[5],
+                S.seconds_phase[6], std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan).count());
     // matrix structure (kept for the refinement SpMV) and per-entry row/col indices
     const int64_t nnz = S.nnz_a;
     std::vector<int32_t> h_rp(rp, rp + n + 1), h_ci(ci, ci + nnz), h_arow((size_t)nnz);

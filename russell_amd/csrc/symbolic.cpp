@@ -488,7 +488,7 @@ static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, s
 } // namespace
 
 int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &opt, Symbolic &S) {
-    auto t_all = clk::now();
+    auto t_all = clk::now(), t_phase = t_all;
     if (n < 1 || !rp || !ci) return -1;
     S = Symbolic();
     S.n = n;
@@ -499,6 +499,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     int rc = build_graph(n, rp, ci, g);
     if (rc != 0) return rc;
 
+    S.seconds_phase[0] = since(t_phase), t_phase = clk::now();
     // ---- ordering --------------------------------------------------------------------------
     auto t_ord = clk::now();
     std::vector<int32_t> perm0((size_t)n), pinv0((size_t)n), leaf_of;
@@ -514,6 +515,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     }
     S.seconds_ordering = since(t_ord);
 
+    S.seconds_phase[1] = since(t_phase), t_phase = clk::now();
     // ---- etree, postorder, final permutation -------------------------------------------------
     Graph gp;
     permute_graph(g, perm0, pinv0, gp);
@@ -530,6 +532,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     permute_graph(g, S.perm, S.pinv, gp);
     { Graph().ptr.swap(g.ptr); std::vector<int32_t>().swap(g.adj); }
 
+    S.seconds_phase[2] = since(t_phase), t_phase = clk::now();
     // ---- column counts and supernodes --------------------------------------------------------
     std::vector<int64_t> cc;
     column_counts(gp, parent, cc);
@@ -642,6 +645,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             if (S.sn_parent[s] >= 0) S.child_idx[w[S.sn_parent[s]]++] = s;
     }
 
+    S.seconds_phase[3] = since(t_phase), t_phase = clk::now();
     // ---- row structure of every supernode ----------------------------------------------------
     S.sn_rowptr.assign((size_t)S.nsuper + 1, 0);
     S.sn_rows.clear();
@@ -698,6 +702,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         }
     }
 
+    S.seconds_phase[4] = since(t_phase), t_phase = clk::now();
     // ---- levels -----------------------------------------------------------------------------
     S.sn_level.assign((size_t)S.nsuper, 0);
     for (int32_t s = 0; s < S.nsuper; s++) {
@@ -737,6 +742,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         S.max_pivots = std::max<int32_t>(S.max_pivots, (int32_t)p);
     }
 
+    S.seconds_phase[5] = since(t_phase), t_phase = clk::now();
     // ---- assembly map: where every input entry lands ------------------------------------------
     S.amap.assign((size_t)S.nnz_a, -1);
     if (sym_lower) S.amap2.assign((size_t)S.nnz_a, -1);
@@ -759,6 +765,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             S.amap[p] = S.front_off[s] + li + lj * f;
             if (sym_lower && i != j) S.amap2[p] = S.front_off[s] + lj + li * f;
         }
+    S.seconds_phase[6] = since(t_phase);
     S.seconds_total = since(t_all);
     return 0;
 }

@@ -64,6 +64,9 @@ struct Symbolic {
     int32_t max_front = 0;
     int32_t max_pivots = 0;
     double seconds_ordering = 0.0, seconds_total = 0.0;
+    // host phases of analyse(): graph, ordering, etree + postorder, column counts + supernodes, row structures + relative indices,
+    // levels + layout, assembly map
+    double seconds_phase[7] = {0, 0, 0, 0, 0, 0, 0};
 
     inline int32_t npiv(int32_t s) const { return sn_first[s + 1] - sn_first[s]; }
     inline int32_t nrow(int32_t s) const { return (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]); }
