@@ -18,6 +18,25 @@ namespace {
 using clk = std::chrono::steady_clock;
 static double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
 
+// fn(begin, end) over [0, n) in contiguous chunks on up to `threads` host threads (index-independent work only: the result
+// does not depend on the number of threads)
+template <typename Fn> static void parallel_ranges(int32_t n, int threads, Fn fn) {
+    threads = std::max(1, std::min(threads, n / 65536));
+    if (threads <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) {
+        const int32_t b = (int32_t)((int64_t)n * t / threads), e = (int32_t)((int64_t)n * (t + 1) / threads);
+        pool.emplace_back([=]() { fn(b, e); });
+    }
+    for (auto &th : pool) th.join();
+}
+static int host_threads(const SymbolicOptions &opt) {
+    return opt.nd_threads > 0 ? opt.nd_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
 struct Graph {
     int32_t n = 0;
     std::vector<int64_t> ptr;
@@ -25,7 +44,7 @@ struct Graph {
 };
 
 // pattern of A + A^T without the diagonal; adjacency lists ascending and duplicate-free
-static int build_graph(int32_t n, const int32_t *rp, const int32_t *ci, Graph &g) {
+static int build_graph(int32_t n, const int32_t *rp, const int32_t *ci, Graph &g, int threads) {
     g.n = n;
     std::vector<int64_t> cnt((size_t)n + 1, 0);
     for (int32_t i = 0; i < n; i++) {
@@ -50,31 +69,37 @@ static int build_graph(int32_t n, const int32_t *rp, const int32_t *ci, Graph &g
                 raw[w[j]++] = i;
             }
         }
+    // sort + dedupe every list in place, then compact
     g.ptr.assign((size_t)n + 1, 0);
-    g.adj.clear();
-    g.adj.reserve(raw.size() / 2 + 16);
-    for (int32_t i = 0; i < n; i++) {
-        auto b = raw.begin() + cnt[i], e = raw.begin() + cnt[i + 1];
-        std::sort(b, e);
-        auto u = std::unique(b, e);
-        g.adj.insert(g.adj.end(), b, u);
-        g.ptr[i + 1] = (int64_t)g.adj.size();
-    }
+    parallel_ranges(n, threads, [&](int32_t i0, int32_t i1) {
+        for (int32_t i = i0; i < i1; i++) {
+            auto b = raw.begin() + cnt[i], e = raw.begin() + cnt[i + 1];
+            std::sort(b, e);
+            g.ptr[i + 1] = (int64_t)(std::unique(b, e) - b);
+        }
+    });
+    for (int32_t i = 0; i < n; i++) g.ptr[i + 1] += g.ptr[i];
+    g.adj.resize((size_t)g.ptr[n]);
+    parallel_ranges(n, threads, [&](int32_t i0, int32_t i1) {
+        for (int32_t i = i0; i < i1; i++) std::copy(raw.begin() + cnt[i], raw.begin() + cnt[i] + (g.ptr[i + 1] - g.ptr[i]), g.adj.begin() + g.ptr[i]);
+    });
     return 0;
 }
 
-static void permute_graph(const Graph &g, const std::vector<int32_t> &perm, const std::vector<int32_t> &pinv, Graph &out) {
+static void permute_graph(const Graph &g, const std::vector<int32_t> &perm, const std::vector<int32_t> &pinv, Graph &out, int threads) {
     int32_t n = g.n;
     out.n = n;
     out.ptr.assign((size_t)n + 1, 0);
     out.adj.resize(g.adj.size());
     for (int32_t k = 0; k < n; k++) out.ptr[k + 1] = out.ptr[k] + (g.ptr[perm[k] + 1] - g.ptr[perm[k]]);
-    for (int32_t k = 0; k < n; k++) {
-        int32_t v = perm[k];
-        int64_t o = out.ptr[k];
-        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) out.adj[o++] = pinv[g.adj[p]];
-        std::sort(out.adj.begin() + out.ptr[k], out.adj.begin() + o);
-    }
+    parallel_ranges(n, threads, [&](int32_t k0, int32_t k1) {
+        for (int32_t k = k0; k < k1; k++) {
+            int32_t v = perm[k];
+            int64_t o = out.ptr[k];
+            for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) out.adj[o++] = pinv[g.adj[p]];
+            std::sort(out.adj.begin() + out.ptr[k], out.adj.begin() + o);
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,7 +367,7 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
     w.stamp.assign((size_t)n, 0);
     const int32_t leaf = std::min<int32_t>(64, std::max<int32_t>(1, opt.nd_leaf));
 
-    int nthreads = opt.nd_threads > 0 ? opt.nd_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int nthreads = host_threads(opt);
     if (n < 20000) nthreads = 1;
     // shared LIFO of regions; a region below `serial_size` vertices is finished by the thread that took it
     const int32_t serial_size = std::max<int32_t>(2048, n / (64 * nthreads));
@@ -496,7 +521,8 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.sym_lower = sym_lower;
 
     Graph g;
-    int rc = build_graph(n, rp, ci, g);
+    const int threads = host_threads(opt);
+    int rc = build_graph(n, rp, ci, g, threads);
     if (rc != 0) return rc;
 
     S.seconds_phase[0] = since(t_phase), t_phase = clk::now();
@@ -518,7 +544,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.seconds_phase[1] = since(t_phase), t_phase = clk::now();
     // ---- etree, postorder, final permutation -------------------------------------------------
     Graph gp;
-    permute_graph(g, perm0, pinv0, gp);
+    permute_graph(g, perm0, pinv0, gp, threads);
     std::vector<int32_t> parent0, post;
     etree(gp, parent0);
     postorder(parent0, post);
@@ -529,7 +555,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     std::vector<int32_t> postinv((size_t)n), parent((size_t)n);
     for (int32_t k = 0; k < n; k++) postinv[post[k]] = k;
     for (int32_t k = 0; k < n; k++) parent[k] = parent0[post[k]] < 0 ? -1 : postinv[parent0[post[k]]];
-    permute_graph(g, S.perm, S.pinv, gp);
+    permute_graph(g, S.perm, S.pinv, gp, threads);
     { Graph().ptr.swap(g.ptr); std::vector<int32_t>().swap(g.adj); }
 
     S.seconds_phase[2] = since(t_phase), t_phase = clk::now();
@@ -754,17 +780,27 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         if (it == e || *it != i) return -1;
         return (int64_t)S.npiv(s) + (it - b);
     };
-    for (int32_t r = 0; r < n; r++)
-        for (int32_t p = rp[r]; p < rp[r + 1]; p++) {
-            int32_t i = S.pinv[r], j = S.pinv[ci[p]];
-            if (sym_lower && ci[p] > r) return -30; // lower storage promised
-            int32_t s = S.sn_of[std::min(i, j)];
-            int64_t f = S.front_ld[s];
-            int64_t li = local(s, i), lj = local(s, j);
-            if (li < 0 || lj < 0) return -31;
-            S.amap[p] = S.front_off[s] + li + lj * f;
-            if (sym_lower && i != j) S.amap2[p] = S.front_off[s] + lj + li * f;
-        }
+    std::atomic<int> amap_err{0};
+    parallel_ranges(n, threads, [&](int32_t r0, int32_t r1) {
+        for (int32_t r = r0; r < r1; r++)
+            for (int32_t p = rp[r]; p < rp[r + 1]; p++) {
+                int32_t i = S.pinv[r], j = S.pinv[ci[p]];
+                if (sym_lower && ci[p] > r) { // lower storage promised
+                    amap_err.store(-30);
+                    return;
+                }
+                int32_t s = S.sn_of[std::min(i, j)];
+                int64_t f = S.front_ld[s];
+                int64_t li = local(s, i), lj = local(s, j);
+                if (li < 0 || lj < 0) {
+                    amap_err.store(-31);
+                    return;
+                }
+                S.amap[p] = S.front_off[s] + li + lj * f;
+                if (sym_lower && i != j) S.amap2[p] = S.front_off[s] + lj + li * f;
+            }
+    });
+    if (amap_err.load() != 0) return amap_err.load();
     S.seconds_phase[6] = since(t_phase);
     S.seconds_total = since(t_all);
     return 0;
