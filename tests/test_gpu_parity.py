@@ -417,3 +417,19 @@ def test_factor_buffers_wrap_as_device_tensors_and_adopt():
     assert np.array_equal(x0, x1) and np.max(np.abs(x0 - xs)) < 1e-11
     src.close()
     dst.close()
+
+
+@pytest.mark.gpu
+def test_device_probes_report_plausible_ceilings():
+    # the two live ceilings bench.py prints beside the spec peaks: device-to-device copy rate and FP64 MFMA rate
+    import ctypes
+
+    from russell_amd import _capi
+
+    lib = _capi.load()
+    gbs, tfs = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    assert lib.hipmf_device_copy_bandwidth(1 << 28, 2, ctypes.byref(gbs)) == 0
+    assert lib.hipmf_device_mfma_rate(512, 1000, ctypes.byref(tfs)) == 0
+    assert 500.0 < gbs.value < 8000.0   # GB/s: below the 8 TB/s spec, far above PCIe
+    assert 5.0 < tfs.value < 78.6       # TFLOP/s: below the data-sheet FP64 matrix peak
+    assert lib.hipmf_device_mfma_rate(0, 10, ctypes.byref(tfs)) != 0  # invalid arguments are refused
