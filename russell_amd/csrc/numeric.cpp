@@ -155,7 +155,19 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
             fprintf(stderr, "hipmf: initialize: the matrix has no perfect matching (structurally singular); continuing without\n");
         }
     }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) so.pool_limit_bytes = 0.95 * (double)free_b;
+        if (const char *e = getenv("HIPMF_POOL_LIMIT_GB")) so.pool_limit_bytes = 0.95e9 * atof(e); // (tests: force the refusal)
+    }
     int rc = matched ? analyse(n, rpB.data(), ciB.data(), false, so, S) : analyse(n, rp, ci, sym_lower, so, S);
+    if (rc == -40) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free)", S.pool_estimate_bytes / 1e9,
+                 so.pool_limit_bytes / 0.95 / 1e9);
+        last_error = msg;
+        return ERROR_HIP_MALLOC;
+    }
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
         return rc <= -30 || rc >= -2 ? ERROR_HIPMF_INVALID_MATRIX : ERROR_HIPMF_SYMBOLIC;

@@ -651,6 +651,21 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     }
     S.nsuper = (int32_t)S.sn_first.size();
     S.sn_first.push_back(n);
+    // Memory guard BEFORE the row structures are built: the column counts already tell how large the fronts will be.  A graph
+    // without small separators (random sparse matrices) would otherwise ask the host for hundreds of GB of row indices and the
+    // device for a pool it does not have; the caller gets the out-of-memory status instead (analyse returns -40).
+    if (!single_front) {
+        double rows_total = 0.0, pool_total = 0.0;
+        for (int32_t s = 0; s < S.nsuper; s++) {
+            const double p = (double)(S.sn_first[s + 1] - S.sn_first[s]);
+            const double m = std::max((double)cc[S.sn_first[s + 1] - 1] - 1.0, (double)cc[S.sn_first[s]] - p);
+            const double f = p + m, ld = f > (double)opt.augment_above ? f + p : f;
+            rows_total += m;
+            pool_total += ld * ld;
+        }
+        S.pool_estimate_bytes = 8.0 * pool_total;
+        if (rows_total > 1.0e9 || (opt.pool_limit_bytes > 0.0 && 8.0 * pool_total > opt.pool_limit_bytes)) return -40;
+    }
     S.sn_of.resize((size_t)n);
     for (int32_t s = 0; s < S.nsuper; s++)
         for (int32_t j = S.sn_first[s]; j < S.sn_first[s + 1]; j++) S.sn_of[j] = s;

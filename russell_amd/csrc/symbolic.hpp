@@ -25,6 +25,7 @@ struct SymbolicOptions {
     int32_t nd_threads = 0;       // host threads of the nested dissection (0: min(16, hardware threads)); the result does not depend on it
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
     int32_t split_pivots = 4096;  // supernodes with more pivots are split into a chain of supernodes (0: never); see symbolic.cpp
+    double pool_limit_bytes = 0.0; // analyse gives up (-40) when the fronts would need more than this (0: no limit)
     int32_t augment_above = 64;   // fronts with f > this are stored augmented (must equal kernels.hpp SMALL_F)
     int32_t relax_ncol[3] = {4, 16, 48};
     double relax_zeros[3] = {0.8, 0.1, 0.05};
@@ -64,6 +65,7 @@ struct Symbolic {
     int32_t max_front = 0;
     int32_t max_pivots = 0;
     double seconds_ordering = 0.0, seconds_total = 0.0;
+    double pool_estimate_bytes = 0.0; // from the column counts, before the row structures exist
     // host phases of analyse(): graph, ordering, etree + postorder, column counts + supernodes, row structures + relative indices,
     // levels + layout, assembly map
     double seconds_phase[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -132,3 +132,33 @@ def test_harness_errors(emu_lib, tmp_path):
     assert rc == 0 and out == ""
     rc, out, err = run(emu_lib, "-h", "1.5", os.path.join(MTX, "ok_general.mtx"))
     assert rc == 1 and "hybrid memory factor must be in [0.01, 0.99]" in err
+
+
+def test_out_of_memory_is_refused_before_any_allocation(emu_lib, tmp_path):
+    # a matrix without small separators (random sparse graph): the analysis sees from the column counts that the fronts cannot fit
+    # and returns the out-of-memory status instead of asking the host for the row structures; the harness then prints the JSON
+    # with main.out_of_memory = true and exits 0 (solve_matrix_market.rs:181-190, stats_lin_sol.rs:334-340)
+    import scipy.sparse as sp
+
+    from russell_amd.backend import Hipmf
+
+    n = 30000
+    rng = np.random.default_rng(6)
+    R = sp.coo_matrix((rng.random(4 * n), (rng.integers(0, n, 4 * n), rng.integers(0, n, 4 * n))), shape=(n, n)).tocsr()
+    R = (R + R.T + sp.diags(np.asarray(abs(R + R.T).sum(axis=1)).ravel() + 1.0)).tocsr()
+    R.sort_indices()
+    s = Hipmf(emu_lib)
+    code = s.initialize(n, R.indptr.astype(np.int32), R.indices.astype(np.int32))
+    assert code == 100  # ERROR_HIP_MALLOC
+    assert "Not enough memory" in str(s._err(code, "initialize")) and is_memory_error(str(s._err(code, "initialize")))
+    s.close()
+    coo = R.tocoo()
+    path = tmp_path / "random.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write("%d %d %d\n" % (n, n, coo.nnz))
+        np.savetxt(f, np.column_stack([coo.row + 1, coo.col + 1, coo.data]), fmt="%d %d %.17g")
+    rc, out, err = run(emu_lib, str(path))
+    assert rc == 0, err
+    d = json.loads(out)
+    assert d["main"]["out_of_memory"] is True and d["matrix"]["nrow"] == n

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Robustness on shapes the benchmark matrices do not have: a 1M tridiagonal chain, a 100k arrow (dense row + column), 1000
+disconnected grids, a small random sparse matrix without good separators, and a larger one whose fronts cannot fit the GPU (the
+analysis must refuse it from the column counts, before any large allocation on the host or the device)."""
+import os, sys, time
+import numpy as np
+import scipy.sparse as sp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from russell_amd.backend import Hipmf
+
+
+def run(name, A, expect_ok=True):
+    A = A.tocsr(); A.sort_indices()
+    n = A.shape[0]
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    xs = 1.0 + (np.arange(n) % 7) / 7.0
+    b = A @ xs
+    s = Hipmf()
+    t0 = time.perf_counter(); code = s.initialize(n, rp, ci, values=v); t1 = time.perf_counter()
+    if code != 0:
+        print("%-28s n=%d: initialize refused with code %d (%s) after %.2f s" % (name, n, code, s._err(code, "initialize"), t1 - t0))
+        assert not expect_ok
+        s.close(); return
+    st = s.stats()
+    code = s.factorize(v); t2 = time.perf_counter()
+    assert code == 0, code
+    x = s.solve(b); t3 = time.perf_counter()
+    r = A @ x - b
+    print("%-28s n=%d nnz=%d: %d supernodes, %d levels, max front %d, pool %.2f GB | initialize %.2f s, factorize %.1f ms, solve %.1f ms | "
+          "relative_error %.1e, max|x-x*| %.1e" % (name, n, A.nnz, st["nsuper"], st["nlevels"], st["max_front"], st["pool_bytes"] / 1e9, t1 - t0,
+                                                    (t2 - t1) * 1e3, (t3 - t2) * 1e3, np.max(np.abs(r)) / (np.max(np.abs(v)) + 1.0), np.max(np.abs(x - xs))))
+    s.close()
+
+
+rng = np.random.default_rng(3)
+n = 1_000_000
+run("tridiagonal chain", sp.diags([-np.ones(n - 1), 2.5 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]))
+n = 100_000
+arrow = sp.lil_matrix((n, n)); arrow.setdiag(4.0 + rng.random(n)); arrow[0, 1:] = 1e-3; arrow[1:, 0] = 2e-3
+run("arrow (dense row + column)", arrow)
+T = lambda k: sp.diags([-1, 2, -1], [-1, 0, 1], shape=(k, k))
+g = sp.kron(sp.identity(20), T(20)) + sp.kron(T(20), sp.identity(20))
+run("1000 disconnected 20x20 grids", sp.block_diag([g] * 1000))
+def random_sym(n, per_row, seed):
+    # (scipy.sparse.random samples without replacement from n^2 positions: minutes of time and tens of GB for n ~ 10^5; this is cheap)
+    r = np.random.default_rng(seed)
+    k = per_row * n
+    R = sp.coo_matrix((r.random(k), (r.integers(0, n, k), r.integers(0, n, k))), shape=(n, n)).tocsr()
+    return R + R.T + sp.diags(np.asarray(abs(R + R.T).sum(axis=1)).ravel() + 1.0)
+
+
+run("random sparse (no separators)", random_sym(6_000, 3, 5))
+run("random sparse, too large", random_sym(150_000, 4, 6), expect_ok=False)
