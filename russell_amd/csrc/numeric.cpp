@@ -130,6 +130,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     if (const char *e = getenv("HIPMF_UPD_G8")) upd_g8 = std::max(upd_g4, atoi(e));
     if (const char *e = getenv("HIPMF_UPD_G16")) upd_g16 = std::max(upd_g8, atoi(e));
     if (const char *e = getenv("HIPMF_SPLIT_PIVOTS")) so.split_pivots = std::max(0, atoi(e)); // tuning knob: chain links of the big supernodes
+    if (const char *e = getenv("HIPMF_DENSE_ROWS")) so.dense_row_factor = atof(e); // degree threshold factor of the hub vertices (0: off)
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;

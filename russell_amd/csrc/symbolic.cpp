@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -361,8 +362,34 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
     NDShared w(g);
     w.part.reset(new std::atomic<int32_t>[(size_t)n]);
     for (int32_t v = 0; v < n; v++) w.part[v].store(0, std::memory_order_relaxed);
-    w.verts.resize((size_t)n);
-    std::iota(w.verts.begin(), w.verts.end(), 0);
+    // Dense rows / columns (hub vertices: the supply nets of circuit matrices, Lagrange multipliers tied to many unknowns) are
+    // taken out first and numbered last, as AMD / COLAMD do: left inside, one hub makes every breadth-first level structure three
+    // levels deep with its whole neighbourhood as the "separator".  Threshold: degree > max(32, min(10 sqrt(n), 40 x the average
+    // degree)) -- AMD's rule, tightened for graphs whose ordinary vertices have few neighbours (meshes: the largest degree of a
+    // finite-element or stencil graph stays within a small multiple of the average).
+    const double avg_deg = n > 0 ? (double)g.ptr[n] / (double)n : 0.0;
+    const int64_t dense_deg =
+        std::max<int64_t>(32, (int64_t)std::min(opt.dense_row_factor * std::sqrt((double)n), 4.0 * opt.dense_row_factor * std::max(avg_deg, 1.0)));
+    int32_t ndense = 0;
+    w.verts.clear();
+    w.verts.reserve((size_t)n);
+    for (int32_t v = 0; v < n; v++) {
+        if (opt.dense_row_factor > 0.0 && g.ptr[v + 1] - g.ptr[v] > dense_deg) ndense++;
+        else w.verts.push_back(v);
+    }
+    if (ndense > 0 && ndense < n) {
+        int32_t k = n - ndense;
+        for (int32_t v = 0; v < n; v++)
+            if (g.ptr[v + 1] - g.ptr[v] > dense_deg) {
+                perm[k++] = v; // ascending vertex order
+                w.set_region(v, -1);
+            }
+    } else if (ndense == n) { // (everything is "dense": a small full matrix; nothing to take out)
+        w.verts.resize((size_t)n);
+        std::iota(w.verts.begin(), w.verts.end(), 0);
+        ndense = 0;
+    }
+    const int32_t nsparse = n - ndense;
     w.lev.assign((size_t)n, 0);
     w.stamp.assign((size_t)n, 0);
     const int32_t leaf = std::min<int32_t>(64, std::max<int32_t>(1, opt.nd_leaf));
@@ -375,7 +402,7 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
     std::condition_variable cv;
     std::vector<NDRegion> shared;
     int busy = 0;
-    shared.push_back({0, n, 0, 0, false});
+    shared.push_back({0, nsparse, 0, 0, false});
     auto worker = [&]() {
         NDScratch t;
         std::vector<NDRegion> local, out;

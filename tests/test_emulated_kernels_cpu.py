@@ -107,3 +107,36 @@ def test_emulated_grouped_updates_and_chain_split(emu_lib, monkeypatch):
         s.close()
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_emulated_hub_vertices_are_ordered_last(emu_lib, monkeypatch):
+    # a grid plus hub rows / columns tied to a third of the unknowns (supply nets of circuit matrices): the hubs are taken out of the
+    # dissection and numbered last -- without that every level structure collapses to three levels and the fronts explode
+    import scipy.sparse as sp
+
+    n0, rp, ci, v = P.poisson2d(40)
+    rng = np.random.default_rng(1)
+    n = n0 + 2
+    B = sp.lil_matrix((n, n))
+    B[:n0, :n0] = sp.csr_matrix((v, ci, rp), shape=(n0, n0))
+    for h in range(2):
+        idx = rng.choice(n0, n0 // 3, replace=False)  # degree 533 > max(32, 10 sqrt(n)) = 400
+        B[n0 + h, idx] = 0.01
+        B[idx, n0 + h] = 0.02
+        B[n0 + h, n0 + h] = 5.0
+    B = B.tocsr()
+    B.sort_indices()
+    rp2, ci2, v2 = B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.astype(np.float64)
+    xs = P.manufactured_solution(n)
+    b = B @ xs
+    s, code, x, st = _solve(emu_lib, n, rp2, ci2, v2, b)
+    assert code == 0 and np.max(np.abs(x - xs)) < 1e-11
+    perm = s.permutation()
+    assert sorted(perm[-2:].tolist()) == [n0, n0 + 1]  # the hubs come last
+    flops_deferred = st["flops"]
+    s.close()
+    monkeypatch.setenv("HIPMF_DENSE_ROWS", "0")
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp2, ci2) == 0
+    assert s.stats()["flops"] > 20 * flops_deferred  # what the deferral saves
+    s.close()

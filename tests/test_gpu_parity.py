@@ -388,35 +388,52 @@ def test_grouped_updates_and_chain_split_match_the_oracle(monkeypatch):
             monkeypatch.delenv(k)
 
 
+_ADOPT_SCRIPT = r"""
+import sys
+import numpy as np
+import torch  # first: torch's HIP runtime initialises before the solver library touches the device
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+from russell_amd.distributed import _as_tensor
+
+n, rp, ci, v = P.poisson2d(70, 64)
+xs = P.manufactured_solution(n)
+b = P.csr_matvec(n, rp, ci, v, xs)
+src, dst = Hipmf(), Hipmf()
+assert src.initialize(n, rp, ci) == 0 and dst.initialize(n, rp, ci) == 0
+assert src.factorize(v) == 0
+dev = torch.device("cuda", 0)
+for (ps, ns), (pd, nd) in zip(src.factor_buffers(), dst.factor_buffers()):
+    assert ns == nd and ns > 0
+    ts, td = _as_tensor(ps, ns, dev), _as_tensor(pd, nd, dev)
+    assert ts.data_ptr() == ps and ts.numel() == ns and ts.dtype == torch.uint8
+    td.copy_(ts)
+torch.cuda.synchronize()
+d_v = dst.dev_alloc(v.nbytes)
+dst.h2d(d_v, v)
+assert dst.adopt_factor(d_v) == 0
+x0, x1 = src.solve(b), dst.solve(b)
+assert np.array_equal(x0, x1) and np.max(np.abs(x0 - xs)) < 1e-11
+src.close()
+dst.close()
+print("ADOPT-OK")
+"""
+
+
 @pytest.mark.gpu
 def test_factor_buffers_wrap_as_device_tensors_and_adopt():
     # the pieces of the multi-GPU factor broadcast that need a device but no second rank: the solver's factor buffers seen as torch
     # tensors without a copy (russell_amd.distributed._as_tensor), a device-to-device copy into a second handle, adopt_factor, and
-    # bit-identical solutions from the adopted factor
-    import torch
+    # bit-identical solutions from the adopted factor.  In its own process, torch first, as the torchrun drivers do (two HIP
+    # runtimes in one process -- torch's and the solver library's -- must come up in that order).
+    import subprocess
+    import sys
 
-    from russell_amd.distributed import _as_tensor
-
-    n, rp, ci, v = P.poisson2d(70, 64)
-    xs = P.manufactured_solution(n)
-    b = P.csr_matvec(n, rp, ci, v, xs)
-    src, dst = Hipmf(), Hipmf()
-    assert src.initialize(n, rp, ci) == 0 and dst.initialize(n, rp, ci) == 0
-    assert src.factorize(v) == 0
-    dev = torch.device("cuda", 0)
-    for (ps, ns), (pd, nd) in zip(src.factor_buffers(), dst.factor_buffers()):
-        assert ns == nd and ns > 0
-        ts, td = _as_tensor(ps, ns, dev), _as_tensor(pd, nd, dev)
-        assert ts.data_ptr() == ps and ts.numel() == ns and ts.dtype == torch.uint8
-        td.copy_(ts)
-    torch.cuda.synchronize()
-    d_v = dst.dev_alloc(v.nbytes)
-    dst.h2d(d_v, v)
-    assert dst.adopt_factor(d_v) == 0
-    x0, x1 = src.solve(b), dst.solve(b)
-    assert np.array_equal(x0, x1) and np.max(np.abs(x0 - xs)) < 1e-11
-    src.close()
-    dst.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _ADOPT_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ADOPT-OK" in p.stdout, p.stderr[-2000:]
 
 
 @pytest.mark.gpu
