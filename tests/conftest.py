@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_pieces_are_built():
+    """The tests load in-tree native libraries; build them first when a fresh checkout has none (no-op otherwise)."""
+    lib = os.path.join(ROOT, "russell_amd", "lib")
+    needed = [os.path.join(lib, f) for f in ("librussell_hipmf.so", "librussell_host.so", "solve_matrix_market")]
+    if not all(os.path.exists(f) for f in needed):
+        import __graft_entry__
+
+        __graft_entry__.build()
+
+
 EMU = os.path.join(ROOT, "tests", "emu", "libhipmf_emu.so")
 CSRC = os.path.join(ROOT, "russell_amd", "csrc")
 
