@@ -39,6 +39,9 @@ const char *rh_coo_mat_vec_mul(void *coo, double *v, int64_t nv, double alpha, c
 
 /* coo_matrix.rs:629 (v += alpha A u), :708 (v = alpha A^T u), :738 assign, :779 add, :823 put_lagrange_block, :468 to_dense
  * (row-major nrow x ncol), :872 get_actual_nnz */
+/* coo_matrix.rs:246-291 (NumCooMatrix::from): a COO matrix from ready triplet arrays (copied) */
+void *rh_coo_from(int64_t nrow, int64_t ncol, int64_t nnz, const int32_t *row_indices, const int32_t *col_indices, const double *values, int32_t sym,
+                  const char **err);
 const char *rh_coo_mat_vec_mul_update(void *coo, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
 const char *rh_coo_mat_t_vec_mul(void *coo, double *v, int64_t nv, double alpha, const double *u, int64_t nu);
 const char *rh_coo_assign(void *coo, double alpha, void *other);

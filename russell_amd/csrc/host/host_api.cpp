@@ -98,6 +98,24 @@ StrError CooMatrix::mat_vec_mul(std::vector<double> &v, double alpha, const std:
     return nullptr;
 }
 
+StrError CooMatrix::from(CooMatrix &out, size_t nrow, size_t ncol, std::vector<int32_t> row_indices, std::vector<int32_t> col_indices,
+                         std::vector<double> values, Sym symmetric) {
+    if (nrow < 1) return "nrow must be ≥ 1";
+    if (ncol < 1) return "ncol must be ≥ 1";
+    const size_t nnz = row_indices.size();
+    if (nnz < 1) return "nnz must be ≥ 1";
+    if (col_indices.size() != nnz) return "col_indices.len() must be = nnz";
+    if (values.size() != nnz) return "values.len() must be = nnz";
+    for (size_t k = 0; k < nnz; k++) {
+        if (row_indices[k] < 0 || (size_t)row_indices[k] >= nrow) return "row index is out-of-range";
+        if (col_indices[k] < 0 || (size_t)col_indices[k] >= ncol) return "col index is out-of-range";
+    }
+    out.symmetric = symmetric;
+    out.nrow = nrow, out.ncol = ncol, out.nnz = nnz, out.max_nnz = nnz;
+    out.indices_i = std::move(row_indices), out.indices_j = std::move(col_indices), out.values = std::move(values);
+    return nullptr;
+}
+
 StrError CooMatrix::mat_vec_mul_update(std::vector<double> &v, double alpha, const std::vector<double> &u) const {
     if (u.size() < ncol) return "u.dim() must be ≥ the number of columns of the matrix";
     if (v.size() < nrow) return "v.dim() must be ≥ the number of rows of the matrix";
@@ -1172,6 +1190,18 @@ const char *rh_coo_mat_vec_mul(void *h, double *v, int64_t nv, double alpha, con
     return e;
 }
 
+void *rh_coo_from(int64_t nrow, int64_t ncol, int64_t nnz, const int32_t *row_indices, const int32_t *col_indices, const double *values, int32_t sym,
+                  const char **err) {
+    CooMatrix *c = new CooMatrix();
+    const size_t k = (size_t)std::max<int64_t>(nnz, 0);
+    *err = CooMatrix::from(*c, (size_t)std::max<int64_t>(nrow, 0), (size_t)std::max<int64_t>(ncol, 0), std::vector<int32_t>(row_indices, row_indices + k),
+                           std::vector<int32_t>(col_indices, col_indices + k), std::vector<double>(values, values + k), (Sym)sym);
+    if (*err) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
 const char *rh_coo_mat_vec_mul_update(void *h, double *v, int64_t nv, double alpha, const double *u, int64_t nu) {
     std::vector<double> vv(v, v + nv), uu(u, u + nu);
     StrError e = ((CooMatrix *)h)->mat_vec_mul_update(vv, alpha, uu);

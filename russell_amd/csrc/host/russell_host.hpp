@@ -52,6 +52,9 @@ struct CooMatrix {
     std::vector<int32_t> indices_i, indices_j;
     std::vector<double> values;
     static StrError create(CooMatrix &out, size_t nrow, size_t ncol, size_t max_nnz, Sym symmetric);
+    // coo_matrix.rs:246-291 (NumCooMatrix::from): adopt ready triplet arrays (nnz = max_nnz = their length)
+    static StrError from(CooMatrix &out, size_t nrow, size_t ncol, std::vector<int32_t> row_indices, std::vector<int32_t> col_indices,
+                         std::vector<double> values, Sym symmetric);
     StrError put(size_t i, size_t j, double aij);
     void reset() { nnz = 0; }
     StrError mat_vec_mul(std::vector<double> &v, double alpha, const std::vector<double> &u) const;

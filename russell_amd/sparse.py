@@ -126,6 +126,7 @@ def _L():
         "rh_coo_info": (None, [vp, pp(i64), pp(i64), pp(i64), pp(i64), pp(i32)]),
         "rh_coo_arrays": (None, [vp, pp(pp(i32)), pp(pp(i32)), pp(pp(f64))]),
         "rh_coo_mat_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
+        "rh_coo_from": (vp, [i64, i64, i64, vp, vp, vp, i32, pp(cp)]),
         "rh_coo_mat_vec_mul_update": (cp, [vp, vp, i64, f64, vp, i64]),
         "rh_coo_mat_t_vec_mul": (cp, [vp, vp, i64, f64, vp, i64]),
         "rh_coo_assign": (cp, [vp, f64, vp]),
@@ -211,6 +212,20 @@ class CooMatrix:
         if getattr(self, "_h", None) and _lib is not None:
             _lib.rh_coo_free(self._h)
             self._h = None
+
+    @classmethod
+    def from_arrays(cls, nrow, ncol, row_indices, col_indices, values, symmetric=Sym.No):
+        """coo_matrix.rs:246-291 (`CooMatrix::from`): the triplet arrays as given (nnz = max_nnz = their length)."""
+        ii, jj = np.ascontiguousarray(row_indices, dtype=np.int32), np.ascontiguousarray(col_indices, dtype=np.int32)
+        aa = np.ascontiguousarray(values, dtype=np.float64)
+        if jj.size != ii.size:
+            raise StrError("col_indices.len() must be = nnz")
+        if aa.size != ii.size:
+            raise StrError("values.len() must be = nnz")
+        err = C.c_char_p()
+        h = _L().rh_coo_from(int(nrow), int(ncol), ii.size, _ptr(ii), _ptr(jj), _ptr(aa), int(symmetric), C.byref(err))
+        _check(err.value)
+        return cls(0, 0, 0, _handle=h)
 
     def put(self, i, j, aij):
         _check(_L().rh_coo_put(self._h, int(i), int(j), float(aij)))

@@ -231,3 +231,18 @@ def test_coo_put_lagrange_block():
         CooMatrix(3, 3, 6, Sym.No).put_lagrange_block(CooMatrix(1, 1, 1, Sym.YesLower))
     with pytest.raises(StrError, match="ncol\\(B\\) \\+ nrow\\(B\\) must be ≤ nrow\\(A\\)"):
         CooMatrix(2, 2, 6, Sym.No).put_lagrange_block(bb)
+
+
+def test_coo_from_arrays():
+    # coo_matrix.rs:246-291 and its tests (:990-1030): validation strings, nnz = max_nnz = len
+    coo = CooMatrix.from_arrays(3, 3, [0, 1, 2, 0], [0, 1, 2, 0], [1.0, 2.0, 3.0, 0.5])
+    assert coo.get_info() == (3, 3, 4, Sym.No)
+    assert coo.to_dense().tolist() == [[1.5, 0, 0], [0, 2.0, 0], [0, 0, 3.0]]
+    with pytest.raises(StrError, match="COO matrix: max number of items has been reached"):
+        coo.put(1, 0, 1.0)
+    for args, msg in [((0, 3, [0], [0], [1.0]), "nrow must be ≥ 1"), ((3, 0, [0], [0], [1.0]), "ncol must be ≥ 1"),
+                      ((3, 3, [], [], []), "nnz must be ≥ 1"), ((3, 3, [0, 1], [0], [1.0, 2.0]), "col_indices.len\\(\\) must be = nnz"),
+                      ((3, 3, [0, 1], [0, 1], [1.0]), "values.len\\(\\) must be = nnz"), ((3, 3, [3], [0], [1.0]), "row index is out-of-range"),
+                      ((3, 3, [0], [-1], [1.0]), "col index is out-of-range")]:
+        with pytest.raises(StrError, match=msg):
+            CooMatrix.from_arrays(*args)
