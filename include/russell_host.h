@@ -49,6 +49,14 @@ const char *rh_coo_add(void *coo, double alpha, void *other);
 const char *rh_coo_put_lagrange_block(void *coo, void *bb);
 const char *rh_coo_to_dense(void *coo, double *a_row_major, int64_t len);
 int64_t rh_coo_actual_nnz(void *coo);
+/* csc_matrix.rs:197-262 / csr_matrix.rs:193-257: validated constructors from ready arrays (np pointers, nv indices / values, copied);
+ * csc_matrix.rs:702 / csr_matrix.rs:676: dense row-major copies */
+void *rh_csc_new(int64_t nrow, int64_t ncol, const int32_t *col_pointers, int64_t np, const int32_t *row_indices, const double *values, int64_t nv,
+                 int32_t sym, const char **err);
+void *rh_csr_new(int64_t nrow, int64_t ncol, const int32_t *row_pointers, int64_t np, const int32_t *col_indices, const double *values, int64_t nv,
+                 int32_t sym, const char **err);
+const char *rh_csc_to_dense(void *csc, double *a_row_major, int64_t len);
+const char *rh_csr_to_dense(void *csr, double *a_row_major, int64_t len);
 /* csc_matrix.rs:508-584 / csr_matrix.rs:483-558 */
 void *rh_csc_from_csr(void *csr, const char **err);
 void *rh_csr_from_csc(void *csc, const char **err);

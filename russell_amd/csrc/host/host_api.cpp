@@ -198,6 +198,75 @@ size_t CooMatrix::get_actual_nnz() const {
     return actual;
 }
 
+// ---- validated constructors and dense copies of the compressed forms (csc_matrix.rs:197-262,702-729; csr_matrix.rs:193-257,676-703) --
+static StrError check_compressed(size_t nmajor, size_t nminor, size_t nrow, size_t ncol, const std::vector<int32_t> &ptr,
+                                 const std::vector<int32_t> &idx, const std::vector<double> &values, Sym symmetric, bool csc) {
+    if (nrow < 1) return "nrow must be ≥ 1";
+    if (ncol < 1) return "ncol must be ≥ 1";
+    if (ptr.size() != nmajor + 1) return csc ? "col_pointers.len() must be = ncol + 1" : "row_pointers.len() must be = nrow + 1";
+    const int32_t nnz = ptr[nmajor];
+    if (nnz < 1) return csc ? "nnz = col_pointers[ncol] must be ≥ 1" : "nnz = row_pointers[nrow] must be ≥ 1";
+    if (idx.size() < (size_t)nnz) return csc ? "row_indices.len() must be ≥ nnz" : "col_indices.len() must be ≥ nnz";
+    if (values.size() < (size_t)nnz) return "values.len() must be ≥ nnz";
+    if (symmetric != Sym::No && nrow != ncol) return "symmetric storage requires a square matrix";
+    for (size_t j = 0; j < nmajor; j++) {
+        if (ptr[j] < 0) return csc ? "col pointers must be ≥ 0" : "row pointers must be ≥ 0";
+        if (ptr[j] > ptr[j + 1]) return csc ? "col pointers must be sorted in ascending order" : "row pointers must be sorted in ascending order";
+        for (int32_t p = ptr[j]; p < ptr[j + 1]; p++) {
+            if (idx[(size_t)p] < 0) return csc ? "row indices must be ≥ 0" : "column indices must be ≥ 0";
+            if ((size_t)idx[(size_t)p] >= nminor) return csc ? "row indices must be < nrow" : "column indices must be < ncol";
+            if (p > ptr[j] && idx[(size_t)p - 1] > idx[(size_t)p])
+                return csc ? "row indices must be sorted in ascending order (within their column)"
+                           : "column indices must be sorted in ascending order (within their row)";
+        }
+    }
+    return nullptr;
+}
+
+StrError CscMatrix::create(CscMatrix &out, size_t nrow, size_t ncol, std::vector<int32_t> col_pointers, std::vector<int32_t> row_indices,
+                           std::vector<double> values, Sym symmetric) {
+    if (StrError e = check_compressed(ncol, nrow, nrow, ncol, col_pointers, row_indices, values, symmetric, true)) return e;
+    out = CscMatrix();
+    out.symmetric = symmetric, out.nrow = nrow, out.ncol = ncol;
+    out.col_pointers = std::move(col_pointers), out.row_indices = std::move(row_indices), out.values = std::move(values);
+    return nullptr;
+}
+
+StrError CsrMatrix::create(CsrMatrix &out, size_t nrow, size_t ncol, std::vector<int32_t> row_pointers, std::vector<int32_t> col_indices,
+                           std::vector<double> values, Sym symmetric) {
+    if (StrError e = check_compressed(nrow, ncol, nrow, ncol, row_pointers, col_indices, values, symmetric, false)) return e;
+    out = CsrMatrix();
+    out.symmetric = symmetric, out.nrow = nrow, out.ncol = ncol;
+    out.row_pointers = std::move(row_pointers), out.col_indices = std::move(col_indices), out.values = std::move(values);
+    return nullptr;
+}
+
+StrError CscMatrix::to_dense(std::vector<double> &a) const {
+    if (a.size() != nrow * ncol) return "wrong matrix dimensions";
+    std::fill(a.begin(), a.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t j = 0; j < ncol; j++)
+        for (int32_t p = col_pointers[j]; p < col_pointers[j + 1]; p++) {
+            const size_t i = (size_t)row_indices[(size_t)p];
+            a[i * ncol + j] += values[(size_t)p];
+            if (mirror && i != j) a[j * ncol + i] += values[(size_t)p];
+        }
+    return nullptr;
+}
+
+StrError CsrMatrix::to_dense(std::vector<double> &a) const {
+    if (a.size() != nrow * ncol) return "wrong matrix dimensions";
+    std::fill(a.begin(), a.end(), 0.0);
+    const bool mirror = triangular(symmetric);
+    for (size_t i = 0; i < nrow; i++)
+        for (int32_t p = row_pointers[i]; p < row_pointers[i + 1]; p++) {
+            const size_t j = (size_t)col_indices[(size_t)p];
+            a[i * ncol + j] += values[(size_t)p];
+            if (mirror && i != j) a[j * ncol + i] += values[(size_t)p];
+        }
+    return nullptr;
+}
+
 // ---- CSC <-> CSR (csc_matrix.rs:508-584, csr_matrix.rs:483-558): counting transposition, entries of a column (row) come out in
 // ascending row (column) order because the source is swept row by row (column by column) ----------------------------------
 StrError CscMatrix::from_csr(CscMatrix &out, const CsrMatrix &csr) {
@@ -1224,6 +1293,40 @@ const char *rh_coo_to_dense(void *h, double *a, int64_t len) {
     return e;
 }
 int64_t rh_coo_actual_nnz(void *h) { return (int64_t)((CooMatrix *)h)->get_actual_nnz(); }
+void *rh_csc_new(int64_t nrow, int64_t ncol, const int32_t *col_pointers, int64_t np, const int32_t *row_indices, const double *values, int64_t nv,
+                 int32_t sym, const char **err) {
+    CscMatrix *m = new CscMatrix();
+    *err = CscMatrix::create(*m, (size_t)std::max<int64_t>(nrow, 0), (size_t)std::max<int64_t>(ncol, 0), std::vector<int32_t>(col_pointers, col_pointers + np),
+                             std::vector<int32_t>(row_indices, row_indices + nv), std::vector<double>(values, values + nv), (Sym)sym);
+    if (*err) {
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+void *rh_csr_new(int64_t nrow, int64_t ncol, const int32_t *row_pointers, int64_t np, const int32_t *col_indices, const double *values, int64_t nv,
+                 int32_t sym, const char **err) {
+    CsrMatrix *m = new CsrMatrix();
+    *err = CsrMatrix::create(*m, (size_t)std::max<int64_t>(nrow, 0), (size_t)std::max<int64_t>(ncol, 0), std::vector<int32_t>(row_pointers, row_pointers + np),
+                             std::vector<int32_t>(col_indices, col_indices + nv), std::vector<double>(values, values + nv), (Sym)sym);
+    if (*err) {
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+const char *rh_csc_to_dense(void *h, double *a, int64_t len) {
+    std::vector<double> aa((size_t)std::max<int64_t>(len, 0));
+    StrError e = ((CscMatrix *)h)->to_dense(aa);
+    if (!e) std::copy(aa.begin(), aa.end(), a);
+    return e;
+}
+const char *rh_csr_to_dense(void *h, double *a, int64_t len) {
+    std::vector<double> aa((size_t)std::max<int64_t>(len, 0));
+    StrError e = ((CsrMatrix *)h)->to_dense(aa);
+    if (!e) std::copy(aa.begin(), aa.end(), a);
+    return e;
+}
 void *rh_csc_from_csr(void *csr, const char **err) {
     CscMatrix *m = new CscMatrix();
     *err = CscMatrix::from_csr(*m, *(CsrMatrix *)csr);

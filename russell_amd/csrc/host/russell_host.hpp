@@ -78,6 +78,10 @@ struct CscMatrix {
     size_t nrow = 0, ncol = 0;
     std::vector<int32_t> col_pointers, row_indices;
     std::vector<double> values;
+    // csc_matrix.rs:197-262: validated constructor from ready arrays (pointers ascending, indices in range and ascending per column)
+    static StrError create(CscMatrix &out, size_t nrow, size_t ncol, std::vector<int32_t> col_pointers, std::vector<int32_t> row_indices,
+                           std::vector<double> values, Sym symmetric);
+    StrError to_dense(std::vector<double> &a_row_major) const; // csc_matrix.rs:702-729 (triangular storage mirrored)
     static StrError from_coo(CscMatrix &out, const CooMatrix &coo);
     static StrError from_csr(CscMatrix &out, const CsrMatrix &csr); // csc_matrix.rs:508-584
     StrError update_from_coo(const CooMatrix &coo);
@@ -95,6 +99,10 @@ struct CsrMatrix {
     size_t nrow = 0, ncol = 0;
     std::vector<int32_t> row_pointers, col_indices;
     std::vector<double> values;
+    // csr_matrix.rs:193-257
+    static StrError create(CsrMatrix &out, size_t nrow, size_t ncol, std::vector<int32_t> row_pointers, std::vector<int32_t> col_indices,
+                           std::vector<double> values, Sym symmetric);
+    StrError to_dense(std::vector<double> &a_row_major) const; // csr_matrix.rs:676-703
     static StrError from_coo(CsrMatrix &out, const CooMatrix &coo);
     static StrError from_csc(CsrMatrix &out, const CscMatrix &csc); // csr_matrix.rs:483-558
     StrError update_from_coo(const CooMatrix &coo);

@@ -134,6 +134,10 @@ def _L():
         "rh_coo_put_lagrange_block": (cp, [vp, vp]),
         "rh_coo_to_dense": (cp, [vp, vp, i64]),
         "rh_coo_actual_nnz": (i64, [vp]),
+        "rh_csc_new": (vp, [i64, i64, vp, i64, vp, vp, i64, i32, pp(cp)]),
+        "rh_csr_new": (vp, [i64, i64, vp, i64, vp, vp, i64, i32, pp(cp)]),
+        "rh_csc_to_dense": (cp, [vp, vp, i64]),
+        "rh_csr_to_dense": (cp, [vp, vp, i64]),
         "rh_csc_from_csr": (vp, [vp, pp(cp)]),
         "rh_csr_from_csc": (vp, [vp, pp(cp)]),
         "rh_csc_from_coo": (vp, [vp, pp(cp)]),
@@ -328,6 +332,30 @@ class _Compressed:
         h = fn(other._h, C.byref(err))
         _check(err.value)
         return cls(h)
+
+    @classmethod
+    def new(cls, nrow, ncol, pointers, indices, values, symmetric=Sym.No):
+        """csc_matrix.rs:197-262 / csr_matrix.rs:193-257: validated constructor from ready arrays."""
+        pp_, ii = np.ascontiguousarray(pointers, dtype=np.int32), np.ascontiguousarray(indices, dtype=np.int32)
+        vv = np.ascontiguousarray(values, dtype=np.float64)
+        nv = min(ii.size, vv.size)
+        if pp_.size > 0 and ((cls._kind == "csc" and pp_.size == ncol + 1) or (cls._kind == "csr" and pp_.size == nrow + 1)):
+            if ii.size < pp_[-1]:
+                raise StrError("%s_indices.len() must be ≥ nnz" % ("row" if cls._kind == "csc" else "col"))
+            if vv.size < pp_[-1]:
+                raise StrError("values.len() must be ≥ nnz")
+        err = C.c_char_p()
+        h = getattr(_L(), "rh_%s_new" % cls._kind)(int(nrow), int(ncol), _ptr(pp_), pp_.size, _ptr(ii), _ptr(vv), nv, int(symmetric), C.byref(err))
+        _check(err.value)
+        obj = cls(h)
+        obj._shape = (int(nrow), int(ncol))
+        return obj
+
+    def to_dense(self, nrow=None, ncol=None):
+        nrow, ncol = (nrow, ncol) if nrow is not None else getattr(self, "_shape")
+        a = np.zeros((nrow, ncol))
+        _check(getattr(_L(), "rh_%s_to_dense" % self._kind)(self._h, _ptr(a), a.size))
+        return a
 
     def update_from_coo(self, coo):
         _check(getattr(_L(), "rh_%s_update_from_coo" % self._kind)(self._h, coo._h))

@@ -246,3 +246,36 @@ def test_coo_from_arrays():
                       ((3, 3, [0], [-1], [1.0]), "col index is out-of-range")]:
         with pytest.raises(StrError, match=msg):
             CooMatrix.from_arrays(*args)
+
+
+def test_compressed_constructors_validate_like_the_reference():
+    # csc_matrix.rs:197-262 / csr_matrix.rs:193-257 and their tests (new_captures_errors): messages, order of the checks
+    from russell_amd.sparse import CscMatrix
+
+    good = CscMatrix.new(3, 3, [0, 2, 3, 5], [0, 2, 1, 0, 2], [1.0, 4.0, 3.0, 2.0, 6.0])
+    assert good.to_dense().tolist() == [[1.0, 0, 2.0], [0, 3.0, 0], [4.0, 0, 6.0]]
+    low = CsrMatrix.new(3, 3, [0, 1, 3, 4], [0, 0, 1, 2], [1.0, 2.0, 3.0, 5.0], Sym.YesLower)
+    assert low.to_dense().tolist() == [[1.0, 2.0, 0], [2.0, 3.0, 0], [0, 0, 5.0]]
+    assert np.array_equal(CsrMatrix.from_csc(good).to_dense(3, 3), good.to_dense())
+    cases = [
+        ((0, 3, [0], [], []), "nrow must be ≥ 1"),
+        ((3, 0, [0], [], []), "ncol must be ≥ 1"),
+        ((3, 3, [0, 1], [0], [1.0]), "col_pointers.len\\(\\) must be = ncol \\+ 1"),
+        ((1, 1, [0, 0], [], []), "nnz = col_pointers\\[ncol\\] must be ≥ 1"),
+        ((1, 1, [0, 1], [], [1.0]), "row_indices.len\\(\\) must be ≥ nnz"),
+        ((1, 1, [0, 1], [0], []), "values.len\\(\\) must be ≥ nnz"),
+        ((2, 2, [-1, 0, 1], [0], [1.0]), "col pointers must be ≥ 0"),
+        ((2, 2, [2, 1, 1], [0, 0], [1.0, 1.0]), "col pointers must be sorted in ascending order"),
+        ((2, 2, [0, 1, 2], [-1, 0], [1.0, 1.0]), "row indices must be ≥ 0"),
+        ((2, 2, [0, 1, 2], [2, 0], [1.0, 1.0]), "row indices must be < nrow"),
+        ((2, 2, [0, 2, 2], [1, 0], [1.0, 1.0]), "row indices must be sorted in ascending order \\(within their column\\)"),
+    ]
+    for args, msg in cases:
+        with pytest.raises(StrError, match=msg):
+            CscMatrix.new(*args)
+    with pytest.raises(StrError, match="symmetric storage requires a square matrix"):
+        CscMatrix.new(2, 1, [0, 1], [0], [1.0], Sym.YesFull)
+    with pytest.raises(StrError, match="column indices must be sorted in ascending order \\(within their row\\)"):
+        CsrMatrix.new(2, 2, [0, 2, 2], [1, 0], [1.0, 1.0])
+    with pytest.raises(StrError, match="row_pointers.len\\(\\) must be = nrow \\+ 1"):
+        CsrMatrix.new(3, 3, [0, 1], [0], [1.0])
