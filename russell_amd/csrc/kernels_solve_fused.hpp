@@ -415,6 +415,15 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     // rows of inv(L11) P are zero right of their own 32-column block
     int jmax = p;
     if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
+    // (K == 1) the first eight entries of this lane's row of E are on their way while the workgroup waits for the children
+    constexpr int NPRE = 8;
+    double e_pre[K == 1 ? NPRE : 1];
+    const int c1_first = jmax < CHK ? jmax : CHK;
+    const bool use_pre = K == 1 && r < r1 && (c1_first - g + G - 1) / G >= NPRE; // at least NPRE positions in the first chunk
+    if (K == 1 && use_pre) {
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) e_pre[K == 1 ? u : 0] = E[r + (int64_t)(g + u * G) * ld];
+    }
     // ---- before the wait: everything that does not depend on the children ----
     //  * the children's descriptors, one child per lane of wave 0, parked in LDS for all waves
     //  * b1 = the first chunk of x (set before the launch; the children write `work`, not x)
@@ -469,7 +478,16 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
             sf_children<2, (K == 1 ? 4 : 2), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         if (nch == 0) __syncthreads();
         // the group's columns of this chunk: g, g + G, ... continue across chunks (CHK is a multiple of every G)
-        if (r < r1) sf_dot<K>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
+        if (K == 1 && c0 == 0 && use_pre) {
+            // consume the prefetched entries exactly as sf_dot would (even positions into acc0, odd ones into acc1), then go on
+#pragma unroll
+            for (int u = 0; u < NPRE; u += 2) {
+                acc0[0] += e_pre[K == 1 ? u : 0] * wc[g + u * G];
+                acc1[0] += e_pre[K == 1 ? u + 1 : 0] * wc[g + (u + 1) * G];
+            }
+            sf_dot<K>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g + NPRE * G, c1, G);
+        } else if (r < r1)
+            sf_dot<K>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
 #pragma unroll
