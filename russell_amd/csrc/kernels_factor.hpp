@@ -245,43 +245,44 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
     // (no integer divisions, loads issued in batches of 8 before the LDS stores: the loop is latency-bound otherwise)
+    // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain)
     if (ltile) {
         if (tid < ext) {
             const double *src = F + (o0 + tid) + (int64_t)k0 * ld; // row tid of the tile, column k at src[k * ld]
+            double v[NB];
 #pragma unroll
-            for (int kb = 0; kb < NB; kb += 8) {
-                double v[8];
+            for (int u = 0; u < NB; u++) v[u] = (u < nb) ? src[(int64_t)u * ld] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = (kb + u < nb) ? src[(int64_t)(kb + u) * ld] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; u++) T[kb + u][tid] = v[u];
-            }
+            for (int u = 0; u < NB; u++) T[u][tid] = v[u];
         }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5; // 4 columns x 32 rows per pass
         const double *src = F + (k0 + k) + (int64_t)o0 * ld;
+        double v[PANEL_T / 4];
 #pragma unroll
-        for (int cb = 0; cb < PANEL_T; cb += 32) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int cc = cb + 4 * u + cq;
-                v[u] = (k < nb && cc < ext) ? src[(int64_t)cc * ld] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) T[k][cb + 4 * u + cq] = v[u];
+        for (int u = 0; u < PANEL_T / 4; u++) {
+            const int cc = 4 * u + cq;
+            v[u] = (k < nb && cc < ext) ? src[(int64_t)cc * ld] : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < PANEL_T / 4; u++) T[k][4 * u + cq] = v[u];
     }
     // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
     //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
     if (k0 > 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
-        for (int e = tid; e < NB * NB; e += PANEL_T) {
-            const int r = e % NB, c = e / NB;
-            const double v = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
-            D[r][c] = v;
-            DT[c][r] = v;
-            if (r == c) dinv[r] = 1.0 / v;
+        double tv[NB * NB / PANEL_T];
+#pragma unroll
+        for (int u = 0; u < NB * NB / PANEL_T; u++) {
+            const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
+            tv[u] = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
+        }
+#pragma unroll
+        for (int u = 0; u < NB * NB / PANEL_T; u++) {
+            const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
+            D[r][c] = tv[u];
+            DT[c][r] = tv[u];
+            if (r == c) dinv[r] = 1.0 / tv[u];
         }
         if (tid < NB) lp[tid] = (tid < nb) ? lperm[fd.first + k0 + tid] - k0 : tid;
     } else if (tid < 64) {
@@ -515,9 +516,6 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         }                                                                                                              \
     }
     HIPMF_FETCH_SLICE(0)
-    HIPMF_STORE_SLICE()
-    __syncthreads();
-    if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
     const bool owner0 = t == 0 && nb2 > 0 && wave == 0; // this wave's block holds the next diagonal tile
     // is entry (sub-tile a, b; register g) of this lane updated by this step?
     auto is_live = [&](int a, int b, int g) {
@@ -525,7 +523,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         const bool corner = owner0 && (b * 16 + l15) < nb2 && (a * 16 + l4 + 4 * g) < nb2;
         return r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner;
     };
-    // the 16 entries of the trailing matrix this lane updates are fetched while the MFMAs run
+    // the 16 entries of the trailing matrix this lane updates are requested together with the first slice (one round trip for
+    // both: a narrow step is a latency chain) and arrive while the MFMAs run
     double cur[MT][MT][4];
 #pragma unroll
     for (int a = 0; a < MT; a++)
@@ -536,6 +535,9 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
                 cur[a][b][g] = is_live(a, b, g) ? F[r + (int64_t)c * ld] : 0.0;
             }
+    HIPMF_STORE_SLICE()
+    __syncthreads();
+    if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
     // strips of a narrow step: a wave whose quarter of the tile holds no live entry has nothing to multiply
     const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + TS / 2 <= cmin) || (r0 + wr >= rmax);
     f64x4 acc[MT][MT];
