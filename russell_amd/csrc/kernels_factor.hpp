@@ -245,7 +245,19 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
     // (no integer divisions, loads issued in batches of 8 before the LDS stores: the loop is latency-bound otherwise)
-    // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain)
+    // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain;
+    //  the factorised diagonal tile of steps k0 > 0 and its row interchanges are requested first, in the same round trip)
+    double tv[NB * NB / PANEL_T];
+    int32_t lpv = 0;
+    if (k0 > 0) {
+        const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
+#pragma unroll
+        for (int u = 0; u < NB * NB / PANEL_T; u++) {
+            const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
+            tv[u] = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
+        }
+        if (tid < nb) lpv = lperm[fd.first + k0 + tid];
+    }
     if (ltile) {
         if (tid < ext) {
             const double *src = F + (o0 + tid) + (int64_t)k0 * ld; // row tid of the tile, column k at src[k * ld]
@@ -270,13 +282,6 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
     //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
     if (k0 > 0) {
-        const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
-        double tv[NB * NB / PANEL_T];
-#pragma unroll
-        for (int u = 0; u < NB * NB / PANEL_T; u++) {
-            const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
-            tv[u] = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
-        }
 #pragma unroll
         for (int u = 0; u < NB * NB / PANEL_T; u++) {
             const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
@@ -284,7 +289,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
             DT[c][r] = tv[u];
             if (r == c) dinv[r] = 1.0 / tv[u];
         }
-        if (tid < NB) lp[tid] = (tid < nb) ? lperm[fd.first + k0 + tid] - k0 : tid;
+        if (tid < NB) lp[tid] = (tid < nb) ? lpv - k0 : tid;
     } else if (tid < 64) {
         double a[NB];
 #pragma unroll
