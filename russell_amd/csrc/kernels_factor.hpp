@@ -439,15 +439,22 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         for (int h = 0; h < nhalf; h++) {
             const int kh = kfirst + h * NB, nbh = (h == nhalf - 1) ? nb : NB;
             if (h > 0) __syncthreads();
-            // U block (rows kh.., columns base..base+32) -> LDS, 16 elements per lane
+            // U block (rows kh.., columns base..base+32) -> LDS, 16 elements per lane; the lane's row of L is requested in the same
+            // round trip (the LDS stores wait for the U loads: everything this slice needs from memory is in flight before them)
+            double um[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u, kk = e & 31, c = e >> 5;
-                UM[kk][c] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * ld] : 0.0;
+                um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * ld] : 0.0;
             }
             double lrow[NB];
 #pragma unroll
             for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * ld] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = tid + 64 * u;
+                UM[e & 31][e >> 5] = um[u];
+            }
             __syncthreads(); // (only wave 0 is left in this workgroup)
 #pragma unroll
             for (int kk = 0; kk < NB; kk++) {
