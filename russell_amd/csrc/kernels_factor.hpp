@@ -496,7 +496,14 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int r0 = base + ti * TS, c0 = base + tj * TS;
     if (t == 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
-        for (int e = tid; e < nb * nb; e += 256) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dw[e];
+        double dv[NB * NB / 256];
+#pragma unroll
+        for (int u = 0; u < NB * NB / 256; u++) dv[u] = (tid + 256 * u < nb * nb) ? dw[tid + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NB * NB / 256; u++) {
+            const int e = tid + 256 * u;
+            if (e < nb * nb) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dv[u];
+        }
     }
     if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
     // entries this step may touch: rows < rmax, columns in [cmin, cmax)
