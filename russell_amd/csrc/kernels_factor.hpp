@@ -187,7 +187,7 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
         const bool cand = lane < NB && step < 0;
         const unsigned mag = __float_as_uint((float)fabs(a[c]));
         const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
-        const double myinv = 1.0 / a[c];
+        const double myinv = fast_rcp(a[c]);
         const int pv = 31 - (int)(wave_max_u32(key) & 31u);
         if (lane == pv) step = c;
         double d = wave_bcast(a[c], pv);

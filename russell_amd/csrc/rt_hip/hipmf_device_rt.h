@@ -92,6 +92,14 @@ __device__ __forceinline__ void flag_store(int *p, int v) { __hip_atomic_store(p
 // must not drop or move this wait)
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void poll_nap() { __builtin_amdgcn_s_sleep(2); }
+// reciprocal without the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup): v_rcp_f64 and two Newton steps, accurate to
+// about an ulp for normal arguments; 0 gives inf, as 1.0 / 0.0 does (callers test the pivot itself, not its reciprocal)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
 // LDS written by some lanes of a wavefront becomes readable by its other lanes (single-wave phases of
 // multi-wave workgroups: no s_barrier, the wave's LDS operations complete in order)
 __device__ __forceinline__ void wave_sync() {

@@ -64,5 +64,6 @@ inline int flag_add(int *p, int v) {
 inline void flag_store(int *p, int v) { *(volatile int *)p = v; }
 inline void drain_stores() {}
 inline void poll_nap() {}
+inline double fast_rcp(double x) { return 1.0 / x; }
 inline void wave_sync() { hipemu::sync_wave(); }
 inline unsigned long long dev_clock() { return 0; }
