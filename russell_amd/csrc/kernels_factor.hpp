@@ -188,7 +188,7 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
         const unsigned mag = __float_as_uint((float)fabs(a[c]));
         const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
         const double myinv = fast_rcp(a[c]);
-        const int pv = 31 - (int)(wave_max_u32(key) & 31u);
+        const int pv = 31 - (int)(wave_max_u32<2>(key) & 31u); // (candidates live in lanes 0..31: two rows)
         if (lane == pv) step = c;
         double d = wave_bcast(a[c], pv);
         double inv = wave_bcast(myinv, pv);

@@ -55,7 +55,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long ke
 
 // wave-wide maximum of a 32-bit key (result wave-uniform): four DPP max steps per 16-lane row, then the
 // four row maxima through v_readlane.
-__device__ __forceinline__ unsigned wave_max_u32(unsigned key) {
+template <int ROWS = 4> __device__ __forceinline__ unsigned wave_max_u32(unsigned key) { // ROWS: 16-lane rows that can hold a candidate
     int k = (int)key;
 #define HIPMF_DPP_MAX32(ctrl)                                                  \
     {                                                                          \
@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned key) {
 #undef HIPMF_DPP_MAX32
     unsigned best = 0;
 #pragma unroll
-    for (int row = 0; row < 4; row++) {
+    for (int row = 0; row < ROWS; row++) {
         unsigned v = (unsigned)__builtin_amdgcn_readlane(k, row * 16);
         best = v > best ? v : best;
     }

@@ -38,7 +38,7 @@ inline unsigned long long wave_max_u64(unsigned long long key) {
     return key;
 }
 
-inline unsigned wave_max_u32(unsigned key) {
+template <int ROWS = 4> inline unsigned wave_max_u32(unsigned key) {
     for (int off = 32; off > 0; off >>= 1) {
         unsigned o = __shfl_xor(key, off);
         key = o > key ? o : key;
