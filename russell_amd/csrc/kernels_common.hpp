@@ -42,6 +42,13 @@ struct FrontDesc {
     int32_t ugroup; // tiled path: 32-pivot panels per read-modify-write pass over the trailing matrix (2, 4, 8 or 16)
 };
 
+// A small front's descriptor and the range of its entry list, in LAUNCH order (index = position in the level's list): the
+// workgroup reads one record instead of list -> FD / sa_ptr, one dependent memory round trip less at the head of its chain.
+struct SmallDesc {
+    FrontDesc fd;
+    int32_t e0, e1; // range in sa_k / sa_pos
+};
+
 struct EaTask {
     int64_t f_off;                    // pool offset of the parent front
     int32_t ld;                       // its leading dimension

@@ -16,11 +16,12 @@ namespace hipmf {
 // Everything a small front needs to ASSEMBLE itself (fused into k_small_factor: no memset, scatter or extend-add
 // traffic for the small fronts, which hold most of the fronts and half of the pool).
 struct SmallAsm {
-    const int32_t *sa_ptr;  // per supernode: its range in sa_k / sa_pos
+    const SmallDesc *sd;    // per position of the small lists
     const int32_t *sa_k;    // input entry k (>= 0), or ~k for the mirrored copy of a symmetric-lower entry
     const uint16_t *sa_pos; // row | column << 8 inside the front
     const double *vs, *vs2; // scaled values (k_absmax): vs2 = the mirrored entries of symmetric-lower storage
     const int32_t *child_idx, *rel;
+    const int32_t *list0;   // start of the device array of lists (sd is indexed like it)
 };
 
 // One wavefront assembles and factorises one small front (f <= SMALL_F = 64) held entirely in LDS: lane r owns row r.
@@ -35,8 +36,8 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     HIPMF_DYN_SHARED(double, sm);
     __shared__ int32_t lp[SMALL_F];
     const int tid = threadIdx.x;
-    const int s = list[blockIdx.x];
-    FrontDesc fd = FD[s];
+    const SmallDesc sdesc = A.sd[(list - A.list0) + blockIdx.x];
+    const FrontDesc fd = sdesc.fd;
     const int p = fd.p, f = fd.p + fd.m;
     double *F = pool + fd.off;
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
         d_rel = cd.rowptr;
         d_m = cd.m;
     }
-    const int e0 = A.sa_ptr[s], e1 = A.sa_ptr[s + 1];
+    const int e0 = sdesc.e0, e1 = sdesc.e1;
     for (int e = tid; e < f * ld; e += 64) sm[e] = 0.0;
     __syncthreads();
     // entries of A, already scaled (LDS atomics: a caller's CSR may hold duplicates)

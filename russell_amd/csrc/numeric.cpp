@@ -51,6 +51,8 @@ void Solver::release() {
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (d_sd) (void)hipFree(d_sd);
+    d_sd = nullptr;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
             if (p) (void)hipFree(p);
@@ -275,6 +277,20 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         }
         (void)nz;
         HIPC(dev_upload(&d_sa_ptr, sa_ptr), ERROR_HIP_MALLOC);
+        {
+            // descriptors in launch order (the plan is on the device already: read it back rather than keep host copies around)
+            std::vector<FrontDesc> h_fd((size_t)ns);
+            std::vector<int32_t> h_lists((size_t)n_lists);
+            HIPC(hipMemcpy(h_fd.data(), d_fd, sizeof(FrontDesc) * (size_t)ns, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
+            if (n_lists > 0) HIPC(hipMemcpy(h_lists.data(), d_lists, sizeof(int32_t) * (size_t)n_lists, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
+            std::vector<SmallDesc> sd(h_lists.size());
+            for (size_t q = 0; q < h_lists.size(); q++) {
+                const int32_t s = h_lists[q];
+                sd[q].fd = h_fd[(size_t)s];
+                sd[q].e0 = sa_ptr[(size_t)s], sd[q].e1 = sa_ptr[(size_t)s + 1]; // (empty ranges for the big fronts, which never read them)
+            }
+            HIPC(dev_upload(&d_sd, sd), ERROR_HIP_MALLOC);
+        }
         HIPC(dev_upload(&d_sa_k, sa_k), ERROR_HIP_MALLOC);
         HIPC(dev_upload(&d_sa_pos, sa_pos), ERROR_HIP_MALLOC);
         // zero-fill tasks: 16 Ki doubles per workgroup over the big fronts
@@ -546,6 +562,7 @@ int32_t Solver::upload_plan() {
     HIPC(hipMalloc((void **)&d_dws, sizeof(double) * 2 * NB * NB * (size_t)std::max(max_big, 1)), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_st, stasks), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_lists, lists), ERROR_HIP_MALLOC);
+    n_lists = (int64_t)lists.size();
     HIPC(dev_upload(&d_tasks, tasks), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_rel, S.rel), ERROR_HIP_MALLOC);
@@ -644,7 +661,7 @@ int32_t Solver::run_factor() {
                 HIPC(hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
                 sst = (hipStream_t)stream2;
             }
-            const SmallAsm sasm = {d_sa_ptr, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel};
+            const SmallAsm sasm = {d_sd, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel, d_lists};
             if (L.small_cnt_a > 0) {
                 const size_t shmem_a = sizeof(double) * (size_t)L.small_ld_a * (size_t)L.small_ld_a;
                 hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,

@@ -9,6 +9,7 @@
 namespace hipmf {
 
 struct FrontDesc;
+struct SmallDesc;
 struct EaTask;
 struct EaRange;
 struct SolveTask;
@@ -155,6 +156,8 @@ class Solver {
     int32_t *d_seg_ptr = nullptr, *d_seg_idx = nullptr; // value map (set_value_map)
     double *d_vin = nullptr;
     int64_t nnz_in = 0;
+    int64_t n_lists = 0;            // entries of d_lists
+    SmallDesc *d_sd = nullptr;      // per position of d_lists: descriptor + entry range of a small front
     double *d_blk = nullptr, *d_work_blk = nullptr; // many-RHS blocks (allocated at the first multi-column solve)
     // further lanes of the solve driver (allocated at the first solve with more than one block): stream, block buffers, hand-off
     // words, norms; lane 0 is the solver's own stream and buffers
