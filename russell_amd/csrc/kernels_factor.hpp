@@ -65,35 +65,56 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     __syncthreads();
     // children's contribution blocks.  Per child the lanes are (row i, column group g) with 16 / 32 / 64 rows per pass by
     // the block's size, sixteen columns in flight per lane; rel of column j comes from the lane that holds it as a row.
-    for (int ci = 0; ci < nch; ci++) {
-        int64_t cbo, ldc, relo;
-        int mc;
-        if (ci < 64) {
-            cbo = __shfl(d_cb, ci), ldc = __shfl(d_ldc, ci), relo = __shfl(d_rel, ci), mc = __shfl(d_m, ci);
-        } else {
-            const FrontDesc cd = FD[A.child_idx[fd.child_begin + ci]];
-            ldc = cd.ld, cbo = cd.off + cd.p + (int64_t)cd.p * cd.ld, relo = cd.rowptr, mc = cd.m;
-        }
-        if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
-        const double *CB = pool + cbo;
-        const int sh = mc <= 16 ? 4 : (mc <= 32 ? 5 : 6);
-        const int i = tid & ((1 << sh) - 1), g = tid >> sh, G = 64 >> sh;
-        const int myrel = i < mc ? A.rel[relo + i] : 0; // lanes 0 .. mc-1 hold rel of rows (= columns) 0 .. mc-1
-        for (int jb = 0; jb < mc; jb += 16 * G) { // (wave-uniform trip count: the shuffles below need every lane)
-            double cb[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int j = jb + g + q * G;
-                cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int j = jb + g + q * G;
-                const int rj = __shfl(myrel, j & 63);
-                if (i < mc && j < mc) sm[myrel + rj * ld] += cb[q];
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+        // descriptors of the children c0 .. c0 + 63, one per lane (the first batch was requested at the top of the kernel)
+        if (c0 > 0) {
+            d_m = 0;
+            if (c0 + tid < nch) {
+                const FrontDesc cd = FD[A.child_idx[fd.child_begin + c0 + tid]];
+                d_ldc = cd.ld;
+                d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
+                d_rel = cd.rowptr;
+                d_m = cd.m;
             }
         }
-        __syncthreads(); // the next child may hit the same entries from other lanes
+        const int nbatch = nch - c0 < 64 ? nch - c0 : 64;
+        if (nch > 64 && __ballot(d_m > 1) == 0ull) {
+            // hub front: every child of this batch brings at most ONE entry (stars: a supply net and the pins that touch nothing
+            // else).  One lane per child fetches it; lane 0 adds them in child order (fixed order: reproducible sums).
+            const int myq = (tid < nbatch && d_m == 1) ? A.rel[d_rel] : -1;
+            const double myv = myq >= 0 ? pool[d_cb] : 0.0;
+            for (int l = 0; l < nbatch; l++) {
+                const int q = __shfl(myq, l);
+                const double v = __shfl(myv, l);
+                if (tid == 0 && q >= 0) sm[q + q * ld] += v;
+            }
+            __syncthreads();
+            continue;
+        }
+        for (int cl = 0; cl < nbatch; cl++) {
+            const int64_t cbo = __shfl(d_cb, cl), ldc = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
+            const int mc = __shfl(d_m, cl);
+            if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
+            const double *CB = pool + cbo;
+            const int sh = mc <= 16 ? 4 : (mc <= 32 ? 5 : 6);
+            const int i = tid & ((1 << sh) - 1), g = tid >> sh, G = 64 >> sh;
+            const int myrel = i < mc ? A.rel[relo + i] : 0; // lanes 0 .. mc-1 hold rel of rows (= columns) 0 .. mc-1
+            for (int jb = 0; jb < mc; jb += 16 * G) { // (wave-uniform trip count: the shuffles below need every lane)
+                double cb[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int j = jb + g + q * G;
+                    cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int j = jb + g + q * G;
+                    const int rj = __shfl(myrel, j & 63);
+                    if (i < mc && j < mc) sm[myrel + rj * ld] += cb[q];
+                }
+            }
+            __syncthreads(); // the next child may hit the same entries from other lanes
+        }
     }
     if (tid < p) lp[tid] = tid;
     __syncthreads();

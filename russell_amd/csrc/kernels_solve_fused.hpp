@@ -82,31 +82,51 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
     const int nch = fd.child_end - fd.child_begin;
     int64_t c_woff = 0, c_rowptr = 0;
     int c_p = 0, c_m = 0;
-    for (int c0 = 0; c0 < nch; c0 += 64) { // (more than 64 children: only the last 64 descriptors stay in registers, see below)
+    for (int c0 = 0; c0 < nch; c0 += 64) { // children in batches of 64: descriptor and completion counter, one child per lane
+        c_m = 0;
         if (c0 + lane < nch) {
             const int ch = child_idx[fd.child_begin + c0 + lane];
             const FrontDesc cd = FD[ch];
             c_woff = cd.woff, c_rowptr = cd.rowptr, c_p = cd.p, c_m = cd.m;
             sf_wait(done + ch, need[ch], err);
         }
-    }
-    wave_sync();
-    for (int ci = 0; ci < nch; ci++) {
-        int64_t woff, rowptr;
-        int cp, cm;
-        if (nch <= 64) {
-            woff = __shfl(c_woff, ci), rowptr = __shfl(c_rowptr, ci), cp = __shfl(c_p, ci), cm = __shfl(c_m, ci);
-        } else {
-            const FrontDesc cd = FD[child_idx[fd.child_begin + ci]];
-            woff = cd.woff, rowptr = cd.rowptr, cp = cd.p, cm = cd.m;
-        }
-        if (lane < cm) { // cm <= f <= 64
-            const int r = rel[rowptr + lane];
+        wave_sync();
+        const int nbatch = nch - c0 < 64 ? nch - c0 : 64;
+        if (nch > 64 && __ballot(c_m > 1) == 0ull) {
+            // hub front: every child of this batch brings at most one entry; one lane per child fetches it, the owning row adds
+            // them in child order (fixed order: reproducible sums)
+            const int myr = (lane < nbatch && c_m == 1) ? rel[c_rowptr] : -1;
+            double myv[K];
+#pragma unroll
+            for (int c = 0; c < K; c++) myv[c] = (c < nk && myr >= 0) ? ld_agent(work + c * wstr + c_woff + c_p) : 0.0;
+            double add[K]; // starts from the row's current value: the same association order as adding child after child
+#pragma unroll
+            for (int c = 0; c < K; c++) add[c] = (c < nk) ? w[c][lane] : 0.0;
+            for (int l = 0; l < nbatch; l++) {
+                const int r = __shfl(myr, l);
+#pragma unroll
+                for (int c = 0; c < K; c++) {
+                    const double v = __shfl(myv[c], l);
+                    if (lane == r) add[c] += v;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < K; c++)
-                if (c < nk) w[c][r] += ld_agent(work + c * wstr + woff + cp + lane);
+                if (c < nk) w[c][lane] = add[c];
+            wave_sync();
+            continue;
         }
-        wave_sync();
+        for (int cl = 0; cl < nbatch; cl++) {
+            const int64_t woff = __shfl(c_woff, cl), rowptr = __shfl(c_rowptr, cl);
+            const int cp = __shfl(c_p, cl), cm = __shfl(c_m, cl);
+            if (lane < cm) { // cm <= f <= 64
+                const int r = rel[rowptr + lane];
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) w[c][r] += ld_agent(work + c * wstr + woff + cp + lane);
+            }
+            wave_sync();
+        }
     }
     // row interchanges of the pivot block, then y1 = L11^{-1} (P w1) column by column, u = w2 - L21 y1;
     double v[K];
