@@ -140,3 +140,29 @@ def test_emulated_hub_vertices_are_ordered_last(emu_lib, monkeypatch):
     assert s.initialize(n, rp2, ci2) == 0
     assert s.stats()["flops"] > 20 * flops_deferred  # what the deferral saves
     s.close()
+
+
+def test_emulated_star_with_many_one_entry_children(emu_lib):
+    # a hub row / column and 300 unknowns tied only to it: the hub front has 300 children with one contribution entry each
+    # (batches of 64 descriptors, one lane per child, added in child order) -- factorisation and forward solve
+    import scipy.sparse as sp
+
+    n = 301
+    rng = np.random.default_rng(4)
+    A = sp.lil_matrix((n, n))
+    A.setdiag(3.0 + rng.random(n))
+    A[0, 1:] = 1e-2 * (1.0 + rng.random(n - 1))
+    A[1:, 0] = 2e-2 * (1.0 + rng.random((n - 1, 1)))
+    A = A.tocsr()
+    A.sort_indices()
+    xs = P.manufactured_solution(n)
+    b = A @ xs
+    s, code, x, st = _solve(emu_lib, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64), b)
+    assert code == 0 and st["nlevels"] == 2 and st["nsuper"] >= 300
+    want = np.linalg.solve(A.toarray(), b)
+    assert np.max(np.abs(x - want)) < 1e-13
+    sign, logdet = np.linalg.slogdet(A.toarray())
+    assert abs(np.log10(abs(s.det_coefficient)) + s.det_exponent - logdet / np.log(10.0)) < 1e-10
+    X = s.solve_many(np.tile(b[None, :], (3, 1)))
+    assert np.max(np.abs(X - want[None, :])) < 1e-13
+    s.close()
