@@ -24,18 +24,26 @@ struct SmallAsm {
     const int32_t *list0;   // start of the device array of lists (sd is indexed like it)
 };
 
-// One wavefront assembles and factorises one small front (f <= SMALL_F = 64) held entirely in LDS: lane r owns row r.
+// One workgroup of NW wavefronts assembles and factorises one small front (f <= SMALL_F = 64) held entirely in LDS: thread
+// (row r = tid mod 64, column group g = tid / 64).
 //   assembly:  F = (scaled entries of A that belong to this front) + sum over the children of their contribution
 //              blocks (children in ascending order, read from the pool where their own factorisation left them)
 //   LU:        partial pivoting searches the whole remaining pivot block (rows c..p-1) with one 32-bit DPP max-reduction.
 // No integer divisions and no per-element index arithmetic: every loop runs over columns with lane = row.
-__global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
-                                                     double *__restrict__ pool, int32_t *__restrict__ lperm,
-                                                     const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
-                                                     FactorInfo *info, int32_t ld, SmallAsm A) {
+// NW = 1: one wavefront per front, the throughput shape of the leaf levels (tens of thousands of fronts per launch).
+// NW = 4: the columns of the rank-1 updates (and the zero-fill, the gather of A's entries, the final store) are spread over four
+//         wavefronts: a third of the latency per pivot, for the launches with few, large fronts between the leaves and the tiled
+//         levels, where one front's LU (up to 64 pivots x ~1.3 us) is the whole launch.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
+                                                          double *__restrict__ pool, int32_t *__restrict__ lperm,
+                                                          const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
+                                                          FactorInfo *info, int32_t ld, SmallAsm A) {
     HIPMF_DYN_SHARED(double, sm);
     __shared__ int32_t lp[SMALL_F];
-    const int tid = threadIdx.x;
+    __shared__ int32_t piv_s;
+    const int tid = threadIdx.x & 63, grp = threadIdx.x >> 6; // row / lane, column group (wave)
+    const int lin = threadIdx.x;
     const SmallDesc sdesc = A.sd[(list - A.list0) + blockIdx.x];
     const FrontDesc fd = sdesc.fd;
     const int p = fd.p, f = fd.p + fd.m;
@@ -45,7 +53,7 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
     const int nch = fd.child_end - fd.child_begin;
     int64_t d_cb = 0, d_ldc = 0, d_rel = 0;
     int d_m = 0;
-    if (tid < nch) { // (nch > 64: the tail is read per child below)
+    if (grp == 0 && tid < nch) { // (nch > 64: later batches are read below)
         const FrontDesc cd = FD[A.child_idx[fd.child_begin + tid]];
         d_ldc = cd.ld;
         d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
@@ -53,98 +61,110 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
         d_m = cd.m;
     }
     const int e0 = sdesc.e0, e1 = sdesc.e1;
-    for (int e = tid; e < f * ld; e += 64) sm[e] = 0.0;
+    for (int e = lin; e < f * ld; e += 64 * NW) sm[e] = 0.0;
     __syncthreads();
     // entries of A, already scaled (LDS atomics: a caller's CSR may hold duplicates)
-    for (int e = e0 + tid; e < e1; e += 64) {
+    for (int e = e0 + lin; e < e1; e += 64 * NW) {
         const int kk = A.sa_k[e];
         const int pos = A.sa_pos[e];
         const double v = kk < 0 ? A.vs2[~kk] : A.vs[kk];
         atomicAdd(&sm[(pos & 255) + (pos >> 8) * ld], v);
     }
     __syncthreads();
-    // children's contribution blocks.  Per child the lanes are (row i, column group g) with 16 / 32 / 64 rows per pass by
-    // the block's size, sixteen columns in flight per lane; rel of column j comes from the lane that holds it as a row.
-    for (int c0 = 0; c0 < nch; c0 += 64) {
-        // descriptors of the children c0 .. c0 + 63, one per lane (the first batch was requested at the top of the kernel)
-        if (c0 > 0) {
-            d_m = 0;
-            if (c0 + tid < nch) {
-                const FrontDesc cd = FD[A.child_idx[fd.child_begin + c0 + tid]];
-                d_ldc = cd.ld;
-                d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
-                d_rel = cd.rowptr;
-                d_m = cd.m;
-            }
-        }
-        const int nbatch = nch - c0 < 64 ? nch - c0 : 64;
-        if (nch > 64 && __ballot(d_m > 1) == 0ull) {
-            // hub front: every child of this batch brings at most ONE entry (stars: a supply net and the pins that touch nothing
-            // else).  One lane per child fetches it; lane 0 adds them in child order (fixed order: reproducible sums).
-            const int myq = (tid < nbatch && d_m == 1) ? A.rel[d_rel] : -1;
-            const double myv = myq >= 0 ? pool[d_cb] : 0.0;
-            for (int l = 0; l < nbatch; l++) {
-                const int q = __shfl(myq, l);
-                const double v = __shfl(myv, l);
-                if (tid == 0 && q >= 0) sm[q + q * ld] += v;
-            }
-            __syncthreads();
-            continue;
-        }
-        for (int cl = 0; cl < nbatch; cl++) {
-            const int64_t cbo = __shfl(d_cb, cl), ldc = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
-            const int mc = __shfl(d_m, cl);
-            if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
-            const double *CB = pool + cbo;
-            const int sh = mc <= 16 ? 4 : (mc <= 32 ? 5 : 6);
-            const int i = tid & ((1 << sh) - 1), g = tid >> sh, G = 64 >> sh;
-            const int myrel = i < mc ? A.rel[relo + i] : 0; // lanes 0 .. mc-1 hold rel of rows (= columns) 0 .. mc-1
-            for (int jb = 0; jb < mc; jb += 16 * G) { // (wave-uniform trip count: the shuffles below need every lane)
-                double cb[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int j = jb + g + q * G;
-                    cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int j = jb + g + q * G;
-                    const int rj = __shfl(myrel, j & 63);
-                    if (i < mc && j < mc) sm[myrel + rj * ld] += cb[q];
+    // children's contribution blocks (wavefront 0).  Per child the lanes are (row i, column group g) with 16 / 32 / 64 rows per pass
+    // by the block's size, sixteen columns in flight per lane; rel of column j comes from the lane that holds it as a row.
+    if (grp == 0) {
+        for (int c0 = 0; c0 < nch; c0 += 64) {
+            // descriptors of the children c0 .. c0 + 63, one per lane (the first batch was requested at the top of the kernel)
+            if (c0 > 0) {
+                d_m = 0;
+                if (c0 + tid < nch) {
+                    const FrontDesc cd = FD[A.child_idx[fd.child_begin + c0 + tid]];
+                    d_ldc = cd.ld;
+                    d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
+                    d_rel = cd.rowptr;
+                    d_m = cd.m;
                 }
             }
-            __syncthreads(); // the next child may hit the same entries from other lanes
+            const int nbatch = nch - c0 < 64 ? nch - c0 : 64;
+            if (nch > 64 && __ballot(d_m > 1) == 0ull) {
+                // hub front: every child of this batch brings at most ONE entry (stars: a supply net and the pins that touch
+                // nothing else).  One lane per child fetches it; lane 0 adds them in child order (fixed order: reproducible sums).
+                const int myq = (tid < nbatch && d_m == 1) ? A.rel[d_rel] : -1;
+                const double myv = myq >= 0 ? pool[d_cb] : 0.0;
+                for (int l = 0; l < nbatch; l++) {
+                    const int q = __shfl(myq, l);
+                    const double v = __shfl(myv, l);
+                    if (tid == 0 && q >= 0) sm[q + q * ld] += v;
+                }
+                wave_sync();
+                continue;
+            }
+            for (int cl = 0; cl < nbatch; cl++) {
+                const int64_t cbo = __shfl(d_cb, cl), ldc = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
+                const int mc = __shfl(d_m, cl);
+                if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
+                const double *CB = pool + cbo;
+                const int sh = mc <= 16 ? 4 : (mc <= 32 ? 5 : 6);
+                const int i = tid & ((1 << sh) - 1), g = tid >> sh, G = 64 >> sh;
+                const int myrel = i < mc ? A.rel[relo + i] : 0; // lanes 0 .. mc-1 hold rel of rows (= columns) 0 .. mc-1
+                for (int jb = 0; jb < mc; jb += 16 * G) { // (wave-uniform trip count: the shuffles below need every lane)
+                    double cb[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int j = jb + g + q * G;
+                        cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int j = jb + g + q * G;
+                        const int rj = __shfl(myrel, j & 63);
+                        if (i < mc && j < mc) sm[myrel + rj * ld] += cb[q];
+                    }
+                }
+                wave_sync(); // the next child may hit the same entries from other lanes
+            }
         }
+        if (tid < p) lp[tid] = tid;
     }
-    if (tid < p) lp[tid] = tid;
     __syncthreads();
     for (int c = 0; c < p; c++) {
-        // arg-max over rows c..p-1 of column c: key = float(|a|) bits, low 7 bits = candidate flag | 63 - row
-        const bool cand = tid >= c && tid < p;
-        const double mine = cand ? sm[tid + c * ld] : 0.0;
-        const unsigned mag = __float_as_uint((float)fabs(mine));
-        const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - tid)) : 0u;
-        const int piv = 63 - (int)(wave_max_u32(key) & 63u);
-        if (piv != c) {
-            if (tid < f) {
-                double a = sm[c + tid * ld];
-                sm[c + tid * ld] = sm[piv + tid * ld];
-                sm[piv + tid * ld] = a;
-            }
-            if (tid == 0) {
-                int a = lp[c];
-                lp[c] = lp[piv];
-                lp[piv] = a;
+        // arg-max over rows c..p-1 of column c (wavefront 0): key = float(|a|) bits, low 7 bits = candidate flag | 63 - row
+        int piv = c;
+        if (grp == 0) {
+            const bool cand = tid >= c && tid < p;
+            const double mine = cand ? sm[tid + c * ld] : 0.0;
+            const unsigned mag = __float_as_uint((float)fabs(mine));
+            const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - tid)) : 0u;
+            piv = 63 - (int)(wave_max_u32(key) & 63u);
+            if (NW > 1 && tid == 0) piv_s = piv;
+        }
+        if (NW > 1) {
+            __syncthreads();
+            piv = piv_s;
+        }
+        if (piv != c) { // (workgroup-uniform)
+            if (grp == 0) {
+                if (tid < f) {
+                    double a = sm[c + tid * ld];
+                    sm[c + tid * ld] = sm[piv + tid * ld];
+                    sm[piv + tid * ld] = a;
+                }
+                if (tid == 0) {
+                    int a = lp[c];
+                    lp[c] = lp[piv];
+                    lp[piv] = a;
+                }
             }
             __syncthreads();
         }
         double d = sm[c + c * ld];
         if (fabs(d) < eps || d == 0.0) {
-            // static pivoting: replace a tiny pivot by +-eps (wave-uniform branch: d is one LDS word)
+            // static pivoting: replace a tiny pivot by +-eps (workgroup-uniform branch: d is one LDS word)
             double dn = (d < 0.0) ? -eps : eps;
             if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
             __syncthreads();
-            if (tid == 0) {
+            if (lin == 0) {
                 if (d == 0.0) atomicAdd(&info->n_zero_pivot, 1);
                 atomicAdd(&info->n_perturbed, 1);
                 sm[c + c * ld] = dn;
@@ -152,41 +172,42 @@ __global__ void __launch_bounds__(64) k_small_factor(const int32_t *__restrict__
             __syncthreads();
             d = dn;
         }
-        // lane = row: multiplier, then the rank-1 update of this row across the remaining columns
+        // thread = (row, column group): multiplier, then the rank-1 update of this row across the group's remaining columns
         const bool below = tid > c && tid < f;
         double l = 0.0;
+        if (below) l = sm[tid + c * ld] / d;
+        if (NW > 1) __syncthreads(); // every group has read the column before group 0 overwrites it with the multipliers
         if (below) {
-            l = sm[tid + c * ld] / d;
-            sm[tid + c * ld] = l;
+            if (grp == 0) sm[tid + c * ld] = l;
             // eight columns per pass, all LDS reads issued before the first write (the compiler cannot
             // reorder them itself: it has to assume the writes alias the pivot row)
-            int cc = c + 1;
-            for (; cc + 7 < f; cc += 8) {
+            int cc = c + 1 + grp;
+            for (; cc + 7 * NW < f; cc += 8 * NW) {
                 double u[8], a[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    u[q] = sm[c + (cc + q) * ld];
-                    a[q] = sm[tid + (cc + q) * ld];
+                    u[q] = sm[c + (cc + q * NW) * ld];
+                    a[q] = sm[tid + (cc + q * NW) * ld];
                 }
 #pragma unroll
-                for (int q = 0; q < 8; q++) sm[tid + (cc + q) * ld] = a[q] - l * u[q];
+                for (int q = 0; q < 8; q++) sm[tid + (cc + q * NW) * ld] = a[q] - l * u[q];
             }
-            for (; cc < f; cc++) sm[tid + cc * ld] -= l * sm[c + cc * ld];
+            for (; cc < f; cc += NW) sm[tid + cc * ld] -= l * sm[c + cc * ld];
         }
         __syncthreads();
     }
     if (tid < f) {
-        int c = 0;
-        for (; c + 7 < f; c += 8) {
+        int c = grp;
+        for (; c + 7 * NW < f; c += 8 * NW) {
             double a[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) a[q] = sm[tid + (c + q) * ld];
+            for (int q = 0; q < 8; q++) a[q] = sm[tid + (c + q * NW) * ld];
 #pragma unroll
-            for (int q = 0; q < 8; q++) F[tid + (c + q) * f] = a[q];
+            for (int q = 0; q < 8; q++) F[tid + (c + q * NW) * f] = a[q];
         }
-        for (; c < f; c++) F[tid + c * f] = sm[tid + c * ld];
+        for (; c < f; c += NW) F[tid + c * f] = sm[tid + c * ld];
     }
-    if (tid < p) lperm[fd.first + tid] = lp[tid];
+    if (grp == 0 && tid < p) lperm[fd.first + tid] = lp[tid];
 }
 
 // LU with partial pivoting of a 32 x 32 tile held one ROW PER LANE in registers (lanes 0..31).  A smaller

@@ -127,6 +127,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
     if (const char *e = getenv("HIPMF_SOLVE_LANES")) solve_lanes = std::max(1, std::min(MAX_SOLVE_LANES, atoi(e)));
+    if (const char *e = getenv("HIPMF_SMALL_WIDE")) small_wide_max = atoi(e);
     if (const char *e = getenv("HIPMF_SMALL_SPLIT")) small_split = atoi(e);
     if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_UPD_G8")) upd_g8 = std::max(upd_g4, atoi(e));
@@ -664,12 +665,18 @@ int32_t Solver::run_factor() {
             const SmallAsm sasm = {d_sd, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel, d_lists};
             if (L.small_cnt_a > 0) {
                 const size_t shmem_a = sizeof(double) * (size_t)L.small_ld_a * (size_t)L.small_ld_a;
-                hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
+                hipLaunchKernelGGL(k_small_factor<1>, dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld_a, sasm);
                 launches++;
             }
-            hipLaunchKernelGGL(k_small_factor, dim3(L.small_cnt - L.small_cnt_a), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd,
-                               d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
+            // few fronts in the launch: four wavefronts per front (the launch lasts as long as one front's LU)
+            const int32_t cnt_b = L.small_cnt - L.small_cnt_a;
+            if (cnt_b <= small_wide_max && L.small_ld > 33)
+                hipLaunchKernelGGL(k_small_factor<4>, dim3(cnt_b), dim3(256), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
+                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
+            else
+                hipLaunchKernelGGL(k_small_factor<1>, dim3(cnt_b), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
+                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
             if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
             launches++;
         }

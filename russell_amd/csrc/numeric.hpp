@@ -144,6 +144,7 @@ class Solver {
     // the read-modify-write of the trailing matrix bounds the large fronts (HIPMF_UPD_G4 / HIPMF_UPD_G8 / HIPMF_UPD_G16)
     int32_t upd_g4 = 2048, upd_g8 = 4096, upd_g16 = 1 << 30;
     int32_t update_group(int32_t f) const { return f >= upd_g16 ? 16 : (f >= upd_g8 ? 8 : (f >= upd_g4 ? 4 : 2)); }
+    int32_t small_wide_max = 7000; // a k_small_factor launch with at most this many fronts uses four wavefronts per front (HIPMF_SMALL_WIDE, 0: never)
     int32_t small_split = 28; // small fronts up to this size get their own launch per level (HIPMF_SMALL_SPLIT, 0: one launch)
     bool slab64 = false;                    // HIPMF_SOLVE_SLAB64=1: same slab shape in both solve paths (bitwise comparable)
     int32_t sf_err[2] = {0, 0};
