@@ -450,3 +450,30 @@ def test_device_probes_report_plausible_ceilings():
     assert 500.0 < gbs.value < 8000.0   # GB/s: below the 8 TB/s spec, far above PCIe
     assert 5.0 < tfs.value < 78.6       # TFLOP/s: below the data-sheet FP64 matrix peak
     assert lib.hipmf_device_mfma_rate(0, 10, ctypes.byref(tfs)) != 0  # invalid arguments are refused
+
+
+@pytest.mark.gpu
+def test_small_front_schedules_are_bitwise_equivalent(monkeypatch):
+    # one or four wavefronts per small front, one or two launches per level: the same arithmetic in the same order per entry,
+    # so the factors -- and with them the solutions and the determinant -- are bit-identical
+    n, rp, ci, v = P.poisson2d(160, 150)
+    rng = np.random.default_rng(9)
+    v = v * (1.0 + 0.3 * rng.uniform(-1, 1, v.size))
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    ref = None
+    for env in ({}, {"HIPMF_SMALL_WIDE": "0"}, {"HIPMF_SMALL_WIDE": "1000000"}, {"HIPMF_SMALL_SPLIT": "0"}, {"HIPMF_SMALL_SPLIT": "40", "HIPMF_SMALL_WIDE": "0"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci) == 0
+        assert s.factorize(v, compute_determinant=True) == 0
+        x = s.solve(b)
+        got = (x.copy(), s.det_coefficient, s.det_exponent)
+        if ref is None:
+            ref = got
+            assert np.max(np.abs(x - xs)) < 1e-11
+        assert np.array_equal(got[0], ref[0]) and got[1:] == ref[1:], env
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
