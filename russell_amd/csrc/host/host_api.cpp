@@ -837,9 +837,22 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
         if (mat.nrow != initialized_ndim) return "subsequent factorizations must use the same matrix (ndim differs)";
         if (mat.nnz != initialized_nnz) return "subsequent factorizations must use the same matrix (nnz differs)";
         if (params) return "subsequent factorizations must not change LinSolParams";
+        // The value map was built from the FIRST call's triplets.  The reference re-reads the indices on every call
+        // (csr_matrix.rs:359-480), so the triplet order may change between calls: the map is only used while the indices are
+        // the ones it was built from (O(nnz) compare); otherwise the values go through the host conversion, and a changed
+        // pattern is refused.
+        if (value_map_set && (std::memcmp(map_i.data(), mat.indices_i.data(), sizeof(int32_t) * mat.nnz) != 0 ||
+                              std::memcmp(map_j.data(), mat.indices_j.data(), sizeof(int32_t) * mat.nnz) != 0)) {
+            value_map_set = false;
+            map_i.clear(), map_j.clear();
+        }
         if (!value_map_set) { // (the device refreshes the values through the map otherwise: no host conversion per call)
+            const std::vector<int32_t> rp0 = csr.row_pointers, ci0 = csr.col_indices;
             StrError e = csr.update_from_coo(mat);
             if (e) return e;
+            const size_t nz0 = (size_t)rp0[csr.nrow];
+            if (csr.row_pointers != rp0 || std::memcmp(ci0.data(), csr.col_indices.data(), sizeof(int32_t) * nz0) != 0)
+                return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
         }
     } else {
         if (mat.nrow != mat.ncol) return "the matrix must be square";
@@ -876,6 +889,10 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
             std::vector<int32_t> w(seg_ptr.begin(), seg_ptr.end() - 1);
             for (size_t k = 0; k < mat.nnz; k++) seg_idx[(size_t)w[pos[k]]++] = (int32_t)k;
             value_map_set = g_backend.set_value_map((InterfaceHIPMF *)solver, (int32_t)mat.nnz, seg_ptr.data(), seg_idx.data()) == SUCCESSFUL_EXIT;
+            if (value_map_set) {
+                map_i.assign(mat.indices_i.begin(), mat.indices_i.begin() + (std::ptrdiff_t)mat.nnz);
+                map_j.assign(mat.indices_j.begin(), mat.indices_j.begin() + (std::ptrdiff_t)mat.nnz);
+            }
         }
         time_initialize_ns = now_ns() - t0;
         initialized = true;
@@ -1133,9 +1150,12 @@ StrError read_matrix_market(MatrixMarketData &data, const std::string &full_path
     if (e) return e;
     // one "put" for both value types (Hermitian files are mirrored WITHOUT conjugation, as read_matrix_market.rs:400-436 does)
     double bij = 0.0;
+    // (the reference unwraps the put result, read_matrix_market.rs:450-463: an entry on the wrong side of a triangular storage
+    // ends the read loudly instead of being dropped)
+    StrError put_err = nullptr;
     auto put = [&](size_t i, size_t j, double aij) {
-        if (complex) zout.put(i, j, aij, bij);
-        else out.put(i, j, aij);
+        StrError pe = complex ? zout.put(i, j, aij, bij) : out.put(i, j, aij);
+        if (pe && !put_err) put_err = pe;
     };
     long pos = 0;
     while (std::getline(in, line)) {
@@ -1180,6 +1200,7 @@ StrError read_matrix_market(MatrixMarketData &data, const std::string &full_path
         } else {
             put((size_t)i, (size_t)j, aij);
         }
+        if (put_err) return put_err;
     }
     if (pos != nnz) return "not all values have been found";
     return nullptr;

@@ -178,6 +178,7 @@ class SolverHIPMF : public LinSolTrait {
 
     bool factorized = false;
     bool value_map_set = false, first_call = false; // repeat factorizations refresh the values on the device through a map
+    std::vector<int32_t> map_i, map_j;              // the triplet indices the map was built from (a repeat call with other triplets rebuilds it)
     int32_t effective_ordering = -1, effective_scaling = -1, perturbed_pivots = 0;
     bool effective_matching = false; // a maximum-product matching pre-permutation is in force (weak diagonal at initialize)
     double rcond_estimate = 0.0, determinant_coefficient = 0.0, determinant_exponent = 0.0;

@@ -152,7 +152,7 @@ int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *h, double *v, double alp
 int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values,
                                    int32_t *matched_row, double *row_scale, double *col_scale) {
     if (!row_pointers || !col_indices || !values || !matched_row || !row_scale || !col_scale) return ERROR_NULL_POINTER;
-    if (ndim < 1) return ERROR_HIPMF_INVALID_MATRIX;
+    if (ndim < 1 || validate_csr(ndim, row_pointers, col_indices) != 0) return ERROR_HIPMF_INVALID_MATRIX;
     std::vector<int32_t> mrow;
     std::vector<double> dr, dc;
     if (max_product_matching(ndim, row_pointers, col_indices, values, mrow, dr, dc) != 0) return ERROR_HIPMF_INVALID_MATRIX;

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
         const int kk = A.sa_k[e];
         const int pos = A.sa_pos[e];
         const double v = kk < 0 ? A.vs2[~kk] : A.vs[kk];
-        atomicAdd(&sm[(pos & 255) + (pos >> 8) * ld], v);
+        sm[(pos & 255) + (pos >> 8) * ld] = v; // (every entry has its own slot: validate_csr refuses duplicates)
     }
     __syncthreads();
     // children's contribution blocks (wavefront 0).  Per child the lanes are (row i, column group g) with 16 / 32 / 64 rows per pass

@@ -29,6 +29,19 @@ namespace hipmf {
 
 #define STREAM ((hipStream_t)stream)
 
+// A phase runs on the handle's device (handles are Send: the calling thread's current device may be another one) and
+// gives the caller's device back on return.
+struct DeviceScope {
+    int prev = -1, dev;
+    explicit DeviceScope(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d) (void)hipSetDevice(d);
+    }
+    ~DeviceScope() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
 constexpr int32_t MAX_LDS_DOUBLES = 7936; // 62 KiB of dynamic LDS for the w1 / v vectors of the big-front solves
 
 template <class T>
@@ -45,6 +58,8 @@ Solver::~Solver() { release(); }
 
 void Solver::release() {
     if (!stream && !d_pool && !d_fd) return;
+    int caller_device = -1; // the caller's current device is restored on the way out
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     (void)hipSetDevice(device);
     void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
                     d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
@@ -92,12 +107,32 @@ void Solver::release() {
             *e = nullptr;
         }
     initialized = factorized = false;
+    if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device);
 }
 
 int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
                            const NumericOptions &nopt, const double *values) {
     if (initialized) return ERROR_ALREADY_INITIALIZED;
+    // any failure leaves the handle as new: nothing allocated on the device, initialize may be tried again
+    const int32_t code = initialize_impl(n, rp, ci, sym_lower, sopt, nopt, values);
+    if (code != SUCCESSFUL_EXIT) {
+        const std::string keep = last_error;
+        release();
+        last_error = keep;
+    }
+    return code;
+}
+
+int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
+                                const NumericOptions &nopt, const double *values) {
     opt = nopt;
+    // the structure is validated once, before the matching / the analysis read through the indices
+    if (const int vc = validate_csr(n, rp, ci)) {
+        last_error = vc == -1 ? "invalid CSR: row pointers must start at 0 and be non-decreasing"
+                              : (vc == -2 ? "invalid CSR: column index out of range"
+                                          : "invalid CSR: the column indices of a row must be strictly increasing (no duplicates)");
+        return ERROR_HIPMF_INVALID_MATRIX;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         last_error = "no HIP device visible";
@@ -183,10 +218,7 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
     }
     const auto t_plan = std::chrono::steady_clock::now();
     int32_t code = upload_plan();
-    if (code != SUCCESSFUL_EXIT) {
-        release();
-        return code;
-    }
+    if (code != SUCCESSFUL_EXIT) return code;
     if (opt.verbose)
         fprintf(stderr,
                 "hipmf: initialize: graph %.3f s, ordering %.3f s, etree %.3f s, supernodes %.3f s, row structures %.3f s, layout %.3f s, "
@@ -576,7 +608,7 @@ int32_t Solver::upload_plan() {
 int32_t Solver::factorize(const double *values, bool on_device) {
     if (!initialized) return ERROR_NEED_INITIALIZATION;
     if (!values) return ERROR_NULL_POINTER;
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     const int64_t nnz = S.nnz_a;
     HIPC(hipMemcpyAsync(d_vals, values, sizeof(double) * nnz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, STREAM),
          ERROR_HIP_MEMCPY);
@@ -595,7 +627,7 @@ int32_t Solver::set_value_map(int64_t nin, const int32_t *seg_ptr, const int32_t
         if (seg_ptr[j + 1] < seg_ptr[j]) return ERROR_HIPMF_INVALID_VALUE;
     for (int64_t q = 0; q < nin; q++)
         if (seg_idx[q] < 0 || seg_idx[q] >= nin) return ERROR_HIPMF_INVALID_VALUE;
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     for (void *p : {(void *)d_seg_ptr, (void *)d_seg_idx, (void *)d_vin})
         if (p) (void)hipFree(p);
     d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr;
@@ -612,7 +644,7 @@ int32_t Solver::factorize_mapped(const double *input, bool on_device) {
     if (!initialized) return ERROR_NEED_INITIALIZATION;
     if (!input) return ERROR_NULL_POINTER;
     if (nnz_in < 1) return ERROR_HIPMF_INVALID_VALUE; // no map set
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     const double *src = input;
     if (!on_device) {
         HIPC(hipMemcpyAsync(d_vin, input, sizeof(double) * nnz_in, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
@@ -837,7 +869,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     if (!factorized) return ERROR_NEED_FACTORIZATION;
     if (!x || !rhs) return ERROR_NULL_POINTER;
     if (nrhs < 1 || ldx < S.n) return ERROR_HIPMF_INVALID_VALUE;
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     const int32_t n = S.n;
     const dim3 g((n + 255) / 256), b(256);
     const double EPS = 2.220446049250313e-16;
@@ -1054,7 +1086,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
 int32_t Solver::spmv(double *y, const double *x, double alpha, bool on_device) {
     if (!factorized) return ERROR_NEED_FACTORIZATION;
     if (!x || !y) return ERROR_NULL_POINTER;
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     const int32_t n = S.n;
     const double *xd = x;
     double *yd = y;
@@ -1072,7 +1104,7 @@ int32_t Solver::spmv(double *y, const double *x, double alpha, bool on_device) {
 int32_t Solver::adopt_factor(const double *d_values) {
     if (!initialized) return ERROR_NEED_INITIALIZATION;
     if (!d_values) return ERROR_NULL_POINTER;
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     HIPC(hipMemcpyAsync(d_vals, d_values, sizeof(double) * S.nnz_a, hipMemcpyDeviceToDevice, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     n_perturbed = n_zero_pivot = 0;
@@ -1082,7 +1114,7 @@ int32_t Solver::adopt_factor(const double *d_values) {
 
 int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
     if (!factorized) return ERROR_NEED_FACTORIZATION;
-    HIPC(hipSetDevice(device), ERROR_HIPMF_NO_DEVICE);
+    DeviceScope dev_scope(device);
     const int32_t n = S.n;
     hipLaunchKernelGGL(k_diag_gather, dim3(S.nsuper), dim3(64), 0, STREAM, S.nsuper, d_fd, d_pool, d_du);
     std::vector<double> du((size_t)n), rs((size_t)n), cs;

@@ -114,6 +114,8 @@ class Solver {
     int32_t match_parity = 0;     // parity of its row permutation (for the determinant)
 
   private:
+    int32_t initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
+                            const NumericOptions &nopt, const double *values);
     int32_t upload_plan();
     int32_t run_factor();
     // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)

@@ -539,6 +539,22 @@ static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, s
 
 } // namespace
 
+int validate_csr(int32_t n, const int32_t *rp, const int32_t *ci) {
+    if (n < 1 || !rp || !ci || rp[0] != 0) return -1;
+    for (int32_t i = 0; i < n; i++) {
+        if (rp[i + 1] < rp[i]) return -1;
+        int32_t prev = -1;
+        for (int32_t p = rp[i]; p < rp[i + 1]; p++) {
+            const int32_t j = ci[p];
+            if (j < 0 || j >= n) return -2;
+            if (j <= prev) return -3;
+            prev = j;
+        }
+    }
+    return 0;
+}
+
+
 int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &opt, Symbolic &S) {
     auto t_all = clk::now(), t_phase = t_all;
     if (n < 1 || !rp || !ci) return -1;

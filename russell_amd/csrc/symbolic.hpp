@@ -76,6 +76,11 @@ struct Symbolic {
     inline int32_t fsize(int32_t s) const { return npiv(s) + nrow(s); }
 };
 
+// Structure check of a 0-based CSR every entry point runs BEFORE anything reads through the indices: 0 = valid,
+// -1 row pointers (rp[0] != 0 or decreasing), -2 column index out of range, -3 column indices of a row not strictly
+// increasing (unsorted or duplicate entries: the assembly map sends every entry to its own slot of a front).
+int validate_csr(int32_t n, const int32_t *row_ptr, const int32_t *col_idx);
+
 // Analyse the n x n matrix given as 0-based CSR (the layout solver_cudss_initialize receives,
 // interface_cudss.cu:190-203).  Returns 0 on success, a negative number on invalid input.
 int analyse(int32_t n, const int32_t *row_ptr, const int32_t *col_idx, bool sym_lower,
