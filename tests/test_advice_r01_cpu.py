@@ -95,5 +95,5 @@ def test_matrix_market_entry_on_the_wrong_triangle_is_an_error(tmp_path):
     path.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 3\n1 1 2.0\n1 2 1.0\n3 3 4.0\n")
     with pytest.raises(RS.StrError):
         RS.read_matrix_market(str(path), RS.MMsym.LeaveAsLower)
-    coo = RS.read_matrix_market(str(path), RS.MMsym.SwapToUpper)
-    assert coo.nnz == 3
+    coo = RS.read_matrix_market(str(path), RS.MMsym.MakeItFull)
+    assert coo.nnz == 4
