@@ -39,7 +39,9 @@ void solver_hipmf_drop(struct InterfaceHIPMF *h) {
 int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
                                 int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, C_BOOL positive_definite,
                                 int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
-    (void)positive_definite; // accepted for API parity; the numeric phase is LU with static pivoting either way
+    // either flag promises the LOWER triangle of a symmetric matrix (interface_cudss.cu:324-333: SYMMETRIC / SPD + lower view); the
+    // tiled fronts are then factorised as L D L^T (positive definite: D > 0, the same arithmetic)
+    const bool sym_lower = general_symmetric == 1 || positive_definite == 1;
     if (!h || !row_pointers || !col_indices) return ERROR_NULL_POINTER;
     if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
     if (ndim < 1) return ERROR_HIPMF_INVALID_MATRIX;
@@ -52,7 +54,7 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int3
     no.verbose = verbose == 1;
     h->ordering_requested = ordering;
     h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
-    int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, general_symmetric == 1, so, no, values);
+    int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, sym_lower, so, no, values);
     if (verbose == 1 && code == SUCCESSFUL_EXIT) {
         const Symbolic &S = h->solver.S;
         printf("solver_hipmf_initialize: n=%d nnz=%lld supernodes=%d levels=%d nnz(L)=%lld nnz(U)=%lld flops=%.3e "

@@ -8,7 +8,7 @@ namespace hipmf {
 // tptr/tidx list, for every row i, the positions of the stored entries (r, i), r != i, that the
 // symmetric-lower storage mirrors into row i (empty for general storage).
 __global__ void k_row_scale(int32_t n, const int32_t *__restrict__ rp, const double *__restrict__ vals,
-                            const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx, int32_t mode,
+                            const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx, int32_t mode, int32_t symmetric,
                             double *__restrict__ rs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -24,7 +24,8 @@ __global__ void k_row_scale(int32_t n, const int32_t *__restrict__ rp, const dou
                 acc = (mode == 1) ? acc + a : (a > acc ? a : acc);
             }
     }
-    rs[i] = (mode == 0 || acc == 0.0) ? 1.0 : 1.0 / acc;
+    // symmetric mode: S A S with s = 1 / sqrt(norm) (the same vector scales rows and columns, the fronts stay symmetric)
+    rs[i] = (mode == 0 || acc == 0.0) ? 1.0 : (symmetric ? 1.0 / sqrt(acc) : 1.0 / acc);
 }
 
 // Value refresh of a fixed structure (the Radau5 / Newton repeat-factorise pattern): CSR entry j is the sum of
@@ -52,7 +53,7 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
         double sv = v * rs[arow[k]];
         if (cs) sv *= cs[acol[k]];
         vs[k] = sv;
-        if (vs2) vs2[k] = v * rs[acol[k]];
+        if (vs2) vs2[k] = cs ? v * rs[acol[k]] * cs[arow[k]] : v * rs[acol[k]];
         const double a = fabs(sv);
         bad |= !(a <= 1.7976931348623157e308); // NaN or Inf
         m = a > m ? a : m;
@@ -67,21 +68,17 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
     if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
 }
 
-// pool[amap[k]] = vs[k] (scaled values, k_absmax) for the entries of the big fronts (the pool regions of the big fronts are
-// zero-filled first; every position is hit once; amap < 0: entry of a small front, assembled by k_small_factor)
-__global__ void k_scatter(int64_t nnz, const double *__restrict__ vs, const double *__restrict__ vs2, const int64_t *__restrict__ amap,
-                          const int64_t *__restrict__ amap2, double *__restrict__ pool) {
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = amap[k];
-        if (q >= 0) pool[q] = vs[k];
-        if (amap2) {
-            const int64_t q2 = amap2[k];
-            if (q2 >= 0) pool[q2] = vs2[k];
-        }
+// pool[at[e]] = vs[k_e] (scaled values, k_absmax; k_e < 0: the mirrored copy vs2[~k_e] of a symmetric-lower entry) for the entries
+// of one level's tiled fronts (their working blocks are zero-filled first; every position is hit once)
+__global__ void k_scatter(int64_t cnt, const int32_t *__restrict__ sc_k, const int64_t *__restrict__ sc_at, const double *__restrict__ vs,
+                          const double *__restrict__ vs2, double *__restrict__ pool) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t k = sc_k[e];
+        pool[sc_at[e]] = k < 0 ? vs2[~k] : vs[k];
     }
 }
 
-// zero-fill of the big fronts only (the small ones are written whole by k_small_factor): one workgroup per chunk
+// zero-fill of the big fronts' blocks (the small fronts are written whole by k_small_factor): one workgroup per chunk
 struct ZeroTask {
     int64_t off; // pool offset (doubles)
     int32_t len; // doubles
@@ -93,14 +90,15 @@ __global__ void __launch_bounds__(256) k_zero(const ZeroTask *__restrict__ tasks
     for (int i = threadIdx.x; i < t.len; i += 256) p[i] = 0.0;
 }
 
-// identity blocks of the augmented big fronts: E(i, f+i) = 1 and E'(f+i, i) = 1 (the pool is zero-filled first)
+// identity blocks of the augmented big fronts: E(i, i) = 1 and E'(i, i) = 1 (the panels are zero-filled first)
 __global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, double *__restrict__ pool) {
     FrontDesc fd = FD[list[blockIdx.x]];
-    const int64_t ld = fd.ld, f = (int64_t)fd.p + fd.m;
-    double *F = pool + fd.off;
+    const int64_t f = (int64_t)fd.p + fd.m, p = fd.p;
+    double *E = pool + fd.eoff;
+    double *Ep = fd.epoff >= 0 ? pool + fd.epoff : nullptr;
     for (int i = threadIdx.x; i < fd.p; i += blockDim.x) {
-        F[i + (f + i) * ld] = 1.0;
-        F[(f + i) + i * ld] = 1.0;
+        E[i + i * f] = 1.0;
+        if (Ep) Ep[i + i * p] = 1.0;
     }
 }
 
@@ -137,7 +135,9 @@ __global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int j = j0 + q * ng;
-                    at[q] = (j < jhi) ? ri + (int64_t)relc[j] * ld : -1;
+                    // (sym: rel is increasing, so child entry (i, j), i >= j, lands on or below the parent's diagonal; the child's
+                    //  own block is valid there whether it was factorised as LU or as L D L^T)
+                    at[q] = (j < jhi && (!t.sym || j <= i)) ? ri + (int64_t)relc[j] * ld : -1;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; q++) {

@@ -1,16 +1,23 @@
 // kernels_common.hpp -- constants, descriptors and small device helpers shared by the HIP kernels.
 //
 // Data layout in HBM
-//   pool   every supernode s owns a column-major frontal matrix at pool + off[s] with leading
-//          dimension ld[s].  f = p + m (p pivot columns, m off-diagonal rows).
-//          * small fronts (f <= SMALL_F): ld = f.  After factorisation the first p columns hold
-//            L11\U11 and L21, rows 0..p of the other columns hold U12, the trailing m x m block is
-//            the contribution block the parent consumes (extend-add).
-//          * big fronts (f > SMALL_F) are AUGMENTED: ld = f + p; columns f..f+p start as [I; 0] and
-//            rows f..f+p start as [I, 0].  The same partial LU leaves
-//                E  = [inv(L11) P ; -L21 inv(L11) P]      in columns f..f+p  (rows 0..f)
-//                E' = [inv(U11) , -inv(U11) U12]           in rows    f..f+p  (columns 0..f)
-//            which turn the triangular solves of a big supernode into dependency-free GEMVs.
+//   pool   ONE device allocation in two parts:  [ persistent factor | temporary arena ].
+//          f = p + m (p pivot columns, m off-diagonal rows) for every supernode s.
+//          * small fronts (f <= SMALL_F): a column-major f x f block at pool + off in the PERSISTENT part, ld = f.  After
+//            factorisation the first p columns hold L11\U11 and L21, rows 0..p of the other columns hold U12, the trailing
+//            m x m block is the contribution block the parent consumes (extend-add).
+//          * big fronts (f > SMALL_F) are factorised AUGMENTED: the partial LU runs on the (f+p) x (f+p) matrix
+//            [F  Ic; Ir  0] (Ic = [I; 0], Ir = [I, 0]) and leaves
+//                E  = [inv(L11) P ; -L21 inv(L11) P]      f x p, column-major ld = f, at pool + eoff   (PERSISTENT)
+//                E' = [inv(U11) , -inv(U11) U12]           p x f, column-major ld = p, at pool + epoff  (PERSISTENT)
+//            which turn the triangular solves of a big supernode into dependency-free GEMVs.  The front itself, F (f x f, ld = f,
+//            at pool + off), lives in the TEMPORARY arena: its storage is handed to other fronts once the parent has consumed the
+//            contribution block (static lifetime plan made at initialize, symbolic.cpp).  Index (r, c) of the augmented matrix:
+//            r < f, c < f -> F;  r < f, c >= f -> E(r, c - f);  r >= f, c < f -> E'(r - f, c)   (AugView below).
+//          * SYMMETRIC mode (FD_SYM; general_symmetric / positive_definite input): a big front is factorised as L D L^T without
+//            interchanges, only the lower triangle of F is assembled, updated and read; E' does not exist: the backward solve
+//            applies E^T:  x1 = E^T [D^{-1} y1; x2].
+//   diag   n doubles: the pivots (diagonal of U, resp. D) in pivot order, written by whoever factorises a diagonal block.
 //   lperm  n int32: for pivot row r of front s, the front-local row that partial pivoting moved there
 //          (search restricted to the pivot block for small fronts, to the 32-row diagonal tile for big ones).
 //   work   one f-vector per front for the multifrontal forward/backward substitutions:
@@ -38,9 +45,35 @@ struct FrontDesc {
     int32_t first;  // first permuted column
     int32_t child_begin, child_end;
     int32_t parent;
-    int32_t ld;     // leading dimension: f (small fronts) or f + p (augmented big fronts)
+    int32_t ld;     // leading dimension of the f x f block at `off`: f
     int32_t ugroup; // tiled path: 32-pivot panels per read-modify-write pass over the trailing matrix (2, 4, 8 or 16)
+    int64_t eoff;   // big fronts: offset of E (f x p, ld f); -1 for small fronts
+    int64_t epoff;  // big fronts, LU mode: offset of E' (p x f, ld p); -1 otherwise
+    int32_t flags;  // FD_BIG | FD_SYM
+    int32_t pad;
 };
+constexpr int32_t FD_BIG = 1; // tiled path (f > SMALL_F)
+constexpr int32_t FD_SYM = 2; // big front factorised as L D L^T: only the lower triangle of F (and of its contribution block) is valid
+
+// The augmented index space of a big front (see the layout note at the top of this file).
+struct AugView {
+    double *F;    // (r, c), r < f, c < f          at F[r + c f]
+    double *Esh;  // (r, c), r < f, c >= f         at Esh[r + c f]     (Esh = E - f f)
+    double *Epsh; // (r, c), r >= f, c < f         at Epsh[r + c p]    (Epsh = E' - f)
+    int32_t f, p;
+    __device__ __forceinline__ double *at(int r, int c) const {
+        if (r >= f) return Epsh + r + (int64_t)c * p;
+        return (c >= f ? Esh : F) + r + (int64_t)c * f;
+    }
+};
+__device__ __forceinline__ AugView aug_view(const FrontDesc &fd, double *pool) {
+    AugView v;
+    v.f = fd.p + fd.m, v.p = fd.p;
+    v.F = pool + fd.off;
+    v.Esh = pool + fd.eoff - (int64_t)v.f * v.f;
+    v.Epsh = pool + fd.epoff - v.f;
+    return v;
+}
 
 // A small front's descriptor and the range of its entry list, in LAUNCH order (index = position in the level's list): the
 // workgroup reads one record instead of list -> FD / sa_ptr, one dependent memory round trip less at the head of its chain.
@@ -53,7 +86,7 @@ struct EaTask {
     int64_t f_off;                    // pool offset of the parent front
     int32_t ld;                       // its leading dimension
     int32_t piece_begin, piece_end;   // the EaRange pieces (children in ascending order) that hit this tile of the parent
-    int32_t pad;
+    int32_t sym;                      // parent factorised as L D L^T: only entries on or below its diagonal are added
 };
 
 // One child's contribution block restricted to one tile of the parent: everything the kernel needs in one load.

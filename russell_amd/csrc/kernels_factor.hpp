@@ -5,9 +5,11 @@
 //                    removes a dependent launch from the critical path) and then solves its own row /
 //                    column tile against it                                                     (latency-bound)
 //   k_update         tiled path, step k0: trailing update on v_mfma_f64_16x16x4_f64            (MFMA / HBM-bound)
-// Big fronts are stored augmented (kernels_common.hpp): the tiled kernels work on the index range
-// [k0 + nb, f + k0 + nb) of both dimensions, which covers the not-yet-eliminated part of F, the columns
-// of E that are already non-zero and the rows of E' that are already non-zero.
+// Big fronts are factorised augmented (kernels_common.hpp): the tiled kernels work on the index range
+// [k0 + nb, f + k0 + nb) of both dimensions of [F Ic; Ir 0], which covers the not-yet-eliminated part of F, the columns
+// of E that are already non-zero and the rows of E' that are already non-zero (AugView maps an index pair to F / E / E').
+// Symmetric mode (template parameter SYM): L D L^T without interchanges on the lower triangle of F; the rows of U a step
+// needs are D times the transposed columns of L, E' does not exist.
 #pragma once
 #include "kernels_common.hpp"
 
@@ -38,7 +40,7 @@ template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
                                                           double *__restrict__ pool, int32_t *__restrict__ lperm,
                                                           const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
-                                                          FactorInfo *info, int32_t ld, SmallAsm A) {
+                                                          FactorInfo *info, int32_t ld, SmallAsm A, double *__restrict__ diag) {
     HIPMF_DYN_SHARED(double, sm);
     __shared__ int32_t lp[SMALL_F];
     __shared__ int32_t piv_s;
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
     int d_m = 0;
     if (grp == 0 && tid < nch) { // (nch > 64: later batches are read below)
         const FrontDesc cd = FD[A.child_idx[fd.child_begin + tid]];
-        d_ldc = cd.ld;
+        d_ldc = (cd.flags & FD_SYM) ? -(int64_t)cd.ld : (int64_t)cd.ld; // (negative: only the lower triangle of the block is valid)
         d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
         d_rel = cd.rowptr;
         d_m = cd.m;
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
                 d_m = 0;
                 if (c0 + tid < nch) {
                     const FrontDesc cd = FD[A.child_idx[fd.child_begin + c0 + tid]];
-                    d_ldc = cd.ld;
+                    d_ldc = (cd.flags & FD_SYM) ? -(int64_t)cd.ld : (int64_t)cd.ld;
                     d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
                     d_rel = cd.rowptr;
                     d_m = cd.m;
@@ -101,7 +103,9 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
                 continue;
             }
             for (int cl = 0; cl < nbatch; cl++) {
-                const int64_t cbo = __shfl(d_cb, cl), ldc = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
+                const int64_t cbo = __shfl(d_cb, cl), ldc_s = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
+                const bool csym = ldc_s < 0; // child factorised as L D L^T: mirror its lower triangle
+                const int64_t ldc = csym ? -ldc_s : ldc_s;
                 const int mc = __shfl(d_m, cl);
                 if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
                 const double *CB = pool + cbo;
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
                         const int j = jb + g + q * G;
-                        cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
+                        cb[q] = (i < mc && j < mc) ? ((csym && i < j) ? CB[j + (int64_t)i * ldc] : CB[i + (int64_t)j * ldc]) : 0.0;
                     }
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
@@ -207,7 +211,10 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
         }
         for (; c < f; c += NW) F[tid + c * f] = sm[tid + c * ld];
     }
-    if (grp == 0 && tid < p) lperm[fd.first + tid] = lp[tid];
+    if (grp == 0 && tid < p) {
+        lperm[fd.first + tid] = lp[tid];
+        diag[fd.first + tid] = sm[tid + tid * ld];
+    }
 }
 
 // LU with partial pivoting of a 32 x 32 tile held one ROW PER LANE in registers (lanes 0..31).  A smaller
@@ -217,6 +224,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
 // lane's row was chosen as the pivot row (ties go to the lowest row: deterministic).  On exit the row
 // holds its multipliers in columns < step and its row of U in columns >= step; npert / nzero count the
 // perturbed / exactly-zero pivots (wave-uniform).
+template <bool PIVOT = true>
 __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero) {
     step = -1;
     npert = 0;
@@ -231,7 +239,8 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
         const unsigned mag = __float_as_uint((float)fabs(a[c]));
         const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
         const double myinv = fast_rcp(a[c]);
-        const int pv = 31 - (int)(wave_max_u32<2>(key) & 31u); // (candidates live in lanes 0..31: two rows)
+        // (PIVOT = false, the symmetric fronts: the pivot of step c is row c -- L D L^T in the guise of an LU without interchanges)
+        const int pv = PIVOT ? 31 - (int)(wave_max_u32<2>(key) & 31u) : c; // (candidates live in lanes 0..31: two rows)
         if (lane == pv) step = c;
         double d = wave_bcast(a[c], pv);
         double inv = wave_bcast(myinv, pv);
@@ -261,10 +270,14 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
 // One thread owns one row (L) / one column (U) and runs a right-looking substitution in registers.
 // The factorised tile is NOT written into F here (other workgroups still read the original): workgroup 0
 // of each front parks it in dws, k_update moves it into place.
+// SYM: the L tiles cover the rows of F below the tile only, the U tiles the columns of E only (U12 = D L21^T is never formed);
+// the tile is factorised without interchanges from its lower triangle.
+template <bool SYM>
 __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                    const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
-                                                   const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
+                                                   const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                   double *__restrict__ diag) {
     // D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
     // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
     __shared__ __attribute__((aligned(16))) double D[NB][NB + 2];
@@ -276,18 +289,19 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int slot = find_slot(pfx, nactive, blockIdx.x);
     const int t = blockIdx.x - pfx[slot];
     FrontDesc fd = FD[list[slot]];
-    const int64_t ld = fd.ld;
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
     const int nT = (f + PANEL_T - 1) / PANEL_T;
-    double *F = pool + fd.off;
+    const AugView A = aug_view(fd, pool);
     const bool ltile = t < nT;
-    const int o0 = base + (ltile ? t : t - nT) * PANEL_T;               // first row (L) / column (U) of this tile
-    const int ext = (limit - o0) < PANEL_T ? (limit - o0) : PANEL_T;     // rows (L) / columns (U) in this tile
+    // first row (L) / column (U) of this tile and its extent
+    const int o0 = SYM ? (ltile ? base + t * PANEL_T : f + (t - nT) * PANEL_T) : base + (ltile ? t : t - nT) * PANEL_T;
+    const int oend = (SYM && ltile) ? f : limit;
+    const int ext = (oend - o0) < PANEL_T ? (oend - o0) : PANEL_T;
+    if (ext <= 0 && !(t == 0 && k0 == 0)) return; // (workgroup 0 of step 0 still factorises and parks the diagonal tile)
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
-    // (no integer divisions, loads issued in batches of 8 before the LDS stores: the loop is latency-bound otherwise)
     // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain;
     //  the factorised diagonal tile of steps k0 > 0 and its row interchanges are requested first, in the same round trip)
     double tv[NB * NB / PANEL_T];
@@ -303,21 +317,23 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     }
     if (ltile) {
         if (tid < ext) {
-            const double *src = F + (o0 + tid) + (int64_t)k0 * ld; // row tid of the tile, column k at src[k * ld]
+            // row o0 + tid of the tile (a row of F, or of E' below it), column k0 + u at src[u * cstride]
+            const int r = o0 + tid;
+            const double *src = A.at(r, k0);
+            const int64_t cstride = r >= f ? A.p : A.f;
             double v[NB];
 #pragma unroll
-            for (int u = 0; u < NB; u++) v[u] = (u < nb) ? src[(int64_t)u * ld] : 0.0;
+            for (int u = 0; u < NB; u++) v[u] = (u < nb) ? src[(int64_t)u * cstride] : 0.0;
 #pragma unroll
             for (int u = 0; u < NB; u++) T[u][tid] = v[u];
         }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5; // 4 columns x 32 rows per pass
-        const double *src = F + (k0 + k) + (int64_t)o0 * ld;
         double v[PANEL_T / 4];
 #pragma unroll
         for (int u = 0; u < PANEL_T / 4; u++) {
             const int cc = 4 * u + cq;
-            v[u] = (k < nb && cc < ext) ? src[(int64_t)cc * ld] : 0.0;
+            v[u] = (k < nb && cc < ext) ? *A.at(k0 + k, o0 + cc) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < PANEL_T / 4; u++) T[k][4 * u + cq] = v[u];
@@ -335,22 +351,28 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         if (tid < NB) lp[tid] = (tid < nb) ? lpv - k0 : tid;
     } else if (tid < 64) {
         double a[NB];
+        const double *F = A.F;
 #pragma unroll
-        for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? F[(k0 + tid) + (int64_t)(k0 + c) * ld] : (tid == c ? 1.0 : 0.0);
+        for (int c = 0; c < NB; c++) {
+            // (SYM: only the lower triangle of F is assembled)
+            const int rr = (SYM && tid < c) ? c : tid, cc = (SYM && tid < c) ? tid : c;
+            a[c] = (tid < nb && c < nb) ? F[(k0 + rr) + (int64_t)(k0 + cc) * f] : (tid == c ? 1.0 : 0.0);
+        }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32(a, tid, eps, step, npert, nzero);
+        tile_lu32<!SYM>(a, tid, eps, step, npert, nzero);
         if (tid < NB) {
             // rows go to LDS in pivot order: row `step` of the interchanged tile is this lane's row
-            double diag = 1.0;
+            double dg = 1.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
                 D[step][c] = a[c];
                 DT[c][step] = a[c];
-                if (c == step) diag = a[c];
+                if (c == step) dg = a[c];
             }
-            dinv[step] = 1.0 / diag;
+            dinv[step] = 1.0 / dg;
             lp[step] = tid;
+            if (t == 0 && tid < nb) diag[fd.first + k0 + step] = dg;
         }
         if (t == 0 && tid == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);
@@ -363,6 +385,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
         if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
     }
+    if (ext <= 0) return;
     // 3. substitution, right-looking, one row / column per thread, branch-free over the padded 32 steps
     if (tid < ext) {
         double x[NB];
@@ -399,18 +422,19 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     __syncthreads();
     if (ltile) {
         if (tid < ext) {
-            double *dst = F + (o0 + tid) + (int64_t)k0 * ld;
+            const int r = o0 + tid;
+            double *dst = A.at(r, k0);
+            const int64_t cstride = r >= f ? A.p : A.f;
 #pragma unroll
             for (int k = 0; k < NB; k++)
-                if (k < nb) dst[(int64_t)k * ld] = T[k][tid];
+                if (k < nb) dst[(int64_t)k * cstride] = T[k][tid];
         }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5;
-        double *dst = F + (k0 + k) + (int64_t)o0 * ld;
 #pragma unroll
         for (int cb = 0; cb < PANEL_T; cb += 4) {
             const int cc = cb + cq;
-            if (k < nb && cc < ext) dst[(int64_t)cc * ld] = T[k][cc];
+            if (k < nb && cc < ext) *A.at(k0 + k, o0 + cc) = T[k][cc];
         }
     }
 }
@@ -438,12 +462,16 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // for columns 0..15, lane r + 32 for columns 16..31), factorises it in registers (tile_lu32) and parks it in
 // dws (other buffer) with its row interchanges.  That 32 x 32 LU -- the longest serial piece of a tiled step --
 // runs beside the trailing update instead of in front of the next panel solve.
+// SYM: only entries of the lower triangle of F (r >= c) and of E are live; a row of U inside F is D times the transposed
+// column of L (U(k, c) = d_k L(c, k), d from `diag`), so the update L D L^T is exactly symmetric; rows of E are read as they are.
 // (Tried and rejected: 128 x 128 tiles, four 64 x 64 waves -- 204 VGPRs + 128 AGPRs, one workgroup per CU: 962 ms instead of
 // 924 ms for the 128^3 Poisson factorisation.)
+template <bool SYM>
 __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
                                                 const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
-                                                const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info) {
+                                                const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                double *__restrict__ diag) {
     constexpr int TS = UPD_T;
     constexpr int LSLD = TS + 16;  // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
     constexpr int MT = TS / 32;    // MFMA tiles per wave and dimension
@@ -457,7 +485,6 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int slot = find_slot(pfx, nactive, blockIdx.x);
     const int t = blockIdx.x - pfx[slot];
     FrontDesc fd = FD[list[slot]];
-    const int64_t ld = fd.ld;
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
@@ -468,7 +495,9 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int nhalf = gpos + 1;                              // 32-column slices of K: every panel of the group so far
     const int kfirst = k0 - gpos * NB;
     const int ntiles = narrow ? 2 * nt : nt * nt;
-    double *F = pool + fd.off;
+    const AugView A = aug_view(fd, pool);
+    double *F = A.F;
+    const double *dg = diag + fd.first; // pivots of this front (SYM: D)
     if (t == ntiles) {
         // ---- look-ahead workgroup: only wave 0 works ----
         if (tid >= 64) return;
@@ -477,7 +506,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const int cc = half * 16 + c;
-            acc[c] = (r < nb2 && cc < nb2) ? F[(base + r) + (int64_t)(base + cc) * ld] : (r == cc ? 1.0 : 0.0);
+            const int rr = (SYM && r < cc) ? cc : r, c2 = (SYM && r < cc) ? r : cc; // (SYM: lower triangle)
+            acc[c] = (r < nb2 && cc < nb2) ? F[(base + rr) + (int64_t)(base + c2) * f] : (r == cc ? 1.0 : 0.0);
         }
         for (int h = 0; h < nhalf; h++) {
             const int kh = kfirst + h * NB, nbh = (h == nhalf - 1) ? nb : NB;
@@ -487,16 +517,23 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             double um[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
-                const int e = tid + 64 * u, kk = e & 31, c = e >> 5;
-                um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * ld] : 0.0;
+                const int e = tid + 64 * u;
+                if (SYM) { // U(kk, c) = d_kk L(base + c, kk): lanes run along c (contiguous rows of a column of L)
+                    const int c = e & 31, kk = e >> 5;
+                    um[u] = (kk < nbh && c < nb2) ? F[(base + c) + (int64_t)(kh + kk) * f] * dg[kh + kk] : 0.0;
+                } else {
+                    const int kk = e & 31, c = e >> 5;
+                    um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * f] : 0.0;
+                }
             }
             double lrow[NB];
 #pragma unroll
-            for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * ld] : 0.0;
+            for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * f] : 0.0;
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u;
-                UM[e & 31][e >> 5] = um[u];
+                if (SYM) UM[e >> 5][e & 31] = um[u];
+                else UM[e & 31][e >> 5] = um[u];
             }
             __syncthreads(); // (only wave 0 is left in this workgroup)
 #pragma unroll
@@ -518,13 +555,17 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32(a2, tid, eps, step, npert, nzero); // lanes >= 32 are not candidates and take no part
+        tile_lu32<!SYM>(a2, tid, eps, step, npert, nzero); // lanes >= 32 are not candidates and take no part
         if (tid < nb2) {
             double *dwo = dws + ((int64_t)(((k0 / NB) + 1) & 1) * dws_stride + slot) * NB * NB;
+            double dgv = 1.0;
 #pragma unroll
-            for (int c = 0; c < NB; c++)
+            for (int c = 0; c < NB; c++) {
                 if (c < nb2) dwo[step + c * nb2] = a2[c];
+                if (c == step) dgv = a2[c];
+            }
             lperm[fd.first + base + step] = base + tid;
+            diag[fd.first + base + step] = dgv;
         }
         if (tid == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);
@@ -545,18 +586,23 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
         for (int u = 0; u < NB * NB / 256; u++) {
             const int e = tid + 256 * u;
-            if (e < nb * nb) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * ld] = dv[u];
+            if (e < nb * nb) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * f] = dv[u];
         }
     }
-    if (r0 >= f && c0 >= f) return; // corner of the augmented front: never read
+    if (r0 >= f && (SYM || c0 >= f)) return; // corner of the augmented front (SYM: there is no E'): never read
+    if (SYM && c0 + TS <= f && r0 + TS <= c0) return; // strictly upper tile of F
     // entries this step may touch: rows < rmax, columns in [cmin, cmax)
-    const int rmax = rowstrip ? base + nb2 : limit;
+    const int rmax = rowstrip ? base + nb2 : (SYM ? f : limit);
     const int cmax = (narrow && !rowstrip) ? base + nb2 : limit;
-    const int cmin = rowstrip ? base + nb2 : 0;
+    const int cmin = rowstrip ? (SYM ? (f > base + nb2 ? f : base + nb2) : base + nb2) : 0;
+    if (SYM && c0 + TS <= cmin) return; // row strip of a symmetric front: only the columns of E are live
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = (wave & 1) * (TS / 2), wc = (wave >> 1) * (TS / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
     double lreg[NE], ureg[NE];
+    // SYM, columns inside F: the rows of U are D times transposed columns of L; lanes then run along the tile's columns (contiguous
+    // rows of L) instead of along k.  (A tile that straddles column f reads its few columns of E with that mapping too.)
+    const bool umap_t = SYM && c0 < f;
     // slice h of the panels: global -> registers, registers -> LDS
 #define HIPMF_FETCH_SLICE(h)                                                                                           \
     {                                                                                                                  \
@@ -564,9 +610,14 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
             const int r = e % TS, kk = e / TS;                                                                         \
-            lreg[u] = (r0 + r < limit && kk < nbh) ? F[(r0 + r) + (int64_t)(kh + kk) * ld] : 0.0;                      \
-            const int k2 = e % NB, c = e / NB;                                                                         \
-            ureg[u] = (c0 + c < limit && k2 < nbh) ? F[(kh + k2) + (int64_t)(c0 + c) * ld] : 0.0;                      \
+            lreg[u] = (r0 + r < (SYM ? f : limit) && kk < nbh) ? *A.at(r0 + r, kh + kk) : 0.0;                         \
+            if (umap_t) {                                                                                              \
+                const int c = c0 + r;                                                                                  \
+                ureg[u] = (c < limit && kk < nbh) ? (c < f ? F[c + (int64_t)(kh + kk) * f] * dg[kh + kk] : A.Esh[(kh + kk) + (int64_t)c * f]) : 0.0; \
+            } else {                                                                                                   \
+                const int k2 = e % NB, c = c0 + e / NB;                                                                \
+                ureg[u] = (c < limit && k2 < nbh) ? (c >= f ? A.Esh : F)[(kh + k2) + (int64_t)c * f] : 0.0;            \
+            }                                                                                                          \
         }                                                                                                              \
     }
 #define HIPMF_STORE_SLICE()                                                                                            \
@@ -574,7 +625,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
             Ls[(e / TS) * LSLD + e % TS] = lreg[u];                                                                    \
-            Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                                   \
+            if (umap_t) Us[(e % TS) * US_LD + e / TS] = ureg[u];                                                       \
+            else Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                              \
         }                                                                                                              \
     }
     HIPMF_FETCH_SLICE(0)
@@ -583,7 +635,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     auto is_live = [&](int a, int b, int g) {
         const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
         const bool corner = owner0 && (b * 16 + l15) < nb2 && (a * 16 + l4 + 4 * g) < nb2;
-        return r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner;
+        const bool tri = !SYM || c >= f || r >= c; // (SYM: lower triangle of F, all of E)
+        return r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner && tri;
     };
     // the 16 entries of the trailing matrix this lane updates are requested together with the first slice (one round trip for
     // both: a narrow step is a latency chain) and arrive while the MFMAs run
@@ -595,13 +648,14 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                cur[a][b][g] = is_live(a, b, g) ? F[r + (int64_t)c * ld] : 0.0;
+                cur[a][b][g] = is_live(a, b, g) ? *A.at(r, c) : 0.0;
             }
     HIPMF_STORE_SLICE()
     __syncthreads();
     if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
     // strips of a narrow step: a wave whose quarter of the tile holds no live entry has nothing to multiply
-    const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + TS / 2 <= cmin) || (r0 + wr >= rmax);
+    const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + TS / 2 <= cmin) || (r0 + wr >= rmax) ||
+                           (SYM && c0 + wc + TS / 2 <= f && r0 + wr + TS / 2 <= c0 + wc);
     f64x4 acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; a++)
@@ -639,7 +693,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                if (is_live(a, b, g)) F[r + (int64_t)c * ld] = cur[a][b][g] - acc[a][b][g];
+                if (is_live(a, b, g)) *A.at(r, c) = cur[a][b][g] - acc[a][b][g];
             }
 }
 

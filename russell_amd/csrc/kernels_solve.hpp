@@ -126,7 +126,7 @@ __device__ __forceinline__ double group_sum(const double (*red)[SLAB], int rr) {
 }
 
 // Forward step of a big (augmented) front, rows [r0, r1) of its f-vector:
-//   [y1; -delta] = E * w1,  E(r, j) = F[r + (f + j) ld]   ->   work[r] = y1[r] (r < p),  work[r] = w2[r] + (E w1)[r] (r >= p)
+//   [y1; -delta] = E * w1,  E(r, j) = E[r + j f]   ->   work[r] = y1[r] (r < p),  work[r] = w2[r] + (E w1)[r] (r >= p)
 // Every workgroup of the front assembles w1 = b1 + (children's updates to the pivot rows) in LDS itself;
 // the children's entries are swept linearly (no searches), in child order.  Dynamic LDS: p doubles.
 template <int SLAB, int G>
@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(SLAB *G) k_fwd_big(const SolveTask *__restrict
     SolveTask tk = tasks[blockIdx.x];
     FrontDesc fd = FD[tk.s];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = fd.ld;
-    const double *E = pool + fd.off + (int64_t)f * ld;
+    const int64_t ld = f;
+    const double *E = pool + fd.eoff;
     double *W = work + fd.woff;
     const int r0 = tk.r0, r1 = tk.r1;
     for (int i = tid; i < p; i += T) w1[i] = x[fd.first + i];
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(SLAB *G) k_fwd_big(const SolveTask *__restrict
 }
 
 // Backward step of a big front, pivot rows [r0, r1):
-//   x1 = E' * [y1; x2],  E'(i, j) = F[(f + i) + j ld],  y1 = work[0..p),  x2 = x[rows]
+//   x1 = E' * [y1; x2],  E'(i, j) = E'[i + j p],  y1 = work[0..p),  x2 = x[rows]
 // Dynamic LDS: f doubles.
 template <int SLAB, int G>
 __global__ void __launch_bounds__(SLAB *G) k_bwd_big(const SolveTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
@@ -189,8 +189,8 @@ __global__ void __launch_bounds__(SLAB *G) k_bwd_big(const SolveTask *__restrict
     SolveTask tk = tasks[blockIdx.x];
     FrontDesc fd = FD[tk.s];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = fd.ld;
-    const double *Ep = pool + fd.off + f;
+    const int64_t ld = p;
+    const double *Ep = pool + fd.epoff;
     const double *W = work + fd.woff;
     const int32_t *rws = rows + fd.rowptr;
     const int r0 = tk.r0, r1 = tk.r1;

@@ -29,6 +29,7 @@ constexpr int SF_SYNC_HEADER = 16;       // ints in front of the completion coun
 constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
 constexpr int SF_CHUNK = 1024;           // doubles of a big front's vector staged in LDS at a time, per right-hand side (the children are
                                          // re-scanned for every chunk; 1024 doubles per right-hand side up to K = 4, 512 at K = 8: 32 KB of LDS)
+constexpr int SF_SYMC = 4;               // columns of E per wavefront in the backward slabs of the symmetric (L D L^T) fronts: slabs of 16 pivots
 constexpr int SF_KMAX = 8;               // right-hand sides solved together by the blocked instances (the factor is read once per block)
 
 struct SfTask {
@@ -425,8 +426,8 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = fd.ld;
-    const double *E = pool + fd.off + (int64_t)f * ld;
+    const int64_t ld = f;
+    const double *E = pool + fd.eoff;
     double *W = work + fd.woff;
     const int r0 = t.b, r1 = t.c, sh = t.kind;
     const int rr = tid & ((1 << sh) - 1), g = tid >> sh, G = 256 >> sh;
@@ -533,11 +534,12 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
 }
 
 // Backward pass, one launch per band of levels (tasks ordered root first).
-template <bool SMALL_ONLY, int K>
+// SYM: instance for factors whose big fronts are L D L^T (x1 = E^T [D^{-1} y1; x2], transposed GEMV); the LU instance carries none of it.
+template <bool SMALL_ONLY, int K, bool SYM>
 __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
-                                                   int64_t xstr, int64_t wstr, unsigned long long *trace) {
+                                                   int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag) {
     constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK;
     __shared__ double wv[4][K][64];
     __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
@@ -556,8 +558,9 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
     if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = fd.ld;
-    const double *Ep = pool + fd.off + f;
+    const bool sym = SYM && (fd.flags & FD_SYM) != 0; // L D L^T front: x1 = E^T [D^{-1} y1; x2]
+    const int64_t ld = p;
+    const double *Ep = sym ? pool + fd.eoff : pool + fd.epoff;
     const double *W = work + fd.woff; // y1: written by the forward launch
     const int32_t *rws = rows + fd.rowptr;
     const int r0 = t.b, r1 = t.c, sh = t.kind;
@@ -574,9 +577,10 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
         xrow[k] = -1;
         if (j < e1) {
             if (j < p) {
+                const double dj = sym ? diag[fd.first + j] : 1.0;
 #pragma unroll
                 for (int c = 0; c < K; c++)
-                    if (c < nk) wc[c * CHK + j - jmin] = W[c * wstr + j];
+                    if (c < nk) wc[c * CHK + j - jmin] = sym ? W[c * wstr + j] / dj : W[c * wstr + j];
             } else {
                 xrow[k] = rws[j - p];
             }
@@ -595,29 +599,85 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
         }
     __syncthreads();
     double acc0[K], acc1[K];
+    double sacc[SYM ? SF_SYMC : 1][K];
 #pragma unroll
     for (int c = 0; c < K; c++) acc0[c] = acc1[c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < (SYM ? SF_SYMC : 1); q++)
+#pragma unroll
+        for (int c = 0; c < K; c++) sacc[q][c] = 0.0;
     for (int c0 = jmin; c0 < f; c0 += CHK) {
         const int c1 = c0 + CHK < f ? c0 + CHK : f;
         if (c0 > jmin) {
             for (int j = c0 + tid; j < c1; j += 256) {
                 const int row = (j < p) ? 0 : rws[j - p];
+                const double dj = (sym && j < p) ? diag[fd.first + j] : 1.0;
 #pragma unroll
                 for (int c = 0; c < K; c++)
-                    if (c < nk) wc[c * CHK + j - c0] = (j < p) ? W[c * wstr + j] : ld_agent(x + c * xstr + row);
+                    if (c < nk) wc[c * CHK + j - c0] = (j < p) ? (sym ? W[c * wstr + j] / dj : W[c * wstr + j]) : ld_agent(x + c * xstr + row);
             }
             __syncthreads();
         }
-        if (i < r1) sf_dot<K>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g, c1, G);
+        if (sym) {
+            // transposed GEMV: wave w owns the columns r0 + w, r0 + w + 4, ... of E (<= SF_SYMC of them: slabs of 16 rows),
+            // lanes run down the column (contiguous), two positions of every column in flight per lane
+            const double *wk = wc - c0;
+            int j = c0 + lane;
+            for (; j + 64 < c1; j += 128) {
+                double e[SF_SYMC][2];
+#pragma unroll
+                for (int q = 0; q < SF_SYMC; q++) {
+                    const int col = r0 + wave + 4 * q;
+                    const double *Ec = Ep + (int64_t)(col < r1 ? col : r0) * f;
+                    e[q][0] = Ec[j], e[q][1] = Ec[j + 64];
+                }
+#pragma unroll
+                for (int q = 0; q < SF_SYMC; q++)
+#pragma unroll
+                    for (int c = 0; c < K; c++)
+                        if (c < nk) {
+                            sacc[SYM ? q : 0][c] += e[q][0] * wk[c * CHK + j];
+                            sacc[SYM ? q : 0][c] += e[q][1] * wk[c * CHK + j + 64];
+                        }
+            }
+            if (j < c1) {
+                double e[SF_SYMC];
+#pragma unroll
+                for (int q = 0; q < SF_SYMC; q++) {
+                    const int col = r0 + wave + 4 * q;
+                    e[q] = Ep[(int64_t)(col < r1 ? col : r0) * f + j];
+                }
+#pragma unroll
+                for (int q = 0; q < SF_SYMC; q++)
+#pragma unroll
+                    for (int c = 0; c < K; c++)
+                        if (c < nk) sacc[SYM ? q : 0][c] += e[q] * wk[c * CHK + j];
+            }
+        } else if (i < r1)
+            sf_dot<K>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
+    if (sym) {
+        // the 64 partial sums of a column are added in a fixed (butterfly) order
 #pragma unroll
-    for (int c = 0; c < K; c++) {
-        if (c < nk) {
-            red[g * (1 << sh) + rr] = acc0[c] + acc1[c];
-            __syncthreads();
-            if (g == 0 && i < r1) st_agent(x + c * xstr + fd.first + i, sf_group_sum(red, 1 << sh, rr, G));
-            if (K > 1) __syncthreads();
+        for (int q = 0; q < SF_SYMC; q++) {
+            const int col = r0 + wave + 4 * q;
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                double v = sacc[SYM ? q : 0][c];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (c < nk && lane == 0 && col < r1) st_agent(x + c * xstr + fd.first + col, v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            if (c < nk) {
+                red[g * (1 << sh) + rr] = acc0[c] + acc1[c];
+                __syncthreads();
+                if (g == 0 && i < r1) st_agent(x + c * xstr + fd.first + i, sf_group_sum(red, 1 << sh, rr, G));
+                if (K > 1) __syncthreads();
+            }
         }
     }
     if (trace && tid == 0) tr2 = dev_clock();

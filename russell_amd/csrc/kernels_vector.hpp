@@ -108,14 +108,4 @@ __global__ void k_spmv(int32_t n, const int32_t *__restrict__ rp, const int32_t 
     y[i] = alpha * acc;
 }
 
-// diagonal of U in pivot order (for the determinant / rcond estimate)
-__global__ void k_diag_gather(int32_t nsuper, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
-                              double *__restrict__ du) {
-    int s = blockIdx.x;
-    if (s >= nsuper) return;
-    FrontDesc fd = FD[s];
-    const int64_t ld = fd.ld;
-    for (int i = threadIdx.x; i < fd.p; i += blockDim.x) du[fd.first + i] = pool[fd.off + i + i * ld];
-}
-
 } // namespace hipmf

@@ -61,8 +61,8 @@ void Solver::release() {
     int caller_device = -1; // the caller's current device is restored on the way out
     if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
-                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_amap, d_amap2, d_pool, d_lperm,
+    void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs == d_rs ? nullptr : d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
+                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -87,7 +87,7 @@ void Solver::release() {
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
-    d_amap = d_amap2 = nullptr;
+    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr;
     for (auto &e : ev)
         if (e) {
             (void)hipEventDestroy((hipEvent_t)e);
@@ -152,6 +152,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     }
     SymbolicOptions so = sopt;
     so.augment_above = SMALL_F;
+    // symmetric-lower input (general_symmetric / positive_definite, interface_cudss.cu:324-333): the big fronts are factorised
+    // as L D L^T on their lower triangle -- half the flops, half the factor (HIPMF_SYM_LDLT=0: LU of the mirrored matrix)
+    so.symmetric_ldlt = sym_lower;
+    if (const char *e = getenv("HIPMF_SYM_LDLT")) so.symmetric_ldlt = sym_lower && atoi(e) != 0;
     // fewer, fatter fronts: nested-dissection leaves of <= 16 vertices become single dense supernodes
     // (1000^2 Poisson: 503 796 -> 113 068 fronts, 29 -> 20 levels, nnz(L) +18 %); see DESIGN.md section 4
     so.nd_leaf = 16;
@@ -213,8 +217,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     }
     if (matched) { // the assembly map back in the order of A's entries
         std::vector<int64_t> am((size_t)rp[n]);
-        for (int64_t k = 0; k < rp[n]; k++) am[k] = S.amap[kB[k]];
+        std::vector<int32_t> as((size_t)rp[n]);
+        for (int64_t k = 0; k < rp[n]; k++) am[k] = S.amap[kB[k]], as[k] = S.amap_sn[kB[k]];
         S.amap.swap(am);
+        S.amap_sn.swap(as);
     }
     const auto t_plan = std::chrono::steady_clock::now();
     int32_t code = upload_plan();
@@ -265,50 +271,48 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     }
     {
         // The entries of A that land in small fronts are gathered by k_small_factor itself (per-front lists: entry index,
-        // position inside the front); only the big fronts are zero-filled and scattered into.
+        // position inside the front); the entries of the big fronts are scattered level by level (their working blocks share
+        // an arena: a block is zero-filled and filled when its level starts).
         const int32_t ns = S.nsuper;
-        // owner front of a pool offset: bucket table (4 Ki doubles per bucket -> first front that ends beyond the bucket's start)
-        const int SHIFT = 12;
-        std::vector<int32_t> bucket((size_t)(S.front_off[ns] >> SHIFT) + 2, 0);
-        {
-            int32_t sf = 0;
-            for (size_t b = 0; b < bucket.size(); b++) {
-                while (sf + 1 < ns && S.front_off[sf + 1] <= (int64_t)(b << SHIFT)) sf++;
-                bucket[b] = sf;
-            }
-        }
-        auto owner = [&](int64_t off) {
-            int32_t sf = bucket[(size_t)(off >> SHIFT)];
-            while (S.front_off[sf + 1] <= off) sf++;
-            return sf;
-        };
         std::vector<int32_t> sa_ptr((size_t)ns + 1, 0);
-        const int64_t nz = S.nnz_a;
+        std::vector<int64_t> sc_cnt((size_t)S.nlevels + 1, 0);
         for (int pass = 0; pass < 2; pass++) {
-            std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
+            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
             for (int64_t k = 0; k < (int64_t)am.size(); k++)
                 if (am[k] >= 0) {
-                    const int32_t s = owner(am[k]);
+                    const int32_t s = S.amap_sn[(size_t)k];
                     if (S.fsize(s) <= SMALL_F) sa_ptr[(size_t)s + 1]++;
+                    else sc_cnt[(size_t)S.sn_level[s] + 1]++;
                 }
         }
         for (int32_t s = 0; s < ns; s++) sa_ptr[(size_t)s + 1] += sa_ptr[s];
+        for (int32_t l = 0; l < S.nlevels; l++) sc_cnt[(size_t)l + 1] += sc_cnt[l];
+        if (sc_cnt[(size_t)S.nlevels] > 0x7fffffffLL) {
+            last_error = "too many entries in the tiled fronts";
+            return ERROR_HIPMF_SYMBOLIC;
+        }
         std::vector<int32_t> sa_k((size_t)sa_ptr[ns]), w(sa_ptr.begin(), sa_ptr.end() - 1);
         std::vector<uint16_t> sa_pos((size_t)sa_ptr[ns]);
+        std::vector<int32_t> sc_k((size_t)sc_cnt[(size_t)S.nlevels]);
+        std::vector<int64_t> sc_at((size_t)sc_cnt[(size_t)S.nlevels]), wl(sc_cnt.begin(), sc_cnt.end() - 1);
         for (int pass = 0; pass < 2; pass++) {
-            std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
+            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
             for (int64_t k = 0; k < (int64_t)am.size(); k++)
                 if (am[k] >= 0) {
-                    const int32_t s = owner(am[k]);
-                    if (S.fsize(s) > SMALL_F) continue;
+                    const int32_t s = S.amap_sn[(size_t)k];
+                    if (S.fsize(s) > SMALL_F) {
+                        const size_t q = (size_t)wl[(size_t)S.sn_level[s]]++;
+                        sc_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
+                        sc_at[q] = am[k];
+                        continue;
+                    }
                     const int64_t off = am[k] - S.front_off[s], f = S.fsize(s);
                     const size_t q = (size_t)w[s]++;
                     sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
                     sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
-                    am[k] = -1; // not scattered
                 }
         }
-        (void)nz;
+        for (int32_t l = 0; l < S.nlevels; l++) levels[(size_t)l].sc_off = (int32_t)sc_cnt[(size_t)l], levels[(size_t)l].sc_cnt = (int32_t)(sc_cnt[(size_t)l + 1] - sc_cnt[(size_t)l]);
         HIPC(dev_upload(&d_sa_ptr, sa_ptr), ERROR_HIP_MALLOC);
         {
             // descriptors in launch order (the plan is on the device already: read it back rather than keep host copies around)
@@ -326,26 +330,46 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         }
         HIPC(dev_upload(&d_sa_k, sa_k), ERROR_HIP_MALLOC);
         HIPC(dev_upload(&d_sa_pos, sa_pos), ERROR_HIP_MALLOC);
-        // zero-fill tasks: 16 Ki doubles per workgroup over the big fronts
+        HIPC(dev_upload(&d_sc_k, sc_k), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sc_at, sc_at), ERROR_HIP_MALLOC);
+        // zero-fill tasks, 16 Ki doubles per workgroup: first the persistent E / E' panels of all big fronts (one launch per
+        // factorisation), then the working blocks level by level
         std::vector<ZeroTask> zt;
+        auto zero_range = [&](int64_t o0, int64_t len) {
+            for (int64_t o = o0; o < o0 + len; o += 16384) zt.push_back({o, (int32_t)std::min<int64_t>(16384, o0 + len - o), 0});
+        };
         for (int32_t s = 0; s < ns; s++) {
             if (S.fsize(s) <= SMALL_F) continue;
-            for (int64_t o = S.front_off[s]; o < S.front_off[s + 1]; o += 16384)
-                zt.push_back({o, (int32_t)std::min<int64_t>(16384, S.front_off[s + 1] - o), 0});
+            const int64_t f = S.fsize(s), p = S.npiv(s);
+            zero_range(S.e_off[s], f * p);
+            if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * p);
         }
         zero_cnt = (int32_t)zt.size();
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            levels[(size_t)l].zero_off = (int32_t)zt.size();
+            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+                const int32_t s = S.level_sn[k];
+                if (S.fsize(s) > SMALL_F) zero_range(S.front_off[s], (int64_t)S.fsize(s) * S.fsize(s));
+            }
+            levels[(size_t)l].zero_cnt = (int32_t)zt.size() - levels[(size_t)l].zero_off;
+        }
+        if (zt.size() > 0x7fffffffULL) {
+            last_error = "too many zero-fill tasks";
+            return ERROR_HIPMF_SYMBOLIC;
+        }
         HIPC(dev_upload(&d_zero, zt), ERROR_HIP_MALLOC);
     }
-    HIPC(dev_upload(&d_amap, S.amap), ERROR_HIP_MALLOC);
-    if (sym_lower) HIPC(dev_upload(&d_amap2, S.amap2), ERROR_HIP_MALLOC);
     std::vector<int64_t>().swap(S.amap);
     std::vector<int64_t>().swap(S.amap2);
+    std::vector<int32_t>().swap(S.amap_sn);
     HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_vs, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     if (sym_lower) HIPC(hipMalloc((void **)&d_vs2, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
     if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_diag, sizeof(double) * n), ERROR_HIP_MALLOC);
+    if (S.sym_mode) d_cs = d_rs; // symmetric scaling S A S keeps the big fronts symmetric: column scale = row scale
     HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     for (auto &e : ev) {
@@ -375,9 +399,12 @@ int32_t Solver::upload_plan() {
         d.parent = S.sn_parent[s];
         d.ld = S.front_ld[s];
         d.ugroup = update_group(S.fsize(s));
+        d.eoff = S.e_off[s], d.epoff = S.ep_off[s];
+        d.flags = S.fsize(s) > SMALL_F ? (FD_BIG | (S.sym_mode ? FD_SYM : 0)) : 0;
+        d.pad = 0;
         work_doubles += d.p + d.m;
     }
-    pool_doubles = S.front_off[ns];
+    pool_doubles = S.persist_doubles + S.temp_doubles;
 
     std::vector<int32_t> lists, tasks, allbig;
     std::vector<EaTask> ea;
@@ -462,8 +489,9 @@ int32_t Solver::upload_plan() {
                     tk.f_off = S.front_off[s];
                     tk.ld = S.front_ld[s];
                     tk.piece_begin = (int32_t)ear.size();
-                    tk.pad = 0;
+                    tk.sym = S.sym_mode ? 1 : 0; // L D L^T parent: lower triangle only
                     const int32_t c1 = std::min(f, c0 + cstep), r1 = std::min(f, r0 + rstep);
+                    if (S.sym_mode && r1 <= c0) continue; // tile strictly above the diagonal
                     for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
                         int32_t ch = S.child_idx[c];
                         const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
@@ -516,6 +544,14 @@ int32_t Solver::upload_plan() {
             }
         }
     }
+    if (S.sym_mode && !allbig.empty()) {
+        // the level-set solve kernels have no L D L^T instance
+        level_path_ok = false;
+        if (!use_fused) {
+            last_error = "the symmetric (L D L^T) factorisation needs the dependency-driven solves (HIPMF_FUSED_SOLVE=1)";
+            return ERROR_NOT_AVAILABLE;
+        }
+    }
     allbig_off = (int32_t)lists.size();
     allbig_cnt = (int32_t)allbig.size();
     lists.insert(lists.end(), allbig.begin(), allbig.end());
@@ -528,6 +564,7 @@ int32_t Solver::upload_plan() {
         // narrow slabs, i.e. more column groups per workgroup and more workgroups per front
         auto kind_of = [&](int32_t s, bool forward) {
             const int32_t len = forward ? S.npiv(s) : S.fsize(s);
+            if (!forward && S.sym_mode) return 4; // transposed GEMV of the L D L^T fronts: 16 columns of E per workgroup
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
         };
         auto emit_level = [&](int32_t l, bool forward) {
@@ -665,20 +702,29 @@ int32_t Solver::run_factor() {
     int64_t launches = 0;
     HIPC(hipEventRecord((hipEvent_t)ev[0], STREAM), ERROR_HIP_SYNCHRONIZE);
     // (with a matching in force the scalings dr, dc of initialize stay: the structure was chosen for them)
-    if (!matched) hipLaunchKernelGGL(k_row_scale, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_vals, d_tptr, d_tidx, opt.scaling, d_rs);
+    if (!matched)
+        hipLaunchKernelGGL(k_row_scale, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_vals, d_tptr, d_tidx, opt.scaling, S.sym_mode ? 1 : 0, d_rs);
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
     hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar, d_info);
-    if (zero_cnt > 0) hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, STREAM, d_zero, d_pool);
-    hipLaunchKernelGGL(k_scatter, dim3(gs), dim3(256), 0, STREAM, nnz, d_vs, d_vs2, d_amap, d_amap2, d_pool);
-    launches += 3;
-    if (allbig_cnt > 0) {
+    launches += 2;
+    if (zero_cnt > 0) { // the E / E' panels start as [I; 0] / [I, 0]
+        hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, STREAM, d_zero, d_pool);
         hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, STREAM, d_lists + allbig_off, d_fd, d_pool);
-        launches++;
+        launches += 2;
     }
     HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
+        if (L.zero_cnt > 0) { // the level's working blocks take over storage other fronts have left
+            hipLaunchKernelGGL(k_zero, dim3(L.zero_cnt), dim3(256), 0, STREAM, d_zero + L.zero_off, d_pool);
+            launches++;
+        }
+        if (L.sc_cnt > 0) {
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)L.sc_cnt + 255) / 256)), dim3(256), 0, STREAM, (int64_t)L.sc_cnt,
+                               d_sc_k + L.sc_off, d_sc_at + L.sc_off, d_vs, d_vs2, d_pool);
+            launches++;
+        }
         if (L.ea_cnt > 0) {
             hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             launches++;
@@ -698,27 +744,34 @@ int32_t Solver::run_factor() {
             if (L.small_cnt_a > 0) {
                 const size_t shmem_a = sizeof(double) * (size_t)L.small_ld_a * (size_t)L.small_ld_a;
                 hipLaunchKernelGGL(k_small_factor<1>, dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
-                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld_a, sasm);
+                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld_a, sasm, d_diag);
                 launches++;
             }
             // few fronts in the launch: four wavefronts per front (the launch lasts as long as one front's LU)
             const int32_t cnt_b = L.small_cnt - L.small_cnt_a;
             if (cnt_b <= small_wide_max && L.small_ld > 33)
                 hipLaunchKernelGGL(k_small_factor<4>, dim3(cnt_b), dim3(256), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
-                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
+                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm, d_diag);
             else
                 hipLaunchKernelGGL(k_small_factor<1>, dim3(cnt_b), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
-                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm);
+                                   d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm, d_diag);
             if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
             launches++;
         }
         int32_t k0 = 0;
         for (const StepPlan &st : L.steps) {
             const int32_t *blist = d_lists + L.big_off;
-            hipLaunchKernelGGL(k_panel, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
-                               d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info);
-            hipLaunchKernelGGL(k_update, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
-                               d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info);
+            if (S.sym_mode) {
+                hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
+                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
+                                   d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+            } else {
+                hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
+                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
+                                   d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+            }
             launches += 2;
             k0 += NB;
         }
@@ -765,9 +818,14 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
 #define HIPMF_FWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f, \
                        sync_err, wrk, xp, nk, xstr, wstr, TRACE)
+#define HIPMF_BWD1(SMALL, KK, SYMM, CNT, TASKS, TRACE)                                                                                     \
+    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b,      \
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag)
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
-    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b, sync_err,  \
-                       wrk, xp, nk, xstr, wstr, TRACE)
+    do {                                                                                                                                  \
+        if (!SMALL && S.sym_mode) HIPMF_BWD1(false, KK, true, CNT, TASKS, TRACE);                                                          \
+        else HIPMF_BWD1(SMALL, KK, false, CNT, TASKS, TRACE);                                                                              \
+    } while (0)
         if (nk == 1) {
             if (fa > 0) HIPMF_FWD(true, 1, fa, d_sf, no_trace);
             if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, timed ? d_trace : no_trace);
@@ -785,6 +843,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         }
 #undef HIPMF_FWD
 #undef HIPMF_BWD
+#undef HIPMF_BWD1
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[5], LST), ERROR_HIP_SYNCHRONIZE);
         times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
         if (timed) tri_pending = true;
@@ -1116,14 +1175,14 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
     if (!factorized) return ERROR_NEED_FACTORIZATION;
     DeviceScope dev_scope(device);
     const int32_t n = S.n;
-    hipLaunchKernelGGL(k_diag_gather, dim3(S.nsuper), dim3(64), 0, STREAM, S.nsuper, d_fd, d_pool, d_du);
     std::vector<double> du((size_t)n), rs((size_t)n), cs;
     std::vector<int32_t> lp((size_t)n);
-    if (matched) {
+    const bool col_scaled = d_cs != nullptr; // matching, or the symmetric scaling S A S
+    if (col_scaled) {
         cs.resize((size_t)n);
         HIPC(hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     }
-    HIPC(hipMemcpyAsync(du.data(), d_du, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpyAsync(du.data(), d_diag, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemcpyAsync(rs.data(), d_rs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemcpyAsync(lp.data(), d_lperm, sizeof(int32_t) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
@@ -1132,7 +1191,7 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
     double m = 1.0, e = 0.0, umin = INFINITY, umax = 0.0;
     bool zero = false;
     for (int32_t i = 0; i < n; i++) {
-        double d = matched ? du[i] / rs[i] / cs[i] : du[i] / rs[i]; // (any pairing: only the products matter)
+        double d = col_scaled ? du[i] / rs[i] / cs[i] : du[i] / rs[i]; // (any pairing: only the products matter)
         umin = std::min(umin, std::fabs(du[i]));
         umax = std::max(umax, std::fabs(du[i]));
         if (d == 0.0 || !std::isfinite(d)) {

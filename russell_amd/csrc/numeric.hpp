@@ -67,6 +67,8 @@ struct LevelPlan {
     int32_t small_cnt_a = 0, small_ld_a = 1;                              // ... the first small_cnt_a of them have f <= small_split
     int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
     int32_t ea_off = 0, ea_cnt = 0;
+    int32_t zero_off = 0, zero_cnt = 0; // zero-fill tasks of the level's working blocks
+    int32_t sc_off = 0, sc_cnt = 0;     // entries of A scattered into the level's working blocks
     int32_t fwd_off = 0, fwd_cnt = 0, bwd_off = 0, bwd_cnt = 0; // SolveTask ranges of the big fronts
     int32_t big_pmax = 0, big_fmax = 0;
     bool wide = false; // solve with 32-row slabs x 32 column groups (few large fronts)
@@ -182,7 +184,9 @@ class Solver {
            *d_du = nullptr;
     int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
     int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
-    int64_t *d_amap = nullptr, *d_amap2 = nullptr;
+    int32_t *d_sc_k = nullptr;   // scatter lists of the tiled fronts, by level: input entry k (or ~k: mirrored copy) ...
+    int64_t *d_sc_at = nullptr;  // ... and the pool offset it goes to
+    double *d_diag = nullptr;    // pivots in pivot order (determinant, rcond, D of the symmetric fronts)
     void *ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -702,9 +702,10 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         for (int32_t s = 0; s < S.nsuper; s++) {
             const double p = (double)(S.sn_first[s + 1] - S.sn_first[s]);
             const double m = std::max((double)cc[S.sn_first[s + 1] - 1] - 1.0, (double)cc[S.sn_first[s]] - p);
-            const double f = p + m, ld = f > (double)opt.augment_above ? f + p : f;
+            const double f = p + m;
             rows_total += m;
-            pool_total += ld * ld;
+            // persistent part only (a lower bound: the arena of the working blocks is planned once the levels are known)
+            pool_total += f > (double)opt.augment_above ? f * p * (opt.symmetric_ldlt ? 1.0 : 2.0) : f * f;
         }
         S.pool_estimate_bytes = 8.0 * pool_total;
         if (rows_total > 1.0e9 || (opt.pool_limit_bytes > 0.0 && 8.0 * pool_total > opt.pool_limit_bytes)) return -40;
@@ -805,18 +806,28 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     }
 
     // ---- front pool layout and statistics ----------------------------------------------------
-    // Fronts larger than opt.augment_above are stored AUGMENTED: an (f+p) x (f+p) array whose extra
-    // p columns / p rows start as identity blocks.  Running the same partial LU on it leaves
-    //   E  = [inv(L11) P ; -L21 inv(L11) P]   in columns f..f+p   (forward-solve panel)
-    //   E' = [inv(U11) , -inv(U11) U12]       in rows    f..f+p   (backward-solve panel)
-    // so the triangular solves of big supernodes become dependency-free GEMVs (see kernels.hpp).
-    S.front_off.assign((size_t)S.nsuper + 1, 0);
+    // Fronts larger than opt.augment_above are factorised AUGMENTED: the partial LU runs on [F Ic; Ir 0] and leaves
+    //   E  = [inv(L11) P ; -L21 inv(L11) P]   f x p   (forward-solve panel)
+    //   E' = [inv(U11) , -inv(U11) U12]       p x f   (backward-solve panel; absent in symmetric mode, which applies E^T)
+    // so the triangular solves of big supernodes become dependency-free GEMVs (see kernels_common.hpp).  E / E' and the small
+    // fronts are persistent; the f x f working block of a big front lives in an arena from its level until its parent's
+    // level has consumed the contribution block (fronts are processed level by level), then the storage is re-used.
+    S.sym_mode = opt.symmetric_ldlt && sym_lower;
+    S.front_off.assign((size_t)S.nsuper, 0);
     S.front_ld.assign((size_t)S.nsuper, 0);
+    S.e_off.assign((size_t)S.nsuper, -1);
+    S.ep_off.assign((size_t)S.nsuper, -1);
+    auto round16 = [](int64_t v) { return (v + 15) / 16 * 16; }; // 128-byte granules for the large blocks
+    int64_t pers = 0;
     for (int32_t s = 0; s < S.nsuper; s++) {
         int64_t p = S.npiv(s), m = S.nrow(s), f = p + m;
-        int64_t ld = (f > opt.augment_above) ? f + p : f;
-        S.front_ld[s] = (int32_t)ld;
-        S.front_off[s + 1] = S.front_off[s] + ld * ld;
+        S.front_ld[s] = (int32_t)f;
+        if (f > opt.augment_above) {
+            S.e_off[s] = pers, pers += round16(f * p);
+            if (!S.sym_mode) S.ep_off[s] = pers, pers += round16(p * f);
+        } else {
+            S.front_off[s] = pers, pers += f * f;
+        }
         S.nnz_l += p * (p - 1) / 2 + p * m;
         S.nnz_u += p * (p + 1) / 2 + p * m;
         double dp = (double)p, dm = (double)m;
@@ -825,10 +836,73 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         S.max_front = std::max<int32_t>(S.max_front, (int32_t)f);
         S.max_pivots = std::max<int32_t>(S.max_pivots, (int32_t)p);
     }
+    pers = round16(pers);
+    S.persist_doubles = pers;
+    {
+        // arena plan: best fit over a coalescing free list, levels in execution order
+        struct Blk {
+            int64_t off, size;
+        };
+        std::vector<Blk> freeb; // ascending by offset
+        int64_t top = 0;
+        auto take = [&](int64_t sz) -> int64_t {
+            int best = -1;
+            for (int i = 0; i < (int)freeb.size(); i++)
+                if (freeb[i].size >= sz && (best < 0 || freeb[i].size < freeb[best].size)) best = i;
+            if (best >= 0) {
+                const int64_t off = freeb[best].off;
+                freeb[best].off += sz, freeb[best].size -= sz;
+                if (freeb[best].size == 0) freeb.erase(freeb.begin() + best);
+                return off;
+            }
+            if (!freeb.empty() && freeb.back().off + freeb.back().size == top) { // grow the free block at the end of the arena
+                const int64_t off = freeb.back().off;
+                freeb.pop_back();
+                top = off + sz;
+                return off;
+            }
+            const int64_t off = top;
+            top += sz;
+            return off;
+        };
+        auto give = [&](int64_t off, int64_t sz) {
+            size_t i = 0;
+            while (i < freeb.size() && freeb[i].off < off) i++;
+            freeb.insert(freeb.begin() + (std::ptrdiff_t)i, Blk{off, sz});
+            if (i + 1 < freeb.size() && freeb[i].off + freeb[i].size == freeb[i + 1].off) {
+                freeb[i].size += freeb[i + 1].size;
+                freeb.erase(freeb.begin() + (std::ptrdiff_t)i + 1);
+            }
+            if (i > 0 && freeb[i - 1].off + freeb[i - 1].size == freeb[i].off) {
+                freeb[i - 1].size += freeb[i].size;
+                freeb.erase(freeb.begin() + (std::ptrdiff_t)i);
+            }
+        };
+        std::vector<std::vector<int32_t>> expire((size_t)S.nlevels);
+        std::vector<int32_t> bigs;
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            bigs.clear();
+            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++)
+                if (S.fsize(S.level_sn[k]) > opt.augment_above) bigs.push_back(S.level_sn[k]);
+            std::stable_sort(bigs.begin(), bigs.end(), [&](int32_t a, int32_t b) { return S.fsize(a) > S.fsize(b); });
+            for (int32_t s : bigs) {
+                const int64_t f = S.fsize(s);
+                S.front_off[s] = pers + take(round16(f * f));
+                const int32_t t = S.sn_parent[s];
+                // the block is needed until the parent's level has pulled the contribution block (no parent / no block: own level)
+                expire[(size_t)((t < 0 || S.nrow(s) == 0) ? l : S.sn_level[t])].push_back(s);
+            }
+            for (int32_t s : expire[(size_t)l]) give(S.front_off[s] - pers, round16((int64_t)S.fsize(s) * S.fsize(s)));
+        }
+        S.temp_doubles = top;
+    }
+    S.pool_estimate_bytes = 8.0 * (double)(S.persist_doubles + S.temp_doubles);
+    if (opt.pool_limit_bytes > 0.0 && S.pool_estimate_bytes > opt.pool_limit_bytes) return -40;
 
     S.seconds_phase[5] = since(t_phase), t_phase = clk::now();
     // ---- assembly map: where every input entry lands ------------------------------------------
     S.amap.assign((size_t)S.nnz_a, -1);
+    S.amap_sn.assign((size_t)S.nnz_a, -1);
     if (sym_lower) S.amap2.assign((size_t)S.nnz_a, -1);
     auto local = [&](int32_t s, int32_t i) -> int64_t {
         int32_t first = S.sn_first[s], last = S.sn_first[s + 1] - 1;
@@ -854,8 +928,14 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
                     amap_err.store(-31);
                     return;
                 }
-                S.amap[p] = S.front_off[s] + li + lj * f;
-                if (sym_lower && i != j) S.amap2[p] = S.front_off[s] + lj + li * f;
+                S.amap_sn[p] = s;
+                if (S.sym_mode && f > opt.augment_above) {
+                    // L D L^T front: the entry goes to the lower triangle only
+                    S.amap[p] = S.front_off[s] + std::max(li, lj) + std::min(li, lj) * f;
+                } else {
+                    S.amap[p] = S.front_off[s] + li + lj * f;
+                    if (sym_lower && i != j) S.amap2[p] = S.front_off[s] + lj + li * f;
+                }
             }
     });
     if (amap_err.load() != 0) return amap_err.load();

@@ -27,7 +27,8 @@ struct SymbolicOptions {
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
     int32_t split_pivots = 4096;  // supernodes with more pivots are split into a chain of supernodes (0: never); see symbolic.cpp
     double pool_limit_bytes = 0.0; // analyse gives up (-40) when the fronts would need more than this (0: no limit)
-    int32_t augment_above = 64;   // fronts with f > this are stored augmented (must equal kernels.hpp SMALL_F)
+    int32_t augment_above = 64;   // fronts with f > this take the tiled, augmented path (must equal kernels_common.hpp SMALL_F)
+    bool symmetric_ldlt = false;  // the big fronts are factorised as L D L^T (symmetric-lower input): no E' panels
     int32_t relax_ncol[3] = {4, 16, 48};
     double relax_zeros[3] = {0.8, 0.1, 0.05};
 };
@@ -53,10 +54,18 @@ struct Symbolic {
     std::vector<int32_t> child_ptr;  // nsuper+1
     std::vector<int32_t> child_idx;  // children of each supernode, ascending
     std::vector<int32_t> rel;        // aligned with sn_rows: position of the row in the PARENT's front
-    std::vector<int64_t> front_off;  // nsuper+1: offset (in doubles) of each ld x ld front in the pool
-    std::vector<int32_t> front_ld;   // nsuper: leading dimension: f, or f + p for augmented (big) fronts
+    // Pool layout (offsets in doubles into ONE device allocation): [0, persist_doubles) holds what the solves need (the small
+    // fronts' f x f blocks, the big fronts' E / E' panels); [persist_doubles, persist_doubles + temp_doubles) is the arena of the
+    // big fronts' f x f working blocks, whose storage is re-used once the parent has consumed the contribution block.
+    std::vector<int64_t> front_off;  // nsuper: offset of the f x f block (small: persistent; big: arena)
+    std::vector<int32_t> front_ld;   // nsuper: its leading dimension = f
+    std::vector<int64_t> e_off;      // nsuper: big fronts: E (f x p, ld f), else -1
+    std::vector<int64_t> ep_off;     // nsuper: big fronts in LU mode: E' (p x f, ld p), else -1
+    int64_t persist_doubles = 0, temp_doubles = 0;
+    bool sym_mode = false;           // big fronts are factorised as L D L^T (lower triangle only)
     std::vector<int64_t> amap;       // nnz_a: pool offset every input entry is added to
     std::vector<int64_t> amap2;      // nnz_a when sym_lower: mirrored position (-1 on the diagonal)
+    std::vector<int32_t> amap_sn;    // nnz_a: the supernode whose front receives the entry
 
     // statistics
     int64_t nnz_l = 0;   // strictly lower entries of L (stored, incl. amalgamation padding)
