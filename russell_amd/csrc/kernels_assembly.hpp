@@ -93,12 +93,25 @@ __global__ void __launch_bounds__(256) k_zero(const ZeroTask *__restrict__ tasks
 // identity blocks of the augmented big fronts: E(i, i) = 1 and E'(i, i) = 1 (the panels are zero-filled first)
 __global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, double *__restrict__ pool) {
     FrontDesc fd = FD[list[blockIdx.x]];
-    const int64_t f = (int64_t)fd.p + fd.m, p = fd.p;
+    const int64_t ld = fd.ld, p = fd.p;
     double *E = pool + fd.eoff;
     double *Ep = fd.epoff >= 0 ? pool + fd.epoff : nullptr;
     for (int i = threadIdx.x; i < fd.p; i += blockDim.x) {
-        E[i + i * f] = 1.0;
+        E[i + i * ld] = 1.0;
         if (Ep) Ep[i + i * p] = 1.0;
+    }
+}
+
+// Symmetric mode: a tiled (L D L^T) front whose PARENT is a small front hands over a full contribution block: its lower triangle
+// is mirrored into the upper one (the small fronts are factorised as general matrices).  One workgroup per such front; m <= SMALL_F.
+__global__ void k_mirror_cb(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, double *__restrict__ pool) {
+    const FrontDesc fd = FD[list[blockIdx.x]];
+    const int m = fd.m;
+    const int64_t ld = fd.ld;
+    double *CB = pool + fd.off + fd.p + (int64_t)fd.p * ld;
+    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+        const int i = e % m, j = e / m;
+        if (i > j) CB[j + (int64_t)i * ld] = CB[i + (int64_t)j * ld];
     }
 }
 
@@ -108,6 +121,7 @@ __global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc
 // The sub-ranges of every child's (sorted) relative-index list that fall into the tile are precomputed on
 // the host (EaRange, one per task and child that actually hits the tile, self-contained): no dependent
 // descriptor loads or binary searches on the device, and tiles no child touches have no task at all.
+template <bool SYM>
 __global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const int32_t *__restrict__ rel,
                              double *__restrict__ pool) {
     const EaTask t = tasks[blockIdx.x];
@@ -137,7 +151,7 @@ __global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__
                     const int j = j0 + q * ng;
                     // (sym: rel is increasing, so child entry (i, j), i >= j, lands on or below the parent's diagonal; the child's
                     //  own block is valid there whether it was factorised as LU or as L D L^T)
-                    at[q] = (j < jhi && (!t.sym || j <= i)) ? ri + (int64_t)relc[j] * ld : -1;
+                    at[q] = (j < jhi && (!SYM || j <= i)) ? ri + (int64_t)relc[j] * ld : -1;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; q++) {

@@ -8,7 +8,7 @@
 //            m x m block is the contribution block the parent consumes (extend-add).
 //          * big fronts (f > SMALL_F) are factorised AUGMENTED: the partial LU runs on the (f+p) x (f+p) matrix
 //            [F  Ic; Ir  0] (Ic = [I; 0], Ir = [I, 0]) and leaves
-//                E  = [inv(L11) P ; -L21 inv(L11) P]      f x p, column-major ld = f, at pool + eoff   (PERSISTENT)
+//                E  = [inv(L11) P ; -L21 inv(L11) P]      f x p, column-major, stride ld, at pool + eoff   (PERSISTENT)
 //                E' = [inv(U11) , -inv(U11) U12]           p x f, column-major ld = p, at pool + epoff  (PERSISTENT)
 //            which turn the triangular solves of a big supernode into dependency-free GEMVs.  The front itself, F (f x f, ld = f,
 //            at pool + off), lives in the TEMPORARY arena: its storage is handed to other fronts once the parent has consumed the
@@ -45,7 +45,7 @@ struct FrontDesc {
     int32_t first;  // first permuted column
     int32_t child_begin, child_end;
     int32_t parent;
-    int32_t ld;     // leading dimension of the f x f block at `off`: f
+    int32_t ld;     // column stride of the f x f block at `off` and of E (>= f; small fronts: f)
     int32_t ugroup; // tiled path: 32-pivot panels per read-modify-write pass over the trailing matrix (2, 4, 8 or 16)
     int64_t eoff;   // big fronts: offset of E (f x p, ld f); -1 for small fronts
     int64_t epoff;  // big fronts, LU mode: offset of E' (p x f, ld p); -1 otherwise
@@ -57,20 +57,22 @@ constexpr int32_t FD_SYM = 2; // big front factorised as L D L^T: only the lower
 
 // The augmented index space of a big front (see the layout note at the top of this file).
 struct AugView {
-    double *F;    // (r, c), r < f, c < f          at F[r + c f]
-    double *Esh;  // (r, c), r < f, c >= f         at Esh[r + c f]     (Esh = E - f f)
+    double *F;    // (r, c), r < f, c < f          at F[r + c ld]
+    double *Esh;  // (r, c), r < f, c >= f         at Esh[r + c ld]    (Esh = E - f ld)
     double *Epsh; // (r, c), r >= f, c < f         at Epsh[r + c p]    (Epsh = E' - f)
+    int64_t ld;   // column stride of F and of E (>= f)
     int32_t f, p;
     __device__ __forceinline__ double *at(int r, int c) const {
         if (r >= f) return Epsh + r + (int64_t)c * p;
-        return (c >= f ? Esh : F) + r + (int64_t)c * f;
+        return (c >= f ? Esh : F) + r + (int64_t)c * ld;
     }
 };
 __device__ __forceinline__ AugView aug_view(const FrontDesc &fd, double *pool) {
     AugView v;
     v.f = fd.p + fd.m, v.p = fd.p;
+    v.ld = fd.ld;
     v.F = pool + fd.off;
-    v.Esh = pool + fd.eoff - (int64_t)v.f * v.f;
+    v.Esh = pool + fd.eoff - (int64_t)v.f * v.ld;
     v.Epsh = pool + fd.epoff - v.f;
     return v;
 }

@@ -29,6 +29,7 @@ struct SmallAsm {
 // One workgroup of NW wavefronts assembles and factorises one small front (f <= SMALL_F = 64) held entirely in LDS: thread
 // (row r = tid mod 64, column group g = tid / 64).
 //   assembly:  F = (scaled entries of A that belong to this front) + sum over the children of their contribution
+//              (a tiled L D L^T child has had its block mirrored to a full one by k_mirror_cb)
 //              blocks (children in ascending order, read from the pool where their own factorisation left them)
 //   LU:        partial pivoting searches the whole remaining pivot block (rows c..p-1) with one 32-bit DPP max-reduction.
 // No integer divisions and no per-element index arithmetic: every loop runs over columns with lane = row.
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
     int d_m = 0;
     if (grp == 0 && tid < nch) { // (nch > 64: later batches are read below)
         const FrontDesc cd = FD[A.child_idx[fd.child_begin + tid]];
-        d_ldc = (cd.flags & FD_SYM) ? -(int64_t)cd.ld : (int64_t)cd.ld; // (negative: only the lower triangle of the block is valid)
+        d_ldc = cd.ld;
         d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
         d_rel = cd.rowptr;
         d_m = cd.m;
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
                 d_m = 0;
                 if (c0 + tid < nch) {
                     const FrontDesc cd = FD[A.child_idx[fd.child_begin + c0 + tid]];
-                    d_ldc = (cd.flags & FD_SYM) ? -(int64_t)cd.ld : (int64_t)cd.ld;
+                    d_ldc = cd.ld;
                     d_cb = cd.off + cd.p + (int64_t)cd.p * cd.ld;
                     d_rel = cd.rowptr;
                     d_m = cd.m;
@@ -103,9 +104,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
                 continue;
             }
             for (int cl = 0; cl < nbatch; cl++) {
-                const int64_t cbo = __shfl(d_cb, cl), ldc_s = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
-                const bool csym = ldc_s < 0; // child factorised as L D L^T: mirror its lower triangle
-                const int64_t ldc = csym ? -ldc_s : ldc_s;
+                const int64_t cbo = __shfl(d_cb, cl), ldc = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
                 const int mc = __shfl(d_m, cl);
                 if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
                 const double *CB = pool + cbo;
@@ -117,7 +116,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
                         const int j = jb + g + q * G;
-                        cb[q] = (i < mc && j < mc) ? ((csym && i < j) ? CB[j + (int64_t)i * ldc] : CB[i + (int64_t)j * ldc]) : 0.0;
+                        cb[q] = (i < mc && j < mc) ? CB[i + (int64_t)j * ldc] : 0.0;
                     }
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
@@ -295,11 +294,14 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int nT = (f + PANEL_T - 1) / PANEL_T;
     const AugView A = aug_view(fd, pool);
     const bool ltile = t < nT;
-    // first row (L) / column (U) of this tile and its extent
+    // first row (L) / column (U) of this tile and its extent.  A tile may straddle row / column f: an L tile's thread owns one row
+    // (its own base pointer and stride: F or E'), a U tile's column is in F or in E (same stride, base picked per column).
     const int o0 = SYM ? (ltile ? base + t * PANEL_T : f + (t - nT) * PANEL_T) : base + (ltile ? t : t - nT) * PANEL_T;
     const int oend = (SYM && ltile) ? f : limit;
     const int ext = (oend - o0) < PANEL_T ? (oend - o0) : PANEL_T;
     if (ext <= 0 && !(t == 0 && k0 == 0)) return; // (workgroup 0 of step 0 still factorises and parks the diagonal tile)
+    double *Lrow = A.at(o0 + tid, k0);                      // L tile: column k0 + u of this thread's row at Lrow[u * lstr]
+    const int64_t lstr = (o0 + tid) >= f ? A.p : A.ld;
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
     // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain;
@@ -317,23 +319,20 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     }
     if (ltile) {
         if (tid < ext) {
-            // row o0 + tid of the tile (a row of F, or of E' below it), column k0 + u at src[u * cstride]
-            const int r = o0 + tid;
-            const double *src = A.at(r, k0);
-            const int64_t cstride = r >= f ? A.p : A.f;
             double v[NB];
 #pragma unroll
-            for (int u = 0; u < NB; u++) v[u] = (u < nb) ? src[(int64_t)u * cstride] : 0.0;
+            for (int u = 0; u < NB; u++) v[u] = (u < nb) ? Lrow[(int64_t)u * lstr] : 0.0;
 #pragma unroll
             for (int u = 0; u < NB; u++) T[u][tid] = v[u];
         }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5; // 4 columns x 32 rows per pass
         double v[PANEL_T / 4];
+        const double *sF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *sE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
 #pragma unroll
         for (int u = 0; u < PANEL_T / 4; u++) {
             const int cc = 4 * u + cq;
-            v[u] = (k < nb && cc < ext) ? *A.at(k0 + k, o0 + cc) : 0.0;
+            v[u] = (k < nb && cc < ext) ? (o0 + cc >= f ? sE : sF)[(int64_t)cc * A.ld] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < PANEL_T / 4; u++) T[k][4 * u + cq] = v[u];
@@ -356,7 +355,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         for (int c = 0; c < NB; c++) {
             // (SYM: only the lower triangle of F is assembled)
             const int rr = (SYM && tid < c) ? c : tid, cc = (SYM && tid < c) ? tid : c;
-            a[c] = (tid < nb && c < nb) ? F[(k0 + rr) + (int64_t)(k0 + cc) * f] : (tid == c ? 1.0 : 0.0);
+            a[c] = (tid < nb && c < nb) ? F[(k0 + rr) + (int64_t)(k0 + cc) * A.ld] : (tid == c ? 1.0 : 0.0);
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
@@ -422,19 +421,17 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     __syncthreads();
     if (ltile) {
         if (tid < ext) {
-            const int r = o0 + tid;
-            double *dst = A.at(r, k0);
-            const int64_t cstride = r >= f ? A.p : A.f;
 #pragma unroll
             for (int k = 0; k < NB; k++)
-                if (k < nb) dst[(int64_t)k * cstride] = T[k][tid];
+                if (k < nb) Lrow[(int64_t)k * lstr] = T[k][tid];
         }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5;
+        double *dF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *dE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
 #pragma unroll
         for (int cb = 0; cb < PANEL_T; cb += 4) {
             const int cc = cb + cq;
-            if (k < nb && cc < ext) *A.at(k0 + k, o0 + cc) = T[k][cc];
+            if (k < nb && cc < ext) (o0 + cc >= f ? dE : dF)[(int64_t)cc * A.ld] = T[k][cc];
         }
     }
 }
@@ -488,7 +485,10 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
-    const int nt = (f + TS - 1) / TS;
+    // Tiles never straddle row / column f: [base, f) (inside F) and [f, limit) (E' rows / E columns) are tiled separately, nt tiles per
+    // dimension cover both parts (the host reserves nt = ceil(f / 64) + 1), so a tile lives in ONE array with uniform base and stride.
+    const int nt = (f + TS - 1) / TS + 1;
+    const int ntF = (f - base + TS - 1) / TS;                // tiles of the part inside F
     const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
     const int gpos = (k0 / NB) % fd.ugroup;                  // position of this step in its group of panels
     const bool narrow = gpos < fd.ugroup - 1 && nb2 > 0;     // not the last step of the group and another step follows
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         for (int c = 0; c < 16; c++) {
             const int cc = half * 16 + c;
             const int rr = (SYM && r < cc) ? cc : r, c2 = (SYM && r < cc) ? r : cc; // (SYM: lower triangle)
-            acc[c] = (r < nb2 && cc < nb2) ? F[(base + rr) + (int64_t)(base + c2) * f] : (r == cc ? 1.0 : 0.0);
+            acc[c] = (r < nb2 && cc < nb2) ? F[(base + rr) + (int64_t)(base + c2) * A.ld] : (r == cc ? 1.0 : 0.0);
         }
         for (int h = 0; h < nhalf; h++) {
             const int kh = kfirst + h * NB, nbh = (h == nhalf - 1) ? nb : NB;
@@ -520,15 +520,15 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
                 const int e = tid + 64 * u;
                 if (SYM) { // U(kk, c) = d_kk L(base + c, kk): lanes run along c (contiguous rows of a column of L)
                     const int c = e & 31, kk = e >> 5;
-                    um[u] = (kk < nbh && c < nb2) ? F[(base + c) + (int64_t)(kh + kk) * f] * dg[kh + kk] : 0.0;
+                    um[u] = (kk < nbh && c < nb2) ? F[(base + c) + (int64_t)(kh + kk) * A.ld] * dg[kh + kk] : 0.0;
                 } else {
                     const int kk = e & 31, c = e >> 5;
-                    um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * f] : 0.0;
+                    um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * A.ld] : 0.0;
                 }
             }
             double lrow[NB];
 #pragma unroll
-            for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * f] : 0.0;
+            for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * A.ld] : 0.0;
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u;
@@ -577,7 +577,9 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const bool rowstrip = narrow && t >= nt;
     const int ti = narrow ? (rowstrip ? 0 : t) : t % nt;
     const int tj = narrow ? (rowstrip ? t - nt : 0) : t / nt;
-    const int r0 = base + ti * TS, c0 = base + tj * TS;
+    const bool rowsE = ti >= ntF, colsE = tj >= ntF; // tile in the rows of E' / in the columns of E
+    const int r0 = rowsE ? f + (ti - ntF) * TS : base + ti * TS, c0 = colsE ? f + (tj - ntF) * TS : base + tj * TS;
+    const int rend = rowsE ? limit : f, cend = colsE ? limit : f;
     if (t == 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         double dv[NB * NB / 256];
@@ -586,23 +588,29 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
         for (int u = 0; u < NB * NB / 256; u++) {
             const int e = tid + 256 * u;
-            if (e < nb * nb) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * f] = dv[u];
+            if (e < nb * nb) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * A.ld] = dv[u];
         }
     }
-    if (r0 >= f && (SYM || c0 >= f)) return; // corner of the augmented front (SYM: there is no E'): never read
-    if (SYM && c0 + TS <= f && r0 + TS <= c0) return; // strictly upper tile of F
+    if (r0 >= rend || c0 >= cend) return;          // no such tile
+    if (rowsE && (SYM || colsE)) return;           // corner of the augmented front (SYM: there is no E'): never read
+    if (SYM && !colsE && r0 + TS <= c0) return;    // strictly upper tile of F
     // entries this step may touch: rows < rmax, columns in [cmin, cmax)
-    const int rmax = rowstrip ? base + nb2 : (SYM ? f : limit);
-    const int cmax = (narrow && !rowstrip) ? base + nb2 : limit;
-    const int cmin = rowstrip ? (SYM ? (f > base + nb2 ? f : base + nb2) : base + nb2) : 0;
-    if (SYM && c0 + TS <= cmin) return; // row strip of a symmetric front: only the columns of E are live
+    const int rmax = rowstrip ? base + nb2 : rend;
+    const int cmax = (narrow && !rowstrip) ? base + nb2 : cend;
+    const int cmin = rowstrip ? base + nb2 : 0;
+    if (SYM && rowstrip && !colsE) return;         // row strip of a symmetric front: only the columns of E are live
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = (wave & 1) * (TS / 2), wc = (wave >> 1) * (TS / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
     double lreg[NE], ureg[NE];
     // SYM, columns inside F: the rows of U are D times transposed columns of L; lanes then run along the tile's columns (contiguous
-    // rows of L) instead of along k.  (A tile that straddles column f reads its few columns of E with that mapping too.)
-    const bool umap_t = SYM && c0 < f;
+    // rows of L) instead of along k.
+    const bool umap_t = SYM && !colsE;
+    const double *Lb = rowsE ? A.Epsh : F;             // rows of the L slice: (r, k) at Lb[r + k * lstr]
+    const int64_t lstr = rowsE ? A.p : A.ld;
+    const double *Ub = colsE ? A.Esh : F;              // columns of the U slice: (k, c) at Ub[k + c * ld]
+    double *Cb = rowsE ? A.Epsh : (colsE ? A.Esh : F); // the tile itself: (r, c) at Cb[r + c * cstr]
+    const int64_t cstr = rowsE ? A.p : A.ld;
     // slice h of the panels: global -> registers, registers -> LDS
 #define HIPMF_FETCH_SLICE(h)                                                                                           \
     {                                                                                                                  \
@@ -610,13 +618,12 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
             const int r = e % TS, kk = e / TS;                                                                         \
-            lreg[u] = (r0 + r < (SYM ? f : limit) && kk < nbh) ? *A.at(r0 + r, kh + kk) : 0.0;                         \
+            lreg[u] = (r0 + r < rend && kk < nbh) ? Lb[(r0 + r) + (int64_t)(kh + kk) * lstr] : 0.0;                    \
             if (umap_t) {                                                                                              \
-                const int c = c0 + r;                                                                                  \
-                ureg[u] = (c < limit && kk < nbh) ? (c < f ? F[c + (int64_t)(kh + kk) * f] * dg[kh + kk] : A.Esh[(kh + kk) + (int64_t)c * f]) : 0.0; \
+                ureg[u] = (c0 + r < cend && kk < nbh) ? F[(c0 + r) + (int64_t)(kh + kk) * A.ld] * dg[kh + kk] : 0.0;   \
             } else {                                                                                                   \
                 const int k2 = e % NB, c = c0 + e / NB;                                                                \
-                ureg[u] = (c < limit && k2 < nbh) ? (c >= f ? A.Esh : F)[(kh + k2) + (int64_t)c * f] : 0.0;            \
+                ureg[u] = (c < cend && k2 < nbh) ? Ub[(kh + k2) + (int64_t)c * A.ld] : 0.0;                            \
             }                                                                                                          \
         }                                                                                                              \
     }
@@ -635,8 +642,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     auto is_live = [&](int a, int b, int g) {
         const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
         const bool corner = owner0 && (b * 16 + l15) < nb2 && (a * 16 + l4 + 4 * g) < nb2;
-        const bool tri = !SYM || c >= f || r >= c; // (SYM: lower triangle of F, all of E)
-        return r < rmax && c < cmax && c >= cmin && !(r >= f && c >= f) && !corner && tri;
+        const bool tri = !SYM || colsE || r >= c; // (SYM: lower triangle of F, all of E)
+        return r < rmax && c < cmax && c >= cmin && !corner && tri;
     };
     // the 16 entries of the trailing matrix this lane updates are requested together with the first slice (one round trip for
     // both: a narrow step is a latency chain) and arrive while the MFMAs run
@@ -648,14 +655,14 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                cur[a][b][g] = is_live(a, b, g) ? *A.at(r, c) : 0.0;
+                cur[a][b][g] = is_live(a, b, g) ? Cb[r + (int64_t)c * cstr] : 0.0;
             }
     HIPMF_STORE_SLICE()
     __syncthreads();
     if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
     // strips of a narrow step: a wave whose quarter of the tile holds no live entry has nothing to multiply
     const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + TS / 2 <= cmin) || (r0 + wr >= rmax) ||
-                           (SYM && c0 + wc + TS / 2 <= f && r0 + wr + TS / 2 <= c0 + wc);
+                           (SYM && !colsE && r0 + wr + TS / 2 <= c0 + wc);
     f64x4 acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; a++)
@@ -693,7 +700,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                if (is_live(a, b, g)) *A.at(r, c) = cur[a][b][g] - acc[a][b][g];
+                if (is_live(a, b, g)) Cb[r + (int64_t)c * cstr] = cur[a][b][g] - acc[a][b][g];
             }
 }
 

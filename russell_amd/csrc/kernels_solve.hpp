@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(SLAB *G) k_fwd_big(const SolveTask *__restrict
     SolveTask tk = tasks[blockIdx.x];
     FrontDesc fd = FD[tk.s];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = f;
+    const int64_t ld = fd.ld;
     const double *E = pool + fd.eoff;
     double *W = work + fd.woff;
     const int r0 = tk.r0, r1 = tk.r1;

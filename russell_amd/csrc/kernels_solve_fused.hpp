@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = f;
+    const int64_t ld = fd.ld;
     const double *E = pool + fd.eoff;
     double *W = work + fd.woff;
     const int r0 = t.b, r1 = t.c, sh = t.kind;
@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
 #pragma unroll
                 for (int q = 0; q < SF_SYMC; q++) {
                     const int col = r0 + wave + 4 * q;
-                    const double *Ec = Ep + (int64_t)(col < r1 ? col : r0) * f;
+                    const double *Ec = Ep + (int64_t)(col < r1 ? col : r0) * fd.ld;
                     e[q][0] = Ec[j], e[q][1] = Ec[j + 64];
                 }
 #pragma unroll
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
 #pragma unroll
                 for (int q = 0; q < SF_SYMC; q++) {
                     const int col = r0 + wave + 4 * q;
-                    e[q] = Ep[(int64_t)(col < r1 ? col : r0) * f + j];
+                    e[q] = Ep[(int64_t)(col < r1 ? col : r0) * fd.ld + j];
                 }
 #pragma unroll
                 for (int q = 0; q < SF_SYMC; q++)

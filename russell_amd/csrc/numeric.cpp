@@ -341,7 +341,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         for (int32_t s = 0; s < ns; s++) {
             if (S.fsize(s) <= SMALL_F) continue;
             const int64_t f = S.fsize(s), p = S.npiv(s);
-            zero_range(S.e_off[s], f * p);
+            zero_range(S.e_off[s], (int64_t)S.front_ld[s] * p);
             if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * p);
         }
         zero_cnt = (int32_t)zt.size();
@@ -349,7 +349,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             levels[(size_t)l].zero_off = (int32_t)zt.size();
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                 const int32_t s = S.level_sn[k];
-                if (S.fsize(s) > SMALL_F) zero_range(S.front_off[s], (int64_t)S.fsize(s) * S.fsize(s));
+                if (S.fsize(s) > SMALL_F) zero_range(S.front_off[s], (int64_t)S.front_ld[s] * S.fsize(s));
             }
             levels[(size_t)l].zero_cnt = (int32_t)zt.size() - levels[(size_t)l].zero_off;
         }
@@ -427,6 +427,11 @@ int32_t Solver::upload_plan() {
             }
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
+        // symmetric mode: the tiled fronts of this level whose parent is a small front (it pulls a FULL contribution block)
+        std::vector<int32_t> mirror;
+        if (S.sym_mode)
+            for (int32_t a : big)
+                if (S.sn_parent[a] >= 0 && S.nrow(a) > 0 && S.fsize(S.sn_parent[a]) <= SMALL_F) mirror.push_back(a);
         // the small fronts of a level go in two launches by size: the LDS a workgroup reserves is that of the largest front of
         // its launch, and the assembly phases of k_small_factor are latency-bound, i.e. they live on the number of resident waves
         std::stable_partition(small.begin(), small.end(), [&](int32_t a) { return S.fsize(a) <= small_split; });
@@ -443,6 +448,9 @@ int32_t Solver::upload_plan() {
         L.big_off = (int32_t)lists.size();
         L.big_cnt = (int32_t)big.size();
         lists.insert(lists.end(), big.begin(), big.end());
+        L.mirror_off = (int32_t)lists.size();
+        L.mirror_cnt = (int32_t)mirror.size();
+        lists.insert(lists.end(), mirror.begin(), mirror.end());
         allbig.insert(allbig.end(), big.begin(), big.end());
         max_big = std::max(max_big, L.big_cnt);
         // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
@@ -462,7 +470,7 @@ int32_t Solver::upload_plan() {
             acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
-                int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T;
+                int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T + 1;
                 const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
                 const int32_t G = update_group(S.fsize(big[a]));
                 const bool narrow = follow && ((k0 / NB) % G) != G - 1; // not the last step of a group: block column + block row only
@@ -715,23 +723,33 @@ int32_t Solver::run_factor() {
         launches += 2;
     }
     HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
-    for (const LevelPlan &L : levels) {
-        if (L.zero_cnt > 0) { // the level's working blocks take over storage other fronts have left
-            hipLaunchKernelGGL(k_zero, dim3(L.zero_cnt), dim3(256), 0, STREAM, d_zero + L.zero_off, d_pool);
+    // The working blocks of a level take over storage other fronts have left: they are zero-filled and receive A's entries when the
+    // level BEFORE has pulled its children's contribution blocks (the storage plan frees a block after its parent's level's
+    // extend-add), on the side stream, beside that level's factorisation.
+    auto fill_level = [&](const LevelPlan &L, hipStream_t st) {
+        if (L.zero_cnt > 0) {
+            hipLaunchKernelGGL(k_zero, dim3(L.zero_cnt), dim3(256), 0, st, d_zero + L.zero_off, d_pool);
             launches++;
         }
         if (L.sc_cnt > 0) {
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)L.sc_cnt + 255) / 256)), dim3(256), 0, STREAM, (int64_t)L.sc_cnt,
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)L.sc_cnt + 255) / 256)), dim3(256), 0, st, (int64_t)L.sc_cnt,
                                d_sc_k + L.sc_off, d_sc_at + L.sc_off, d_vs, d_vs2, d_pool);
             launches++;
         }
+    };
+    if (!levels.empty()) fill_level(levels[0], STREAM);
+    for (size_t li = 0; li < levels.size(); li++) {
+        const LevelPlan &L = levels[li];
+        const LevelPlan *Lnext = li + 1 < levels.size() ? &levels[li + 1] : nullptr;
+        const bool fill_next = Lnext && (Lnext->zero_cnt > 0 || Lnext->sc_cnt > 0);
         if (L.ea_cnt > 0) {
-            hipLaunchKernelGGL(k_extend_add, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
+            if (S.sym_mode) hipLaunchKernelGGL(k_extend_add<true>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
+            else hipLaunchKernelGGL(k_extend_add<false>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             launches++;
         }
         // a level's small fronts and its big fronts are independent of each other (both only need the level's extend-add):
         // when the level has both, the small ones are factorised on a second stream beside the tiled steps
-        const bool forked = L.small_cnt > 0 && !L.steps.empty() && overlap_small;
+        const bool forked = overlap_small && ((L.small_cnt > 0 && !L.steps.empty()) || fill_next);
         if (L.small_cnt > 0) {
             size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
             hipStream_t sst = STREAM;
@@ -755,9 +773,13 @@ int32_t Solver::run_factor() {
             else
                 hipLaunchKernelGGL(k_small_factor<1>, dim3(cnt_b), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm, d_diag);
-            if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
             launches++;
+        } else if (forked) {
+            HIPC(hipEventRecord((hipEvent_t)ev_fork, STREAM), ERROR_HIP_SYNCHRONIZE);
+            HIPC(hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
         }
+        if (fill_next) fill_level(*Lnext, forked ? (hipStream_t)stream2 : STREAM);
+        if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
         int32_t k0 = 0;
         for (const StepPlan &st : L.steps) {
             const int32_t *blist = d_lists + L.big_off;
@@ -774,6 +796,10 @@ int32_t Solver::run_factor() {
             }
             launches += 2;
             k0 += NB;
+        }
+        if (L.mirror_cnt > 0) {
+            hipLaunchKernelGGL(k_mirror_cb, dim3(L.mirror_cnt), dim3(256), 0, STREAM, d_lists + L.mirror_off, d_fd, d_pool);
+            launches++;
         }
         if (forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
     }

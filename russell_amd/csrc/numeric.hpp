@@ -67,6 +67,7 @@ struct LevelPlan {
     int32_t small_cnt_a = 0, small_ld_a = 1;                              // ... the first small_cnt_a of them have f <= small_split
     int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
     int32_t ea_off = 0, ea_cnt = 0;
+    int32_t mirror_off = 0, mirror_cnt = 0; // symmetric mode: tiled fronts of the level with a small parent (k_mirror_cb)
     int32_t zero_off = 0, zero_cnt = 0; // zero-fill tasks of the level's working blocks
     int32_t sc_off = 0, sc_cnt = 0;     // entries of A scattered into the level's working blocks
     int32_t fwd_off = 0, fwd_cnt = 0, bwd_off = 0, bwd_cnt = 0; // SolveTask ranges of the big fronts

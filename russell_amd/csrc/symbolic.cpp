@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -817,13 +818,17 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.front_ld.assign((size_t)S.nsuper, 0);
     S.e_off.assign((size_t)S.nsuper, -1);
     S.ep_off.assign((size_t)S.nsuper, -1);
+    const bool arena_reuse = !(getenv("HIPMF_ARENA_REUSE") && atoi(getenv("HIPMF_ARENA_REUSE")) == 0); // (debug knob: 0 = every block keeps its own storage)
     auto round16 = [](int64_t v) { return (v + 15) / 16 * 16; }; // 128-byte granules for the large blocks
+    // column stride of a big front's working block and of its E panel (measured: padding the stride to f + p, to a multiple of 16 or to
+    // an odd multiple of 16 changes nothing on MI355X; the kernels take any stride >= f)
+    auto ld_of = [&](int64_t f, int64_t) -> int64_t { return f; };
     int64_t pers = 0;
     for (int32_t s = 0; s < S.nsuper; s++) {
         int64_t p = S.npiv(s), m = S.nrow(s), f = p + m;
-        S.front_ld[s] = (int32_t)f;
+        S.front_ld[s] = (int32_t)(f > opt.augment_above ? ld_of(f, p) : f);
         if (f > opt.augment_above) {
-            S.e_off[s] = pers, pers += round16(f * p);
+            S.e_off[s] = pers, pers += round16((int64_t)S.front_ld[s] * p);
             if (!S.sym_mode) S.ep_off[s] = pers, pers += round16(p * f);
         } else {
             S.front_off[s] = pers, pers += f * f;
@@ -887,12 +892,17 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             std::stable_sort(bigs.begin(), bigs.end(), [&](int32_t a, int32_t b) { return S.fsize(a) > S.fsize(b); });
             for (int32_t s : bigs) {
                 const int64_t f = S.fsize(s);
-                S.front_off[s] = pers + take(round16(f * f));
+                S.front_off[s] = pers + take(round16((int64_t)S.front_ld[s] * f));
                 const int32_t t = S.sn_parent[s];
-                // the block is needed until the parent's level has pulled the contribution block (no parent / no block: own level)
-                expire[(size_t)((t < 0 || S.nrow(s) == 0) ? l : S.sn_level[t])].push_back(s);
+                // The block is needed until the parent's level has pulled the contribution block.  The blocks released after level l
+                // are handed out from level l + 1 on, whose blocks are zero-filled while level l is still being factorised (side
+                // stream, after level l's extend-add): a front without a parent / without a block therefore keeps its storage one
+                // level longer than its own.
+                const int32_t last = (t < 0 || S.nrow(s) == 0) ? l + 1 : S.sn_level[t];
+                if (last < S.nlevels) expire[(size_t)last].push_back(s);
             }
-            for (int32_t s : expire[(size_t)l]) give(S.front_off[s] - pers, round16((int64_t)S.fsize(s) * S.fsize(s)));
+            if (arena_reuse)
+                for (int32_t s : expire[(size_t)l]) give(S.front_off[s] - pers, round16((int64_t)S.front_ld[s] * S.fsize(s)));
         }
         S.temp_doubles = top;
     }
@@ -929,7 +939,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
                     return;
                 }
                 S.amap_sn[p] = s;
-                if (S.sym_mode && f > opt.augment_above) {
+                if (S.sym_mode && S.fsize(s) > opt.augment_above) {
                     // L D L^T front: the entry goes to the lower triangle only
                     S.amap[p] = S.front_off[s] + std::max(li, lj) + std::min(li, lj) * f;
                 } else {
