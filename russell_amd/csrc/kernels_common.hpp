@@ -55,6 +55,20 @@ struct FrontDesc {
 constexpr int32_t FD_BIG = 1; // tiled path (f > SMALL_F)
 constexpr int32_t FD_SYM = 2; // big front factorised as L D L^T: only the lower triangle of F (and of its contribution block) is valid
 
+// Every field of a (workgroup-uniform) descriptor is requested in ONE scalar-memory round trip: without this the compiler fetches
+// the fields an early-exit test needs first and the rest after the branch -- one more dependent round trip (~1.5 us) at the head
+// of every tiled kernel, which are latency chains.
+__device__ __forceinline__ void fd_resident(const FrontDesc &fd) {
+    HIPMF_KEEP_SCALAR(fd.off);
+    HIPMF_KEEP_SCALAR(fd.eoff);
+    HIPMF_KEEP_SCALAR(fd.epoff);
+    HIPMF_KEEP_SCALAR(fd.p);
+    HIPMF_KEEP_SCALAR(fd.m);
+    HIPMF_KEEP_SCALAR(fd.first);
+    HIPMF_KEEP_SCALAR(fd.ld);
+    HIPMF_KEEP_SCALAR(fd.ugroup);
+}
+
 // The augmented index space of a big front (see the layout note at the top of this file).
 struct AugView {
     double *F;    // (r, c), r < f, c < f          at F[r + c ld]
@@ -137,6 +151,27 @@ __device__ __forceinline__ int find_slot(const int32_t *pfx, int n, int g) {
         if (pfx[mid] <= g) lo = mid;
         else hi = mid;
     }
+    return lo;
+}
+
+// find_slot plus pfx[slot]: with up to 64 slots both come out of the one vector load (no second memory access); the tiled kernels
+// then fetch their front's descriptor from a per-level table indexed by the slot -- two dependent round trips from the start of
+// the kernel to the first load of matrix data (task prefix, descriptor), where pfx -> pfx[slot] -> list[slot] -> FD[front] took four.
+__device__ __forceinline__ int find_slot_pfx(const int32_t *pfx, int n, int g, int &pfx_slot) {
+    if (n <= 64) {
+        const int lane = threadIdx.x & 63;
+        const int v = lane < n ? pfx[lane] : 0x7fffffff;
+        const int slot = wave_uniform(__popcll(__ballot(v <= g)) - 1);
+        pfx_slot = wave_uniform(__shfl(v, slot));
+        return slot;
+    }
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (pfx[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    pfx_slot = pfx[lo];
     return lo;
 }
 

@@ -272,8 +272,8 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
 // SYM: the L tiles cover the rows of F below the tile only, the U tiles the columns of E only (U12 = D L21^T is never formed);
 // the tile is factorised without interchanges from its lower triangle.
 template <bool SYM>
-__global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
-                                                   const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
+__global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+                                                   int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
                                                    const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
                                                    double *__restrict__ diag) {
@@ -285,9 +285,11 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     __shared__ double dinv[NB];
     __shared__ int32_t lp[NB];
     const int tid = threadIdx.x;
-    const int slot = find_slot(pfx, nactive, blockIdx.x);
-    const int t = blockIdx.x - pfx[slot];
-    FrontDesc fd = FD[list[slot]];
+    int pfx_slot;
+    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    const int t = blockIdx.x - pfx_slot;
+    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
+    fd_resident(fd);
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
@@ -464,8 +466,8 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // (Tried and rejected: 128 x 128 tiles, four 64 x 64 waves -- 204 VGPRs + 128 AGPRs, one workgroup per CU: 962 ms instead of
 // 924 ms for the 128^3 Poisson factorisation.)
 template <bool SYM>
-__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const int32_t *__restrict__ list,
-                                                const FrontDesc *__restrict__ FD, int32_t k0, double *__restrict__ pool,
+__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+                                                int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
                                                 double *__restrict__ diag) {
@@ -479,9 +481,11 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     double *Ls = LsUM;
     double(*UM)[NB + 2] = reinterpret_cast<double(*)[NB + 2]>(LsUM);
     const int tid = threadIdx.x;
-    const int slot = find_slot(pfx, nactive, blockIdx.x);
-    const int t = blockIdx.x - pfx[slot];
-    FrontDesc fd = FD[list[slot]];
+    int pfx_slot;
+    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    const int t = blockIdx.x - pfx_slot;
+    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
+    fd_resident(fd);
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;

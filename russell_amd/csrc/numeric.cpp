@@ -62,7 +62,7 @@ void Solver::release() {
     if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     (void)hipSetDevice(device);
     void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs == d_rs ? nullptr : d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
-                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_pool, d_lperm,
+                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_bigfd, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -87,7 +87,7 @@ void Solver::release() {
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
-    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr;
+    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr, d_bigfd = nullptr;
     for (auto &e : ev)
         if (e) {
             (void)hipEventDestroy((hipEvent_t)e);
@@ -407,6 +407,7 @@ int32_t Solver::upload_plan() {
     pool_doubles = S.persist_doubles + S.temp_doubles;
 
     std::vector<int32_t> lists, tasks, allbig;
+    std::vector<FrontDesc> bigfd;
     std::vector<EaTask> ea;
     std::vector<EaRange> ear;
     int32_t max_big = 0;
@@ -451,6 +452,8 @@ int32_t Solver::upload_plan() {
         L.mirror_off = (int32_t)lists.size();
         L.mirror_cnt = (int32_t)mirror.size();
         lists.insert(lists.end(), mirror.begin(), mirror.end());
+        L.bigfd_off = (int32_t)bigfd.size();
+        for (int32_t a : big) bigfd.push_back(fd[(size_t)a]);
         allbig.insert(allbig.end(), big.begin(), big.end());
         max_big = std::max(max_big, L.big_cnt);
         // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
@@ -634,6 +637,7 @@ int32_t Solver::upload_plan() {
         HIPC(hipMemset(d_sync, 0, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
     }
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_bigfd, bigfd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ear, ear), ERROR_HIP_MALLOC);
     dws_stride = std::max(max_big, 1);
@@ -782,16 +786,16 @@ int32_t Solver::run_factor() {
         if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
         int32_t k0 = 0;
         for (const StepPlan &st : L.steps) {
-            const int32_t *blist = d_lists + L.big_off;
+            const FrontDesc *lfd = d_bigfd + L.bigfd_off; // descriptors of the level's tiled fronts, in slot order
             if (S.sym_mode) {
-                hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
+                hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
-                hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
+                hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                    d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             } else {
-                hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, blist, d_fd, k0,
+                hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
-                hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, blist, d_fd, k0,
+                hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                    d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             }
             launches += 2;

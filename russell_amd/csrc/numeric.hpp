@@ -66,6 +66,7 @@ struct LevelPlan {
     int32_t small_off = 0, small_cnt = 0, small_ld = 0, small_pmax = 1; // fronts with f <= SMALL_F
     int32_t small_cnt_a = 0, small_ld_a = 1;                              // ... the first small_cnt_a of them have f <= small_split
     int32_t big_off = 0, big_cnt = 0;                   // tiled path, sorted by p descending
+    int32_t bigfd_off = 0;                              // their descriptors in d_bigfd (slot order)
     int32_t ea_off = 0, ea_cnt = 0;
     int32_t mirror_off = 0, mirror_cnt = 0; // symmetric mode: tiled fronts of the level with a small parent (k_mirror_cb)
     int32_t zero_off = 0, zero_cnt = 0; // zero-fill tasks of the level's working blocks
@@ -131,6 +132,7 @@ class Solver {
     int32_t allbig_off = 0, allbig_cnt = 0, dws_stride = 1;
     // device buffers
     FrontDesc *d_fd = nullptr;
+    FrontDesc *d_bigfd = nullptr; // copies of the tiled fronts' descriptors, level by level in slot order
     EaTask *d_ea = nullptr;
     EaRange *d_ear = nullptr;
     double *d_dws = nullptr; // factorised diagonal tiles of the current tiled step, one per active big front

@@ -12,6 +12,8 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// the value is needed (in a scalar register) at this point of the program: its load cannot sink below
+#define HIPMF_KEEP_SCALAR(x) asm volatile("" ::"s"(x))
 #define HIPMF_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 
 // broadcast of lane `src` (wave-uniform) to every lane: two v_readlane_b32, result lives in SGPRs

@@ -24,6 +24,7 @@ inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
     return c;
 }
 
+#define HIPMF_KEEP_SCALAR(x) ((void)(x))
 #define HIPMF_DYN_SHARED(T, name) T *name = (T *)(((uintptr_t)hipemu::g_dynshared.data() + 15) & ~(uintptr_t)15)
 
 inline double wave_bcast(double v, int src) { return __shfl(v, src); }

@@ -7,15 +7,21 @@ sys.path.insert(0, ROOT)
 from russell_amd import problems as P
 from russell_amd.backend import Hipmf
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 48
-nrhs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = sys.argv[2] if len(sys.argv) > 2 else "lu"  # "lu": general storage; "sym": lower triangle -> L D L^T on the tiled fronts
 n, rp, ci, v = P.poisson3d(N)
 xs = P.manufactured_solution(n)
 b = P.csr_matvec(n, rp, ci, v, xs)
+if mode == "sym":
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    keep = ci <= rows
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=n))]).astype(np.int32)
+    ci, v = ci[keep], v[keep]
 s = Hipmf()
-t0 = time.perf_counter(); code = s.initialize(n, rp, ci); t1 = time.perf_counter()
+t0 = time.perf_counter(); code = s.initialize(n, rp, ci, general_symmetric=(mode == "sym")); t1 = time.perf_counter()
 print("N=%d n=%d nnz=%d initialize code %d in %.2f s" % (N, n, rp[-1], code, t1 - t0), flush=True)
 if code != 0:
-    print(s._err(code, "initialize")); sys.exit(1)
+    print(s._err(code, "initialize"))  # (out of memory: the message states the bytes the fronts need and the bytes free)
+    sys.exit(1)
 st = s.stats()
 print({k: st[k] for k in ("nsuper", "nlevels", "max_front", "nnz_l", "flops", "pool_bytes")}, flush=True)
 d_v, d_b, d_x = s.dev_alloc(v.nbytes), s.dev_alloc(b.nbytes), s.dev_alloc(b.nbytes)
