@@ -53,6 +53,7 @@ extern "C" {
 #define ERROR_HIPMF_INVALID_MATRIX 600
 #define ERROR_HIPMF_SYMBOLIC 700
 #define ERROR_HIPMF_INVALID_VALUE 803
+#define ERROR_HIPMF_COMM 900 /* an RCCL call failed */
 #define ERROR_HIPMF_NO_DEVICE 1000
 
 /* ordering argument of solver_hipmf_initialize */
@@ -158,10 +159,29 @@ int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, co
 int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *solver, int64_t *istats, double *dstats);
 int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 
-/* factor export/import for the many-RHS multi-GPU path: the numeric factor is one contiguous
- * device buffer; a peer that ran initialize on the same structure can adopt it. */
-int32_t solver_hipmf_factor_buffers(struct InterfaceHIPMF *solver, void **d_pool, int64_t *pool_bytes, void **d_lperm,
-                                    int64_t *lperm_bytes, void **d_row_scale, int64_t *row_scale_bytes);
+/* ---- many right-hand sides over the GPUs of one node (the reference has no counterpart: lin_solver.rs:51,
+ * interface_cudss.cu:275,281 create b and x with ONE column).  One process (or thread) per GPU, every rank runs
+ * solver_hipmf_initialize on the same structure (the analysis is deterministic), ONE rank factorises, the factor travels over
+ * RCCL / xGMI, every rank solves its block of columns.
+ *
+ * The numeric factor of a handle = 4 device buffers (solver_hipmf_factor_parts): [0] the persistent part of the front pool (small
+ * fronts, E / E' panels), [1] row interchanges (int32 x n), [2] scaling (f64 x n), [3] pivots (f64 x n).  A peer that ran
+ * initialize on the same structure may be handed their contents by any transport and then calls solver_hipmf_adopt_factor.
+ * solver_hipmf_broadcast_factor does it with ncclBroadcast in 256 MB messages on the solver's stream (plus the matrix values for the
+ * refinement SpMV), every rank of `comm` calls it; `comm` is an ncclComm_t -- the caller's own, or one made by
+ * hipmf_comm_unique_id (rank 0; send the 128 bytes to the others by any means) + hipmf_comm_init_rank (every rank), so that a host
+ * language needs no RCCL binding of its own.  RCCL is loaded on first use (dlopen). */
+#define HIPMF_COMM_ID_BYTES 128
+int32_t solver_hipmf_factor_parts(struct InterfaceHIPMF *solver, int32_t max_parts, void **d_ptrs, int64_t *bytes); /* returns 4 */
+int32_t hipmf_comm_unique_id(void *id128);
+int32_t hipmf_comm_init_rank(void **comm, int32_t nranks, const void *id128, int32_t rank);
+void hipmf_comm_destroy(void *comm);
+int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *solver, void *comm, int32_t root, int32_t rank, double *seconds,
+                                      int64_t *bytes_sent);
+/* This rank's block of the nrhs_total columns (contiguous blocks, sizes differ by at most one): solves columns
+ * [first, first + count) of the n x nrhs_total device arrays d_rhs -> d_x (column-major, leading dimension ld) in place. */
+int32_t solver_hipmf_solve_many_sharded(struct InterfaceHIPMF *solver, double *d_x, const double *d_rhs, int32_t nrhs_total, int32_t ld,
+                                        int32_t nranks, int32_t rank, int32_t *first_column, int32_t *num_columns);
 int32_t solver_hipmf_adopt_factor(struct InterfaceHIPMF *solver, const double *d_values);
 
 const char *solver_hipmf_last_error(struct InterfaceHIPMF *solver);

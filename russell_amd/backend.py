@@ -157,15 +157,30 @@ class Hipmf:
         return self.lib.solver_hipmf_factorize_device(self.h, d_values)
 
     def factor_buffers(self):
-        """(pointer, bytes) of the three device buffers that hold the numeric factor: front pool, local row interchanges, row
-        scaling.  A peer that ran `initialize` on the same structure can be handed their contents and then `adopt_factor`."""
-        ptrs = [C.c_void_p() for _ in range(3)]
-        sizes = [C.c_int64() for _ in range(3)]
-        code = self.lib.solver_hipmf_factor_buffers(self.h, C.byref(ptrs[0]), C.byref(sizes[0]), C.byref(ptrs[1]), C.byref(sizes[1]),
-                                                    C.byref(ptrs[2]), C.byref(sizes[2]))
+        """(pointer, bytes) of the device buffers that hold the numeric factor: persistent part of the front pool, local row
+        interchanges, scaling, pivots.  A peer that ran `initialize` on the same structure can be handed their contents and then
+        `adopt_factor`."""
+        ptrs = (C.c_void_p * 4)()
+        sizes = (C.c_int64 * 4)()
+        k = self.lib.solver_hipmf_factor_parts(self.h, 4, ptrs, sizes)
+        if k != 4:
+            raise self._err(k, "solver_hipmf_factor_parts")
+        return [(int(ptrs[i] or 0), int(sizes[i])) for i in range(4)]
+
+    def broadcast_factor(self, comm, root, rank):
+        """RCCL broadcast of the factor (and the matrix values) from `root`; returns (seconds, bytes)."""
+        sec, nb = C.c_double(0.0), C.c_int64(0)
+        code = self.lib.solver_hipmf_broadcast_factor(self.h, comm, root, rank, C.byref(sec), C.byref(nb))
         if code != 0:
-            raise self._err(code, "solver_hipmf_factor_buffers")
-        return [(int(p.value), int(n.value)) for p, n in zip(ptrs, sizes)]
+            raise self._err(code, "solver_hipmf_broadcast_factor")
+        return sec.value, nb.value
+
+    def solve_many_sharded(self, d_x, d_rhs, nrhs_total, nranks, rank, ld=None):
+        first, count = C.c_int32(0), C.c_int32(0)
+        code = self.lib.solver_hipmf_solve_many_sharded(self.h, d_x, d_rhs, nrhs_total, ld or self.n, nranks, rank, C.byref(first), C.byref(count))
+        if code != 0:
+            raise self._err(code, "solver_hipmf_solve_many_sharded")
+        return first.value, count.value
 
     def adopt_factor(self, d_values):
         """Declare the factor buffers (filled by a peer) valid; d_values: the matrix values on the device (refinement SpMV)."""

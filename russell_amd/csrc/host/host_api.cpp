@@ -812,6 +812,7 @@ StrError handle_hipmf_error_code(int32_t err) {
     case ERROR_HIPMF_INVALID_MATRIX: return "HIPMF symbolic analysis failed: invalid CSR structure";
     case ERROR_HIPMF_SYMBOLIC: return "HIPMF symbolic analysis failed: internal error";
     case ERROR_HIPMF_INVALID_VALUE: return "HIPMF solve failed: invalid value";
+    case ERROR_HIPMF_COMM: return "HIPMF: an RCCL call failed";
     case ERROR_HIPMF_NO_DEVICE: return "HIPMF: no HIP device is visible";
     default: return "Error: unknown error returned by c-code (HIPMF)";
     }

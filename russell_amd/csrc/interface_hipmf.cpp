@@ -6,8 +6,15 @@
 #include <hipmf_device_rt.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <mutex>
 #include <new>
+#ifdef HIPMF_HAVE_RCCL
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#endif
 
 #include "numeric.hpp"
 #include "matching.hpp"
@@ -187,17 +194,15 @@ int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *h, int64_t *is, double *ds
     return SUCCESSFUL_EXIT;
 }
 
-int32_t solver_hipmf_factor_buffers(struct InterfaceHIPMF *h, void **d_pool, int64_t *pool_bytes, void **d_lperm, int64_t *lperm_bytes,
-                                    void **d_row_scale, int64_t *row_scale_bytes) {
-    if (!h) return ERROR_NULL_POINTER;
+int32_t solver_hipmf_factor_parts(struct InterfaceHIPMF *h, int32_t max_parts, void **d_ptrs, int64_t *bytes) {
+    if (!h || !d_ptrs || !bytes) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
-    if (d_pool) *d_pool = h->solver.d_pool;
-    if (pool_bytes) *pool_bytes = h->solver.pool_doubles * 8;
-    if (d_lperm) *d_lperm = h->solver.d_lperm;
-    if (lperm_bytes) *lperm_bytes = (int64_t)h->solver.S.n * 4;
-    if (d_row_scale) *d_row_scale = h->solver.d_rs;
-    if (row_scale_bytes) *row_scale_bytes = (int64_t)h->solver.S.n * 8;
-    return SUCCESSFUL_EXIT;
+    const Solver &s = h->solver;
+    void *p[4] = {s.d_pool, s.d_lperm, s.d_rs, s.d_diag_ptr()};
+    const int64_t nb[4] = {s.S.persist_doubles * 8, (int64_t)s.S.n * 4, (int64_t)s.S.n * 8, (int64_t)s.S.n * 8};
+    if (max_parts < 4) return ERROR_HIPMF_INVALID_VALUE;
+    for (int i = 0; i < 4; i++) d_ptrs[i] = p[i], bytes[i] = nb[i];
+    return 4;
 }
 
 int32_t solver_hipmf_adopt_factor(struct InterfaceHIPMF *h, const double *d_values) {
@@ -214,6 +219,111 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *h) {
     t.acc_assemble_ms = t.acc_factor_ms = t.acc_fwd_ms = t.acc_bwd_ms = 0.0;
     t.acc_factor_count = t.acc_tri_count = 0;
     return SUCCESSFUL_EXIT;
+}
+
+// ---- many-RHS over the GPUs of a node: the factor goes from the rank that factorised to the others over RCCL (xGMI) ----
+// RCCL is bound at the first use (dlopen): a single-GPU caller never loads it.
+#ifdef HIPMF_HAVE_RCCL
+namespace {
+struct Rccl {
+    void *dl = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    bool tried = false, ok = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+bool rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.tried) return g_rccl.ok;
+    g_rccl.tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.dl = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.dl) break;
+    }
+    if (!g_rccl.dl) return false;
+    g_rccl.get_unique_id = (decltype(g_rccl.get_unique_id))dlsym(g_rccl.dl, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(g_rccl.dl, "ncclCommInitRank");
+    g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(g_rccl.dl, "ncclCommDestroy");
+    g_rccl.broadcast = (decltype(g_rccl.broadcast))dlsym(g_rccl.dl, "ncclBroadcast");
+    g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.broadcast;
+    return g_rccl.ok;
+}
+} // namespace
+
+int32_t hipmf_comm_unique_id(void *id128) {
+    if (!id128) return ERROR_NULL_POINTER;
+    if (!rccl_load()) return ERROR_NOT_AVAILABLE;
+    static_assert(sizeof(ncclUniqueId) == HIPMF_COMM_ID_BYTES, "ncclUniqueId size");
+    return g_rccl.get_unique_id((ncclUniqueId *)id128) == ncclSuccess ? SUCCESSFUL_EXIT : ERROR_HIPMF_COMM;
+}
+
+int32_t hipmf_comm_init_rank(void **comm, int32_t nranks, const void *id128, int32_t rank) {
+    if (!comm || !id128) return ERROR_NULL_POINTER;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return ERROR_HIPMF_INVALID_VALUE;
+    if (!rccl_load()) return ERROR_NOT_AVAILABLE;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    if (g_rccl.comm_init_rank(&c, nranks, id, rank) != ncclSuccess) return ERROR_HIPMF_COMM;
+    *comm = (void *)c;
+    return SUCCESSFUL_EXIT;
+}
+
+void hipmf_comm_destroy(void *comm) {
+    if (comm && rccl_load()) (void)g_rccl.comm_destroy((ncclComm_t)comm);
+}
+
+int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *h, void *comm, int32_t root, int32_t rank, double *seconds, int64_t *bytes_sent) {
+    if (!h || !comm) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    if (rank == root && !h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+    if (!rccl_load()) return ERROR_NOT_AVAILABLE;
+    Solver &s = h->solver;
+    void *ptrs[5];
+    int64_t nb[5];
+    if (solver_hipmf_factor_parts(h, 4, ptrs, nb) != 4) return ERROR_HIPMF_INVALID_VALUE;
+    ptrs[4] = s.d_vals_ptr(), nb[4] = s.S.nnz_a * 8; // the matrix values: the refinement SpMV of every rank needs them
+    if (hipSetDevice(s.device) != hipSuccess) return ERROR_HIPMF_NO_DEVICE;
+    const auto t0 = std::chrono::steady_clock::now();
+    // ring / tree collectives over xGMI are per-link bound: large messages (256 MB) keep every link busy
+    const int64_t chunk = 256ll << 20;
+    int64_t total = 0;
+    for (int i = 0; i < 5; i++)
+        for (int64_t off = 0; off < nb[i]; off += chunk) {
+            const int64_t len = std::min(chunk, nb[i] - off);
+            char *p = (char *)ptrs[i] + off;
+            if (g_rccl.broadcast(p, p, (size_t)len, ncclChar, root, (ncclComm_t)comm, (hipStream_t)s.stream) != ncclSuccess) return ERROR_HIPMF_COMM;
+            total += len;
+        }
+    if (hipStreamSynchronize((hipStream_t)s.stream) != hipSuccess) return ERROR_HIP_SYNCHRONIZE;
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (bytes_sent) *bytes_sent = total;
+    if (rank != root) s.mark_factor_adopted();
+    return SUCCESSFUL_EXIT;
+}
+#else
+int32_t hipmf_comm_unique_id(void *) { return ERROR_NOT_AVAILABLE; }
+int32_t hipmf_comm_init_rank(void **, int32_t, const void *, int32_t) { return ERROR_NOT_AVAILABLE; }
+void hipmf_comm_destroy(void *) {}
+int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *, void *, int32_t, int32_t, double *, int64_t *) { return ERROR_NOT_AVAILABLE; }
+#endif
+
+int32_t solver_hipmf_solve_many_sharded(struct InterfaceHIPMF *h, double *d_x, const double *d_rhs, int32_t nrhs_total, int32_t ld, int32_t nranks,
+                                        int32_t rank, int32_t *first_column, int32_t *num_columns) {
+    // columns [first, first + count) of B belong to this rank (contiguous blocks whose sizes differ by at most one); they are solved
+    // in place of the caller's n x nrhs_total arrays: d_rhs / d_x point at column 0 of the WHOLE arrays resident on this rank's GPU
+    if (!h || !d_x || !d_rhs) return ERROR_NULL_POINTER;
+    if (nranks < 1 || rank < 0 || rank >= nranks || nrhs_total < 0) return ERROR_HIPMF_INVALID_VALUE;
+    if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+    const int32_t base = nrhs_total / nranks, extra = nrhs_total % nranks;
+    const int32_t count = base + (rank < extra ? 1 : 0), first = rank * base + std::min(rank, extra);
+    if (first_column) *first_column = first;
+    if (num_columns) *num_columns = count;
+    if (count == 0) return SUCCESSFUL_EXIT;
+    return h->solver.solve(d_x + (int64_t)first * ld, d_rhs + (int64_t)first * ld, count, ld, true);
 }
 
 const char *solver_hipmf_last_error(struct InterfaceHIPMF *h) { return h ? h->solver.last_error.c_str() : "null solver"; }

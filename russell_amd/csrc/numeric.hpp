@@ -35,6 +35,7 @@ enum : int32_t {
     ERROR_HIPMF_INVALID_MATRIX = 600,
     ERROR_HIPMF_SYMBOLIC = 700,
     ERROR_HIPMF_INVALID_VALUE = 803,
+    ERROR_HIPMF_COMM = 900,
     ERROR_HIPMF_NO_DEVICE = 1000,
     // numerical status, same value UMFPACK uses for a singular matrix (solver_umfpack.rs:492)
     WARNING_SINGULAR_MATRIX = 1,
@@ -92,6 +93,9 @@ class Solver {
     int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
     int32_t determinant(double *mantissa, double *exponent, double *rcond);
     int32_t adopt_factor(const double *d_values); // factor buffers were filled by a peer (many-RHS multi-GPU path)
+    void mark_factor_adopted() { n_perturbed = n_zero_pivot = 0, factorized = true; } // ... including the matrix values
+    void *d_diag_ptr() const { return d_diag; }
+    void *d_vals_ptr() const { return d_vals; }
     void release();
 
     Symbolic S;

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#define HIPMF_HAVE_RCCL 1 // the product build binds RCCL (lazily, dlopen) for the multi-GPU entry points
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) * B(4x16) + C.
