@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- factorize+solve of the 1M-DOF 2D 5-point Poisson matrix (BASELINE.json configs[1]) on MI355X.
 
-A "step" is one pass of the hot path: numeric factorisation (values already resident in HBM) followed
-by one solve (rhs resident in HBM, default iterative refinement).  Prints ONE JSON line (rank 0).
+A "step" (the headline `value`) is one pass of the hot path on every rank: numeric LU factorisation (values already resident in
+HBM) followed by one solve (rhs resident in HBM, default iterative refinement) of the general-storage matrix -- the call the
+reference's Radau5 / Newton callers repeat, and the one the north_star compares with UMFPACK.  Prints ONE JSON line (rank 0).
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1 (many-RHS path): the right-hand sides are sharded over the ranks (one block per
-GPU, weak scaling); every rank holds the factor of the same matrix.  No data-path collective is needed
-for the solves themselves; see DESIGN.md ("multi-GPU").
+Beside the headline the same line carries (all measured in this run, outside the K timed steps):
+  symmetric    the same matrix handed over as its lower triangle (Sym::YesLower, what russell_pde gives a GPU genie):
+               L D L^T on the tiled fronts;
+  host_api     solver_hipmf_factorize / _solve with HOST pointers through the mirror of the Rust layer, i.e. including the
+               COO -> CSR value refresh and the H2D / D2H copies the reference's boundary includes (interface_cudss.cu:424,524,553);
+  many_rhs     the north_star split: 256 right-hand sides sharded over the ranks; one rank factorises, the factor travels over
+               RCCL (solver_hipmf_broadcast_factor), every rank solves its block -- with the factorize / broadcast / solve split,
+               beside the replicated-factorisation alternative;
+  roofline     SpTRSV pass (HBM) of the headline, roofline_factor (FP64 MFMA), fused-solve fallback count;
+  cpu_baseline the CPU path on this box's host cores, best available tier: UMFPACK itself (oracle/umfpack_probe.c, when a
+               libumfpack can be loaded), else SuperLU through scipy (labelled: NOT UMFPACK), else the repo's own CPU port.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -25,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 (vector = matrix) peak, datasheet
+NRHS_TOTAL = 256           # BASELINE config 4 / north_star: 256 right-hand sides over the GPUs of the node
 
 
 def sptrsv_bytes(st, n, k=1):
@@ -33,32 +44,88 @@ def sptrsv_bytes(st, n, k=1):
 
 
 def measured_traffic(grid):
-    """HBM bytes per SpTRSV pass from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed
-    loop; the counters were collected with this same command on the same workload, see profiles/r01_v6_pmc_hbm.txt)."""
-    path = os.path.join(ROOT, "profiles", "r01_sptrsv_traffic.json")
-    if grid != 1000 or not os.path.exists(path):
-        return None, None
-    with open(path) as fh:
-        t = json.load(fh)
-    return t["traffic_bytes_per_pass"], t["source"]
+    """HBM bytes per SpTRSV pass from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed loop;
+    the counters were collected with this same command on the same workload; the file names the run they come from)."""
+    for name in ("r02_sptrsv_traffic.json", "r01_sptrsv_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if grid == 1000 and os.path.exists(path):
+            with open(path) as fh:
+                t = json.load(fh)
+            return t["traffic_bytes_per_pass"], t["source"]
+    return None, None
 
 
-def cpu_baseline(n, rp, ci, v, b, perm):
-    """The CPU oracle (kind 'port') timed on this box's host cores, single thread, same matrix/ordering."""
-    import oracle_lib as O
+def lower_triangle(n, rp, ci, v):
     rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    keep = ci <= rows
+    lrp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=n))]).astype(np.int32)
+    return lrp, np.ascontiguousarray(ci[keep]), np.ascontiguousarray(v[keep])
+
+
+def residual_metric(n, rp, ci, v, x, b):
+    """relative_error of VerifyLinSys (verify_lin_sys.rs:60-96): |A x - b|_inf / (max|a| + 1)"""
+    r = np.zeros(n)
+    np.add.at(r, np.repeat(np.arange(n), np.diff(rp)), v * x[ci])
+    return float(np.max(np.abs(r - b)) / (np.max(np.abs(v)) + 1.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the only part of this file that touches oracle/
+def cpu_baseline(n, rp, ci, v, b, perm, tier):
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    ncores = os.cpu_count() or 0
+    tried = []
+    if tier in ("auto", "umfpack"):
+        so = os.path.join(ROOT, "oracle", "libumfpack_probe.so")
+        if os.path.exists(so):
+            import oracle_lib as O
+            cp, ri, vx = O.coo_to_csc(n, n, rows, ci, v)
+            lib = ctypes.CDLL(so)
+            i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+            f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+            lib.umfpack_probe.restype = ctypes.c_int
+            lib.umfpack_probe.argtypes = [ctypes.c_int32, i32p, i32p, f64p, f64p, f64p, f64p, ctypes.c_char_p, ctypes.c_int32]
+            x, sec, name = np.zeros(n), np.zeros(3), ctypes.create_string_buffer(256)
+            rc = lib.umfpack_probe(n, cp, ri, vx, np.ascontiguousarray(b), x, sec, name, 256)
+            if rc == 0:
+                return {"value": round((sec[1] + sec[2]) * 1e3, 2), "unit": "ms", "cores": int(os.environ.get("OMP_NUM_THREADS", ncores) or ncores),
+                        "kind": "reference",
+                        "sample": "UMFPACK (%s, dlopen) with the reference shim's call sequence and controls (strategy AUTO, ordering AMD, scale SUM; "
+                                  "interface_umfpack.c:47,99-109,167,229) on the SAME %d-DOF matrix: symbolic %.1f ms, numeric %.1f ms, solve %.1f ms, "
+                                  "relative_error %.1e; BLAS threads as configured on this host (%d cores)"
+                                  % (name.value.decode(), n, sec[0] * 1e3, sec[1] * 1e3, sec[2] * 1e3, residual_metric(n, rp, ci, v, x, b), ncores)}
+            tried.append("UMFPACK: no libumfpack can be loaded on this box (umfpack_probe rc %d)" % rc)
+        else:
+            tried.append("UMFPACK: oracle/libumfpack_probe.so not built")
+    if tier in ("auto", "superlu"):
+        try:
+            import scipy.sparse as sp
+            import scipy.sparse.linalg as spla
+            A = sp.csr_matrix((v, ci, rp), shape=(n, n)).tocsc()
+            t0 = time.perf_counter()
+            lu = spla.splu(A, permc_spec="MMD_AT_PLUS_A")  # symmetric-pattern ordering, SuperLU's counterpart of UMFPACK's AMD choice
+            t1 = time.perf_counter()
+            x = lu.solve(b)
+            t2 = time.perf_counter()
+            return {"value": round((t2 - t0) * 1e3, 2), "unit": "ms", "cores": 1,
+                    "kind": "third-party stand-in: SuperLU (scipy.sparse.linalg.splu), NOT the reference's UMFPACK",
+                    "sample": "SuperLU, permc_spec MMD_AT_PLUS_A, one thread, on the SAME %d-DOF matrix: factorize (ordering + symbolic + numeric) "
+                              "%.1f ms + solve %.1f ms, nnz(L+U) %d, relative_error %.1e; host has %d cores; %s"
+                              % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, int(lu.L.nnz + lu.U.nnz), residual_metric(n, rp, ci, v, x, b), ncores,
+                                 "; ".join(tried))}
+        except Exception as exc:  # scipy missing or out of memory: fall through to the port
+            tried.append("SuperLU: %s" % exc)
+    import oracle_lib as O
     cp, ri, vx = O.coo_to_csc(n, n, rows, ci, v)
     t0 = time.perf_counter()
     lu = O.OracleLU(n, cp, ri, vx, q=perm)
     t1 = time.perf_counter()
     x = lu.solve(b, nrefine=2)
     t2 = time.perf_counter()
-    r = np.zeros(n)
-    np.add.at(r, rows, v * x[ci])
     return {"value": round((t2 - t0) * 1e3, 2), "unit": "ms", "cores": 1, "kind": "port",
-            "sample": "oracle/oracle.c left-looking LU (threshold pivoting, SUM scaling, <=2 refinement steps) on the SAME %d-DOF "
-                      "matrix with the same fill-reducing ordering: factorize %.1f ms + solve %.1f ms, residual %.1e; host has %d cores"
-                      % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, float(np.max(np.abs(r - b))), os.cpu_count() or 0)}
+            "sample": "oracle/oracle.c left-looking LU (threshold pivoting, SUM scaling, <=2 refinement steps) on the SAME %d-DOF matrix with the "
+                      "same fill-reducing ordering: factorize %.1f ms + solve %.1f ms, relative_error %.1e; host has %d cores; %s"
+                      % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, residual_metric(n, rp, ci, v, x, b), ncores, "; ".join(tried))}
 
 
 def main():
@@ -68,30 +135,47 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=1000, help="nx = ny of the 2D 5-point Poisson grid (1000 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU-baseline sample (0 = same as --grid)")
+    ap.add_argument("--cpu-tier", default="auto", choices=["auto", "umfpack", "superlu", "port"])
+    ap.add_argument("--nrhs", type=int, default=NRHS_TOTAL, help="right-hand sides of the many-RHS section (0: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    tdev = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        tdev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=tdev)
 
     from russell_amd import problems as P
-    from russell_amd.backend import Hipmf
-
     from russell_amd import _capi
-    if _capi.load().hipmf_set_device(local_rank) != 0:
+    from russell_amd.backend import Hipmf
+    from russell_amd.distributed import max_over_ranks, rhs_block
+
+    lib = _capi.load()
+    if lib.hipmf_set_device(local_rank) != 0:
         raise RuntimeError("hipmf_set_device(%d) failed" % local_rank)
+
+    def sync_all():
+        lib.hipmf_device_synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def rank_max(value):
+        return max_over_ranks(value, dist, device=tdev) if dist is not None else float(value)
 
     n, rp, ci, v = P.poisson2d(args.grid)
     xs = P.manufactured_solution(n)
     b = P.csr_matvec(n, rp, ci, v, xs) + float(rank)  # every rank owns a different right-hand side
 
+    # ---------------------------------------------------------------- headline: general storage, LU, 1 RHS per GPU
     s = Hipmf()
     t0 = time.perf_counter()
     code = s.initialize(n, rp, ci)
@@ -108,44 +192,165 @@ def main():
         assert c == 0, c
         s.solve_device(d_x, d_b)
 
-    def barrier():
-        s.lib.hipmf_device_synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     s.reset_timers()
-    barrier()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        from russell_amd.distributed import max_over_ranks
-        elapsed = max_over_ranks(elapsed, dist, device=torch.device("cuda", local_rank))
+    sync_all()
+    elapsed = rank_max(time.perf_counter() - t0)
     ms_per_step = elapsed * 1e3 / args.steps
 
     st = s.stats()
     x = np.zeros(n)
     s.d2h(x, d_x)
-    resid = np.zeros(n)
-    np.add.at(resid, np.repeat(np.arange(n), np.diff(rp)), v * x[ci])
-    rel_err = float(np.max(np.abs(resid - b)) / (np.max(np.abs(v)) + 1.0))
+    rel_err = residual_metric(n, rp, ci, v, x, b)
+    perm = s.permutation() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+    extras = {}
+    # ---------------------------------------------------------------- the same matrix as its lower triangle: L D L^T
+    if not args.no_extras:
+        lrp, lci, lv = lower_triangle(n, rp, ci, v)
+        s2 = Hipmf()
+        assert s2.initialize(n, lrp, lci, general_symmetric=True) == 0
+        d_lv = s2.dev_alloc(lv.nbytes)
+        s2.h2d(d_lv, lv)
+        for _ in range(max(args.warmup, 1)):
+            assert s2.factorize_device(d_lv) == 0
+            s2.solve_device(d_x, d_b)
+        s2.reset_timers()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            assert s2.factorize_device(d_lv) == 0
+            s2.solve_device(d_x, d_b)
+        sync_all()
+        sym_ms = rank_max(time.perf_counter() - t0) * 1e3 / args.steps
+        st2 = s2.stats()
+        x2 = np.zeros(n)
+        s2.d2h(x2, d_x)
+        tri2 = (st2["acc_fwd_ms"] + st2["acc_bwd_ms"]) / max(st2["acc_tri_count"], 1.0)
+        extras["symmetric"] = {
+            "workload": "same matrix handed over as its LOWER triangle with general_symmetric = 1 (Sym::YesLower, interface_cudss.cu:324-333): "
+                        "L D L^T on the tiled fronts, values and rhs resident in HBM",
+            "value_ms": round(sym_ms, 3), "factor_ms": round(st2["acc_factor_ms"] / max(st2["acc_factor_count"], 1.0), 3),
+            "sptrsv_pair_ms": round(tri2, 4), "pool_gb": round(st2["pool_bytes"] / 1e9, 3), "relative_error": residual_metric(n, rp, ci, v, x2, b),
+            "max_abs_diff_vs_lu": float(np.max(np.abs(x2 - x)))}
+        s2.dev_free(d_lv)
+        s2.close()
+
+    # ---------------------------------------------------------------- host-pointer boundary through the mirror of the Rust layer
+    if not args.no_extras and rank == 0:
+        try:
+            from russell_amd import sparse as RS
+            rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+            coo = RS.CooMatrix(n, n, len(v))
+            coo.put_many(rows, ci.astype(np.int32), v)
+            hs = RS.LinSolver(RS.Genie.Hipmf)
+            t0 = time.perf_counter()
+            hs.actual.factorize(coo)  # first call: COO -> CSR, initialize, value map, factorize
+            t_first = time.perf_counter() - t0
+            tf = ts = 0.0
+            reps = 3
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                hs.actual.factorize(coo)  # repeat call (params None): values through the device-side map + numeric LU
+                t1 = time.perf_counter()
+                xh = hs.actual.solve(b)
+                t2 = time.perf_counter()
+                tf += t1 - t0
+                ts += t2 - t1
+            extras["host_api"] = {
+                "workload": "LinSolTrait::factorize(&coo, None) repeat call + solve(&mut x, &rhs) with HOST vectors (H2D of 4 996 000 triplet values, "
+                            "device-side COO->CSR value refresh, numeric LU; H2D rhs, solve, D2H x), wall clock",
+                "factorize_ms": round(tf / reps * 1e3, 3), "solve_ms": round(ts / reps * 1e3, 3), "total_ms": round((tf + ts) / reps * 1e3, 3),
+                "first_call_ms": round(t_first * 1e3, 1), "relative_error": residual_metric(n, rp, ci, v, xh, b)}
+            del hs
+        except Exception as exc:  # never lose the headline to an extra
+            extras["host_api"] = {"error": repr(exc)}
+
+    # ---------------------------------------------------------------- many right-hand sides, sharded (north_star)
+    if not args.no_extras and args.nrhs > 0:
+        try:
+            first, count = rhs_block(args.nrhs, world, rank)
+            b0 = P.csr_matvec(n, rp, ci, v, xs)
+            Bh = np.empty((max(count, 1), n))
+            for j in range(count):
+                Bh[j] = b0 * (1.0 + 0.01 * (first + j))  # column j has the known solution xs * (1 + 0.01 j)
+            d_B = s.dev_alloc(Bh.nbytes)
+            d_X = s.dev_alloc(Bh.nbytes)
+            s.h2d(d_B, Bh)
+            # (a) replicated: every rank factorises (no data-path collective at all)
+            sync_all()
+            t0 = time.perf_counter()
+            assert s.factorize_device(d_vals) == 0
+            lib.hipmf_device_synchronize()
+            t_fact_rep = rank_max(time.perf_counter() - t0)
+            sync_all()
+            t0 = time.perf_counter()
+            if count > 0:
+                s.solve_device(d_X, d_B, nrhs=count)
+            lib.hipmf_device_synchronize()
+            t_solve = rank_max(time.perf_counter() - t0)
+            Xh = np.zeros_like(Bh)
+            s.d2h(Xh, d_X)
+            worst = max([float(np.max(np.abs(Xh[j] - xs * (1.0 + 0.01 * (first + j))))) for j in range(count)] + [0.0])
+            many = {"nrhs_total": args.nrhs, "rhs_per_gpu": count, "solve_ms": round(t_solve * 1e3, 3),
+                    "replicate": {"factorize_ms": round(t_fact_rep * 1e3, 3), "total_ms": round((t_fact_rep + t_solve) * 1e3, 3),
+                                  "rhs_per_s": round(args.nrhs / (t_fact_rep + t_solve), 1)},
+                    "max_abs_error_all_columns": worst}
+            # (b) north_star: ONE rank factorises, the factor goes to the others over RCCL / xGMI
+            if world > 1:
+                import torch
+                idt = torch.zeros(128, dtype=torch.uint8, device=tdev)
+                if rank == 0:
+                    idbuf = (ctypes.c_uint8 * 128)()
+                    assert lib.hipmf_comm_unique_id(idbuf) == 0
+                    idt.copy_(torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                idb = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+                comm = ctypes.c_void_p()
+                assert lib.hipmf_comm_init_rank(ctypes.byref(comm), world, idb, rank) == 0
+                s.broadcast_factor(comm, 0, rank)  # warm-up of the communicator (first collective sets up the rings)
+                sync_all()
+                t0 = time.perf_counter()
+                if rank == 0:
+                    assert s.factorize_device(d_vals) == 0
+                lib.hipmf_device_synchronize()
+                sync_all()
+                t_fact = rank_max(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                sec, nbytes = s.broadcast_factor(comm, 0, rank)
+                sync_all()
+                t_bc = rank_max(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                if count > 0:
+                    s.solve_device(d_X, d_B, nrhs=count)
+                lib.hipmf_device_synchronize()
+                t_solve2 = rank_max(time.perf_counter() - t0)
+                s.d2h(Xh, d_X)
+                worst2 = max([float(np.max(np.abs(Xh[j] - xs * (1.0 + 0.01 * (first + j))))) for j in range(count)] + [0.0])
+                lib.hipmf_comm_destroy(comm)
+                many["broadcast"] = {"factorize_ms": round(t_fact * 1e3, 3), "broadcast_ms": round(t_bc * 1e3, 3),
+                                     "broadcast_bytes": int(nbytes), "broadcast_gbs": round(nbytes / t_bc / 1e9, 1) if t_bc > 0 else None,
+                                     "solve_ms": round(t_solve2 * 1e3, 3), "total_ms": round((t_fact + t_bc + t_solve2) * 1e3, 3),
+                                     "rhs_per_s": round(args.nrhs / (t_fact + t_bc + t_solve2), 1), "max_abs_error_all_columns": worst2}
+            many["rhs_per_s"] = max(many["replicate"]["rhs_per_s"], many.get("broadcast", {}).get("rhs_per_s", 0.0))
+            extras["many_rhs"] = many
+            s.dev_free(d_B), s.dev_free(d_X)
+        except Exception as exc:
+            extras["many_rhs"] = {"error": repr(exc)}
 
     if rank == 0:
         tri = max(st["acc_tri_count"], 1.0)
         tri_ms = (st["acc_fwd_ms"] + st["acc_bwd_ms"]) / tri
-        import ctypes
         copy_gbs = ctypes.c_double(0.0)
-        if s.lib.hipmf_device_copy_bandwidth(1 << 30, 3, ctypes.byref(copy_gbs)) != 0:
+        if lib.hipmf_device_copy_bandwidth(1 << 30, 3, ctypes.byref(copy_gbs)) != 0:
             copy_gbs.value = 0.0
         mfma_tfs = ctypes.c_double(0.0)
-        if s.lib.hipmf_device_mfma_rate(1024, 4000, ctypes.byref(mfma_tfs)) != 0:
+        if lib.hipmf_device_mfma_rate(1024, 4000, ctypes.byref(mfma_tfs)) != 0:
             mfma_tfs.value = 0.0
         bytes_alg = sptrsv_bytes(st, n)
         traffic, traffic_src = measured_traffic(args.grid)
@@ -165,7 +370,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "2D 5-point Poisson %dx%d grid (n=%d, nnz=%d) f64, 1 RHS per GPU, numeric factorize + solve "
+            "config": {"workload": "2D 5-point Poisson %dx%d grid (n=%d, nnz=%d) f64, general storage, 1 RHS per GPU, numeric LU factorize + solve "
                                    "with values and rhs resident in HBM" % (args.grid, args.grid, n, int(rp[-1])),
                        "rhs_per_gpu": 1, "refinement_steps": st["refinement_steps"]},
             "sptrsv_gbs": round(achieved, 1),
@@ -176,7 +381,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4),
                          "measured_copy_gbs": round(copy_gbs.value, 1),
-                         "frac_of_measured_copy": round(achieved / copy_gbs.value, 4) if copy_gbs.value > 0 else None},
+                         "frac_of_measured_copy": round(achieved / copy_gbs.value, 4) if copy_gbs.value > 0 else None,
+                         "fused_solve_fallbacks": st.get("fused_fallbacks", 0)},
             "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_panel, k_update MFMA f64, k_extend_add)",
                                 "bound": "mfma", "achieved": round(st["flops"] / (fact_ms * 1e-3) / 1e12, 3) if fact_ms > 0 else 0.0,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -191,16 +397,10 @@ def main():
                        "factor_launches": st["factor_launches"], "perturbed": st["n_perturbed"]},
             "relative_error": rel_err,
         }
-        if not args.no_cpu_baseline and world == 1:
-            if args.cpu_grid and args.cpu_grid != args.grid:
-                n2, rp2, ci2, v2 = P.poisson2d(args.cpu_grid)
-                s2 = Hipmf()
-                s2.initialize(n2, rp2, ci2)
-                perm2 = s2.permutation()
-                s2.close()
-                out["cpu_baseline"] = cpu_baseline(n2, rp2, ci2, v2, P.csr_matvec(n2, rp2, ci2, v2, P.manufactured_solution(n2)), perm2)
-            else:
-                out["cpu_baseline"] = cpu_baseline(n, rp, ci, v, b, s.permutation())
+        out.update(extras)
+        if perm is not None:
+            out["cpu_baseline"] = cpu_baseline(n, rp, ci, v, b, perm, args.cpu_tier)
+            out["cpu_baseline"]["host_cores"] = os.cpu_count() or 0
         line = json.dumps(out)
     else:
         line = None
@@ -212,7 +412,6 @@ def main():
     if line is not None:
         # the JSON line goes out LAST and unbuffered: RCCL prints its banner through C stdio, which would otherwise
         # land after Python's buffered print
-        import ctypes
         sys.stdout.flush()
         try:
             ctypes.CDLL(None).fflush(None)

@@ -151,7 +151,8 @@ int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, co
 
 /* istats[16]: 0 ndim, 1 nnz(A), 2 nsuper, 3 nlevels, 4 nnz(L) strict, 5 nnz(U) incl. diag, 6 max front,
  *             7 max pivots, 8 perturbed pivots, 9 zero pivots, 10 refinement steps, 11 factor launches,
- *             12 solve launches, 13 pool bytes, 14 maximum-product matching in force (0/1)
+ *             12 solve launches, 13 pool bytes (persistent factor + arena of working blocks), 14 maximum-product matching in
+ *             force (0/1), 15 solves that fell back from the dependency-driven to the level-set launches (hand-off timeout)
  * dstats[16]: 0 flops, 1 gemm flops, 2 ordering s, 3 symbolic total s, 4 assemble ms, 5 factor ms, 6 fwd ms,
  *             7 bwd ms, 8 solve total ms, 9 last residual inf-norm; accumulated since the last reset (HIP events on
  *             the solver's stream): 10 assemble ms, 11 factor ms, 12 #factorizations, 13 forward-solve ms,

@@ -10,7 +10,7 @@ import numpy as np
 from . import _capi
 
 ISTAT_NAMES = ["ndim", "nnz_a", "nsuper", "nlevels", "nnz_l", "nnz_u", "max_front", "max_pivots", "n_perturbed", "n_zero_pivot",
-               "refinement_steps", "factor_launches", "solve_launches", "pool_bytes"]
+               "refinement_steps", "factor_launches", "solve_launches", "pool_bytes", "matched", "fused_fallbacks"]
 DSTAT_NAMES = ["flops", "flops_gemm", "ordering_s", "symbolic_s", "assemble_ms", "factor_ms", "fwd_ms", "bwd_ms", "solve_total_ms",
                "residual_inf", "acc_assemble_ms", "acc_factor_ms", "acc_factor_count", "acc_fwd_ms", "acc_bwd_ms", "acc_tri_count"]
 

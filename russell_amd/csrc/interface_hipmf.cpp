@@ -186,6 +186,7 @@ int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *h, int64_t *is, double *ds
     is[10] = s.refinement_steps_done, is[11] = s.times.n_kernel_launches_factor, is[12] = s.times.n_kernel_launches_solve;
     is[13] = s.pool_doubles * 8;
     is[14] = s.matched ? 1 : 0;
+    is[15] = s.fused_fallbacks;
     ds[0] = s.S.flops, ds[1] = s.S.flops_gemm, ds[2] = s.S.seconds_ordering, ds[3] = s.S.seconds_total;
     ds[4] = s.times.scale_assemble_ms, ds[5] = s.times.factor_ms, ds[6] = s.times.fwd_ms, ds[7] = s.times.bwd_ms;
     ds[8] = s.times.solve_total_ms, ds[9] = s.last_residual_inf;

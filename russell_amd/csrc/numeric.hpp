@@ -104,6 +104,8 @@ class Solver {
     bool initialized = false, factorized = false;
     int32_t n_perturbed = 0, n_zero_pivot = 0;
     int32_t refinement_steps_done = 0;
+    int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
+    int64_t persist_bytes() const { return S.persist_doubles * 8; }
     double last_residual_inf = 0.0, last_omega = 0.0;
     int device = 0;
     void *stream = nullptr;
@@ -182,6 +184,7 @@ class Solver {
     };
     std::vector<LaneBuffers> extra_lanes;
     double *h_nrm = nullptr;   // pinned: norms of every lane
+    double *h_stage = nullptr; // pinned: rhs | x of a single host-pointer solve
     int32_t solve_lanes = 2;   // HIPMF_SOLVE_LANES (1..4)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
