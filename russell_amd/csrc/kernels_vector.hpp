@@ -24,88 +24,150 @@ __global__ void k_perm_out(int32_t n, const int32_t *__restrict__ perm, const do
     }
 }
 
-// r = b - A x and, fused, the two norms the refinement needs: nrm[0] = max_i |r_i|, nrm[1] = omega = max_i |r_i| / den_i
+// CSR SpMV in "stream" form, shared by y = alpha A x (mat_vec_mul, csr_matrix.rs:709-729) and by the residual of the iterative
+// refinement.  The rows are cut at initialize into blocks of at most SPMV_CAP stored entries (row_blk, host); a workgroup
+//   1. streams its block's entries: lanes read CONSECUTIVE entries of vals / ci (12 B per entry in whole cache lines, four loads
+//      in flight per lane, no dependence on the row pointers), gather x and park the products in LDS;
+//   2. reduces the rows from LDS: L lanes per row (L = the power of two that fills the workgroup, 1 for stencil matrices, 8-16 for
+//      FE matrices with ~40 entries per row), entries in order, lanes combined by a fixed butterfly -- the sums are reproducible;
+//      the mirrored entries of symmetric-lower storage (tptr / tidx / arow lists) are added here by the row's first lane.
+// A row longer than SPMV_CAP is a block of its own and is summed in strides by the whole workgroup.
+// RESID: r = b - A x and, fused, the two norms the refinement needs: nrm[0] = max_i |r_i|, nrm[1] = omega = max_i |r_i| / den_i
 // with den_i = (|A| |x| + |b|)_i (ordered bits of non-negative doubles, atomicMax; nrm is zeroed before the launch; see RES_SLOTS).
-// CSR; for symmetric-lower storage the mirrored entries come from tptr/tidx/arow.  omega, the componentwise backward
-// error, decides as in UMFPACK's / LAPACK's refinement whether another step can still help.
-// RES_LANES = 8 lanes share a row (stencil matrices have 5-7 entries per row): consecutive lanes read consecutive entries of
-// vals / ci, i.e. the 12 B per entry stream in whole cache lines (one thread per row reads them with a stride of a row).
-constexpr int RES_LANES = 8;
+// omega, the componentwise backward error, decides as in UMFPACK's / LAPACK's refinement whether another step can still help.
 // The maxima of the workgroups are combined with atomicMax on RES_SLOTS separate cache lines (workgroup b uses slot b mod
-// RES_SLOTS; one word takes only ~90 atomics per microsecond, which would bound a launch of 31 000 workgroups); the host takes
-// the maximum over the slots.  Layout per column: slot s at nrm[s * RES_SLOT_WORDS] (|r|) and nrm[s * RES_SLOT_WORDS + 1] (omega).
+// RES_SLOTS; one word takes only ~90 atomics per microsecond); the host takes the maximum over the slots.
+// Layout per column: slot s at nrm[s * RES_SLOT_WORDS] (|r|) and nrm[s * RES_SLOT_WORDS + 1] (omega).
+constexpr int SPMV_CAP = 1024;
 constexpr int RES_SLOTS = 64, RES_SLOT_WORDS = 16, RES_NORM_WORDS = RES_SLOTS * RES_SLOT_WORDS;
-__global__ void __launch_bounds__(256) k_residual(int32_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                  const double *__restrict__ vals, const int32_t *__restrict__ tptr,
-                                                  const int32_t *__restrict__ tidx, const int32_t *__restrict__ arow,
-                                                  const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ r,
-                                                  unsigned long long *nrm) {
-    __shared__ double red[256 / RES_LANES], red2[256 / RES_LANES];
-    const int sub = threadIdx.x & (RES_LANES - 1), grp = threadIdx.x / RES_LANES;
-    double a = 0.0, q = 0.0;
-    {
-        const int i = blockIdx.x * (256 / RES_LANES) + grp;
+template <bool RESID>
+__global__ void __launch_bounds__(256) k_spmv_stream(const int32_t *__restrict__ row_blk, const int32_t *__restrict__ rp,
+                                                     const int32_t *__restrict__ ci, const double *__restrict__ vals,
+                                                     const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx,
+                                                     const int32_t *__restrict__ arow, double alpha, const double *__restrict__ x,
+                                                     const double *__restrict__ b, double *__restrict__ y, unsigned long long *nrm) {
+    __shared__ double prod[SPMV_CAP];
+    __shared__ double aprod[RESID ? SPMV_CAP : 1];
+    __shared__ double red[256], red2[RESID ? 256 : 1];
+    const int tid = threadIdx.x;
+    const int r0 = row_blk[blockIdx.x], r1 = row_blk[blockIdx.x + 1];
+    const int e0 = rp[r0], e1 = rp[r1];
+    double a_max = 0.0, q_max = 0.0;
+    if (e1 - e0 > SPMV_CAP) {
+        // one long row (r1 == r0 + 1): strided partial sums, fixed-order tree over the workgroup
         double acc = 0.0, d = 0.0;
-        if (i < n) {
-            for (int p = rp[i] + sub; p < rp[i + 1]; p += RES_LANES) {
-                double t = vals[p] * x[ci[p]];
-                acc -= t;
+        for (int e = e0 + tid; e < e1; e += 256) {
+            const double t = vals[e] * x[ci[e]];
+            acc += t;
+            d += fabs(t);
+        }
+        if (tptr)
+            for (int q = tptr[r0] + tid; q < tptr[r0 + 1]; q += 256) {
+                const double t = vals[tidx[q]] * x[arow[tidx[q]]];
+                acc += t;
                 d += fabs(t);
             }
-            if (tptr)
-                for (int k = tptr[i] + sub; k < tptr[i + 1]; k += RES_LANES) {
-                    double t = vals[tidx[k]] * x[arow[tidx[k]]];
-                    acc -= t;
-                    d += fabs(t);
-                }
+        red[tid] = acc;
+        if (RESID) red2[tid] = d;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                red[tid] += red[tid + s];
+                if (RESID) red2[tid] += red2[tid + s];
+            }
+            __syncthreads();
         }
-        // fixed-order tree over the lanes of a row (the same order in every run: the refinement stays deterministic)
+        if (tid == 0) {
+            if (RESID) {
+                const double ri = b[r0] - red[0], di = red2[0] + fabs(b[r0]);
+                y[r0] = ri;
+                a_max = fabs(ri);
+                q_max = di > 0.0 ? a_max / di : (a_max > 0.0 ? 1.0 : 0.0);
+            } else {
+                y[r0] = alpha * red[0];
+            }
+        }
+    } else {
+        const int ne = e1 - e0;
+        for (int k = tid; k < ne; k += 4 * 256) {
+            double v[4];
+            int c[4];
 #pragma unroll
-        for (int o = RES_LANES / 2; o > 0; o >>= 1) {
-            acc += __shfl_xor(acc, o);
-            d += __shfl_xor(d, o);
-        }
-        if (i < n && sub == 0) {
-            acc += b[i];
-            d += fabs(b[i]);
-            r[i] = acc;
-            const double ai = fabs(acc);
-            const double qi = (d > 0.0) ? ai / d : (ai > 0.0 ? 1.0 : 0.0);
-            if (ai > a) a = ai;
-            if (qi > q) q = qi;
-        }
-    }
-    // a NaN never wins a maximum: a NaN residual ends the refinement through the "no progress" test
-    if (sub == 0) {
-        red[grp] = a > 0.0 ? a : 0.0;
-        red2[grp] = q > 0.0 ? q : 0.0;
-    }
-    __syncthreads();
-    for (int s = 256 / RES_LANES / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            if (red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
-            if (red2[threadIdx.x + s] > red2[threadIdx.x]) red2[threadIdx.x] = red2[threadIdx.x + s];
+            for (int u = 0; u < 4; u++) {
+                const int kk = k + 256 * u;
+                v[u] = kk < ne ? vals[e0 + kk] : 0.0;
+                c[u] = kk < ne ? ci[e0 + kk] : 0;
+            }
+            double xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) xv[u] = (k + 256 * u < ne) ? x[c[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int kk = k + 256 * u;
+                if (kk < ne) {
+                    const double t = v[u] * xv[u];
+                    prod[kk] = t;
+                    if (RESID) aprod[kk] = fabs(t);
+                }
+            }
         }
         __syncthreads();
+        const int nr = r1 - r0;
+        int lsh = 0; // log2(lanes per row)
+        while (lsh < 6 && (nr << (lsh + 1)) <= 256) lsh++;
+        const int L = 1 << lsh, sub = tid & (L - 1);
+        for (int rr = tid >> lsh; rr < ((nr + (256 >> lsh) - 1) / (256 >> lsh)) * (256 >> lsh); rr += 256 >> lsh) {
+            const int i = r0 + rr;
+            double acc = 0.0, d = 0.0;
+            if (rr < nr) {
+                for (int e = rp[i] - e0 + sub; e < rp[i + 1] - e0; e += L) {
+                    acc += prod[e];
+                    if (RESID) d += aprod[e];
+                }
+                if (tptr && sub == 0)
+                    for (int q = tptr[i]; q < tptr[i + 1]; q++) {
+                        const double t = vals[tidx[q]] * x[arow[tidx[q]]];
+                        acc += t;
+                        d += fabs(t);
+                    }
+            }
+            for (int o = L >> 1; o > 0; o >>= 1) { // (every lane of the wavefront takes part: the trip count above is uniform)
+                acc += __shfl_xor(acc, o);
+                if (RESID) d += __shfl_xor(d, o);
+            }
+            if (rr < nr && sub == 0) {
+                if (RESID) {
+                    const double ri = b[i] - acc, di = d + fabs(b[i]);
+                    y[i] = ri;
+                    const double ai = fabs(ri);
+                    const double qi = di > 0.0 ? ai / di : (ai > 0.0 ? 1.0 : 0.0);
+                    if (ai > a_max) a_max = ai;
+                    if (qi > q_max) q_max = qi;
+                } else {
+                    y[i] = alpha * acc;
+                }
+            }
+        }
     }
-    if (threadIdx.x == 0) {
-        unsigned long long *slot = nrm + (size_t)(blockIdx.x & (RES_SLOTS - 1)) * RES_SLOT_WORDS;
-        atomicMax(slot, (unsigned long long)__double_as_longlong(red[0]));
-        atomicMax(slot + 1, (unsigned long long)__double_as_longlong(red2[0]));
+    if (RESID) {
+        // a NaN never wins a maximum: a NaN residual ends the refinement through the "no progress" test
+        __syncthreads();
+        red[tid] = a_max > 0.0 ? a_max : 0.0;
+        red2[tid] = q_max > 0.0 ? q_max : 0.0;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                if (red[tid + s] > red[tid]) red[tid] = red[tid + s];
+                if (red2[tid + s] > red2[tid]) red2[tid] = red2[tid + s];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            unsigned long long *slot = nrm + (size_t)(blockIdx.x & (RES_SLOTS - 1)) * RES_SLOT_WORDS;
+            atomicMax(slot, (unsigned long long)__double_as_longlong(red[0]));
+            atomicMax(slot + 1, (unsigned long long)__double_as_longlong(red2[0]));
+        }
     }
-}
-
-// y = alpha * A x  (CSR SpMV, the mat_vec_mul of csr_matrix.rs:709-729), one thread per row
-__global__ void k_spmv(int32_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                       const double *__restrict__ vals, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx,
-                       const int32_t *__restrict__ arow, double alpha, const double *__restrict__ x, double *__restrict__ y) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double acc = 0.0;
-    for (int p = rp[i]; p < rp[i + 1]; p++) acc += vals[p] * x[ci[p]];
-    if (tptr)
-        for (int q = tptr[i]; q < tptr[i + 1]; q++) acc += vals[tidx[q]] * x[arow[tidx[q]]];
-    y[i] = alpha * acc;
 }
 
 } // namespace hipmf

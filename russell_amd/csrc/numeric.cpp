@@ -62,7 +62,7 @@ void Solver::release() {
     if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     (void)hipSetDevice(device);
     void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs == d_rs ? nullptr : d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
-                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_bigfd, d_pool, d_lperm,
+                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_bigfd, d_row_blk, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -89,7 +89,7 @@ void Solver::release() {
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
-    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr, d_bigfd = nullptr;
+    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr, d_bigfd = nullptr, d_row_blk = nullptr;
     for (auto &e : ev)
         if (e) {
             (void)hipEventDestroy((hipEvent_t)e);
@@ -238,6 +238,17 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     std::vector<int32_t> h_rp(rp, rp + n + 1), h_ci(ci, ci + nnz), h_arow((size_t)nnz);
     for (int32_t i = 0; i < n; i++)
         for (int32_t p = rp[i]; p < rp[i + 1]; p++) h_arow[p] = i;
+    {
+        // row blocks of the stream SpMV: consecutive rows with at most SPMV_CAP stored entries (a longer row stands alone)
+        std::vector<int32_t> rb(1, 0);
+        int32_t start = 0;
+        for (int32_t i = 0; i < n; i++)
+            if (rp[i + 1] - rp[start] > SPMV_CAP && i > start) rb.push_back(i), start = i;
+        // (the row that opens a block may itself exceed the cap: it is closed by the next row)
+        rb.push_back(n);
+        spmv_blocks = (int32_t)rb.size() - 1;
+        HIPC(dev_upload(&d_row_blk, rb), ERROR_HIP_MALLOC);
+    }
     HIPC(dev_upload(&d_rp, h_rp), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ci, h_ci), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_arow, h_arow), ERROR_HIP_MALLOC);
@@ -1026,8 +1037,8 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         HIPC(hipMemsetAsync(L.norms, 0, (size_t)RES_NORM_WORDS * L.nk * sizeof(unsigned long long), L.st), ERROR_HIP_MEMCPY);
         for (int32_t c = 0; c < L.nk; c++) {
             if (!L.active[c]) continue;
-            hipLaunchKernelGGL(k_residual, dim3((n + 256 / RES_LANES - 1) / (256 / RES_LANES)), b, 0, L.st, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, L.xj[c], L.bj[c], L.RR + (size_t)c * n,
-                               L.norms + (size_t)RES_NORM_WORDS * c);
+            hipLaunchKernelGGL(k_spmv_stream<true>, dim3(spmv_blocks), b, 0, L.st, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, 1.0, L.xj[c], L.bj[c],
+                               L.RR + (size_t)c * n, L.norms + (size_t)RES_NORM_WORDS * c);
         }
         HIPC(hipMemcpyAsync(L.h_nrm, L.norms, (size_t)RES_NORM_WORDS * L.nk * sizeof(double), hipMemcpyDeviceToHost, L.st), ERROR_HIP_MEMCPY);
         return SUCCESSFUL_EXIT;
@@ -1197,7 +1208,8 @@ int32_t Solver::spmv(double *y, const double *x, double alpha, bool on_device) {
         xd = d_b;
         yd = d_x;
     }
-    hipLaunchKernelGGL(k_spmv, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, alpha, xd, yd);
+    hipLaunchKernelGGL(k_spmv_stream<false>, dim3(spmv_blocks), dim3(256), 0, STREAM, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, alpha, xd,
+                       (const double *)nullptr, yd, (unsigned long long *)nullptr);
     if (!on_device) HIPC(hipMemcpyAsync(y, d_x, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     return SUCCESSFUL_EXIT;

@@ -197,6 +197,8 @@ class Solver {
     int32_t *d_sc_k = nullptr;   // scatter lists of the tiled fronts, by level: input entry k (or ~k: mirrored copy) ...
     int64_t *d_sc_at = nullptr;  // ... and the pool offset it goes to
     double *d_diag = nullptr;    // pivots in pivot order (determinant, rcond, D of the symmetric fronts)
+    int32_t *d_row_blk = nullptr; // row blocks of the stream SpMV (k_spmv_stream)
+    int32_t spmv_blocks = 0;
     void *ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -59,6 +59,47 @@ def convection_diffusion2d(nx, ny=None, peclet=0.7, seed=20260927, scale_decades
     return n, rp, ci, v * r[rows]
 
 
+def fe_block2d(nx, ny, dof, symmetric, seed=20260927, scale_decades=0.0, shift=None):
+    """FE-like stand-in for BASELINE config 3 (bbmat / af_shell10 are not in the tree): nx x ny nodes with `dof` unknowns each,
+    every node coupled to its 8 neighbours (Q4 elements) by dense dof x dof blocks -> 9 dof stored entries per interior row
+    (dof = 5: 45 per row, bbmat has ~46; dof = 4: 36 per row, af_shell10 has ~35).  Values: uniform random blocks (symmetrised when
+    `symmetric`), diagonal shifted to the row's absolute off-diagonal sum times `shift` (default 1.05 unsymmetric: non-singular but
+    far from diagonally dominant after the scaling below; 1.0 + 1e-3 symmetric: SPD, condition ~1e3 x grid), then rows scaled by
+    10^U(-d, d) (unsymmetric only).  Returns general-storage CSR; symmetric=True also keeps the matrix exactly symmetric."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    ex = sp.diags([1.0, 1.0, 1.0], [-1, 0, 1], shape=(nx, nx))
+    ey = sp.diags([1.0, 1.0, 1.0], [-1, 0, 1], shape=(ny, ny))
+    S = sp.kron(ey, ex).tocsr()                       # 9-point node graph, node m = i + j nx
+    A = sp.kron(S, np.ones((dof, dof))).tocsr()
+    A.sort_indices()
+    A.data = rng.uniform(-1.0, 1.0, A.nnz)
+    if symmetric:
+        A = ((A + A.T) * 0.5).tocsr()
+        A.sort_indices()
+    n = A.shape[0]
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    diag = A.indices == rows
+    off = np.abs(A.data) * (~diag)
+    rowsum = np.zeros(n)
+    np.add.at(rowsum, rows, off)
+    if shift is None:
+        shift = 1.0 + 1e-3 if symmetric else 1.05
+    A.data[diag] = shift * rowsum
+    v = A.data.copy()
+    if not symmetric and scale_decades > 0.0:
+        v *= (10.0 ** rng.uniform(-scale_decades, scale_decades, n))[rows]
+    return n, A.indptr.astype(np.int32), A.indices.astype(np.int32), v
+
+
+def lower_triangle(n, rp, ci, v):
+    """the stored lower triangle (Sym::YesLower) of a general-storage CSR"""
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    keep = ci <= rows
+    lrp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=n))]).astype(np.int32)
+    return lrp, np.ascontiguousarray(ci[keep]), np.ascontiguousarray(v[keep])
+
+
 def brusselator_pattern(npoint, gamma=1.0e4 * 4.0, seed=7):
     """K = gamma*I - J with J's sparsity of the Brusselator-PDE Jacobian
     (/root/reference/russell_ode/src/samples.rs:549-571): ndim = 2*npoint^2, unknowns (u, v) interleaved
