@@ -16,7 +16,7 @@ def pytest_configure(config):
 def _native_pieces_are_built():
     """The tests load in-tree native libraries; build them first when a fresh checkout has none (no-op otherwise)."""
     lib = os.path.join(ROOT, "russell_amd", "lib")
-    needed = [os.path.join(lib, f) for f in ("librussell_hipmf.so", "librussell_host.so", "solve_matrix_market")]
+    needed = [os.path.join(lib, f) for f in ("librussell_hipmf.so", "librussell_host.so", "solve_matrix_market", "brusselator_pde")]
     if not all(os.path.exists(f) for f in needed):
         import __graft_entry__
 

@@ -222,3 +222,24 @@ def test_config4_matrix_160_cubed_on_one_gpu():
     s.close()
     for j in range(8):
         assert np.max(np.abs(X[j] - xs * (1.0 + 0.25 * j))) < 1e-9 * (1.0 + 0.25 * j)
+
+
+def test_config5_radau5_brusselator_reference_test_on_device():
+    # the reference's own Radau5 test (russell_ode/tests/test_radau5_brusselator_pde.rs:31-44) with real + complex handles factorised
+    # and solved on two threads (radau5.rs:270-296), repeat factorisations through the device-side value refresh
+    from test_radau5_brusselator_cpu import check_reference_test, run
+    d = run(None, "--npoint", "9", "--first-book", "--neg-exp-tol", "3", "--t1", "0.1")
+    check_reference_test(d)
+    assert d["concurrent"] is True
+    d2 = run(None, "--npoint", "9", "--first-book", "--neg-exp-tol", "3", "--t1", "0.1", "--serial")
+    assert d2["u_mid"] == d["u_mid"] and d2["v_mid"] == d["v_mid"] and d2["n_function"] == 24
+
+
+def test_config5_radau5_brusselator_second_book_npoint_129():
+    # the benchmark problem of bin/brusselator_pde.rs at npoint = 129 (ndim = 33 282), tolerance 1e-4, t1 = 1.5: a full run with
+    # step rejections and Jacobian / factorisation re-use; conservation-free sanity: finite, bounded solution and consistent counters
+    from test_radau5_brusselator_cpu import run
+    d = run(None, "--npoint", "129")
+    assert d["ndim"] == 2 * 129 * 129 and d["jac_nnz"] == 14 * 129 * 129
+    assert d["n_accepted"] + d["n_rejected"] <= d["n_steps"] and d["n_factor"] <= d["n_steps"]
+    assert d["n_lin_sol"] >= d["n_steps"] and 0.0 < d["u_mid"] < 10.0 and 0.0 < d["v_mid"] < 10.0
