@@ -95,7 +95,11 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *solver,
                                 const double *values);
 
 /* Phase 2 (repeatable): numeric multifrontal LU of the same structure with new values.
- * Returns 0, or 1 when an exactly-zero pivot was met ("Matrix is singular"). */
+ * Returns 0, or 1 when an exactly-zero pivot was met ("Matrix is singular").
+ * Pivot order: static (nested dissection + the matching of initialize).  Every factorize checks the diagonal of the system it is
+ * about to factorise; when THESE values call for another maximum-product matching (general storage: initialize had no values, or
+ * the values changed a lot) the matching is recomputed from them and the analysis redone inside this call (cost of an initialize;
+ * HIPMF_COUNTER_REMATCH counts it).  UMFPACK pivots dynamically in every numeric phase (interface_umfpack.c:167). */
 int32_t solver_hipmf_factorize(struct InterfaceHIPMF *solver,
                                int32_t *effective_ordering,
                                int32_t *effective_scaling,
@@ -159,6 +163,14 @@ int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, co
  *             14 backward-solve ms, 15 #triangular passes */
 int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *solver, int64_t *istats, double *dstats);
 int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
+/* further counters (-1: unknown counter or handle not initialized) */
+#define HIPMF_COUNTER_REMATCH 0            /* factorisations that recomputed the maximum-product matching + analysis for new values */
+#define HIPMF_COUNTER_WEAK_DIAGONAL_ROWS 1 /* rows with a weak diagonal under the pivot order, values of the last factorize */
+#define HIPMF_COUNTER_FUSED_FALLBACKS 2    /* = istats[15] */
+#define HIPMF_COUNTER_PERSISTENT_BYTES 3   /* pool: the factor proper (small fronts, E / E' panels) */
+#define HIPMF_COUNTER_ARENA_BYTES 4        /* pool: arena of the tiled fronts' working blocks */
+#define HIPMF_COUNTER_SYMMETRIC_LDLT 5     /* 1: the tiled fronts are factorised as L D L^T */
+int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* ---- many right-hand sides over the GPUs of one node (the reference has no counterpart: lin_solver.rs:51,
  * interface_cudss.cu:275,281 create b and x with ONE column).  One process (or thread) per GPU, every rank runs

@@ -39,6 +39,7 @@ SYMBOLS = {
     "hipmf_max_product_matching": (C.c_int32, [C.c_int32, i32p, i32p, f64p, i32p, f64p, f64p]),
     "solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
     "solver_hipmf_reset_timers": (C.c_int32, [C.c_void_p]),
+    "solver_hipmf_get_counter": (C.c_int64, [C.c_void_p, C.c_int32]),
     "solver_hipmf_factor_parts": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "hipmf_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "hipmf_comm_init_rank": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32]),

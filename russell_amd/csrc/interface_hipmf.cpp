@@ -195,6 +195,20 @@ int32_t solver_hipmf_get_stats(struct InterfaceHIPMF *h, int64_t *is, double *ds
     return SUCCESSFUL_EXIT;
 }
 
+int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
+    if (!h || !h->solver.initialized) return -1;
+    const Solver &s = h->solver;
+    switch (which) {
+    case HIPMF_COUNTER_REMATCH: return s.rematch_count;
+    case HIPMF_COUNTER_WEAK_DIAGONAL_ROWS: return s.n_weak_diag;
+    case HIPMF_COUNTER_FUSED_FALLBACKS: return s.fused_fallbacks;
+    case HIPMF_COUNTER_PERSISTENT_BYTES: return s.S.persist_doubles * 8;
+    case HIPMF_COUNTER_ARENA_BYTES: return s.S.temp_doubles * 8;
+    case HIPMF_COUNTER_SYMMETRIC_LDLT: return s.S.sym_mode ? 1 : 0;
+    default: return -1;
+    }
+}
+
 int32_t solver_hipmf_factor_parts(struct InterfaceHIPMF *h, int32_t max_parts, void **d_ptrs, int64_t *bytes) {
     if (!h || !d_ptrs || !bytes) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;

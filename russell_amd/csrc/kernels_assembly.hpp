@@ -68,6 +68,24 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
     if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
 }
 
+// Is the static pivot order still sound for THESE values?  Row r of A is pivot row dcol[r] of the (matched) system: its entry in
+// column dcol[r] is the diagonal of the matrix that is factorised.  A row whose scaled diagonal is missing, zero or below
+// `threshold` times the row's largest scaled entry counts as weak -- the criterion initialize uses to decide on the maximum-product
+// matching (matching.cpp, diagonal_is_weak).  One thread per row; dcol == nullptr: identity.
+__global__ void k_diag_check(int32_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ vs,
+                             const int32_t *__restrict__ dcol, double threshold, FactorInfo *info) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int dc = dcol ? dcol[r] : r;
+    double dg = 0.0, mx = 0.0;
+    for (int p = rp[r]; p < rp[r + 1]; p++) {
+        const double a = fabs(vs[p]);
+        mx = a > mx ? a : mx;
+        if (ci[p] == dc) dg = a;
+    }
+    if (!(dg > threshold * mx) || dg == 0.0) atomicAdd(&info->n_weak_diag, 1);
+}
+
 // pool[at[e]] = vs[k_e] (scaled values, k_absmax; k_e < 0: the mirrored copy vs2[~k_e] of a symmetric-lower entry) for the entries
 // of one level's tiled fronts (their working blocks are zero-filled first; every position is hit once)
 __global__ void k_scatter(int64_t cnt, const int32_t *__restrict__ sc_k, const int64_t *__restrict__ sc_at, const double *__restrict__ vs,

@@ -123,7 +123,7 @@ struct FactorInfo {
     int32_t n_perturbed;  // pivots replaced by +-eps (cf. CUDSS_DATA_NPIVOTS, interface_cudss.cu:466-475)
     int32_t n_zero_pivot; // exactly-zero pivots met (singular in the UMFPACK sense, solver_umfpack.rs:492)
     int32_t n_nonfinite;  // NaN / Inf among the scaled input values (the factorisation is refused)
-    int32_t pad1;
+    int32_t n_weak_diag;  // rows whose (matched, scaled) diagonal is below 1 % of the row's largest entry (k_diag_check)
 };
 
 __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int v) {

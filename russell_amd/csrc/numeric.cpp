@@ -62,7 +62,7 @@ void Solver::release() {
     if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     (void)hipSetDevice(device);
     void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs == d_rs ? nullptr : d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
-                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_bigfd, d_row_blk, d_pool, d_lperm,
+                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_bigfd, d_row_blk, d_dcol, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -89,7 +89,7 @@ void Solver::release() {
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
-    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr, d_bigfd = nullptr, d_row_blk = nullptr;
+    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr, d_bigfd = nullptr, d_row_blk = nullptr, d_dcol = nullptr;
     for (auto &e : ev)
         if (e) {
             (void)hipEventDestroy((hipEvent_t)e);
@@ -151,6 +151,12 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
         HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
         ev_fork = e1, ev_join = e2;
+    }
+    if (!rematching) {
+        h_rp_keep.assign(rp, rp + n + 1);
+        h_ci_keep.assign(ci, ci + rp[n]);
+        sopt_keep = sopt;
+        sym_lower_keep = sym_lower;
     }
     SymbolicOptions so = sopt;
     so.augment_above = SMALL_F;
@@ -272,6 +278,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         for (int32_t k = 0; k < n; k++) rperm[k] = mrow[S.perm[k]];
         HIPC(dev_upload(&d_rperm, rperm), ERROR_HIP_MALLOC);
         HIPC(dev_upload(&d_cs, dc), ERROR_HIP_MALLOC);
+        std::vector<int32_t> dcol((size_t)n);
+        for (int32_t j = 0; j < n; j++) dcol[(size_t)mrow[j]] = j; // row mrow[j] of A is pivot row j: its diagonal entry sits in column j
+        HIPC(dev_upload(&d_dcol, dcol), ERROR_HIP_MALLOC);
         // parity of the row permutation (determinant)
         std::vector<char> seen((size_t)n, 0);
         match_parity = 0;
@@ -676,8 +685,44 @@ int32_t Solver::factorize(const double *values, bool on_device) {
          ERROR_HIP_MEMCPY);
     int32_t code = run_factor();
     if (code != SUCCESSFUL_EXIT) return code;
+    if (n_weak_diag > 0 && !rematching) return rematch_and_factorize();
     factorized = true;
     return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
+}
+
+// The pivot order of a handle is static: nested dissection on the pattern, plus -- for a weak diagonal -- the maximum-product matching
+// of the values seen at initialize.  UMFPACK pivots dynamically in every umfpack_di_numeric (interface_umfpack.c:167); here every
+// factorize checks the diagonal of the system it is about to factorise (k_diag_check) and, when the values call for another
+// matching (none was computed because initialize had no values, or the values changed a lot), computes it from THESE values and
+// redoes the analysis: the price of an initialize, paid only when the diagonal really is weak.  The value map and all options survive.
+int32_t Solver::rematch_and_factorize() {
+    const int32_t n = S.n;
+    const int64_t nnz = S.nnz_a;
+    std::vector<double> hv((size_t)nnz);
+    HIPC(hipMemcpy(hv.data(), d_vals, sizeof(double) * nnz, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
+    const NumericOptions nopt = opt;
+    const std::vector<int32_t> seg_ptr = h_seg_ptr, seg_idx = h_seg_idx;
+    const int64_t nin = nnz_in;
+    const PhaseTimes keep_times = times;
+    const int64_t keep_rematch = rematch_count, keep_fallbacks = fused_fallbacks;
+    release();
+    rematching = true;
+    int32_t code = initialize_impl(n, h_rp_keep.data(), h_ci_keep.data(), sym_lower_keep, sopt_keep, nopt, hv.data());
+    if (code == SUCCESSFUL_EXIT && nin > 0) code = set_value_map(nin, seg_ptr.data(), seg_idx.data());
+    if (code != SUCCESSFUL_EXIT) {
+        rematching = false;
+        const std::string keep = last_error;
+        release();
+        last_error = "re-analysis after a change of the matching failed: " + keep;
+        return code;
+    }
+    times = keep_times;
+    rematch_count = keep_rematch + 1;
+    fused_fallbacks = keep_fallbacks;
+    code = factorize(hv.data(), false); // (rematching is still set: one re-analysis per call)
+    rematching = false;
+    if (opt.verbose) fprintf(stderr, "hipmf: factorize: weak diagonal for these values: maximum-product matching recomputed, analysis redone\n");
+    return code;
 }
 
 int32_t Solver::set_value_map(int64_t nin, const int32_t *seg_ptr, const int32_t *seg_idx) {
@@ -699,6 +744,7 @@ int32_t Solver::set_value_map(int64_t nin, const int32_t *seg_ptr, const int32_t
     HIPC(hipMemcpy(d_seg_ptr, seg_ptr, sizeof(int32_t) * (nnz + 1), hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     HIPC(hipMemcpy(d_seg_idx, seg_idx, sizeof(int32_t) * nin, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     nnz_in = nin;
+    if (h_seg_ptr.data() != seg_ptr) h_seg_ptr.assign(seg_ptr, seg_ptr + nnz + 1), h_seg_idx.assign(seg_idx, seg_idx + nin);
     return SUCCESSFUL_EXIT;
 }
 
@@ -717,6 +763,7 @@ int32_t Solver::factorize_mapped(const double *input, bool on_device) {
                        src, d_vals);
     int32_t code = run_factor();
     if (code != SUCCESSFUL_EXIT) return code;
+    if (n_weak_diag > 0 && !rematching) return rematch_and_factorize();
     factorized = true;
     return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
 }
@@ -734,6 +781,10 @@ int32_t Solver::run_factor() {
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
     hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar, d_info);
     launches += 2;
+    if (!S.sym_lower && opt.matching > 0) { // (general storage: would a maximum-product matching be called for with these values?)
+        hipLaunchKernelGGL(k_diag_check, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_ci, d_vs, d_dcol, 0.01, d_info);
+        launches++;
+    }
     if (zero_cnt > 0) { // the E / E' panels start as [I; 0] / [I, 0]
         hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, STREAM, d_zero, d_pool);
         hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, STREAM, d_lists + allbig_off, d_fd, d_pool);
@@ -827,6 +878,7 @@ int32_t Solver::run_factor() {
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
     n_perturbed = hinfo.n_perturbed;
     n_zero_pivot = hinfo.n_zero_pivot;
+    n_weak_diag = hinfo.n_weak_diag;
     if (hinfo.n_nonfinite > 0) {
         last_error = "the matrix values contain NaN or Inf";
         factorized = false;

@@ -103,6 +103,8 @@ class Solver {
     PhaseTimes times;
     bool initialized = false, factorized = false;
     int32_t n_perturbed = 0, n_zero_pivot = 0;
+    int32_t n_weak_diag = 0;   // rows with a weak diagonal under the current pivot order, for the values of the last factorize
+    int64_t rematch_count = 0; // factorisations that recomputed the maximum-product matching (and the analysis) for new values
     int32_t refinement_steps_done = 0;
     int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
     int64_t persist_bytes() const { return S.persist_doubles * 8; }
@@ -127,6 +129,12 @@ class Solver {
     int32_t initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
                             const NumericOptions &nopt, const double *values);
     int32_t upload_plan();
+    int32_t rematch_and_factorize(); // the values in d_vals invalidate the pivot order: new matching + analysis, then factorize
+    // what a re-analysis needs: the caller's structure and options, the value map
+    std::vector<int32_t> h_rp_keep, h_ci_keep, h_seg_ptr, h_seg_idx;
+    SymbolicOptions sopt_keep;
+    bool sym_lower_keep = false, rematching = false;
+    int32_t *d_dcol = nullptr; // column of the (matched) diagonal entry of every row of A (nullptr: identity)
     int32_t run_factor();
     // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)
     struct SolveLane;

@@ -243,3 +243,15 @@ def test_config5_radau5_brusselator_second_book_npoint_129():
     assert d["ndim"] == 2 * 129 * 129 and d["jac_nnz"] == 14 * 129 * 129
     assert d["n_accepted"] + d["n_rejected"] <= d["n_steps"] and d["n_factor"] <= d["n_steps"]
     assert d["n_lin_sol"] >= d["n_steps"] and 0.0 < d["u_mid"] < 10.0 and 0.0 < d["v_mid"] < 10.0
+
+
+def test_config5_npoint_513_reproduces_the_reference_log():
+    # data/logs/brus_pde_2nd_umfpack_24.txt (UMFPACK, npoint = 513, ndim = 526 338): the step / Newton / factorisation counters of the
+    # whole integration and the last step size must come out the same with the HIPMF backend -- every linear solve of the run feeds
+    # the step-size controller, so the counters only match when the solves are accurate to the controller's resolution
+    from test_radau5_brusselator_cpu import run
+    d = run(None, "--npoint", "513")
+    assert d["ndim"] == 526338 and d["jac_nnz"] == 3684366
+    assert (d["n_function"], d["n_jacobian"], d["n_factor"], d["n_lin_sol"]) == (266, 23, 44, 75)
+    assert (d["n_steps"], d["n_accepted"], d["n_rejected"], d["n_iterations_max"]) == (44, 35, 9, 4)
+    assert abs(d["h_accepted"] - 0.267457533813765) < 1e-9
