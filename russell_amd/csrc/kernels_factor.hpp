@@ -304,6 +304,8 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     if (ext <= 0 && !(t == 0 && k0 == 0)) return; // (workgroup 0 of step 0 still factorises and parks the diagonal tile)
     double *Lrow = A.at(o0 + tid, k0);                      // L tile: column k0 + u of this thread's row at Lrow[u * lstr]
     const int64_t lstr = (o0 + tid) >= f ? A.p : A.ld;
+    const bool lmixed = o0 < f && o0 + ext > f;             // (workgroup-uniform)
+    const int64_t lstr_u = o0 >= f ? A.p : A.ld;
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
     // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain;
@@ -322,8 +324,13 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     if (ltile) {
         if (tid < ext) {
             double v[NB];
+            if (lmixed) { // (the one tile per front that straddles row f: per-thread stride)
 #pragma unroll
-            for (int u = 0; u < NB; u++) v[u] = (u < nb) ? Lrow[(int64_t)u * lstr] : 0.0;
+                for (int u = 0; u < NB; u++) v[u] = (u < nb) ? Lrow[(int64_t)u * lstr] : 0.0;
+            } else { // workgroup-uniform stride: the address arithmetic stays on the scalar unit
+#pragma unroll
+                for (int u = 0; u < NB; u++) v[u] = (u < nb) ? Lrow[(int64_t)u * lstr_u] : 0.0;
+            }
 #pragma unroll
             for (int u = 0; u < NB; u++) T[u][tid] = v[u];
         }
@@ -331,10 +338,21 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         const int k = tid & (NB - 1), cq = tid >> 5; // 4 columns x 32 rows per pass
         double v[PANEL_T / 4];
         const double *sF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *sE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
+        // (a per-element choice between the two arrays costs ~1.2 us per launch in this latency chain -- measured: only the one tile
+        //  per front that straddles column f pays it)
+        if (o0 < f && o0 + ext > f) {
 #pragma unroll
-        for (int u = 0; u < PANEL_T / 4; u++) {
-            const int cc = 4 * u + cq;
-            v[u] = (k < nb && cc < ext) ? (o0 + cc >= f ? sE : sF)[(int64_t)cc * A.ld] : 0.0;
+            for (int u = 0; u < PANEL_T / 4; u++) {
+                const int cc = 4 * u + cq;
+                v[u] = (k < nb && cc < ext) ? (o0 + cc >= f ? sE : sF)[(int64_t)cc * A.ld] : 0.0;
+            }
+        } else {
+            const double *sU = o0 >= f ? sE : sF;
+#pragma unroll
+            for (int u = 0; u < PANEL_T / 4; u++) {
+                const int cc = 4 * u + cq;
+                v[u] = (k < nb && cc < ext) ? sU[(int64_t)cc * A.ld] : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < PANEL_T / 4; u++) T[k][4 * u + cq] = v[u];
@@ -423,17 +441,32 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     __syncthreads();
     if (ltile) {
         if (tid < ext) {
+            if (lmixed) {
 #pragma unroll
-            for (int k = 0; k < NB; k++)
-                if (k < nb) Lrow[(int64_t)k * lstr] = T[k][tid];
+                for (int k = 0; k < NB; k++)
+                    if (k < nb) Lrow[(int64_t)k * lstr] = T[k][tid];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+                    if (k < nb) Lrow[(int64_t)k * lstr_u] = T[k][tid];
+            }
         }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5;
         double *dF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *dE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
+        if (o0 < f && o0 + ext > f) {
 #pragma unroll
-        for (int cb = 0; cb < PANEL_T; cb += 4) {
-            const int cc = cb + cq;
-            if (k < nb && cc < ext) (o0 + cc >= f ? dE : dF)[(int64_t)cc * A.ld] = T[k][cc];
+            for (int cb = 0; cb < PANEL_T; cb += 4) {
+                const int cc = cb + cq;
+                if (k < nb && cc < ext) (o0 + cc >= f ? dE : dF)[(int64_t)cc * A.ld] = T[k][cc];
+            }
+        } else {
+            double *dU = o0 >= f ? dE : dF;
+#pragma unroll
+            for (int cb = 0; cb < PANEL_T; cb += 4) {
+                const int cc = cb + cq;
+                if (k < nb && cc < ext) dU[(int64_t)cc * A.ld] = T[k][cc];
+            }
         }
     }
 }
@@ -490,9 +523,9 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
     // Tiles never straddle row / column f: [base, f) (inside F) and [f, limit) (E' rows / E columns) are tiled separately, nt tiles per
-    // dimension cover both parts (the host reserves nt = ceil(f / 64) + 1), so a tile lives in ONE array with uniform base and stride.
-    const int nt = (f + TS - 1) / TS + 1;
+    // dimension cover both parts, so a tile lives in ONE array with uniform base and stride.
     const int ntF = (f - base + TS - 1) / TS;                // tiles of the part inside F
+    const int nt = ntF + (base + TS - 1) / TS;               // ... plus those of the E' rows / E columns (the host counts the same way)
     const int nb2 = (fd.p - base) < NB ? (fd.p - base) : NB; // size of the next diagonal tile (<= 0: none)
     const int gpos = (k0 / NB) % fd.ugroup;                  // position of this step in its group of panels
     const bool narrow = gpos < fd.ugroup - 1 && nb2 > 0;     // not the last step of the group and another step follows

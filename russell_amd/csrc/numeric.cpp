@@ -495,7 +495,9 @@ int32_t Solver::upload_plan() {
             acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
-                int64_t nt = (S.fsize(big[a]) + UPD_T - 1) / UPD_T + 1;
+                // tiles per dimension of k_update at this step: [base, f) and [f, f + base) are tiled separately (base = k0 + nb)
+                const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
+                int64_t nt = (fa - basea + UPD_T - 1) / UPD_T + (basea + UPD_T - 1) / UPD_T;
                 const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
                 const int32_t G = update_group(S.fsize(big[a]));
                 const bool narrow = follow && ((k0 / NB) % G) != G - 1; // not the last step of a group: block column + block row only
