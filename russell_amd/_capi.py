@@ -39,6 +39,18 @@ SYMBOLS = {
     "hipmf_max_product_matching": (C.c_int32, [C.c_int32, i32p, i32p, f64p, i32p, f64p, f64p]),
     "solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
     "solver_hipmf_reset_timers": (C.c_int32, [C.c_void_p]),
+    "complex_solver_hipmf_new": (C.c_void_p, []),
+    "complex_solver_hipmf_drop": (None, [C.c_void_p]),
+    "complex_solver_hipmf_initialize": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                     i32p, i32p, C.c_void_p]),
+    "complex_solver_hipmf_factorize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                    C.POINTER(C.c_double), C.c_int32, C.c_int32, f64p]),
+    "complex_solver_hipmf_solve": (C.c_int32, [C.c_void_p, f64p, f64p, C.c_int32]),
+    "complex_solver_hipmf_set_value_map": (C.c_int32, [C.c_void_p, C.c_int32, i32p, i32p]),
+    "complex_solver_hipmf_factorize_mapped": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                           C.POINTER(C.c_double), C.c_int32, f64p]),
+    "complex_solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
+    "complex_solver_hipmf_last_error": (C.c_char_p, [C.c_void_p]),
     "solver_hipmf_get_counter": (C.c_int64, [C.c_void_p, C.c_int32]),
     "solver_hipmf_factor_parts": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "hipmf_comm_unique_id": (C.c_int32, [C.c_void_p]),

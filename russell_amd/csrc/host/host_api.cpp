@@ -733,6 +733,14 @@ struct Backend {
     decltype(&solver_hipmf_set_value_map) set_value_map = nullptr;
     decltype(&solver_hipmf_factorize_mapped) factorize_mapped = nullptr;
     decltype(&solver_hipmf_get_stats) get_stats = nullptr;
+    decltype(&complex_solver_hipmf_new) znew = nullptr;
+    decltype(&complex_solver_hipmf_drop) zdrop = nullptr;
+    decltype(&complex_solver_hipmf_initialize) zinitialize = nullptr;
+    decltype(&complex_solver_hipmf_factorize) zfactorize = nullptr;
+    decltype(&complex_solver_hipmf_solve) zsolve = nullptr;
+    decltype(&complex_solver_hipmf_set_value_map) zset_value_map = nullptr;
+    decltype(&complex_solver_hipmf_factorize_mapped) zfactorize_mapped = nullptr;
+    decltype(&complex_solver_hipmf_get_stats) zget_stats = nullptr;
     bool tried = false;
 };
 Backend g_backend;
@@ -771,6 +779,14 @@ bool load_backend() {
     BIND(set_value_map, "solver_hipmf_set_value_map")
     BIND(factorize_mapped, "solver_hipmf_factorize_mapped")
     BIND(get_stats, "solver_hipmf_get_stats")
+    BIND(znew, "complex_solver_hipmf_new")
+    BIND(zdrop, "complex_solver_hipmf_drop")
+    BIND(zinitialize, "complex_solver_hipmf_initialize")
+    BIND(zfactorize, "complex_solver_hipmf_factorize")
+    BIND(zsolve, "complex_solver_hipmf_solve")
+    BIND(zset_value_map, "complex_solver_hipmf_set_value_map")
+    BIND(zfactorize_mapped, "complex_solver_hipmf_factorize_mapped")
+    BIND(zget_stats, "complex_solver_hipmf_get_stats")
 #undef BIND
     g_backend.dl = dl;
     return true;
@@ -976,14 +992,63 @@ StrError ComplexCooMatrix::mat_vec_mul(std::vector<double> &v, double ar, double
 }
 
 StrError ComplexSolverHIPMF::create(std::unique_ptr<ComplexSolverHIPMF> &out) {
-    std::unique_ptr<ComplexSolverHIPMF> s(new ComplexSolverHIPMF());
-    StrError e = SolverHIPMF::create(s->real);
-    if (e) return e;
-    out = std::move(s);
+    if (!load_backend()) return "HIPMF solver is not available";
+    void *h = g_backend.znew();
+    if (!h) return "c-code failed to allocate the HIPMF solver";
+    out.reset(new ComplexSolverHIPMF());
+    out->solver = h;
+    return nullptr;
+}
+
+ComplexSolverHIPMF::~ComplexSolverHIPMF() {
+    if (solver && g_backend.zdrop) g_backend.zdrop((InterfaceComplexHIPMF *)solver);
+}
+
+// complex COO -> CSR with the duplicates summed in COO order within a row (the order the reference's conversion adds them,
+// csr_matrix.rs:359-480 for NumCsrMatrix<Complex64>), columns ascending; also the triplet map (CSR entry <- its triplets)
+StrError ComplexSolverHIPMF::to_csr(const ComplexCooMatrix &mat, bool pattern_too) {
+    const size_t n = mat.nrow, nz = mat.nnz;
+    if (pattern_too) {
+        std::vector<int32_t> cnt(n + 1, 0);
+        for (size_t k = 0; k < nz; k++) {
+            if (mat.indices_i[k] < 0 || (size_t)mat.indices_i[k] >= n || mat.indices_j[k] < 0 || (size_t)mat.indices_j[k] >= n) return "COO matrix: index out of range";
+            cnt[(size_t)mat.indices_i[k] + 1]++;
+        }
+        for (size_t i = 0; i < n; i++) cnt[i + 1] += cnt[i];
+        std::vector<int32_t> byrow(nz), w(cnt.begin(), cnt.end() - 1);
+        for (size_t k = 0; k < nz; k++) byrow[(size_t)w[(size_t)mat.indices_i[k]]++] = (int32_t)k; // (stable: COO order within a row)
+        zrp.assign(n + 1, 0);
+        zci.clear();
+        seg_ptr.clear();
+        seg_idx.clear();
+        seg_idx.reserve(nz);
+        std::vector<int32_t> row;
+        for (size_t i = 0; i < n; i++) {
+            row.assign(byrow.begin() + cnt[i], byrow.begin() + cnt[i + 1]);
+            std::stable_sort(row.begin(), row.end(), [&](int32_t a, int32_t b) { return mat.indices_j[(size_t)a] < mat.indices_j[(size_t)b]; });
+            for (size_t q = 0; q < row.size(); q++) {
+                if (q == 0 || mat.indices_j[(size_t)row[q]] != mat.indices_j[(size_t)row[q - 1]]) { // a new CSR entry starts
+                    seg_ptr.push_back((int32_t)seg_idx.size());
+                    zci.push_back(mat.indices_j[(size_t)row[q]]);
+                }
+                seg_idx.push_back(row[q]);
+            }
+            zrp[i + 1] = (int32_t)zci.size();
+        }
+        seg_ptr.push_back((int32_t)seg_idx.size());
+    }
+    zvals.assign(2 * zci.size(), 0.0);
+    for (size_t c = 0; c < zci.size(); c++)
+        for (int32_t q = seg_ptr[c]; q < seg_ptr[c + 1]; q++) {
+            zvals[2 * c] += mat.values[2 * (size_t)seg_idx[(size_t)q]];
+            zvals[2 * c + 1] += mat.values[2 * (size_t)seg_idx[(size_t)q] + 1];
+        }
     return nullptr;
 }
 
 StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSolParams *params) {
+    LinSolParams par = params ? *params : LinSolParams();
+    const int32_t verbose = par.verbose ? 1 : 0;
     if (initialized) {
         if (mat.symmetric != initialized_sym) return "subsequent factorizations must use the same matrix (symmetric differs)";
         if (mat.nrow != initialized_ndim) return "subsequent factorizations must use the same matrix (ndim differs)";
@@ -993,32 +1058,55 @@ StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSol
         if (mat.nrow != mat.ncol) return "the matrix must be square";
         if (mat.nnz < 1) return "the COO matrix must have at least one non-zero value";
         if (mat.symmetric == Sym::YesFull || mat.symmetric == Sym::YesUpper) return "HIPMF requires Sym::YesLower for symmetric matrices";
-        if (params && params->compute_determinant) return "the complex twin of HIPMF does not compute the determinant";
+        if (par.compute_determinant) return "the complex twin of HIPMF does not compute the determinant";
+        StrError e = to_csr(mat, true);
+        if (e) return e;
+        uint64_t t0 = now_ns();
+        int32_t status = g_backend.zinitialize((InterfaceComplexHIPMF *)solver, hipmf_ordering(par.ordering), hipmf_scaling(par.scaling),
+                                               par.has_pivot_epsilon ? par.pivot_epsilon : -1.0, par.has_refinement_nstep ? par.refinement_nstep : -1,
+                                               verbose, mat.symmetric == Sym::YesLower ? 1 : 0, (int32_t)mat.nrow, zrp.data(), zci.data(), zvals.data());
+        if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+        value_map_set = g_backend.zset_value_map((InterfaceComplexHIPMF *)solver, (int32_t)mat.nnz, seg_ptr.data(), seg_idx.data()) == SUCCESSFUL_EXIT;
+        if (value_map_set) {
+            map_i.assign(mat.indices_i.begin(), mat.indices_i.begin() + (std::ptrdiff_t)mat.nnz);
+            map_j.assign(mat.indices_j.begin(), mat.indices_j.begin() + (std::ptrdiff_t)mat.nnz);
+        }
+        time_initialize_ns = now_ns() - t0;
         initialized_sym = mat.symmetric;
         initialized_ndim = mat.nrow;
         initialized_nnz = mat.nnz;
-        // a complex SYMMETRIC matrix has an unsymmetric real-equivalent form: mirrored entries are written out
-        size_t nz = 0;
-        for (size_t k = 0; k < mat.nnz; k++) nz += (mat.symmetric == Sym::YesLower && mat.indices_i[k] != mat.indices_j[k]) ? 8 : 4;
-        StrError e = CooMatrix::create(requiv, 2 * mat.nrow, 2 * mat.nrow, nz, Sym::No);
-        if (e) return e;
+        initialized = true;
     }
-    requiv.reset();
-    for (size_t k = 0; k < mat.nnz; k++) {
-        const size_t i = (size_t)mat.indices_i[k], j = (size_t)mat.indices_j[k];
-        const double a = mat.values[2 * k], b = mat.values[2 * k + 1];
-        for (int t = 0; t < ((mat.symmetric == Sym::YesLower && i != j) ? 2 : 1); t++) {
-            const size_t r = t ? j : i, c = t ? i : j;
-            requiv.put(2 * r, 2 * c, a);
-            requiv.put(2 * r, 2 * c + 1, -b);
-            requiv.put(2 * r + 1, 2 * c, b);
-            requiv.put(2 * r + 1, 2 * c + 1, a);
+    // the value map belongs to the triplet order it was built from (the reference re-reads the indices on every call)
+    if (value_map_set && (std::memcmp(map_i.data(), mat.indices_i.data(), sizeof(int32_t) * mat.nnz) != 0 ||
+                          std::memcmp(map_j.data(), mat.indices_j.data(), sizeof(int32_t) * mat.nnz) != 0)) {
+        const std::vector<int32_t> rp0 = zrp, ci0 = zci;
+        StrError e = to_csr(mat, true);
+        if (e) return e;
+        if (zrp != rp0 || zci != ci0) return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
+        value_map_set = g_backend.zset_value_map((InterfaceComplexHIPMF *)solver, (int32_t)mat.nnz, seg_ptr.data(), seg_idx.data()) == SUCCESSFUL_EXIT;
+        if (value_map_set) {
+            map_i.assign(mat.indices_i.begin(), mat.indices_i.begin() + (std::ptrdiff_t)mat.nnz);
+            map_j.assign(mat.indices_j.begin(), mat.indices_j.begin() + (std::ptrdiff_t)mat.nnz);
         }
     }
-    StrError e = real->factorize(requiv, initialized ? nullptr : params);
-    if (e) return e;
-    initialized = true;
+    uint64_t t0 = now_ns();
+    int32_t status;
+    if (value_map_set) {
+        status = g_backend.zfactorize_mapped((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
+                                             verbose, mat.values.data());
+    } else {
+        StrError e = to_csr(mat, false);
+        if (e) return e;
+        status = g_backend.zfactorize((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate, 0,
+                                      verbose, zvals.data());
+    }
+    if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+    time_factorize_ns = now_ns() - t0;
     factorized = true;
+    int64_t istats[16];
+    double dstats[16];
+    if (g_backend.zget_stats((InterfaceComplexHIPMF *)solver, istats, dstats) == SUCCESSFUL_EXIT) effective_matching = istats[14] != 0;
     return nullptr;
 }
 
@@ -1026,7 +1114,24 @@ StrError ComplexSolverHIPMF::solve(std::vector<double> &x, const std::vector<dou
     if (!factorized) return "the function factorize must be called before solve";
     if (x.size() != 2 * initialized_ndim) return "the dimension of the vector of unknown values x is incorrect";
     if (rhs.size() != 2 * initialized_ndim) return "the dimension of the right-hand side vector is incorrect";
-    return real->solve(x, rhs, verbose); // (re, im) interleaving of the vectors is the ordering of the real-equivalent unknowns
+    uint64_t t0 = now_ns();
+    int32_t status = g_backend.zsolve((InterfaceComplexHIPMF *)solver, x.data(), rhs.data(), verbose ? 1 : 0);
+    if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
+    time_solve_ns = now_ns() - t0;
+    return nullptr;
+}
+
+void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
+    stats.solver = "HIPMF";
+    stats.initialize_ns.push_back(time_initialize_ns);
+    stats.factorize_ns.push_back(time_factorize_ns);
+    stats.solve_ns.push_back(time_solve_ns);
+    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Metis"; // nested dissection
+    stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
+    stats.rcond_estimate = rcond_estimate;
+    stats.det_mantissa = 0.0, stats.det_base = 0.0, stats.det_exponent = 0.0; // (not available: see include/russell_hipmf.h)
+    stats.perturbed_pivots = perturbed_pivots;
+    stats.effective_matching = effective_matching ? "MaxProdScaled" : "None";
 }
 
 StrError SolverHIPMF::solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs) {
@@ -1053,11 +1158,6 @@ void SolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.det_exponent = determinant_exponent;
     stats.perturbed_pivots = perturbed_pivots;
     stats.effective_matching = effective_matching ? "MaxProdScaled" : "None";
-}
-
-void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
-    if (real) real->update_stats(stats); // the real-equivalent solver did the work; the determinant is not available (see determinant note)
-    stats.det_mantissa = 0.0, stats.det_base = 0.0, stats.det_exponent = 0.0;
 }
 
 StrError LinSolver::create(LinSolver &out, Genie genie) {

@@ -214,23 +214,33 @@ struct ComplexCooMatrix {
 class ComplexSolverHIPMF {
   public:
     static StrError create(std::unique_ptr<ComplexSolverHIPMF> &out);
-    // complex_solver_umfpack.rs:232-329 with this backend's symmetry rule (Sym::No or Sym::YesLower)
+    ~ComplexSolverHIPMF();
+    // complex_solver_umfpack.rs:232-329 with this backend's symmetry rule (Sym::No or Sym::YesLower): COO -> complex CSR on the host at
+    // the first call (duplicates summed in COO order, as complex_csr_matrix from_coo does), then the complex C-ABI
+    // (complex_solver_hipmf_*, include/russell_hipmf.h); repeat calls hand the raw triplet values to the device-side value refresh
     StrError factorize(const ComplexCooMatrix &mat, const LinSolParams *params);
     // x, rhs: interleaved complex vectors of length 2 n
     StrError solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose);
     bool factorized = false;
     void update_stats(StatsLinSol &stats) const; // complex_lin_solver.rs:12-104 (ComplexLinSolTrait::update_stats)
-    uint64_t get_ns_init() const { return real ? real->get_ns_init() : 0; }
-    uint64_t get_ns_fact() const { return real ? real->get_ns_fact() : 0; }
-    uint64_t get_ns_solve() const { return real ? real->get_ns_solve() : 0; }
+    uint64_t get_ns_init() const { return time_initialize_ns; }
+    uint64_t get_ns_fact() const { return time_factorize_ns; }
+    uint64_t get_ns_solve() const { return time_solve_ns; }
 
   private:
     ComplexSolverHIPMF() {}
-    std::unique_ptr<SolverHIPMF> real;
-    CooMatrix requiv; // the real-equivalent matrix, rebuilt (same triplet order) at every factorize
-    bool initialized = false;
+    void *solver = nullptr; // struct InterfaceComplexHIPMF*
+    bool initialized = false, value_map_set = false;
     Sym initialized_sym = Sym::No;
     size_t initialized_ndim = 0, initialized_nnz = 0;
+    std::vector<int32_t> map_i, map_j; // the triplet indices the value map was built from
+    std::vector<int32_t> zrp, zci, seg_ptr, seg_idx;
+    std::vector<double> zvals;          // summed CSR values (first call / fallback when the triplet order changes)
+    int32_t effective_ordering = -1, effective_scaling = -1, perturbed_pivots = 0;
+    double rcond_estimate = 0.0;
+    bool effective_matching = false;
+    uint64_t time_initialize_ns = 0, time_factorize_ns = 0, time_solve_ns = 0;
+    StrError to_csr(const ComplexCooMatrix &mat, bool pattern_too);
 };
 
 class LinSolver {

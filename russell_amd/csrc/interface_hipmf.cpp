@@ -84,6 +84,10 @@ static int32_t finish_factorize(struct InterfaceHIPMF *h, int32_t code, int32_t 
     if (compute_determinant == 1) {
         int32_t c2 = h->solver.determinant(det_c, det_e, rcond);
         if (c2 != SUCCESSFUL_EXIT) return c2;
+    } else if (rcond) {
+        // the reference reports Info[UMFPACK_RCOND] after every numeric phase (interface_umfpack.c:179-184): a device reduction here
+        int32_t c2 = h->solver.rcond_estimate(rcond);
+        if (c2 != SUCCESSFUL_EXIT) return c2;
     }
     return code;
 }

@@ -30,12 +30,15 @@ __global__ void k_row_scale(int32_t n, const int32_t *__restrict__ rp, const dou
 
 // Value refresh of a fixed structure (the Radau5 / Newton repeat-factorise pattern): CSR entry j is the sum of
 // the caller's entries in[seg_idx[q]], q in [seg_ptr[j], seg_ptr[j + 1]), added in that (fixed) order: the caller's COO
-// triplets with their duplicates, without a host-side COO -> CSR conversion per factorisation.
+// triplets with their duplicates, without a host-side COO -> CSR conversion per factorisation.  A negative index ~k subtracts in[k].
 __global__ void k_gather_values(int64_t nnz, const int32_t *__restrict__ seg_ptr, const int32_t *__restrict__ seg_idx,
                                 const double *__restrict__ in, double *__restrict__ out) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x) {
         double acc = 0.0;
-        for (int32_t q = seg_ptr[j]; q < seg_ptr[j + 1]; q++) acc += in[seg_idx[q]];
+        for (int32_t q = seg_ptr[j]; q < seg_ptr[j + 1]; q++) {
+            const int32_t k = seg_idx[q]; // k < 0: the entry ~k is SUBTRACTED (imaginary parts of the real-equivalent form of a complex matrix)
+            acc += k < 0 ? -in[~k] : in[k];
+        }
         out[j] = acc;
     }
 }

@@ -170,4 +170,30 @@ __global__ void __launch_bounds__(256) k_spmv_stream(const int32_t *__restrict__
     }
 }
 
+// min and max of |d_i| over the pivots (the cheap reciprocal-condition estimate min |u_ii| / max |u_ii|, UMFPACK_RCOND's definition):
+// out[0] = bits of the minimum, out[1] = bits of the maximum (non-negative doubles order like their bit patterns);
+// the caller sets out[0] = +inf bits, out[1] = 0
+__global__ void __launch_bounds__(256) k_diag_minmax(int32_t n, const double *__restrict__ d, unsigned long long *out) {
+    __shared__ double smin[256], smax[256];
+    double mn = INFINITY, mx = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double a = fabs(d[i]);
+        mn = a < mn ? a : mn;
+        mx = a > mx ? a : mx;
+    }
+    smin[threadIdx.x] = mn, smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            if (smin[threadIdx.x + s] < smin[threadIdx.x]) smin[threadIdx.x] = smin[threadIdx.x + s];
+            if (smax[threadIdx.x + s] > smax[threadIdx.x]) smax[threadIdx.x] = smax[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMin(out, (unsigned long long)__double_as_longlong(smin[0]));
+        atomicMax(out + 1, (unsigned long long)__double_as_longlong(smax[0]));
+    }
+}
+
 } // namespace hipmf

@@ -710,7 +710,7 @@ int32_t Solver::rematch_and_factorize() {
     release();
     rematching = true;
     int32_t code = initialize_impl(n, h_rp_keep.data(), h_ci_keep.data(), sym_lower_keep, sopt_keep, nopt, hv.data());
-    if (code == SUCCESSFUL_EXIT && nin > 0) code = set_value_map(nin, seg_ptr.data(), seg_idx.data());
+    if (code == SUCCESSFUL_EXIT && nin > 0) code = set_value_map(nin, seg_ptr.data(), seg_idx.data(), true);
     if (code != SUCCESSFUL_EXIT) {
         rematching = false;
         const std::string keep = last_error;
@@ -727,26 +727,32 @@ int32_t Solver::rematch_and_factorize() {
     return code;
 }
 
-int32_t Solver::set_value_map(int64_t nin, const int32_t *seg_ptr, const int32_t *seg_idx) {
+int32_t Solver::set_value_map(int64_t nin, const int32_t *seg_ptr, const int32_t *seg_idx, bool signed_map) {
     if (!initialized) return ERROR_NEED_INITIALIZATION;
     if (!seg_ptr || !seg_idx) return ERROR_NULL_POINTER;
     const int64_t nnz = S.nnz_a;
-    if (nin < 1 || nin > 0x7fffffffLL || seg_ptr[0] != 0 || seg_ptr[nnz] != nin) return ERROR_HIPMF_INVALID_VALUE;
+    // (seg_ptr[nnz] = number of map entries: nin for a plain triplet map; a signed map -- the real-equivalent form of a complex matrix,
+    //  interface_complex_hipmf.cpp -- uses every input value twice and marks subtracted entries ~k)
+    if (nin < 1 || nin > 0x7fffffffLL || seg_ptr[0] != 0 || (signed_map ? seg_ptr[nnz] < 1 : seg_ptr[nnz] != nin)) return ERROR_HIPMF_INVALID_VALUE;
     for (int64_t j = 0; j < nnz; j++)
         if (seg_ptr[j + 1] < seg_ptr[j]) return ERROR_HIPMF_INVALID_VALUE;
-    for (int64_t q = 0; q < nin; q++)
-        if (seg_idx[q] < 0 || seg_idx[q] >= nin) return ERROR_HIPMF_INVALID_VALUE;
+    const int64_t nmap = seg_ptr[nnz];
+    for (int64_t q = 0; q < nmap; q++) {
+        if (seg_idx[q] < 0 && !signed_map) return ERROR_HIPMF_INVALID_VALUE;
+        const int64_t k = seg_idx[q] < 0 ? ~(int64_t)seg_idx[q] : (int64_t)seg_idx[q]; // (~k: subtracted entry)
+        if (k >= nin) return ERROR_HIPMF_INVALID_VALUE;
+    }
     DeviceScope dev_scope(device);
     for (void *p : {(void *)d_seg_ptr, (void *)d_seg_idx, (void *)d_vin})
         if (p) (void)hipFree(p);
     d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr;
     HIPC(hipMalloc((void **)&d_seg_ptr, sizeof(int32_t) * (nnz + 1)), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_seg_idx, sizeof(int32_t) * nin), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_seg_idx, sizeof(int32_t) * nmap), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_vin, sizeof(double) * nin), ERROR_HIP_MALLOC);
     HIPC(hipMemcpy(d_seg_ptr, seg_ptr, sizeof(int32_t) * (nnz + 1), hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
-    HIPC(hipMemcpy(d_seg_idx, seg_idx, sizeof(int32_t) * nin, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpy(d_seg_idx, seg_idx, sizeof(int32_t) * nmap, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
     nnz_in = nin;
-    if (h_seg_ptr.data() != seg_ptr) h_seg_ptr.assign(seg_ptr, seg_ptr + nnz + 1), h_seg_idx.assign(seg_idx, seg_idx + nin);
+    if (h_seg_ptr.data() != seg_ptr) h_seg_ptr.assign(seg_ptr, seg_ptr + nnz + 1), h_seg_idx.assign(seg_idx, seg_idx + nmap);
     return SUCCESSFUL_EXIT;
 }
 
@@ -1277,6 +1283,24 @@ int32_t Solver::adopt_factor(const double *d_values) {
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     n_perturbed = n_zero_pivot = 0;
     factorized = true;
+    return SUCCESSFUL_EXIT;
+}
+
+// rcond estimate alone: a reduction over the pivots on the device (the determinant needs all of them on the host)
+int32_t Solver::rcond_estimate(double *rcond) {
+    if (!factorized) return ERROR_NEED_FACTORIZATION;
+    if (!rcond) return ERROR_NULL_POINTER;
+    DeviceScope dev_scope(device);
+    const unsigned long long init[2] = {0x7ff0000000000000ull, 0ull};
+    unsigned long long got[2];
+    HIPC(hipMemcpyAsync(d_scalar + 2, init, sizeof init, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
+    hipLaunchKernelGGL(k_diag_minmax, dim3((unsigned)std::min<int64_t>(1024, (S.n + 255) / 256)), dim3(256), 0, STREAM, S.n, d_diag, d_scalar + 2);
+    HIPC(hipMemcpyAsync(got, d_scalar + 2, sizeof got, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    double mn, mx;
+    memcpy(&mn, &got[0], 8);
+    memcpy(&mx, &got[1], 8);
+    *rcond = (mx > 0.0 && std::isfinite(mn)) ? mn / mx : 0.0;
     return SUCCESSFUL_EXIT;
 }
 

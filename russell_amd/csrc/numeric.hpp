@@ -87,14 +87,17 @@ class Solver {
     // values: nnz doubles in the CSR order given to initialize; on_device tells where they live
     int32_t factorize(const double *values, bool on_device);
     // value refresh through a map: CSR entry j = sum of input[seg_idx[seg_ptr[j] .. seg_ptr[j + 1])]
-    int32_t set_value_map(int64_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx);
+    // signed_map: seg_ptr[nnz] map entries (any number), an index ~k subtracts input[k]
+    int32_t set_value_map(int64_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx, bool signed_map = false);
     int32_t factorize_mapped(const double *input, bool on_device);
     int32_t solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device);
     int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
     int32_t determinant(double *mantissa, double *exponent, double *rcond);
+    int32_t rcond_estimate(double *rcond); // min |u_ii| / max |u_ii| by a device reduction
     int32_t adopt_factor(const double *d_values); // factor buffers were filled by a peer (many-RHS multi-GPU path)
     void mark_factor_adopted() { n_perturbed = n_zero_pivot = 0, factorized = true; } // ... including the matrix values
     void *d_diag_ptr() const { return d_diag; }
+    int64_t nnz_in_values() const { return nnz_in; } // inputs the installed value map reads (0: none)
     void *d_vals_ptr() const { return d_vals; }
     void release();
 

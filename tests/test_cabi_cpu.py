@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     _build()
     lib = _capi.load()
     header = open(os.path.join(ROOT, "include", "russell_hipmf.h")).read()
-    declared = set(re.findall(r"\b((?:solver_hipmf|hipmf)_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b((?:complex_solver_hipmf|solver_hipmf|hipmf)_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:

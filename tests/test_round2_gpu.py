@@ -255,3 +255,72 @@ def test_config5_npoint_513_reproduces_the_reference_log():
     assert (d["n_function"], d["n_jacobian"], d["n_factor"], d["n_lin_sol"]) == (266, 23, 44, 75)
     assert (d["n_steps"], d["n_accepted"], d["n_rejected"], d["n_iterations_max"]) == (44, 35, 9, 4)
     assert abs(d["h_accepted"] - 0.267457533813765) < 1e-9
+
+
+def _complex_handle():
+    import ctypes as C
+    from russell_amd import _capi
+    lib = _capi.load()
+    h = lib.complex_solver_hipmf_new()
+    assert h
+    return lib, h
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_complex_cabi_direct(symmetric):
+    # complex_solver_hipmf_* (include/russell_hipmf.h; replaces interface_complex_umfpack.c:82-248): general and symmetric-lower complex
+    # CSR, interleaved (re, im) values, against numpy's dense complex solve; value refresh through a triplet map with duplicates
+    import ctypes as C
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    n = 300
+    A = sp.random(n, n, density=0.03, random_state=3, format="csr") * (1.0 + 0.0j)
+    A = A + 1j * sp.random(n, n, density=0.03, random_state=4, format="csr") + sp.diags((4.0 + 1.5j) * np.ones(n))
+    if symmetric:
+        A = (A + A.T) * 0.5
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    S = sp.tril(A).tocsr() if symmetric else A
+    S.sort_indices()
+    rp, ci = S.indptr.astype(np.int32), S.indices.astype(np.int32)
+    zv = np.ascontiguousarray(np.stack([S.data.real, S.data.imag], axis=1).ravel())
+    xs = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    b = A @ xs
+    rhs = np.ascontiguousarray(np.stack([b.real, b.imag], axis=1).ravel())
+    lib, h = _complex_handle()
+    assert lib.complex_solver_hipmf_initialize(h, 0, 1, -1.0, -1, 0, int(symmetric), n, rp, ci, zv.ctypes.data) == 0
+    assert lib.complex_solver_hipmf_initialize(h, 0, 1, -1.0, -1, 0, int(symmetric), n, rp, ci, None) == 700000
+    eo, es, npert, rc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+    assert lib.complex_solver_hipmf_factorize(h, C.byref(eo), C.byref(es), C.byref(npert), C.byref(rc), 1, 0, zv) == 400000  # no determinant
+    assert lib.complex_solver_hipmf_factorize(h, C.byref(eo), C.byref(es), C.byref(npert), C.byref(rc), 0, 0, zv) == 0
+    x = np.zeros(2 * n)
+    assert lib.complex_solver_hipmf_solve(h, x, rhs, 0) == 0
+    xz = x[0::2] + 1j * x[1::2]
+    xd = np.linalg.solve(A.toarray(), b)
+    assert np.max(np.abs(xz - xd)) < 1e-11 and np.max(np.abs(xz - xs)) < 1e-11
+    # every stored entry split into two triplets (a + ib = (0.25 a + i 2 b) + (0.75 a - i b)), shuffled
+    nnz = ci.size
+    trip_of = np.concatenate([np.arange(nnz), np.arange(nnz)])
+    order = rng.permutation(2 * nnz)
+    seg_idx = np.argsort(trip_of[order], kind="stable").astype(np.int32)
+    seg_ptr = (2 * np.arange(nnz + 1)).astype(np.int32)
+    scale = 1.7 - 0.4j
+    tv = np.empty(2 * nnz, complex)
+    first = np.zeros(2 * nnz, bool)
+    first[seg_idx[0::2]] = True
+    src = trip_of[order]
+    vals = S.data * scale
+    tv[first] = 0.25 * vals.real[src[first]] + 2.0j * vals.imag[src[first]]
+    tv[~first] = 0.75 * vals.real[src[~first]] - 1.0j * vals.imag[src[~first]]
+    tin = np.ascontiguousarray(np.stack([tv.real, tv.imag], axis=1).ravel())
+    assert lib.complex_solver_hipmf_set_value_map(h, 2 * nnz, seg_ptr, seg_idx) == 0
+    assert lib.complex_solver_hipmf_factorize_mapped(h, None, None, None, None, 0, tin) == 0
+    assert lib.complex_solver_hipmf_solve(h, x, rhs, 0) == 0
+    xz2 = x[0::2] + 1j * x[1::2]
+    assert np.max(np.abs(xz2 - xd / scale)) < 1e-11
+    # plain CSR values again: the identity map comes back
+    assert lib.complex_solver_hipmf_factorize(h, None, None, None, None, 0, 0, zv) == 0
+    assert lib.complex_solver_hipmf_solve(h, x, rhs, 0) == 0
+    assert np.array_equal(x[0::2] + 1j * x[1::2], xz)
+    lib.complex_solver_hipmf_drop(h)
+    lib.complex_solver_hipmf_drop(None)

@@ -230,6 +230,11 @@ inline int atomicMax(int *p, int v) {
     *p = std::max(o, v);
     return o;
 }
+inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
+    unsigned long long o = *p;
+    if (v < o) *p = v;
+    return o;
+}
 inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) {
     unsigned long long o = *p;
     *p = std::max(o, v);
