@@ -269,7 +269,8 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
 // One thread owns one row (L) / one column (U) and runs a right-looking substitution in registers.
 // The factorised tile is NOT written into F here (other workgroups still read the original): workgroup 0
 // of each front parks it in dws, k_update moves it into place.
-// SYM: the L tiles cover the rows of F below the tile only, the U tiles the columns of E only (U12 = D L21^T is never formed);
+// SYM: the L tiles cover the rows of F below the tile only (and leave U12 = D L21^T in the upper triangle for the trailing update),
+// the U tiles the columns of E only;
 // the tile is factorised without interchanges from its lower triangle.
 template <bool SYM>
 __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
@@ -451,6 +452,18 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
                     if (k < nb) Lrow[(int64_t)k * lstr_u] = T[k][tid];
             }
         }
+        if (SYM) {
+            // the rows of U the trailing update multiplies with: U12(k, c) = d_k L21(c, k) into the (otherwise unused) upper triangle
+            // of F, rows k0 .. k0 + nb, columns of this tile (32-row segments of a column: the store pattern of the U tiles)
+            const int k = tid & (NB - 1), cq = tid >> 5;
+            const double dk = (k < nb) ? D[k][k] : 0.0;
+            double *dst = A.F + (k0 + k) + (int64_t)o0 * A.ld;
+#pragma unroll
+            for (int cb = 0; cb < PANEL_T; cb += 4) {
+                const int cc = cb + cq;
+                if (k < nb && cc < ext) dst[(int64_t)cc * A.ld] = dk * T[k][cc];
+            }
+        }
     } else {
         const int k = tid & (NB - 1), cq = tid >> 5;
         double *dF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *dE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
@@ -494,8 +507,9 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // for columns 0..15, lane r + 32 for columns 16..31), factorises it in registers (tile_lu32) and parks it in
 // dws (other buffer) with its row interchanges.  That 32 x 32 LU -- the longest serial piece of a tiled step --
 // runs beside the trailing update instead of in front of the next panel solve.
-// SYM: only entries of the lower triangle of F (r >= c) and of E are live; a row of U inside F is D times the transposed
-// column of L (U(k, c) = d_k L(c, k), d from `diag`), so the update L D L^T is exactly symmetric; rows of E are read as they are.
+// SYM: only entries of the lower triangle of F (r >= c) and of E are live; the rows of U inside F are U(k, c) = d_k L(c, k), written by
+// k_panel into the otherwise unused upper triangle of the panel rows, so the update L D L^T is exactly symmetric and reads its operands
+// exactly as the LU instance does; rows of E are read as they are.
 // (Tried and rejected: 128 x 128 tiles, four 64 x 64 waves -- 204 VGPRs + 128 AGPRs, one workgroup per CU: 962 ms instead of
 // 924 ms for the 128^3 Poisson factorisation.)
 template <bool SYM>
@@ -531,10 +545,15 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const bool narrow = gpos < fd.ugroup - 1 && nb2 > 0;     // not the last step of the group and another step follows
     const int nhalf = gpos + 1;                              // 32-column slices of K: every panel of the group so far
     const int kfirst = k0 - gpos * NB;
-    const int ntiles = narrow ? 2 * nt : nt * nt;
+    // SYM: only the tiles that hold live entries are enumerated (a grid of nt^2 workgroups of which half return at once is bound by the
+    // workgroup dispatch rate on the large fronts: 38 000 empty workgroups cost 1.5 ms of a 3.9 ms launch at 100^3): the lower
+    // triangle of the F part column by column, then the rows of F against the columns of E; narrow steps: block column, then E part of
+    // the block row.  The host counts the same way.
+    const int ntE = nt - ntF;
+    const int ntri = ntF * (ntF + 1) / 2;
+    const int ntiles = SYM ? (narrow ? nt : ntri + ntF * ntE) : (narrow ? 2 * nt : nt * nt);
     const AugView A = aug_view(fd, pool);
     double *F = A.F;
-    const double *dg = diag + fd.first; // pivots of this front (SYM: D)
     if (t == ntiles) {
         // ---- look-ahead workgroup: only wave 0 works ----
         if (tid >= 64) return;
@@ -555,13 +574,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u;
-                if (SYM) { // U(kk, c) = d_kk L(base + c, kk): lanes run along c (contiguous rows of a column of L)
-                    const int c = e & 31, kk = e >> 5;
-                    um[u] = (kk < nbh && c < nb2) ? F[(base + c) + (int64_t)(kh + kk) * A.ld] * dg[kh + kk] : 0.0;
-                } else {
-                    const int kk = e & 31, c = e >> 5;
-                    um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * A.ld] : 0.0;
-                }
+                const int kk = e & 31, c = e >> 5; // (SYM: k_panel left U12 = D L21^T in the upper triangle of the panel rows)
+                um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * A.ld] : 0.0;
             }
             double lrow[NB];
 #pragma unroll
@@ -569,8 +583,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u;
-                if (SYM) UM[e >> 5][e & 31] = um[u];
-                else UM[e & 31][e >> 5] = um[u];
+                UM[e & 31][e >> 5] = um[u];
             }
             __syncthreads(); // (only wave 0 is left in this workgroup)
 #pragma unroll
@@ -611,9 +624,33 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         return;
     }
     // tile of this workgroup; a narrow step has the nt tiles of the block column, then the nt tiles of the block row
-    const bool rowstrip = narrow && t >= nt;
-    const int ti = narrow ? (rowstrip ? 0 : t) : t % nt;
-    const int tj = narrow ? (rowstrip ? t - nt : 0) : t / nt;
+    bool rowstrip;
+    int ti, tj;
+    if (!SYM) {
+        rowstrip = narrow && t >= nt;
+        ti = narrow ? (rowstrip ? 0 : t) : t % nt;
+        tj = narrow ? (rowstrip ? t - nt : 0) : t / nt;
+    } else if (narrow) {
+        rowstrip = t >= ntF;
+        ti = rowstrip ? 0 : t;
+        tj = rowstrip ? t : 0; // (tiles ntF .. nt - 1 of the block row: the columns of E)
+    } else {
+        rowstrip = false;
+        if (t < ntri) { // column tj of the lower triangle starts at off(tj) = tj ntF - tj (tj - 1) / 2
+            const double bq = 2.0 * ntF + 1.0;
+            int c = (int)((bq - sqrt(bq * bq - 8.0 * (double)t)) * 0.5);
+            if (c < 0) c = 0;
+            if (c > ntF - 1) c = ntF - 1;
+            while (c > 0 && c * ntF - c * (c - 1) / 2 > t) c--;
+            while (c + 1 < ntF && (c + 1) * ntF - (c + 1) * c / 2 <= t) c++;
+            tj = c;
+            ti = c + (t - (c * ntF - c * (c - 1) / 2));
+        } else {
+            const int e = t - ntri;
+            ti = e % ntF;
+            tj = ntF + e / ntF;
+        }
+    }
     const bool rowsE = ti >= ntF, colsE = tj >= ntF; // tile in the rows of E' / in the columns of E
     const int r0 = rowsE ? f + (ti - ntF) * TS : base + ti * TS, c0 = colsE ? f + (tj - ntF) * TS : base + tj * TS;
     const int rend = rowsE ? limit : f, cend = colsE ? limit : f;
@@ -640,9 +677,6 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const int wr = (wave & 1) * (TS / 2), wc = (wave >> 1) * (TS / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
     double lreg[NE], ureg[NE];
-    // SYM, columns inside F: the rows of U are D times transposed columns of L; lanes then run along the tile's columns (contiguous
-    // rows of L) instead of along k.
-    const bool umap_t = SYM && !colsE;
     const double *Lb = rowsE ? A.Epsh : F;             // rows of the L slice: (r, k) at Lb[r + k * lstr]
     const int64_t lstr = rowsE ? A.p : A.ld;
     const double *Ub = colsE ? A.Esh : F;              // columns of the U slice: (k, c) at Ub[k + c * ld]
@@ -656,12 +690,8 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             const int e = tid + 256 * u;                                                                               \
             const int r = e % TS, kk = e / TS;                                                                         \
             lreg[u] = (r0 + r < rend && kk < nbh) ? Lb[(r0 + r) + (int64_t)(kh + kk) * lstr] : 0.0;                    \
-            if (umap_t) {                                                                                              \
-                ureg[u] = (c0 + r < cend && kk < nbh) ? F[(c0 + r) + (int64_t)(kh + kk) * A.ld] * dg[kh + kk] : 0.0;   \
-            } else {                                                                                                   \
-                const int k2 = e % NB, c = c0 + e / NB;                                                                \
-                ureg[u] = (c < cend && k2 < nbh) ? Ub[(kh + k2) + (int64_t)c * A.ld] : 0.0;                            \
-            }                                                                                                          \
+            const int k2 = e % NB, c = c0 + e / NB;                                                                    \
+            ureg[u] = (c < cend && k2 < nbh) ? Ub[(kh + k2) + (int64_t)c * A.ld] : 0.0;                                \
         }                                                                                                              \
     }
 #define HIPMF_STORE_SLICE()                                                                                            \
@@ -669,8 +699,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
             Ls[(e / TS) * LSLD + e % TS] = lreg[u];                                                                    \
-            if (umap_t) Us[(e % TS) * US_LD + e / TS] = ureg[u];                                                       \
-            else Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                              \
+            Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                                   \
         }                                                                                                              \
     }
     HIPMF_FETCH_SLICE(0)

@@ -497,11 +497,14 @@ int32_t Solver::upload_plan() {
                 tasks.push_back((int32_t)acc);
                 // tiles per dimension of k_update at this step: [base, f) and [f, f + base) are tiled separately (base = k0 + nb)
                 const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
-                int64_t nt = (fa - basea + UPD_T - 1) / UPD_T + (basea + UPD_T - 1) / UPD_T;
+                const int64_t ntF = (fa - basea + UPD_T - 1) / UPD_T, ntE = (basea + UPD_T - 1) / UPD_T;
+                int64_t nt = ntF + ntE;
                 const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
                 const int32_t G = update_group(S.fsize(big[a]));
                 const bool narrow = follow && ((k0 / NB) % G) != G - 1; // not the last step of a group: block column + block row only
-                acc += (narrow ? 2 * nt : nt * nt) + (follow ? 1 : 0);
+                // (symmetric fronts enumerate only the tiles with live entries: lower triangle of F, rows of F x columns of E)
+                if (S.sym_mode) acc += (narrow ? nt : ntF * (ntF + 1) / 2 + ntF * ntE) + (follow ? 1 : 0);
+                else acc += (narrow ? 2 * nt : nt * nt) + (follow ? 1 : 0);
             }
             tasks.push_back((int32_t)acc);
             if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
@@ -862,7 +865,7 @@ int32_t Solver::run_factor() {
             if (S.sym_mode) {
                 hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
-                hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                if (st.n_update > 0) hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                    d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             } else {
                 hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
