@@ -272,76 +272,158 @@ def main():
             extras["host_api"] = {"error": repr(exc)}
 
     # ---------------------------------------------------------------- many right-hand sides, sharded (north_star)
+    # Every rank runs the same sequence of collectives whatever happens locally: local work sits in try blocks that only set a
+    # flag, the ranks agree on the flag (MIN over ranks) before the next collective step -- a failure on one rank skips the
+    # section everywhere instead of leaving the others waiting in a collective.
+    def all_ok(flag):
+        if dist is None:
+            return bool(flag)
+        import torch
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     if not args.no_extras and args.nrhs > 0:
+        many, err = {}, None
+        first, count = rhs_block(args.nrhs, world, rank)
+        d_B = d_X = None
+        Bh = Xh = None
         try:
-            first, count = rhs_block(args.nrhs, world, rank)
             b0 = P.csr_matvec(n, rp, ci, v, xs)
             Bh = np.empty((max(count, 1), n))
             for j in range(count):
                 Bh[j] = b0 * (1.0 + 0.01 * (first + j))  # column j has the known solution xs * (1 + 0.01 j)
+            Xh = np.zeros_like(Bh)
             d_B = s.dev_alloc(Bh.nbytes)
             d_X = s.dev_alloc(Bh.nbytes)
             s.h2d(d_B, Bh)
-            # (a) replicated: every rank factorises (no data-path collective at all)
+        except Exception as exc:
+            err = "setup: %r" % (exc,)
+        ok = all_ok(err is None)
+
+        def column_error():
+            s.d2h(Xh, d_X)
+            return max([float(np.max(np.abs(Xh[j] - xs * (1.0 + 0.01 * (first + j))))) for j in range(count)] + [0.0])
+
+        # (a) replicated: every rank factorises (no data-path collective at all)
+        if ok:
+            t_fact_rep = t_solve = 0.0
+            worst = -1.0
             sync_all()
             t0 = time.perf_counter()
-            assert s.factorize_device(d_vals) == 0
-            lib.hipmf_device_synchronize()
+            try:
+                assert s.factorize_device(d_vals) == 0
+                lib.hipmf_device_synchronize()
+            except Exception as exc:
+                err = "replicate factorize: %r" % (exc,)
             t_fact_rep = rank_max(time.perf_counter() - t0)
             sync_all()
             t0 = time.perf_counter()
-            if count > 0:
-                s.solve_device(d_X, d_B, nrhs=count)
-            lib.hipmf_device_synchronize()
-            t_solve = rank_max(time.perf_counter() - t0)
-            Xh = np.zeros_like(Bh)
-            s.d2h(Xh, d_X)
-            worst = max([float(np.max(np.abs(Xh[j] - xs * (1.0 + 0.01 * (first + j))))) for j in range(count)] + [0.0])
-            many = {"nrhs_total": args.nrhs, "rhs_per_gpu": count, "solve_ms": round(t_solve * 1e3, 3),
-                    "replicate": {"factorize_ms": round(t_fact_rep * 1e3, 3), "total_ms": round((t_fact_rep + t_solve) * 1e3, 3),
-                                  "rhs_per_s": round(args.nrhs / (t_fact_rep + t_solve), 1)},
-                    "max_abs_error_all_columns": worst}
-            # (b) north_star: ONE rank factorises, the factor goes to the others over RCCL / xGMI
-            if world > 1:
-                import torch
-                idt = torch.zeros(128, dtype=torch.uint8, device=tdev)
-                if rank == 0:
-                    idbuf = (ctypes.c_uint8 * 128)()
-                    assert lib.hipmf_comm_unique_id(idbuf) == 0
-                    idt.copy_(torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8))
-                dist.broadcast(idt, src=0)
-                idb = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
-                comm = ctypes.c_void_p()
-                assert lib.hipmf_comm_init_rank(ctypes.byref(comm), world, idb, rank) == 0
-                s.broadcast_factor(comm, 0, rank)  # warm-up of the communicator (first collective sets up the rings)
-                sync_all()
-                t0 = time.perf_counter()
-                if rank == 0:
-                    assert s.factorize_device(d_vals) == 0
-                lib.hipmf_device_synchronize()
-                sync_all()
-                t_fact = rank_max(time.perf_counter() - t0)
-                t0 = time.perf_counter()
-                sec, nbytes = s.broadcast_factor(comm, 0, rank)
-                sync_all()
-                t_bc = rank_max(time.perf_counter() - t0)
-                t0 = time.perf_counter()
-                if count > 0:
+            try:
+                if count > 0 and err is None:
                     s.solve_device(d_X, d_B, nrhs=count)
                 lib.hipmf_device_synchronize()
-                t_solve2 = rank_max(time.perf_counter() - t0)
-                s.d2h(Xh, d_X)
-                worst2 = max([float(np.max(np.abs(Xh[j] - xs * (1.0 + 0.01 * (first + j))))) for j in range(count)] + [0.0])
-                lib.hipmf_comm_destroy(comm)
-                many["broadcast"] = {"factorize_ms": round(t_fact * 1e3, 3), "broadcast_ms": round(t_bc * 1e3, 3),
-                                     "broadcast_bytes": int(nbytes), "broadcast_gbs": round(nbytes / t_bc / 1e9, 1) if t_bc > 0 else None,
-                                     "solve_ms": round(t_solve2 * 1e3, 3), "total_ms": round((t_fact + t_bc + t_solve2) * 1e3, 3),
-                                     "rhs_per_s": round(args.nrhs / (t_fact + t_bc + t_solve2), 1), "max_abs_error_all_columns": worst2}
+            except Exception as exc:
+                err = "replicate solve: %r" % (exc,)
+            t_solve = rank_max(time.perf_counter() - t0)
+            try:
+                if err is None:
+                    worst = column_error()
+            except Exception as exc:
+                err = "replicate check: %r" % (exc,)
+            worst = rank_max(worst)
+            ok = all_ok(err is None)
+            if ok:
+                many = {"nrhs_total": args.nrhs, "rhs_per_gpu": count, "solve_ms": round(t_solve * 1e3, 3),
+                        "replicate": {"factorize_ms": round(t_fact_rep * 1e3, 3), "total_ms": round((t_fact_rep + t_solve) * 1e3, 3),
+                                      "rhs_per_s": round(args.nrhs / (t_fact_rep + t_solve), 1)},
+                        "max_abs_error_all_columns": worst}
+        # (b) north_star: ONE rank factorises, the factor goes to the others over RCCL / xGMI
+        if ok and world > 1:
+            import torch
+            comm = ctypes.c_void_p()
+            idt = torch.zeros(129, dtype=torch.uint8, device=tdev)  # 128 bytes of id + a "valid" byte
+            try:
+                if rank == 0:
+                    idbuf = (ctypes.c_uint8 * 128)()
+                    if lib.hipmf_comm_unique_id(idbuf) == 0:
+                        idt.copy_(torch.tensor(list(bytes(idbuf)) + [1], dtype=torch.uint8))
+            except Exception as exc:
+                err = "unique id: %r" % (exc,)
+            dist.broadcast(idt, src=0)
+            idh = bytes(idt.cpu().numpy().tobytes())
+            have_comm = False
+            try:
+                if idh[128] == 1:
+                    idb = (ctypes.c_uint8 * 128).from_buffer_copy(idh[:128])
+                    have_comm = lib.hipmf_comm_init_rank(ctypes.byref(comm), world, idb, rank) == 0
+            except Exception as exc:
+                err = "comm init: %r" % (exc,)
+            ok_b = all_ok(idh[128] == 1 and have_comm and err is None)
+            if ok_b:
+                t_fact = t_bc = t_solve2 = 0.0
+                nbytes, worst2 = 0, -1.0
+                try:
+                    s.broadcast_factor(comm, 0, rank)  # warm-up of the communicator (the first collective sets up the rings)
+                    if rank != 0:
+                        # the other ranks overwrite their replicated factor with that of ANOTHER matrix (values x 2): the columns below
+                        # only come out right if the broadcast really delivered rank 0's factor
+                        d_v2 = s.dev_alloc(v.nbytes)
+                        s.h2d(d_v2, 2.0 * v)
+                        assert s.factorize_device(d_v2) == 0
+                        s.dev_free(d_v2)
+                except Exception as exc:
+                    err = "broadcast warm-up: %r" % (exc,)
+                if all_ok(err is None):
+                    sync_all()
+                    t0 = time.perf_counter()
+                    try:
+                        if rank == 0:
+                            assert s.factorize_device(d_vals) == 0
+                        lib.hipmf_device_synchronize()
+                    except Exception as exc:
+                        err = "root factorize: %r" % (exc,)
+                    sync_all()
+                    t_fact = rank_max(time.perf_counter() - t0)
+                    if all_ok(err is None):
+                        t0 = time.perf_counter()
+                        try:
+                            sec, nbytes = s.broadcast_factor(comm, 0, rank)
+                        except Exception as exc:  # (an RCCL failure inside the collective may still hang the others: nothing a caller can do)
+                            err = "broadcast: %r" % (exc,)
+                        sync_all()
+                        t_bc = rank_max(time.perf_counter() - t0)
+                        t0 = time.perf_counter()
+                        try:
+                            if count > 0 and err is None:
+                                s.solve_device(d_X, d_B, nrhs=count)
+                            lib.hipmf_device_synchronize()
+                            if err is None:
+                                worst2 = column_error()
+                        except Exception as exc:
+                            err = "sharded solve: %r" % (exc,)
+                        t_solve2 = rank_max(time.perf_counter() - t0)
+                        worst2 = rank_max(worst2)
+                        if all_ok(err is None) and t_bc > 0:
+                            many["broadcast"] = {"factorize_ms": round(t_fact * 1e3, 3), "broadcast_ms": round(t_bc * 1e3, 3),
+                                                 "broadcast_bytes": int(nbytes), "broadcast_gbs": round(nbytes / t_bc / 1e9, 1),
+                                                 "solve_ms": round(t_solve2 * 1e3, 3), "total_ms": round((t_fact + t_bc + t_solve2) * 1e3, 3),
+                                                 "rhs_per_s": round(args.nrhs / (t_fact + t_bc + t_solve2), 1),
+                                                 "max_abs_error_all_columns": worst2}
+                try:
+                    lib.hipmf_comm_destroy(comm)
+                except Exception:
+                    pass
+            if "broadcast" not in many:
+                many["broadcast"] = {"error": err or "RCCL communicator not available on every rank"}
+        if many:
             many["rhs_per_s"] = max(many["replicate"]["rhs_per_s"], many.get("broadcast", {}).get("rhs_per_s", 0.0))
             extras["many_rhs"] = many
-            s.dev_free(d_B), s.dev_free(d_X)
-        except Exception as exc:
-            extras["many_rhs"] = {"error": repr(exc)}
+        else:
+            extras["many_rhs"] = {"error": err or "skipped: another rank failed"}
+        for ptr in (d_B, d_X):
+            if ptr:
+                s.dev_free(ptr)
 
     if rank == 0:
         tri = max(st["acc_tri_count"], 1.0)
