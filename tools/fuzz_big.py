@@ -29,11 +29,24 @@ for c in range(cases):
              "HIPMF_SOLVE_LANES": str(rng.choice([1, 2, 3]))}
     os.environ.update(knobs)
     A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    sym = rng.random() < 0.4
+    if sym:
+        # symmetric (positive definite or with a few negative pivots) and handed over as the lower triangle: L D L^T on the tiled fronts
+        A = sp.csr_matrix((np.abs(v), ci, rp), shape=(n, n))
+        A = ((A + A.T) * 0.5).tocsr()
+        d = np.asarray(abs(A).sum(axis=1)).ravel() * (1.0 + rng.random(n))
+        if rng.random() < 0.5:
+            d[rng.choice(n, max(1, n // 50), replace=False)] *= -1.0   # indefinite: a few negative diagonal entries
+        A = (A - sp.diags(A.diagonal()) + sp.diags(d)).tocsr()
+        A.sort_indices()
+        L = sp.tril(A).tocsr()
+        L.sort_indices()
+        rp, ci, v = L.indptr.astype(np.int32), L.indices.astype(np.int32), L.data.astype(np.float64)
     nr = int(rng.choice([1, 1, 5, 19]))
     XS = rng.standard_normal((nr, n))
     B = (A @ XS.T).T
     s = Hipmf()
-    assert s.initialize(n, rp, ci, values=v if rng.random() < 0.5 else None) == 0
+    assert s.initialize(n, rp, ci, general_symmetric=sym, values=v if (rng.random() < 0.5 and not sym) else None) == 0
     code = s.factorize(v)
     assert code == 0, (seed0 + c, code)
     X = s.solve_many(B) if nr > 1 else s.solve(B[0])[None, :]
