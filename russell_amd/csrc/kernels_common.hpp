@@ -37,6 +37,23 @@ constexpr int US_LD = 34;      // LDS leading dimension of the U slice in the up
 constexpr int SOLVE_SLAB_WIDE = 32; // rows per 1024-thread workgroup on the levels near the root (32 rows x 32 column groups)
 constexpr int SOLVE_SLAB = 64; // rows of a solve panel per 256-thread workgroup (64 rows x 4 column groups)
 
+// Optional device-clock stamps for kernel tuning (builds with -DHIPMF_STAMPS only; tools/stamps.py reads them through
+// hipmf_debug_read_stamps): HIPMF_STAMP(row, i) stores the 100 MHz clock into row `row`, slot i (16 slots per row, 1024 rows).
+#ifdef HIPMF_STAMPS
+__device__ unsigned long long hipmf_stamps[16 * 1024];
+#define HIPMF_STAMP(row, i)                                                                  \
+    do {                                                                                     \
+        if (threadIdx.x == 0 && (row) >= 0 && (row) < 1024) hipmf_stamps[(row) * 16 + (i)] = dev_clock(); \
+    } while (0)
+#define HIPMF_STAMP_VAL(row, i, v)                                                           \
+    do {                                                                                     \
+        if (threadIdx.x == 0 && (row) >= 0 && (row) < 1024) hipmf_stamps[(row) * 16 + (i)] = (unsigned long long)(v); \
+    } while (0)
+#else
+#define HIPMF_STAMP(row, i) ((void)0)
+#define HIPMF_STAMP_VAL(row, i, v) ((void)0)
+#endif
+
 struct FrontDesc {
     int64_t off;    // offset of the front in the pool (doubles)
     int64_t rowptr; // offset of the row structure / relative indices

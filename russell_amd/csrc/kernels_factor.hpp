@@ -1,5 +1,6 @@
 // kernels_factor.hpp -- dense partial factorisation of the fronts:  P F = [L11 0; L21 I] [U11 U12; 0 S]
-//   k_small_factor   one wavefront per front with f <= SMALL_F, whole front in LDS            (LDS / latency-bound)
+//   k_small_factor   one or four wavefronts per front with f <= SMALL_F, whole front in LDS, blocked LU with the trailing
+//                    update on MFMA (lds_lu_blocked)                                            (LDS / latency-bound)
 //   k_panel          tiled path, step k0: every workgroup factorises the 32 x 32 diagonal tile in
 //                    REGISTERS (one row per lane, v_readlane broadcasts; redundant per workgroup, which
 //                    removes a dependent launch from the critical path) and then solves its own row /
@@ -14,6 +15,182 @@
 #include "kernels_common.hpp"
 
 namespace hipmf {
+
+// Partial LU of an f x f front (f <= 64) held in LDS (column-major, stride ld), p pivots, by a workgroup of NW wavefronts, LU_KB = 8
+// pivots at a time -- the elimination of k_small_factor.  A rank-1 update per pivot moves every trailing entry through LDS three
+// times per pivot (read, read of the pivot row, write) and needs three workgroup barriers per pivot.  Per block of eight pivots:
+//   P1  wavefront 0 holds the eight panel columns in registers, one row per lane, and eliminates them with partial pivoting over
+//       the rows c .. p-1 (implicit pivoting, v_readlane broadcasts, no barrier); it records where the interchanges of LAPACK's
+//       row-swap convention put every row, writes the panel back in that order and leaves the eight interchanges in pivpos
+//   P2  the interchanges are applied to all other columns (one thread per column)
+//   P3  the eight rows of U right of the panel: substitution with the unit lower 8 x 8 block (one thread per column)
+//   P4  trailing matrix -= L21 U12 on v_mfma_f64_16x16x4_f64, 16 x 16 tiles dealt to the wavefronts: every entry passes through LDS
+//       once per eight pivots (this phase is bound by the LDS read-modify-write of the tiles, ~150 clocks per tile).
+// lp[position] = front-local row that ended up there (identity on entry).  Static pivoting as everywhere: |pivot| < eps -> +-eps.
+// (PIVOT = false: the pivot of step c is row c.)
+constexpr int LU_KB = 8;
+template <int NW, bool PIVOT>
+__device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int ld, const int f, const int p, int32_t *lp, int32_t *pivpos,
+                                               const double eps, FactorInfo *info) {
+    constexpr int KB = LU_KB, T = 64 * NW;
+    const int lin = threadIdx.x, lane = lin & 63, wave = lin >> 6;
+    for (int c0 = 0; c0 < p; c0 += KB) {
+        const int kb = (p - c0) < KB ? (p - c0) : KB;
+        // ---- P1 ----
+        if (wave == 0) {
+            const int r = lane;
+            const bool active = r >= c0 && r < f;
+            double a[KB];
+#pragma unroll
+            for (int q = 0; q < KB; q++) a[q] = (active && q < kb) ? S[r + (c0 + q) * ld] : 0.0;
+            int pos = r; // physical row this lane's row occupies after the interchanges so far
+            bool chosen = false;
+            int npert = 0, nzero = 0;
+            const int lp_old = (PIVOT && r >= c0 && r < p) ? lp[r] : 0;
+#pragma unroll
+            for (int st = 0; st < KB; st++) {
+                if (st < kb) { // (wave-uniform)
+                    int pv;
+                    // (every lane forms the reciprocal of its own entry while the arg-max runs: the divide is off the dependent chain)
+                    const double myinv = fast_rcp(a[st]);
+                    if (PIVOT) {
+                        const bool cand = active && !chosen && r < p;
+                        const unsigned mag = __float_as_uint((float)fabs(a[st]));
+                        const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - r)) : 0u;
+                        pv = 63 - (int)(wave_max_u32(key) & 63u);
+                    } else {
+                        pv = c0 + st;
+                    }
+                    double d = wave_bcast(a[st], pv);
+                    double inv = wave_bcast(myinv, pv);
+                    if (fabs(d) < eps || d == 0.0) {
+                        double dn = (d < 0.0) ? -eps : eps;
+                        if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
+                        if (lane == pv) a[st] = dn;
+                        npert++;
+                        if (d == 0.0) nzero++;
+                        d = dn;
+                        inv = 1.0 / dn;
+                    }
+                    if (PIVOT) {
+                        const int P = wave_bcast_i32(pos, pv);
+                        if (pos == c0 + st) pos = P; // the row at the pivot position moves to where the chosen row was
+                        if (lane == pv) pos = c0 + st;
+                        if (lane == 0) pivpos[st] = P;
+                    }
+                    if (lane == pv) chosen = true;
+                    const bool below = active && !chosen;
+                    const double l = below ? a[st] * inv : 0.0;
+                    if (below) a[st] = l;
+#pragma unroll
+                    for (int q = st + 1; q < KB; q++) a[q] -= l * wave_bcast(a[q], pv);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int q = 0; q < KB; q++)
+                    if (q < kb) S[pos + (c0 + q) * ld] = a[q];
+            }
+            if (PIVOT && r >= c0 && r < p) lp[pos] = lp_old; // (all reads of lp happened above)
+            if (lane == 0 && npert > 0) {
+                atomicAdd(&info->n_perturbed, npert);
+                if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
+            }
+        }
+        __syncthreads();
+        // ---- P2 ----
+        if (PIVOT) {
+            int pp[KB];
+#pragma unroll
+            for (int st = 0; st < KB; st++) pp[st] = pivpos[st]; // (stale beyond kb: not used)
+            for (int col = lin; col < f; col += T) {
+                if (col >= c0 && col < c0 + kb) continue;
+#pragma unroll
+                for (int st = 0; st < KB; st++) {
+                    const int P = pp[st];
+                    if (st < kb && P != c0 + st) {
+                        const double t = S[(c0 + st) + col * ld];
+                        S[(c0 + st) + col * ld] = S[P + col * ld];
+                        S[P + col * ld] = t;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int R0 = c0 + kb; // first row / column of the trailing part
+        if (R0 >= f) break;
+        // ---- P3 ----
+        for (int col = R0 + lin; col < f; col += T) {
+            double x[KB];
+#pragma unroll
+            for (int t = 0; t < KB; t++) x[t] = (t < kb) ? S[(c0 + t) + col * ld] : 0.0;
+#pragma unroll
+            for (int t = 1; t < KB; t++) {
+                if (t < kb) {
+#pragma unroll
+                    for (int q = 0; q < t; q++) x[t] -= S[(c0 + t) + (c0 + q) * ld] * x[q];
+                }
+            }
+#pragma unroll
+            for (int t = 1; t < KB; t++)
+                if (t < kb) S[(c0 + t) + col * ld] = x[t];
+        }
+        __syncthreads();
+        // ---- P4 ----
+        {
+            const int nt = (f - R0 + 15) >> 4, ntot = nt * nt;
+            const int l15 = lane & 15, l4 = lane >> 4;
+            // operands and the 16 x 16 tile itself with clamped addresses: every load is issued unconditionally (one LDS round trip per
+            // tile), out-of-range operands are zeroed afterwards, stores are guarded.  C - L U is formed as (-L) U + C.
+            const int ka = l4 < kb ? l4 : kb - 1, kb2 = 4 + l4 < kb ? 4 + l4 : kb - 1;
+            const bool k0ok = l4 < kb, k1ok = 4 + l4 < kb;
+            auto tile_load = [&](int ti, int tj, double &a0, double &a1, double &b0, double &b1, f64x4 &acc) {
+                const int rA = R0 + 16 * ti + l15, cB = R0 + 16 * tj + l15;
+                const int rAc = rA < f ? rA : f - 1, cBc = cB < f ? cB : f - 1;
+                a0 = S[rAc + (c0 + ka) * ld], a1 = S[rAc + (c0 + kb2) * ld];
+                b0 = S[(c0 + ka) + cBc * ld], b1 = S[(c0 + kb2) + cBc * ld];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int rr = R0 + 16 * ti + l4 + 4 * g;
+                    acc[g] = S[(rr < f ? rr : f - 1) + cBc * ld];
+                }
+                if (rA >= f || !k0ok) a0 = 0.0;
+                if (rA >= f || !k1ok) a1 = 0.0;
+                if (cB >= f || !k0ok) b0 = 0.0;
+                if (cB >= f || !k1ok) b1 = 0.0;
+            };
+            auto tile_store = [&](int ti, int tj, const f64x4 &acc) {
+                const int cB = R0 + 16 * tj + l15;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int rr = R0 + 16 * ti + l4 + 4 * g;
+                    if (rr < f && cB < f) S[rr + cB * ld] = acc[g];
+                }
+            };
+            int ti = wave % nt, tj = wave / nt;
+            for (int tile = wave; tile < ntot; tile += 2 * NW) { // two tiles per pass: their LDS round trips overlap
+                int ti2 = ti + NW, tj2 = tj;
+                while (ti2 >= nt) ti2 -= nt, tj2++;
+                const bool two = tile + NW < ntot; // (wave-uniform)
+                double a0, a1, b0, b1, c0a, c1a, d0, d1;
+                f64x4 acc, acc2;
+                tile_load(ti, tj, a0, a1, b0, b1, acc);
+                if (two) tile_load(ti2, tj2, c0a, c1a, d0, d1, acc2);
+                acc = mfma_f64_16x16x4(-a0, b0, acc);
+                acc = mfma_f64_16x16x4(-a1, b1, acc);
+                if (two) {
+                    acc2 = mfma_f64_16x16x4(-c0a, d0, acc2);
+                    acc2 = mfma_f64_16x16x4(-c1a, d1, acc2);
+                }
+                tile_store(ti, tj, acc);
+                if (two) tile_store(ti2, tj2, acc2);
+                ti = ti2 + NW, tj = tj2;
+                while (ti >= nt) ti -= nt, tj++;
+            }
+        }
+        __syncthreads();
+    }
+}
 
 // Everything a small front needs to ASSEMBLE itself (fused into k_small_factor: no memset, scatter or extend-add
 // traffic for the small fronts, which hold most of the fronts and half of the pool).
@@ -44,7 +221,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
                                                           FactorInfo *info, int32_t ld, SmallAsm A, double *__restrict__ diag) {
     HIPMF_DYN_SHARED(double, sm);
     __shared__ int32_t lp[SMALL_F];
-    __shared__ int32_t piv_s;
+    __shared__ int32_t pivpos[LU_KB];
     const int tid = threadIdx.x & 63, grp = threadIdx.x >> 6; // row / lane, column group (wave)
     const int lin = threadIdx.x;
     const SmallDesc sdesc = A.sd[(list - A.list0) + blockIdx.x];
@@ -131,74 +308,7 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
         if (tid < p) lp[tid] = tid;
     }
     __syncthreads();
-    for (int c = 0; c < p; c++) {
-        // arg-max over rows c..p-1 of column c (wavefront 0): key = float(|a|) bits, low 7 bits = candidate flag | 63 - row
-        int piv = c;
-        if (grp == 0) {
-            const bool cand = tid >= c && tid < p;
-            const double mine = cand ? sm[tid + c * ld] : 0.0;
-            const unsigned mag = __float_as_uint((float)fabs(mine));
-            const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - tid)) : 0u;
-            piv = 63 - (int)(wave_max_u32(key) & 63u);
-            if (NW > 1 && tid == 0) piv_s = piv;
-        }
-        if (NW > 1) {
-            __syncthreads();
-            piv = piv_s;
-        }
-        if (piv != c) { // (workgroup-uniform)
-            if (grp == 0) {
-                if (tid < f) {
-                    double a = sm[c + tid * ld];
-                    sm[c + tid * ld] = sm[piv + tid * ld];
-                    sm[piv + tid * ld] = a;
-                }
-                if (tid == 0) {
-                    int a = lp[c];
-                    lp[c] = lp[piv];
-                    lp[piv] = a;
-                }
-            }
-            __syncthreads();
-        }
-        double d = sm[c + c * ld];
-        if (fabs(d) < eps || d == 0.0) {
-            // static pivoting: replace a tiny pivot by +-eps (workgroup-uniform branch: d is one LDS word)
-            double dn = (d < 0.0) ? -eps : eps;
-            if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
-            __syncthreads();
-            if (lin == 0) {
-                if (d == 0.0) atomicAdd(&info->n_zero_pivot, 1);
-                atomicAdd(&info->n_perturbed, 1);
-                sm[c + c * ld] = dn;
-            }
-            __syncthreads();
-            d = dn;
-        }
-        // thread = (row, column group): multiplier, then the rank-1 update of this row across the group's remaining columns
-        const bool below = tid > c && tid < f;
-        double l = 0.0;
-        if (below) l = sm[tid + c * ld] / d;
-        if (NW > 1) __syncthreads(); // every group has read the column before group 0 overwrites it with the multipliers
-        if (below) {
-            if (grp == 0) sm[tid + c * ld] = l;
-            // eight columns per pass, all LDS reads issued before the first write (the compiler cannot
-            // reorder them itself: it has to assume the writes alias the pivot row)
-            int cc = c + 1 + grp;
-            for (; cc + 7 * NW < f; cc += 8 * NW) {
-                double u[8], a[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    u[q] = sm[c + (cc + q * NW) * ld];
-                    a[q] = sm[tid + (cc + q * NW) * ld];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) sm[tid + (cc + q * NW) * ld] = a[q] - l * u[q];
-            }
-            for (; cc < f; cc += NW) sm[tid + cc * ld] -= l * sm[c + cc * ld];
-        }
-        __syncthreads();
-    }
+    lds_lu_blocked<NW, true>(sm, ld, f, p, lp, pivpos, eps, info);
     if (tid < f) {
         int c = grp;
         for (; c + 7 * NW < f; c += 8 * NW) {

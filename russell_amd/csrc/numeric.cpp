@@ -1363,3 +1363,12 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
 }
 
 } // namespace hipmf
+
+#ifdef HIPMF_STAMPS
+extern "C" int32_t hipmf_debug_read_stamps(unsigned long long *out, int64_t n) {
+    if (n > 16 * 1024) n = 16 * 1024;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hipmf::hipmf_stamps), sizeof(unsigned long long) * (size_t)n) != hipSuccess) return 1;
+    static unsigned long long zeros[16 * 1024];
+    return hipMemcpyToSymbol(HIP_SYMBOL(hipmf::hipmf_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 2;
+}
+#endif

@@ -17,6 +17,8 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
 // the value is needed (in a scalar register) at this point of the program: its load cannot sink below
 #define HIPMF_KEEP_SCALAR(x) asm volatile("" ::"s"(x))
 #define HIPMF_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+// a kernel that asks for more than 64 KB of dynamic LDS (gfx950 has 160 KB per workgroup) announces it once
+#define HIPMF_ALLOW_LDS(kernel, bytes) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 
 // broadcast of lane `src` (wave-uniform) to every lane: two v_readlane_b32, result lives in SGPRs
 __device__ __forceinline__ double wave_bcast(double v, int src) {
@@ -26,6 +28,7 @@ __device__ __forceinline__ double wave_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ int wave_bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 // tells the compiler that a value equal on all lanes is wave-uniform (moves it to an SGPR)
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -25,10 +25,12 @@ inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
 }
 
 #define HIPMF_KEEP_SCALAR(x) ((void)(x))
+#define HIPMF_ALLOW_LDS(kernel, bytes) ((void)0)
 #define HIPMF_DYN_SHARED(T, name) T *name = (T *)(((uintptr_t)hipemu::g_dynshared.data() + 15) & ~(uintptr_t)15)
 
 inline double wave_bcast(double v, int src) { return __shfl(v, src); }
 
+inline int wave_bcast_i32(int v, int src) { return __shfl(v, src); }
 inline int wave_uniform(int v) { return v; }
 
 inline unsigned long long wave_max_u64(unsigned long long key) {
