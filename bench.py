@@ -253,20 +253,24 @@ def main():
             hs.actual.factorize(coo)  # first call: COO -> CSR, initialize, value map, factorize
             t_first = time.perf_counter() - t0
             tf = ts = 0.0
-            reps = 3
-            for _ in range(reps):
+            reps, first_solves = 5, []
+            for it in range(reps + 2):
                 t0 = time.perf_counter()
                 hs.actual.factorize(coo)  # repeat call (params None): values through the device-side map + numeric LU
                 t1 = time.perf_counter()
                 xh = hs.actual.solve(b)
                 t2 = time.perf_counter()
+                if it < 2:  # the first two host solves pay one-time runtime costs (code objects, pinned staging, first DMA): reported apart
+                    first_solves.append(round((t2 - t1) * 1e3, 1))
+                    continue
                 tf += t1 - t0
                 ts += t2 - t1
             extras["host_api"] = {
                 "workload": "LinSolTrait::factorize(&coo, None) repeat call + solve(&mut x, &rhs) with HOST vectors (H2D of 4 996 000 triplet values, "
                             "device-side COO->CSR value refresh, numeric LU; H2D rhs, solve, D2H x), wall clock",
                 "factorize_ms": round(tf / reps * 1e3, 3), "solve_ms": round(ts / reps * 1e3, 3), "total_ms": round((tf + ts) / reps * 1e3, 3),
-                "first_call_ms": round(t_first * 1e3, 1), "relative_error": residual_metric(n, rp, ci, v, xh, b)}
+                "first_call_ms": round(t_first * 1e3, 1), "first_two_solves_ms": first_solves, "timed_repeats": reps,
+                "relative_error": residual_metric(n, rp, ci, v, xh, b)}
             del hs
         except Exception as exc:  # never lose the headline to an extra
             extras["host_api"] = {"error": repr(exc)}
