@@ -371,6 +371,45 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
     }
 }
 
+// Tiled path, step 0 of the levels with MANY tiled fronts: one wavefront per front factorises the first diagonal tile and parks it
+// (with its interchanges and pivots) where k_panel finds the tiles of the later steps.  k_panel's own "every workgroup factorises
+// the tile itself" saves a dependent launch for the few large fronts near the root; with a thousand fronts in the level it is three
+// redundant 5 us factorisations per front in workgroups whose other wavefront waits.
+template <bool SYM>
+__global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD, double *__restrict__ pool, int32_t *__restrict__ lperm,
+                                              double *__restrict__ dws, const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
+                                              FactorInfo *info, double *__restrict__ diag) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    FrontDesc fd = LFD[slot];
+    const int nb = fd.p < NB ? fd.p : NB;
+    const double *F = pool + fd.off;
+    const int64_t ld = fd.ld;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+        const int rr = (SYM && tid < c) ? c : tid, cc = (SYM && tid < c) ? tid : c; // (SYM: only the lower triangle of F is assembled)
+        a[c] = (tid < nb && c < nb) ? F[rr + (int64_t)cc * ld] : (tid == c ? 1.0 : 0.0);
+    }
+    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    int step, npert, nzero;
+    tile_lu32<!SYM>(a, tid, eps, step, npert, nzero);
+    if (tid < nb) {
+        double *dw = dws + (int64_t)slot * NB * NB; // step 0 uses buffer 0
+        double dg = 1.0;
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            if (c < nb) dw[step + c * nb] = a[c];
+            if (c == step) dg = a[c];
+        }
+        lperm[fd.first + step] = tid;
+        diag[fd.first + step] = dg;
+    }
+    if (tid == 0 && npert > 0) {
+        atomicAdd(&info->n_perturbed, npert);
+        if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
+    }
+}
+
 // Tiled path, step k0 (base = k0 + nb, active range [base, f + base)):
 //   every workgroup factorises the diagonal tile itself (wave 0, registers) while all its threads prefetch
 //   the workgroup's own tile;  then
@@ -387,7 +426,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
                                                    int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
                                                    const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                   double *__restrict__ diag) {
+                                                   double *__restrict__ diag, int32_t pre_lu) {
     // D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
     // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
     __shared__ __attribute__((aligned(16))) double D[NB][NB + 2];
@@ -412,7 +451,8 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     const int o0 = SYM ? (ltile ? base + t * PANEL_T : f + (t - nT) * PANEL_T) : base + (ltile ? t : t - nT) * PANEL_T;
     const int oend = (SYM && ltile) ? f : limit;
     const int ext = (oend - o0) < PANEL_T ? (oend - o0) : PANEL_T;
-    if (ext <= 0 && !(t == 0 && k0 == 0)) return; // (workgroup 0 of step 0 still factorises and parks the diagonal tile)
+    const bool from_dws = k0 > 0 || pre_lu != 0; // the factorised diagonal tile is in dws (look-ahead of the previous step / k_diag0)
+    if (ext <= 0 && (from_dws || t != 0)) return; // (workgroup 0 of step 0 still factorises and parks the diagonal tile)
     double *Lrow = A.at(o0 + tid, k0);                      // L tile: column k0 + u of this thread's row at Lrow[u * lstr]
     const int64_t lstr = (o0 + tid) >= f ? A.p : A.ld;
     const bool lmixed = o0 < f && o0 + ext > f;             // (workgroup-uniform)
@@ -423,7 +463,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     //  the factorised diagonal tile of steps k0 > 0 and its row interchanges are requested first, in the same round trip)
     double tv[NB * NB / PANEL_T];
     int32_t lpv = 0;
-    if (k0 > 0) {
+    if (from_dws) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
 #pragma unroll
         for (int u = 0; u < NB * NB / PANEL_T; u++) {
@@ -470,7 +510,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     }
     // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
     //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
-    if (k0 > 0) {
+    if (from_dws) {
 #pragma unroll
         for (int u = 0; u < NB * NB / PANEL_T; u++) {
             const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
@@ -510,7 +550,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         }
     }
     __syncthreads();
-    if (t == 0 && k0 == 0) {
+    if (t == 0 && !from_dws) {
         double *dw = dws + (int64_t)slot * NB * NB; // step 0 uses buffer 0
         for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
         if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];

@@ -184,6 +184,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
     // Maximum-product matching + scaling (matching.cpp) when the numbers are known and the diagonal is weak: the
@@ -862,14 +863,21 @@ int32_t Solver::run_factor() {
         int32_t k0 = 0;
         for (const StepPlan &st : L.steps) {
             const FrontDesc *lfd = d_bigfd + L.bigfd_off; // descriptors of the level's tiled fronts, in slot order
+            // step 0 of a level with many tiled fronts: the first diagonal tiles are factorised once, by a launch of their own (k_diag0)
+            const int32_t pre_lu = (k0 == 0 && st.n_panel >= diag0_min_panels) ? 1 : 0;
+            if (pre_lu) {
+                if (S.sym_mode) hipLaunchKernelGGL(k_diag0<true>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else hipLaunchKernelGGL(k_diag0<false>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                launches++;
+            }
             if (S.sym_mode) {
                 hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
-                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
                 if (st.n_update > 0) hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                    d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             } else {
                 hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
-                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
                 hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                    d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             }

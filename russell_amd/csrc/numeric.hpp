@@ -162,6 +162,7 @@ class Solver {
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream
+    int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
     // Tiled path: fronts with at least upd_g4 (upd_g8, upd_g16) rows apply 4 (8, 16) panels per pass over the trailing matrix instead of 2:

@@ -518,7 +518,9 @@ def test_small_front_schedules_are_bitwise_equivalent(monkeypatch):
     xs = P.manufactured_solution(n)
     b = P.csr_matvec(n, rp, ci, v, xs)
     ref = None
-    for env in ({}, {"HIPMF_SMALL_WIDE": "0"}, {"HIPMF_SMALL_WIDE": "1000000"}, {"HIPMF_SMALL_SPLIT": "0"}, {"HIPMF_SMALL_SPLIT": "40", "HIPMF_SMALL_WIDE": "0"}):
+    # (k_diag0: the first diagonal tile of the tiled fronts factorised by a launch of its own or inside every panel workgroup)
+    for env in ({}, {"HIPMF_SMALL_WIDE": "0"}, {"HIPMF_SMALL_WIDE": "1000000"}, {"HIPMF_SMALL_SPLIT": "0"}, {"HIPMF_SMALL_SPLIT": "40", "HIPMF_SMALL_WIDE": "0"},
+                {"HIPMF_DIAG0_MIN": "1"}, {"HIPMF_DIAG0_MIN": "100000000"}):
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         s = Hipmf()
