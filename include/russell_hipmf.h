@@ -240,6 +240,25 @@ int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_
 int32_t hipmf_device_mfma_rate(int32_t workgroups, int32_t iters, double *tflops);
 int32_t hipmf_set_device(int32_t device); /* selects the device later solver_hipmf_new() calls of this thread bind to */
 
+/* ---- finite-difference Laplacian assembled on the device -------------------------------------------------
+ * Replaces, for callers that keep the matrix in HBM, Fdm2d::get_matrices_sps of russell_pde
+ * (/root/reference/russell_pde/src/fdm_2d.rs:603-649; molecule :376-386; mirrored / wrapped neighbours :944-979; local numbering
+ * russell_pde/src/equation_handler.rs:153-190): the COO triplets of K-bar (unknown x unknown) and K-check (unknown x prescribed)
+ * in the reference's order -- unknown nodes ascending, per node CUR, LEF, RIG, BOT, TOP -- duplicates of mirrored ghost nodes kept.
+ *   nz = 1: the reference's 2D operator; nz > 1: the 7-point analogue (two more molecule entries: the z neighbours)
+ *   sym: 0 every entry (Sym::No / YesFull), 1 lower triangle (Sym::YesLower), 2 upper triangle (Sym::YesUpper)
+ *   prescribed: HOST array of nx*ny*nz bytes, non-zero = node with an essential boundary condition (NULL: none)
+ * hipmf_fdm_new returns NULL on invalid sizes or allocation failure.  The *_device calls write DEVICE arrays of the sizes reported by
+ * hipmf_fdm_dims (the K-check pointers may be NULL when np = 0); indices are the local numbers iu / ip.  Values can be regenerated
+ * for new coefficients without touching the structure and handed to solver_hipmf_factorize_mapped_device. */
+void *hipmf_fdm_new(int32_t nx, int32_t ny, int32_t nz, int32_t periodic_x, int32_t periodic_y, int32_t periodic_z, int32_t sym,
+                    const uint8_t *prescribed);
+void hipmf_fdm_drop(void *fdm);
+int32_t hipmf_fdm_dims(const void *fdm, int64_t *nu, int64_t *np, int64_t *nnz_bar, int64_t *nnz_check);
+int32_t hipmf_fdm_structure_device(const void *fdm, int32_t *d_bar_i, int32_t *d_bar_j, int32_t *d_check_i, int32_t *d_check_j);
+int32_t hipmf_fdm_values_device(const void *fdm, double dx, double dy, double dz, double kx, double ky, double kz, double alpha,
+                                double *d_bar_values, double *d_check_values);
+
 #ifdef __cplusplus
 }
 #endif

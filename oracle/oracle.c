@@ -552,3 +552,69 @@ double oracle_lu_rcond(const OracleLU *f) {
     if (f->max_abs_pivot == 0.0 || !isfinite(f->min_abs_pivot)) return 0.0;
     return f->min_abs_pivot / f->max_abs_pivot;
 }
+
+/* ---- finite-difference Laplacian: the K-bar / K-check triplets of Fdm2d::get_matrices_sps -----------------------------------
+ * Plain restatement of /root/reference/russell_pde/src/fdm_2d.rs:603-649 (loop over the unknown nodes and their molecule),
+ * :376-386 (molecule), :944-979 (mirrored / wrapped ghost nodes) and equation_handler.rs:153-190 (local numbers iu / ip).
+ * nz > 1: the 7-point analogue with the same rules along z (the reference has no 3D operator; checker of the repo's extension).
+ * Pinned on the dense matrices the reference's own tests print (fdm_2d.rs:1040-1207 -> tests/golden/fdm2d_reference_cases.json).
+ * Output arrays must hold 7 entries per node; returns nnz(K-bar), *nnz_check = nnz(K-check); local (ntot int32) = iu or ip. */
+int64_t oracle_fdm_sps(int32_t nx, int32_t ny, int32_t nz, int32_t px, int32_t py, int32_t pz, int32_t sym, const uint8_t *presc,
+                       double dx, double dy, double dz, double kx, double ky, double kz, double alpha, int32_t *local,
+                       int32_t *bar_i, int32_t *bar_j, double *bar_v, int32_t *chk_i, int32_t *chk_j, double *chk_v, int64_t *nnz_check) {
+    const int64_t nxy = (int64_t)nx * ny, ntot = nxy * nz;
+    int32_t iu = 0, ip = 0;
+    for (int64_t e = 0; e < ntot; e++) local[e] = (presc && presc[e]) ? ip++ : iu++;
+    const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+    double mol[7];
+    mol[0] = 2.0 * (kx / dx2 + ky / dy2 + (nz > 1 ? kz / dz2 : 0.0));
+    mol[1] = mol[2] = -kx / dx2;
+    mol[3] = mol[4] = -ky / dy2;
+    mol[5] = mol[6] = nz > 1 ? -kz / dz2 : 0.0;
+    const int nb = nz > 1 ? 7 : 5;
+    int64_t nbar = 0, nchk = 0;
+    for (int64_t m = 0; m < ntot; m++) {
+        if (presc && presc[m]) continue;
+        const int32_t i = (int32_t)(m % nx), j = (int32_t)((m / nx) % ny), k = (int32_t)(m / nxy);
+        int64_t nn[7];
+        nn[0] = m;
+        if (px) {
+            nn[1] = i != 0 ? m - 1 : m + (nx - 1);
+            nn[2] = i != nx - 1 ? m + 1 : m - (nx - 1);
+        } else {
+            nn[1] = i != 0 ? m - 1 : m + 1;
+            nn[2] = i != nx - 1 ? m + 1 : m - 1;
+        }
+        if (py) {
+            nn[3] = j != 0 ? m - nx : m + (int64_t)(ny - 1) * nx;
+            nn[4] = j != ny - 1 ? m + nx : m - (int64_t)(ny - 1) * nx;
+        } else {
+            nn[3] = j != 0 ? m - nx : m + nx;
+            nn[4] = j != ny - 1 ? m + nx : m - nx;
+        }
+        if (pz) {
+            nn[5] = k != 0 ? m - nxy : m + (int64_t)(nz - 1) * nxy;
+            nn[6] = k != nz - 1 ? m + nxy : m - (int64_t)(nz - 1) * nxy;
+        } else {
+            nn[5] = k != 0 ? m - nxy : m + nxy;
+            nn[6] = k != nz - 1 ? m + nxy : m - nxy;
+        }
+        for (int b = 0; b < nb; b++) {
+            const int64_t n = nn[b];
+            double val = mol[b];
+            if (m == n) val += alpha;
+            if (!px && (i == 0 || i == nx - 1)) val /= 2.0;
+            if (!py && (j == 0 || j == ny - 1)) val /= 2.0;
+            if (nz > 1 && !pz && (k == 0 || k == nz - 1)) val /= 2.0;
+            if (presc && presc[n]) {
+                chk_i[nchk] = local[m], chk_j[nchk] = local[n], chk_v[nchk] = val;
+                nchk++;
+            } else if (!((sym == 1 && m < n) || (sym == 2 && m > n))) {
+                bar_i[nbar] = local[m], bar_j[nbar] = local[n], bar_v[nbar] = val;
+                nbar++;
+            }
+        }
+    }
+    *nnz_check = nchk;
+    return nbar;
+}

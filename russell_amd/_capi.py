@@ -70,6 +70,12 @@ SYMBOLS = {
     "hipmf_device_copy_bandwidth": (C.c_int32, [C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "hipmf_device_mfma_rate": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "hipmf_set_device": (C.c_int32, [C.c_int32]),
+    "hipmf_fdm_new": (C.c_void_p, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hipmf_fdm_drop": (None, [C.c_void_p]),
+    "hipmf_fdm_dims": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hipmf_fdm_structure_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hipmf_fdm_values_device": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                            C.c_void_p, C.c_void_p]),
 }
 
 _cache = {}

@@ -161,6 +161,10 @@ class Hipmf:
     def factorize_device(self, d_values):
         return self.lib.solver_hipmf_factorize_device(self.h, d_values)
 
+    def factorize_mapped_device(self, d_input_values):
+        """Numeric factorisation from a DEVICE array of input values (e.g. COO triplets) through the installed value map."""
+        return self.lib.solver_hipmf_factorize_mapped_device(self.h, d_input_values)
+
     def factor_buffers(self):
         """(pointer, bytes) of the device buffers that hold the numeric factor: persistent part of the front pool, local row
         interchanges, scaling, pivots.  A peer that ran `initialize` on the same structure can be handed their contents and then

@@ -34,7 +34,7 @@ def emu_lib():
     Used by the CPU tests of kernel logic and of the host layers above the C-ABI; never part of the product."""
     import subprocess
 
-    srcs = [os.path.join(CSRC, f) for f in ("symbolic.cpp", "matching.cpp", "numeric.cpp", "interface_hipmf.cpp", "interface_complex_hipmf.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("symbolic.cpp", "matching.cpp", "numeric.cpp", "interface_hipmf.cpp", "interface_complex_hipmf.cpp", "fdm_device.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     deps += [os.path.join(ROOT, "tools", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "tools", "hipemu", "hipmf_device_rt.h")]
     if not os.path.exists(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
