@@ -273,16 +273,17 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
                 const int myq = (tid < nbatch && d_m == 1) ? A.rel[d_rel] : -1;
                 const double myv = myq >= 0 ? pool[d_cb] : 0.0;
                 for (int l = 0; l < nbatch; l++) {
-                    const int q = __shfl(myq, l);
-                    const double v = __shfl(myv, l);
+                    const int q = wave_bcast_i32(myq, l);
+                    const double v = wave_bcast(myv, l);
                     if (tid == 0 && q >= 0) sm[q + q * ld] += v;
                 }
                 wave_sync();
                 continue;
             }
             for (int cl = 0; cl < nbatch; cl++) {
-                const int64_t cbo = __shfl(d_cb, cl), ldc = __shfl(d_ldc, cl), relo = __shfl(d_rel, cl);
-                const int mc = __shfl(d_m, cl);
+                // (cl is wave-uniform: v_readlane broadcasts)
+                const int64_t cbo = wave_bcast_i64(d_cb, cl), ldc = wave_bcast_i64(d_ldc, cl), relo = wave_bcast_i64(d_rel, cl);
+                const int mc = wave_bcast_i32(d_m, cl);
                 if (mc == 0) continue; // (wave-uniform)  mc <= f <= 64
                 const double *CB = pool + cbo;
                 const int sh = mc <= 16 ? 4 : (mc <= 32 ? 5 : 6);

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) k_fwd(const int32_t *__restrict__ list, co
     // row interchanges of the pivot block, then y1 = L11^{-1} (P w1) column by column, u = w2 - L21 y1
     double v = (tid < p) ? w[lperm[fd.first + tid]] : ((tid < f) ? w[tid] : 0.0);
     for (int j = 0; j < p; j++) {
-        const double vj = __shfl(v, j);
+        const double vj = wave_bcast(v, j);
         if (tid > j && tid < f) v -= P[tid + j * ldp] * vj;
     }
     if (tid < p) xs[tid] = v;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) k_bwd(const int32_t *__restrict__ list, co
     // x1 = U11^{-1} t: columns from right to left among lanes 0..p-1
     for (int j = p - 1; j >= 0; j--) {
         if (tid == j) v /= P[j + j * ldp];
-        const double vj = __shfl(v, j);
+        const double vj = wave_bcast(v, j);
         if (tid < j) v -= P[tid + j * ldp] * vj;
     }
     if (tid < p) xs[tid] = v;

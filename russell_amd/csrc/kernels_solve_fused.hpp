@@ -104,10 +104,10 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
 #pragma unroll
             for (int c = 0; c < K; c++) add[c] = (c < nk) ? w[c][lane] : 0.0;
             for (int l = 0; l < nbatch; l++) {
-                const int r = __shfl(myr, l);
+                const int r = wave_bcast_i32(myr, l);
 #pragma unroll
                 for (int c = 0; c < K; c++) {
-                    const double v = __shfl(myv[c], l);
+                    const double v = wave_bcast(myv[c], l);
                     if (lane == r) add[c] += v;
                 }
             }
@@ -118,8 +118,9 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             continue;
         }
         for (int cl = 0; cl < nbatch; cl++) {
-            const int64_t woff = __shfl(c_woff, cl), rowptr = __shfl(c_rowptr, cl);
-            const int cp = __shfl(c_p, cl), cm = __shfl(c_m, cl);
+            // (cl is wave-uniform: v_readlane, not a trip through the LDS crossbar)
+            const int64_t woff = wave_bcast_i64(c_woff, cl), rowptr = wave_bcast_i64(c_rowptr, cl);
+            const int cp = wave_bcast_i32(c_p, cl), cm = wave_bcast_i32(c_m, cl);
             if (lane < cm) { // cm <= f <= 64
                 const int r = rel[rowptr + lane];
 #pragma unroll
@@ -142,7 +143,7 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             const int j = j0 + q;
 #pragma unroll
             for (int c = 0; c < K; c++) {
-                const double vj = __shfl(v[c], j & 63);
+                const double vj = wave_bcast(v[c], j & 63); // (j is wave-uniform: v_readlane)
                 if (lane > j) v[c] -= a[q] * vj; // a[q] == 0 for j >= p and for lanes >= f
             }
         }
@@ -227,7 +228,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
 #pragma unroll
                 for (int c = 0; c < K; c++) {
                     if (lane == j) v[c] /= a[q];
-                    const double vj = __shfl(v[c], j);
+                    const double vj = wave_bcast(v[c], j);
                     if (lane < j) v[c] -= a[q] * vj;
                 }
             }

@@ -29,6 +29,11 @@ __device__ __forceinline__ double wave_bcast(double v, int src) {
 }
 
 __device__ __forceinline__ int wave_bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ long long wave_bcast_i64(long long v, int src) {
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, src);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 // tells the compiler that a value equal on all lanes is wave-uniform (moves it to an SGPR)
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -31,6 +31,7 @@ inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
 inline double wave_bcast(double v, int src) { return __shfl(v, src); }
 
 inline int wave_bcast_i32(int v, int src) { return __shfl(v, src); }
+inline long long wave_bcast_i64(long long v, int src) { return __shfl(v, src); }
 inline int wave_uniform(int v) { return v; }
 
 inline unsigned long long wave_max_u64(unsigned long long key) {
