@@ -184,6 +184,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
+    if (const char *e = getenv("HIPMF_SF_BIG_FRONT")) sf_big_front = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -604,6 +606,10 @@ int32_t Solver::upload_plan() {
         auto kind_of = [&](int32_t s, bool forward) {
             const int32_t len = forward ? S.npiv(s) : S.fsize(s);
             if (!forward && S.sym_mode) return 4; // transposed GEMV of the L D L^T fronts: 16 columns of E per workgroup
+            // fronts of thousands of rows: every slab workgroup gathers ALL children's update vectors, so 16-row slabs (625 of them
+            // for 10 000 rows) re-read them hundreds of times; 64-row slabs still give >= 32 workgroups per front
+            // (3D 100^3: pass pair 3.44 -> 3.33 ms, 64 right-hand sides 182 -> 160 ms)
+            if (forward && sf_big_rows > 0 && S.fsize(s) >= sf_big_front) return sf_big_rows;
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
         };
         auto emit_level = [&](int32_t l, bool forward) {
