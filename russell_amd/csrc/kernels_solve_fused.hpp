@@ -255,14 +255,14 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
 // Sixteen unconditional loads are in flight per lane (then eight, then the last partial group of eight with clamped
 // addresses: a loop of predicated loads compiles to a wait per load); the order of the additions is the one of
 // kernels_solve.hpp's strided_dot: even positions into acc0, odd ones into acc1, the tail into acc0.
-template <int K>
+template <int K, bool WIDE = (K == 1)>
 __device__ __forceinline__ void sf_dot(double (&acc0)[K], double (&acc1)[K], const double *__restrict__ col, int64_t ld, const double *w, int wld,
                                        int c0, int j0, int j1, int step) {
     int j = j0;
     const int nfull = (j1 - j0 + step - 1) / step / 8 * 8; // positions covered by whole groups of 8
     const int jend8 = j0 + nfull * step;
     // (K > 1: eight in flight -- the blocked instances sit at the edge of a register-occupancy step)
-    for (; K == 1 && j + 15 * step < jend8; j += 16 * step) {
+    for (; WIDE && j + 15 * step < jend8; j += 16 * step) {
         double e[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) e[u] = col[(int64_t)(j + u * step) * ld];
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
             __syncthreads();
         }
         if (cm_max <= 256)
-            sf_children<(K == 1 ? 8 : 4), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+            sf_children<(K == 1 ? 8 : 2), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         else
             sf_children<2, (K == 1 ? 4 : 2), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         if (nch == 0) __syncthreads();
@@ -507,9 +507,9 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
                 acc0[0] += e_pre[K == 1 ? u : 0] * wc[g + u * G];
                 acc1[0] += e_pre[K == 1 ? u + 1 : 0] * wc[g + (u + 1) * G];
             }
-            sf_dot<K>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g + NPRE * G, c1, G);
+            sf_dot<K, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g + NPRE * G, c1, G);
         } else if (r < r1)
-            sf_dot<K>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
+            sf_dot<K, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
 #pragma unroll
