@@ -83,9 +83,12 @@ __global__ void __launch_bounds__(64) k_bwd(const int32_t *__restrict__ list, co
     }
     for (int off = 1 << sh; off < 64; off <<= 1) acc += __shfl_xor(acc, off); // sum over the column groups (fixed order)
     double v = (tid < p) ? xs[tid] - acc : 0.0;
-    // x1 = U11^{-1} t: columns from right to left among lanes 0..p-1
+    // x1 = U11^{-1} t: columns from right to left among lanes 0..p-1.  The reciprocal of the lane's own pivot is formed once: a
+    // double-precision division per pivot (a dozen quarter-rate instructions executed by the whole wavefront) was the larger part
+    // of this loop's instruction count.
+    const double inv_d = (tid < p) ? 1.0 / P[tid + tid * ldp] : 1.0;
     for (int j = p - 1; j >= 0; j--) {
-        if (tid == j) v /= P[j + j * ldp];
+        if (tid == j) v *= inv_d;
         const double vj = wave_bcast(v, j);
         if (tid < j) v -= P[tid + j * ldp] * vj;
     }

@@ -187,6 +187,9 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
         const int j = p - 1 - q;
         a[q] = (lane < p && j >= 0) ? F[lane + (int64_t)j * f] : 1.0;
     }
+    // the reciprocal of the lane's own pivot, once (a division per pivot step was the larger part of the substitution's instructions);
+    // requested and formed before the wait
+    const double inv_d = (lane < p) ? 1.0 / F[lane + (int64_t)lane * f] : 1.0;
     if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
     wave_sync();
     if (lane < m) {
@@ -227,7 +230,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
             if (j >= 0) { // wave-uniform
 #pragma unroll
                 for (int c = 0; c < K; c++) {
-                    if (lane == j) v[c] /= a[q];
+                    if (lane == j) v[c] *= inv_d;
                     const double vj = wave_bcast(v[c], j);
                     if (lane < j) v[c] -= a[q] * vj;
                 }
