@@ -5,7 +5,9 @@
 //          f = p + m (p pivot columns, m off-diagonal rows) for every supernode s.
 //          * small fronts (f <= SMALL_F): a column-major f x f block at pool + off in the PERSISTENT part, ld = f.  After
 //            factorisation the first p columns hold L11\U11 and L21, rows 0..p of the other columns hold U12, the trailing
-//            m x m block is the contribution block the parent consumes (extend-add).
+//            m x m block is the contribution block the parent consumes (extend-add).  The rows of U are stored once more, packed:
+//            [U11 | U12] as a p x f block with stride p at pool + epoff (PERSISTENT; fronts with m = 0 have none): the backward
+//            solve reads that block only.
 //          * big fronts (f > SMALL_F) are factorised AUGMENTED: the partial LU runs on the (f+p) x (f+p) matrix
 //            [F  Ic; Ir  0] (Ic = [I; 0], Ir = [I, 0]) and leaves
 //                E  = [inv(L11) P ; -L21 inv(L11) P]      f x p, column-major, stride ld, at pool + eoff   (PERSISTENT)
@@ -65,7 +67,7 @@ struct FrontDesc {
     int32_t ld;     // column stride of the f x f block at `off` and of E (>= f; small fronts: f)
     int32_t ugroup; // tiled path: 32-pivot panels per read-modify-write pass over the trailing matrix (2, 4, 8 or 16)
     int64_t eoff;   // big fronts: offset of E (f x p, ld f); -1 for small fronts
-    int64_t epoff;  // big fronts, LU mode: offset of E' (p x f, ld p); -1 otherwise
+    int64_t epoff;  // big fronts, LU mode: offset of E' (p x f, ld p); small fronts with m > 0: packed rows of U (p x f, ld p); else -1
     int32_t flags;  // FD_BIG | FD_SYM
     int32_t pad;
 };

@@ -321,6 +321,10 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
         }
         for (; c < f; c += NW) F[tid + c * f] = sm[tid + c * ld];
     }
+    if (fd.epoff >= 0 && tid < p) { // packed rows of U for the backward solve (lane = row: p-entry contiguous pieces)
+        double *Up = pool + fd.epoff;
+        for (int c = grp; c < f; c += NW) Up[tid + c * p] = sm[tid + c * ld];
+    }
     if (grp == 0 && tid < p) {
         lperm[fd.first + tid] = lp[tid];
         diag[fd.first + tid] = sm[tid + tid * ld];

@@ -63,23 +63,26 @@ __global__ void __launch_bounds__(64) k_bwd(const int32_t *__restrict__ list, co
     // lanes are arranged as (row i, column group jq): pw = p rounded up to 16 / 32 / 64 lanes per column
     const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
     const int i = tid & ((1 << sh) - 1), jq = tid >> sh, ng = 64 >> sh;
+    // (the rows of U come from the packed p x f copy when the front has one -- m > 0 --, else from the front itself: same values)
+    const double *Ub = fd.epoff >= 0 ? pool + fd.epoff : F;
+    const int64_t us = fd.epoff >= 0 ? p : f;
     if (tid < m) xg[tid] = x[rws[tid]];
     for (int j = jq; j < p; j += ng)
-        if (i < p) P[i + j * ldp] = F[i + (int64_t)j * f];
+        if (i < p) P[i + j * ldp] = Ub[i + (int64_t)j * us];
     __syncthreads();
     // t = y1 - U12 x2: U12 is streamed from HBM exactly once, ng columns per pass, 4 passes in flight
     double acc = 0.0;
     if (i < p) {
-        const double *Ui = F + i + (int64_t)p * f;
+        const double *Ui = Ub + i + (int64_t)p * us;
         int j = jq;
         for (; j + 3 * ng < m; j += 4 * ng) {
-            const double e0 = Ui[(int64_t)j * f], e1 = Ui[(int64_t)(j + ng) * f], e2 = Ui[(int64_t)(j + 2 * ng) * f], e3 = Ui[(int64_t)(j + 3 * ng) * f];
+            const double e0 = Ui[(int64_t)j * us], e1 = Ui[(int64_t)(j + ng) * us], e2 = Ui[(int64_t)(j + 2 * ng) * us], e3 = Ui[(int64_t)(j + 3 * ng) * us];
             acc += e0 * xg[j];
             acc += e1 * xg[j + ng];
             acc += e2 * xg[j + 2 * ng];
             acc += e3 * xg[j + 3 * ng];
         }
-        for (; j < m; j += ng) acc += Ui[(int64_t)j * f] * xg[j];
+        for (; j < m; j += ng) acc += Ui[(int64_t)j * us] * xg[j];
     }
     for (int off = 1 << sh; off < 64; off <<= 1) acc += __shfl_xor(acc, off); // sum over the column groups (fixed order)
     double v = (tid < p) ? xs[tid] - acc : 0.0;

@@ -178,18 +178,21 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     const int i = lane & ((1 << sh) - 1), jq = lane >> sh, ng = 64 >> sh;
     // read-only factor data on their way before the wait: the first 8 of this lane's U12 entries and the
     // rightmost 16 columns of its row of U11
-    const double *Ui = F + i + (int64_t)p * f;
+    // (the rows of U come from the packed p x f copy when the front has one -- m > 0 --, else from the front itself: same values)
+    const double *Ub = fd.epoff >= 0 ? pool + fd.epoff : F;
+    const int64_t us = fd.epoff >= 0 ? p : f; // column stride of U
+    const double *Ui = Ub + i + (int64_t)p * us;
     double e[8], a[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) e[k] = (i < p && jq + k * ng < m) ? Ui[(int64_t)(jq + k * ng) * f] : 0.0;
+    for (int k = 0; k < 8; k++) e[k] = (i < p && jq + k * ng < m) ? Ui[(int64_t)(jq + k * ng) * us] : 0.0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int j = p - 1 - q;
-        a[q] = (lane < p && j >= 0) ? F[lane + (int64_t)j * f] : 1.0;
+        a[q] = (lane < p && j >= 0) ? Ub[lane + (int64_t)j * us] : 1.0;
     }
     // the reciprocal of the lane's own pivot, once (a division per pivot step was the larger part of the substitution's instructions);
     // requested and formed before the wait
-    const double inv_d = (lane < p) ? 1.0 / F[lane + (int64_t)lane * f] : 1.0;
+    const double inv_d = (lane < p) ? 1.0 / Ub[lane + (int64_t)lane * us] : 1.0;
     if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
     wave_sync();
     if (lane < m) {
@@ -210,7 +213,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
                     if (c < nk) acc[c] += e[k] * xg[c][jq + k * ng];
             }
         for (int j = jq + 8 * ng; j < m; j += ng) {
-            const double u = Ui[(int64_t)j * f];
+            const double u = Ui[(int64_t)j * us];
 #pragma unroll
             for (int c = 0; c < K; c++)
                 if (c < nk) acc[c] += u * xg[c][j];
@@ -240,7 +243,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int j = jhi - 17 - q;
-                a[q] = (lane < p && j >= 0) ? F[lane + (int64_t)j * f] : 1.0;
+                a[q] = (lane < p && j >= 0) ? Ub[lane + (int64_t)j * us] : 1.0;
             }
         }
     }

@@ -706,7 +706,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             const double f = p + m;
             rows_total += m;
             // persistent part only (a lower bound: the arena of the working blocks is planned once the levels are known)
-            pool_total += f > (double)opt.augment_above ? f * p * (opt.symmetric_ldlt ? 1.0 : 2.0) : f * f;
+            pool_total += f > (double)opt.augment_above ? f * p * (opt.symmetric_ldlt ? 1.0 : 2.0) : f * f + p * f;
         }
         S.pool_estimate_bytes = 8.0 * pool_total;
         if (rows_total > 1.0e9 || (opt.pool_limit_bytes > 0.0 && 8.0 * pool_total > opt.pool_limit_bytes)) return -40;
@@ -832,6 +832,9 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             if (!S.sym_mode) S.ep_off[s] = pers, pers += round16(p * f);
         } else {
             S.front_off[s] = pers, pers += f * f;
+            // the rows of U of a small front once more, packed (p x f, stride p): the backward solve reads [U11 | U12] as one
+            // contiguous block instead of p-entry pieces of f columns (which drags the whole f x f block through the cache lines)
+            if (p > 0 && m > 0) S.ep_off[s] = pers, pers += p * f;
         }
         S.nnz_l += p * (p - 1) / 2 + p * m;
         S.nnz_u += p * (p + 1) / 2 + p * m;
