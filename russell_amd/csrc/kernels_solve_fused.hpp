@@ -57,7 +57,8 @@ __device__ __forceinline__ bool sf_wait(const int *cnt, int need, int *err) {
 // All kernels are templates on K = the number of right-hand sides a launch carries (1: the instances the
 // benchmark path uses; SF_KMAX: the many-RHS instances, which read every factor entry ONCE for K columns -- the
 // solves are HBM-bound, so K columns cost little more than one).  Column c of x lives at x + c * xstr, its solve
-// workspace at work + c * wstr; nk <= K columns are live.  Per column the arithmetic and its order are those of K = 1.
+// workspace at work + c * wstr; nk <= K columns are live.  Small fronts: per column the arithmetic and its order are those of K = 1;
+// big-front slabs of the blocked instances run on MFMA tiles (sf_mma_chunk): another summation order, equal to rounding.
 
 // ---- forward step of one small front by one wavefront; w = K x 64 doubles of LDS owned by this wave ----
 template <int K>
@@ -402,17 +403,96 @@ __device__ __forceinline__ double sf_group_sum(const double *red, int rows, int 
     return tsum[0];
 }
 
+// ---- blocked instances (K > 1): the slab's dot products on v_mfma_f64_16x16x4_f64 ----
+// A slab of `rows` = 16 nsub outputs against K <= 16 right-hand sides is nsub tiles  Y(16 x 16) += M(16 x 4) W(4 x 16)  per four
+// positions of the contraction index: one load of M per lane and MFMA instead of K multiply-adds and K LDS reads per loaded entry
+// (the scalar form made the blocked instances instruction-bound: 8 columns cost 3x one column).  Half of every MFMA works on the
+// zero columns K..15; at 64 cycles per instruction the matrix pipe still takes 512 B of M per 64 cycles and SIMD, above what HBM
+// delivers.  The summation order differs from the single-column kernels': blocked and single solves agree to rounding, not bit for bit.
+//   TRANS = false:  output o, position k  ->  M[o + k ld]   (forward E, backward E': outputs run along memory)
+//   TRANS = true:   output o, position k  ->  M[k + o ld]   (backward E^T of the L D L^T fronts: positions run along memory)
+// Work split over the four wavefronts: nsub >= 4: wave w owns the tiles w, w + 4 for every position; nsub < 4: 4 / nsub waves share a
+// tile and split the positions of each chunk into contiguous parts (partial tiles are added in a fixed order by sf_mma_finish).
+// w: the chunk [c0, c1) of the K vectors in LDS, column c at w + c wld, position k at index k - c0.
+template <bool TRANS>
+__device__ __forceinline__ void sf_mma_chunk(f64x4 (&acc)[2], const double *__restrict__ M, int64_t ld, const double *w, int wld, int c0, int c1,
+                                             int nk, int nsub, int nout, int wave, int lane) {
+    const int o = lane & 15, kk = lane >> 4;
+    const int ksplit = nsub >= 4 ? 1 : 4 / nsub;
+    const int part = nsub >= 4 ? 0 : wave / nsub;
+    int ka = c0, kb = c1;
+    if (ksplit > 1) {
+        const int len = ((c1 - c0 + ksplit - 1) / ksplit + 3) & ~3;
+        ka = c0 + part * len;
+        kb = ka + len < c1 ? ka + len : c1;
+    }
+    const double wmask = o < nk ? 1.0 : 0.0; // (columns >= nk of the W tile are zero)
+    const double *wl = w + (o < nk ? o : 0) * wld - c0;
+#pragma unroll
+    for (int tq = 0; tq < 2; tq++) {
+        const int tile = nsub >= 4 ? wave + 4 * tq : wave % nsub;
+        if (tile >= nsub || (nsub < 4 && tq > 0)) continue; // (wave-uniform)
+        const int oo = 16 * tile + o;
+        const int oc = oo < nout ? oo : nout - 1; // outputs past the slab's end: clamped address, result discarded
+        const double *Mo = TRANS ? M + (int64_t)oc * ld : M + oc;
+        const int64_t ks = TRANS ? 1 : ld;
+        int k = ka;
+        for (; k + 32 <= kb; k += 32) { // eight loads of M in flight per lane
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = Mo[(int64_t)(k + 4 * u + kk) * ks];
+#pragma unroll
+            for (int u = 0; u < 8; u++) b[u] = wl[k + 4 * u + kk] * wmask;
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[tq] = mfma_f64_16x16x4(a[u], b[u], acc[tq]);
+        }
+        for (; k < kb; k += 4) {
+            const int kq = k + kk;
+            const bool in = kq < kb;
+            const double a = Mo[(int64_t)(in ? kq : kb - 1) * ks];
+            const double b = in ? wl[kq] * wmask : 0.0;
+            acc[tq] = mfma_f64_16x16x4(a, b, acc[tq]);
+        }
+    }
+}
+
+// The tiles go to LDS (mt: 8 tiles x 256 doubles; tile slot = tile + nsub * part), then thread rr < rows adds the parts of its row in a
+// fixed order: result of output rr, column c.  Call sf_mma_store, __syncthreads(), then sf_mma_sum.
+__device__ __forceinline__ void sf_mma_store(const f64x4 (&acc)[2], double *mt, int nsub, int wave, int lane) {
+#pragma unroll
+    for (int tq = 0; tq < 2; tq++) {
+        const int tile = nsub >= 4 ? wave + 4 * tq : wave % nsub;
+        if (tile >= nsub || (nsub < 4 && tq > 0)) continue;
+        const int slot = nsub >= 4 ? tile : tile + nsub * (wave / nsub);
+#pragma unroll
+        for (int g = 0; g < 4; g++) mt[slot * 256 + ((lane >> 4) + 4 * g) * 16 + (lane & 15)] = acc[tq][g]; // [output][column]
+    }
+}
+__device__ __forceinline__ double sf_mma_sum(const double *mt, int nsub, int rr, int c) {
+    const int tile = rr >> 4, o = rr & 15;
+    if (nsub >= 4) return mt[tile * 256 + o * 16 + c];
+    double s = mt[tile * 256 + o * 16 + c];
+    for (int part = 1; part < 4 / nsub; part++) s += mt[(tile + nsub * part) * 256 + o * 16 + c];
+    return s;
+}
+
 // Forward pass, one launch per band of levels.  sync[SF_SYNC_HEADER + s] = completed tasks of front s (zeroed before
 // every pass); *err is sticky: set when a wait timed out.
 template <bool SMALL_ONLY, int K>
-__global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+__global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
                                                    const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace) {
     constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK; // chunk of w1 per right-hand side
-    __shared__ double wv[4][K][64];
-    __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
+    // One LDS buffer, three uses that never overlap in time: a workgroup either runs four small fronts (wv: K x 64 doubles per wave)
+    // or one slab of a big front (wc: the chunk of the K vectors; mt: the slab's MFMA tiles, written after the last chunk is consumed).
+    // As separate arrays they added up to 75 KB in the blocked instance: two workgroups per CU.
+    constexpr int LDS_D = SMALL_ONLY ? 4 * K * 64 : (K * CHK > 4 * K * 64 ? K * CHK : 4 * K * 64);
+    static_assert(SMALL_ONLY || K == 1 || K * CHK >= 8 * 256, "the MFMA tiles share the chunk buffer");
+    __shared__ double lds[LDS_D];
+    double(*wv)[K][64] = reinterpret_cast<double(*)[K][64]>(lds);
+    double *wc = lds, *mt = lds;
     __shared__ double wsl[SMALL_ONLY ? 1 : K * 128];
     __shared__ double red[256];
     __shared__ int64_t cd_woff[SMALL_ONLY ? 1 : 64], cd_rel[SMALL_ONLY ? 1 : 64];
@@ -487,9 +567,9 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
     if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
     const int cm_max = cm_max_s;
-    double acc0[K], acc1[K];
-#pragma unroll
-    for (int c = 0; c < K; c++) acc0[c] = acc1[c] = 0.0;
+    double acc0[1] = {0.0}, acc1[1] = {0.0}; // (K = 1: the scalar dot products)
+    f64x4 macc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    const int nsub = (1 << sh) >> 4; // 16-output tiles of the slab
     for (int c0 = 0; c0 < jmax; c0 += CHK) {
         const int c1 = c0 + CHK < jmax ? c0 + CHK : jmax;
         // w1[c0, c1) = b1 + the children's updates to these pivot rows (children in ascending order)
@@ -501,7 +581,7 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
             __syncthreads();
         }
         if (cm_max <= 256)
-            sf_children<(K == 1 ? 8 : 2), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+            sf_children<(K == 1 ? 8 : 4), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         else
             sf_children<2, (K == 1 ? 4 : 2), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         if (nch == 0) __syncthreads();
@@ -513,21 +593,31 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
                 acc0[0] += e_pre[K == 1 ? u : 0] * wc[g + u * G];
                 acc1[0] += e_pre[K == 1 ? u + 1 : 0] * wc[g + (u + 1) * G];
             }
-            sf_dot<K, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g + NPRE * G, c1, G);
+            sf_dot<1, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g + NPRE * G, c1, G);
+        } else if (K > 1) {
+            sf_mma_chunk<false>(macc, E + r0, ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
         } else if (r < r1)
-            sf_dot<K, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
+            sf_dot<1, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
+    if (K > 1) {
+        sf_mma_store(macc, mt, nsub, wave, lane);
+        __syncthreads();
+        if (tid < (1 << sh) && r0 + tid < r1) {
+            const int ro = r0 + tid;
 #pragma unroll
-    for (int c = 0; c < K; c++) {
-        if (c < nk) { // workgroup-uniform
-            red[g * (1 << sh) + rr] = acc0[c] + acc1[c];
-            __syncthreads();
-            if (g == 0 && r < r1) {
-                const double tot = sf_group_sum(red, 1 << sh, rr, G);
-                st_agent(W + c * wstr + r, (r < p) ? tot : wsl[c * 128 + rr] + tot);
-            }
-            if (K > 1) __syncthreads();
+            for (int c = 0; c < K; c++)
+                if (c < nk) {
+                    const double tot = sf_mma_sum(mt, nsub, tid, c);
+                    st_agent(W + c * wstr + ro, (ro < p) ? tot : wsl[c * 128 + tid] + tot);
+                }
+        }
+    } else {
+        red[g * (1 << sh) + rr] = acc0[0] + acc1[0];
+        __syncthreads();
+        if (g == 0 && r < r1) {
+            const double tot = sf_group_sum(red, 1 << sh, rr, G);
+            st_agent(W + r, (r < p) ? tot : wsl[rr] + tot);
         }
     }
     if (trace && tid == 0) tr2 = dev_clock();
@@ -543,13 +633,17 @@ __global__ void __launch_bounds__(256) k_fwd_fused(const SfTask *__restrict__ ta
 // Backward pass, one launch per band of levels (tasks ordered root first).
 // SYM: instance for factors whose big fronts are L D L^T (x1 = E^T [D^{-1} y1; x2], transposed GEMV); the LU instance carries none of it.
 template <bool SMALL_ONLY, int K, bool SYM>
-__global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+__global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag) {
     constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK;
-    __shared__ double wv[4][K][64];
-    __shared__ double wc[SMALL_ONLY ? 1 : K * CHK];
+    // (one LDS buffer for the small fronts' vectors, the chunk of a big front's vectors and its MFMA tiles: see k_fwd_fused)
+    constexpr int LDS_D = SMALL_ONLY ? 4 * K * 64 : (K * CHK > 4 * K * 64 ? K * CHK : 4 * K * 64);
+    static_assert(SMALL_ONLY || K == 1 || K * CHK >= 8 * 256, "the MFMA tiles share the chunk buffer");
+    __shared__ double lds[LDS_D];
+    double(*wv)[K][64] = reinterpret_cast<double(*)[K][64]>(lds);
+    double *wc = lds, *mt = lds;
     __shared__ double red[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *done = sync + SF_SYNC_HEADER;
@@ -605,14 +699,13 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
                 if (c < nk) wc[c * CHK + tid + 256 * k] = ld_agent(x + c * xstr + xrow[k]);
         }
     __syncthreads();
-    double acc0[K], acc1[K];
-    double sacc[SYM ? SF_SYMC : 1][K];
+    // (K = 1: scalar dot products; K > 1: MFMA tiles, see sf_mma_chunk)
+    double acc0[1] = {0.0}, acc1[1] = {0.0};
+    double sacc[(SYM && K == 1) ? SF_SYMC : 1][1];
 #pragma unroll
-    for (int c = 0; c < K; c++) acc0[c] = acc1[c] = 0.0;
-#pragma unroll
-    for (int q = 0; q < (SYM ? SF_SYMC : 1); q++)
-#pragma unroll
-        for (int c = 0; c < K; c++) sacc[q][c] = 0.0;
+    for (int q = 0; q < ((SYM && K == 1) ? SF_SYMC : 1); q++) sacc[q][0] = 0.0;
+    f64x4 macc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    const int nsub = (1 << sh) >> 4; // 16-output tiles of the slab
     for (int c0 = jmin; c0 < f; c0 += CHK) {
         const int c1 = c0 + CHK < f ? c0 + CHK : f;
         if (c0 > jmin) {
@@ -625,7 +718,10 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
             }
             __syncthreads();
         }
-        if (sym) {
+        if (K > 1) {
+            if (sym) sf_mma_chunk<true>(macc, Ep + (int64_t)r0 * fd.ld, fd.ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
+            else sf_mma_chunk<false>(macc, Ep + r0, ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
+        } else if (sym) {
             // transposed GEMV: wave w owns the columns r0 + w, r0 + w + 4, ... of E (<= SF_SYMC of them: slabs of 16 rows),
             // lanes run down the column (contiguous), two positions of every column in flight per lane
             const double *wk = wc - c0;
@@ -639,13 +735,10 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
                     e[q][0] = Ec[j], e[q][1] = Ec[j + 64];
                 }
 #pragma unroll
-                for (int q = 0; q < SF_SYMC; q++)
-#pragma unroll
-                    for (int c = 0; c < K; c++)
-                        if (c < nk) {
-                            sacc[SYM ? q : 0][c] += e[q][0] * wk[c * CHK + j];
-                            sacc[SYM ? q : 0][c] += e[q][1] * wk[c * CHK + j + 64];
-                        }
+                for (int q = 0; q < SF_SYMC; q++) {
+                    sacc[(SYM && K == 1) ? q : 0][0] += e[q][0] * wk[j];
+                    sacc[(SYM && K == 1) ? q : 0][0] += e[q][1] * wk[j + 64];
+                }
             }
             if (j < c1) {
                 double e[SF_SYMC];
@@ -655,37 +748,33 @@ __global__ void __launch_bounds__(256) k_bwd_fused(const SfTask *__restrict__ ta
                     e[q] = Ep[(int64_t)(col < r1 ? col : r0) * fd.ld + j];
                 }
 #pragma unroll
-                for (int q = 0; q < SF_SYMC; q++)
-#pragma unroll
-                    for (int c = 0; c < K; c++)
-                        if (c < nk) sacc[SYM ? q : 0][c] += e[q] * wk[c * CHK + j];
+                for (int q = 0; q < SF_SYMC; q++) sacc[(SYM && K == 1) ? q : 0][0] += e[q] * wk[j];
             }
         } else if (i < r1)
-            sf_dot<K>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g, c1, G);
+            sf_dot<1>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
-    if (sym) {
+    if (K > 1) {
+        sf_mma_store(macc, mt, nsub, wave, lane);
+        __syncthreads();
+        if (tid < (1 << sh) && r0 + tid < r1) {
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk) st_agent(x + c * xstr + fd.first + r0 + tid, sf_mma_sum(mt, nsub, tid, c));
+        }
+    } else if (sym) {
         // the 64 partial sums of a column are added in a fixed (butterfly) order
 #pragma unroll
         for (int q = 0; q < SF_SYMC; q++) {
             const int col = r0 + wave + 4 * q;
-#pragma unroll
-            for (int c = 0; c < K; c++) {
-                double v = sacc[SYM ? q : 0][c];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if (c < nk && lane == 0 && col < r1) st_agent(x + c * xstr + fd.first + col, v);
-            }
+            double v = sacc[(SYM && K == 1) ? q : 0][0];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && col < r1) st_agent(x + fd.first + col, v);
         }
     } else {
-#pragma unroll
-        for (int c = 0; c < K; c++) {
-            if (c < nk) {
-                red[g * (1 << sh) + rr] = acc0[c] + acc1[c];
-                __syncthreads();
-                if (g == 0 && i < r1) st_agent(x + c * xstr + fd.first + i, sf_group_sum(red, 1 << sh, rr, G));
-                if (K > 1) __syncthreads();
-            }
-        }
+        red[g * (1 << sh) + rr] = acc0[0] + acc1[0];
+        __syncthreads();
+        if (g == 0 && i < r1) st_agent(x + fd.first + i, sf_group_sum(red, 1 << sh, rr, G));
     }
     if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();

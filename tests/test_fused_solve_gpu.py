@@ -87,9 +87,10 @@ def test_poisson3d_fronts_beyond_the_lds_staging_limit():
 
 
 @pytest.mark.parametrize("grid,nrhs", [(60, 6), (300, 9), (200, 20)])
-def test_many_rhs_blocks_equal_single_solves_bitwise(grid, nrhs):
+def test_many_rhs_blocks_agree_with_single_solves(grid, nrhs):
     # solve_many sends blocks of SF_KMAX (8) right-hand sides through the dependency-driven kernels together (the factor is read
-    # once per block); per column the arithmetic is the single-column one
+    # once per block).  The small fronts use the single-column arithmetic per column; the slabs of the big fronts run on MFMA tiles
+    # (E tile x 8 vectors), i.e. with another summation order: blocked and single solves agree to rounding, not bit for bit.
     n, rp, ci, v = P.poisson2d(grid)
     rng = np.random.default_rng(grid)
     XS = rng.standard_normal((nrhs, n))
@@ -99,6 +100,7 @@ def test_many_rhs_blocks_equal_single_solves_bitwise(grid, nrhs):
     assert s.factorize(v) == 0
     X = s.solve_many(B)
     for j in range(nrhs):
-        assert np.array_equal(X[j], s.solve(B[j]))
+        xj = s.solve(B[j])
+        assert np.max(np.abs(X[j] - xj)) <= 1e-12 * np.max(np.abs(xj))
     assert np.max(np.abs(X - XS)) / np.max(np.abs(XS)) < 1e-10
     s.close()
