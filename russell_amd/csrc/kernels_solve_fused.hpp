@@ -34,7 +34,10 @@ constexpr int SF_KMAX = 8;               // right-hand sides solved together by 
 
 struct SfTask {
     int32_t kind;       // 0: group of small fronts, one per wavefront (a, b, c, d; -1 = none)
-                        // 3..7: slab of a big front, kind = log2(rows per slab): a = front, rows [b, c)
+                        // 3..7: slab of a big front, kind = log2(rows per slab): a = front, rows [b, c); forward pass: d = number of
+                        //       ASSEMBLE tasks of the front (0: the slab gathers the children's vectors itself)
+                        // 1:    forward pass only, fronts of thousands of rows: assemble rows [b, c) of front a's vector ONCE
+                        //       (right-hand side + the children's updates, children in ascending order) for all of its slabs
     int32_t a, b, c, d;
     int32_t pad;
 };
@@ -508,6 +511,67 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         return;
     }
     if (SMALL_ONLY) return; // (never reached: the small-only instance is launched on all-small bands)
+    if (t.kind == 1) {
+        // ---- assemble rows [q0, q1) of the big front t.a: w = b (pivot rows) + the children's updates, once for all slabs.  Every
+        //      slab used to gather all children itself: hundreds of redundant gathers on fronts of thousands of rows.  The pivot part
+        //      goes back into x (the slabs read their w1 from there), the rest into the front's work vector (the slabs add E w1). ----
+        const FrontDesc fd = FD[t.a];
+        const int p = fd.p;
+        const int q0 = t.b, q1 = t.c, nq = q1 - q0; // nq <= CHK
+        double *W = work + fd.woff;
+        const int nch = fd.child_end - fd.child_begin;
+        for (int i = tid; i < nq; i += 256) {
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk) wc[c * CHK + i] = (q0 + i < p) ? ld_agent(x + c * xstr + fd.first + q0 + i) : 0.0;
+        }
+        for (int cb = 0; cb < nch; cb += 256) { // wait for the children (one per thread)
+            if (cb + tid < nch) {
+                const int ch = child_idx[fd.child_begin + cb + tid];
+                sf_wait(done + ch, need[ch], err);
+            }
+        }
+        __syncthreads();
+        __shared__ int32_t a_lo[64], a_hi[64], a_m[64];
+        __shared__ int64_t a_woff[64], a_rel[64];
+        for (int cb = 0; cb < nch; cb += 64) {
+            // the entries of up to 64 children that fall into [q0, q1): relative indices ascend, two binary searches per child
+            if (tid < 64 && cb + tid < nch) {
+                const FrontDesc cd = FD[child_idx[fd.child_begin + cb + tid]];
+                const int32_t *rl = rel + cd.rowptr;
+                a_lo[tid] = lower_bound_i32(rl, cd.m, q0);
+                a_hi[tid] = lower_bound_i32(rl, cd.m, q1);
+                a_woff[tid] = cd.woff + cd.p;
+                a_rel[tid] = cd.rowptr;
+                a_m[tid] = cd.m;
+            }
+            __syncthreads();
+            const int nb = nch - cb < 64 ? nch - cb : 64;
+            for (int k = 0; k < nb; k++) { // children in ascending order: the order fixes the floating-point sums
+                const int lo = a_lo[k], hi = a_hi[k];
+                const int64_t woff = a_woff[k], relo = a_rel[k];
+                for (int i = lo + tid; i < hi; i += 256) {
+                    const int q = rel[relo + i] - q0;
+#pragma unroll
+                    for (int c = 0; c < K; c++)
+                        if (c < nk) wc[c * CHK + q] += ld_agent(work + c * wstr + woff + i);
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < nq; i += 256) {
+#pragma unroll
+            for (int c = 0; c < K; c++)
+                if (c < nk) {
+                    if (q0 + i < p) st_agent(x + c * xstr + fd.first + q0 + i, wc[c * CHK + i]);
+                    else st_agent(W + c * wstr + q0 + i, wc[c * CHK + i]);
+                }
+        }
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) flag_add(done + t.a, 1);
+        return;
+    }
     // ---- slab [r0, r1) of the big front t.a:  [y1; -delta] = E w1,  work[r] = y1[r] (r < p) or w2[r] + (E w1)[r] ----
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (trace && tid == 0) tr0 = dev_clock();
@@ -535,12 +599,23 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
     // ---- before the wait: everything that does not depend on the children ----
     //  * the children's descriptors, one child per lane of wave 0, parked in LDS for all waves
     //  * b1 = the first chunk of x (set before the launch; the children write `work`, not x)
-    const int nch = fd.child_end - fd.child_begin;
+    const int nasm = t.d; // > 0: the front's vector is assembled by its own tasks (kind 1); this slab waits for them, not for the children
+    const int nch = nasm > 0 ? 0 : fd.child_end - fd.child_begin;
     const int ncd = nch < 64 ? nch : 64; // children with a parked descriptor
+    if (nasm > 0) {
+        if (tid == 0) sf_wait(done + t.a, nasm, err);
+        __syncthreads();
+    }
 #pragma unroll
     for (int c = 0; c < K; c++)
         if (c < nk)
             for (int i = tid; i < (jmax < CHK ? jmax : CHK); i += 256) wc[c * CHK + i] = ld_agent(x + c * xstr + fd.first + i);
+    if (nasm > 0 && r0 + (tid & 127) < r1 && r0 + (tid & 127) >= p && tid < 128) {
+        // the assembled update part of the slab's own rows (what the children sweep leaves in wsl otherwise)
+#pragma unroll
+        for (int c = 0; c < K; c++)
+            if (c < nk) wsl[c * 128 + tid] = ld_agent(W + c * wstr + r0 + tid);
+    }
     if (wave == 0) {
         int mym = 0;
         if (lane < ncd) {

@@ -186,6 +186,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
     if (const char *e = getenv("HIPMF_SF_BIG_FRONT")) sf_big_front = std::max(65, atoi(e));
+    if (const char *e = getenv("HIPMF_SF_ASM_FRONT")) sf_asm_front = atoi(e); // forward solve: fronts with at least this many rows assemble their vector once (0: never)
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -621,8 +622,14 @@ int32_t Solver::upload_plan() {
                     continue;
                 }
                 const int32_t kind = kind_of(s, forward), rows = 1 << kind, ext = forward ? S.fsize(s) : S.npiv(s);
-                need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows;
-                for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), 0, 0});
+                // forward pass of the largest fronts: the front's vector (right-hand side + children's updates) is assembled ONCE by
+                // tasks of their own, 512 rows each (the chunk the blocked instances stage in LDS); the slabs wait for those
+                int32_t nasm = 0;
+                if (forward && sf_asm_front > 0 && S.fsize(s) >= sf_asm_front && S.child_ptr[s + 1] > S.child_ptr[s]) {
+                    for (int32_t q0 = 0; q0 < ext; q0 += SF_CHUNK / 2) sf.push_back({1, s, q0, std::min(ext, q0 + SF_CHUNK / 2), 0, 0}), nasm++;
+                }
+                need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows + nasm;
+                for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), nasm, 0});
             }
             for (size_t k = 0; k < small.size(); k += 4) {
                 SfTask t = {0, small[k], -1, -1, -1, 0};

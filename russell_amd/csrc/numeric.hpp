@@ -163,6 +163,7 @@ class Solver {
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream
     int32_t sf_big_rows = 6, sf_big_front = 2048; // forward solve: fronts with at least sf_big_front rows use slabs of 2^sf_big_rows rows
+    int32_t sf_asm_front = 2048;                  // forward solve: fronts with at least this many rows assemble their vector once, in tasks of their own (0: never; then sf_big_rows applies)
     int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)

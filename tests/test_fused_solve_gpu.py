@@ -104,3 +104,32 @@ def test_many_rhs_blocks_agree_with_single_solves(grid, nrhs):
         assert np.max(np.abs(X[j] - xj)) <= 1e-12 * np.max(np.abs(xj))
     assert np.max(np.abs(X - XS)) / np.max(np.abs(XS)) < 1e-10
     s.close()
+
+
+@pytest.mark.gpu
+def test_assemble_once_tasks_give_the_same_bits(monkeypatch):
+    # forward pass of the largest fronts: the front's vector (right-hand side + children's updates) is assembled once by tasks of
+    # their own instead of by every slab (numeric.cpp, kind-1 SfTask).  Forced onto every tiled front of a small problem: the
+    # single-column results are bit-identical (same sums in the same order), the blocked ones agree to rounding.
+    n, rp, ci, v = P.poisson2d(150, 140)
+    rng = np.random.default_rng(11)
+    v = v * (1.0 + 0.3 * rng.uniform(-1, 1, v.size))
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    B = np.array([b * (1.0 + 0.1 * j) for j in range(11)])
+    got = []
+    for env in ({"HIPMF_SF_ASM_FRONT": "0", "HIPMF_SF_BIG_ROWS": "0"}, {"HIPMF_SF_ASM_FRONT": "65", "HIPMF_SF_BIG_FRONT": "65"},
+                {"HIPMF_SF_ASM_FRONT": "65", "HIPMF_SF_BIG_ROWS": "0"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci) == 0
+        assert s.factorize(v) == 0
+        got.append((s.solve(b), s.solve_many(B)))
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert np.max(np.abs(got[0][0] - xs)) < 1e-10
+    for x1, X in got[1:]:
+        assert np.array_equal(x1, got[0][0])
+        assert np.max(np.abs(X - got[0][1])) <= 1e-12 * np.max(np.abs(got[0][1]))
