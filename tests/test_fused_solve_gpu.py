@@ -130,6 +130,9 @@ def test_assemble_once_tasks_give_the_same_bits(monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
     assert np.max(np.abs(got[0][0] - xs)) < 1e-10
-    for x1, X in got[1:]:
-        assert np.array_equal(x1, got[0][0])
+    # same slab shapes (third configuration against the first): the same sums in the same order
+    assert np.array_equal(got[2][0], got[0][0])
+    # with the 64-row slabs of the largest fronts the dot products are grouped differently: equal to rounding
+    assert np.max(np.abs(got[1][0] - got[0][0])) <= 1e-12 * np.max(np.abs(got[0][0]))
+    for _, X in got[1:]:
         assert np.max(np.abs(X - got[0][1])) <= 1e-12 * np.max(np.abs(got[0][1]))
