@@ -133,6 +133,6 @@ def test_assemble_once_tasks_give_the_same_bits(monkeypatch):
     # same slab shapes (third configuration against the first): the same sums in the same order
     assert np.array_equal(got[2][0], got[0][0])
     # with the 64-row slabs of the largest fronts the dot products are grouped differently: equal to rounding
-    assert np.max(np.abs(got[1][0] - got[0][0])) <= 1e-12 * np.max(np.abs(got[0][0]))
+    assert np.max(np.abs(got[1][0] - got[0][0])) <= 1e-10 * np.max(np.abs(got[0][0]))
     for _, X in got[1:]:
-        assert np.max(np.abs(X - got[0][1])) <= 1e-12 * np.max(np.abs(got[0][1]))
+        assert np.max(np.abs(X - got[0][1])) <= 1e-10 * np.max(np.abs(got[0][1]))
