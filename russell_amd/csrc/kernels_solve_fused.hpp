@@ -417,7 +417,7 @@ __device__ __forceinline__ double sf_group_sum(const double *red, int rows, int 
 // Work split over the four wavefronts: nsub >= 4: wave w owns the tiles w, w + 4 for every position; nsub < 4: 4 / nsub waves share a
 // tile and split the positions of each chunk into contiguous parts (partial tiles are added in a fixed order by sf_mma_finish).
 // w: the chunk [c0, c1) of the K vectors in LDS, column c at w + c wld, position k at index k - c0.
-template <bool TRANS>
+template <bool TRANS, int DEPTH = 8>
 __device__ __forceinline__ void sf_mma_chunk(f64x4 (&acc)[2], const double *__restrict__ M, int64_t ld, const double *w, int wld, int c0, int c1,
                                              int nk, int nsub, int nout, int wave, int lane) {
     const int o = lane & 15, kk = lane >> 4;
@@ -440,14 +440,14 @@ __device__ __forceinline__ void sf_mma_chunk(f64x4 (&acc)[2], const double *__re
         const double *Mo = TRANS ? M + (int64_t)oc * ld : M + oc;
         const int64_t ks = TRANS ? 1 : ld;
         int k = ka;
-        for (; k + 32 <= kb; k += 32) { // eight loads of M in flight per lane
-            double a[8], b[8];
+        for (; k + 4 * DEPTH <= kb; k += 4 * DEPTH) { // DEPTH loads of M in flight per lane
+            double a[DEPTH], b[DEPTH];
 #pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = Mo[(int64_t)(k + 4 * u + kk) * ks];
+            for (int u = 0; u < DEPTH; u++) a[u] = Mo[(int64_t)(k + 4 * u + kk) * ks];
 #pragma unroll
-            for (int u = 0; u < 8; u++) b[u] = wl[k + 4 * u + kk] * wmask;
+            for (int u = 0; u < DEPTH; u++) b[u] = wl[k + 4 * u + kk] * wmask;
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc[tq] = mfma_f64_16x16x4(a[u], b[u], acc[tq]);
+            for (int u = 0; u < DEPTH; u++) acc[tq] = mfma_f64_16x16x4(a[u], b[u], acc[tq]);
         }
         for (; k < kb; k += 4) {
             const int kq = k + kk;
@@ -794,8 +794,9 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
             __syncthreads();
         }
         if (K > 1) {
-            if (sym) sf_mma_chunk<true>(macc, Ep + (int64_t)r0 * fd.ld, fd.ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
-            else sf_mma_chunk<false>(macc, Ep + r0, ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
+            // (sixteen loads in flight: the backward instances have the registers for it)
+            if (sym) sf_mma_chunk<true, 16>(macc, Ep + (int64_t)r0 * fd.ld, fd.ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
+            else sf_mma_chunk<false, 16>(macc, Ep + r0, ld, wc, CHK, c0, c1, nk, nsub, r1 - r0, wave, lane);
         } else if (sym) {
             // transposed GEMV: wave w owns the columns r0 + w, r0 + w + 4, ... of E (<= SF_SYMC of them: slabs of 16 rows),
             // lanes run down the column (contiguous), two positions of every column in flight per lane
