@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Device-clock stamps of an instrumented build (-DHIPMF_STAMPS, see kernels_common.hpp): factorise the 2D Poisson problem and
-print the per-workgroup phase times of the kernels that carry HIPMF_STAMP marks.
+print what the HIPMF_STAMP(row, slot) / HIPMF_STAMP_VAL(row, slot, value) marks of the kernel under study recorded.
+The tree carries no marks: add them to a kernel (row = e.g. blockIdx.x, slot 0 at its entry), build the library with
+-DHIPMF_STAMPS, run this script on it.  profiles/r02_rejected_experiments.txt shows a table obtained this way.
 
 usage: python tools/stamps.py <instrumented librussell_hipmf.so> [grid]
 """
@@ -25,13 +27,17 @@ raw = C.CDLL(lib)
 buf = np.zeros(16 * 1024, np.uint64)
 assert raw.hipmf_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), C.c_int64(buf.size)) == 0
 rows = buf.reshape(1024, 16).astype(np.int64)
-print("row: p f | microseconds from the first stamp")
+print("row | microseconds from slot 0 for the clock slots (HIPMF_STAMP), raw values for the others (HIPMF_STAMP_VAL)")
 for k in range(1024):
     r = rows[k]
     if r[0] == 0:
         continue
     if k > 90 and k % 37:
         continue
-    d = [(int(x) - int(r[0])) / 100.0 for x in r[1:8] if x]
-    e = [(int(x) - int(r[1])) / 100.0 for x in r[10:14] if x]
-    print("%4d: p %3d f %3d | %s | first block from stamp 1: %s" % (k, r[8], r[9], " ".join("%7.2f" % x for x in d), " ".join("%6.2f" % x for x in e)))
+    out = []
+    for x in r[1:]:
+        if x == 0:
+            continue
+        d = int(x) - int(r[0])
+        out.append("%8.2f" % (d / 100.0) if 0 <= d < 10 ** 9 else "%8d" % int(x))  # a clock near slot 0's, else a stored value
+    print("%4d | %s" % (k, " ".join(out)))
