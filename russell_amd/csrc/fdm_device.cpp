@@ -183,8 +183,22 @@ struct FdmHandle {
     int device = 0;
 };
 
+// a handle lives on the device that was current when it was created; every entry point switches to it and restores the caller's
+struct FdmDeviceScope {
+    int saved = -1;
+    explicit FdmDeviceScope(int dev) {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        if (saved != dev) (void)hipSetDevice(dev);
+        else saved = -1;
+    }
+    ~FdmDeviceScope() {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
 void fdm_free(FdmHandle *h) {
     if (!h) return;
+    FdmDeviceScope scope(h->device);
     if (h->d_presc) (void)hipFree(h->d_presc);
     if (h->d_local) (void)hipFree(h->d_local);
     if (h->d_off_bar) (void)hipFree(h->d_off_bar);
@@ -250,6 +264,7 @@ int32_t hipmf_fdm_structure_device(const void *handle, int32_t *d_bar_i, int32_t
     const FdmHandle *h = (const FdmHandle *)handle;
     if (!h || !d_bar_i || !d_bar_j) return 100000;
     if (h->totals[3] > 0 && (!d_check_i || !d_check_j)) return 100000;
+    FdmDeviceScope scope(h->device);
     const int64_t nblocks = (h->ntot + FDM_T - 1) / FDM_T;
     hipLaunchKernelGGL(k_fdm_fill<false>, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, h->d_presc, h->ntot, h->d_local, h->d_off_bar, h->d_off_chk, d_bar_i,
                        d_bar_j, d_check_i, d_check_j, (double *)nullptr, (double *)nullptr, 0.0, 0.0, 0.0, 0.0, 0.0);
@@ -263,6 +278,7 @@ int32_t hipmf_fdm_values_device(const void *handle, double dx, double dy, double
     if (!h || !d_bar_values) return 100000;
     if (h->totals[3] > 0 && !d_check_values) return 100000;
     if (!(dx > 0.0) || !(dy > 0.0) || (h->g.nz > 1 && !(dz > 0.0))) return 803; // ERROR_HIPMF_INVALID_VALUE
+    FdmDeviceScope scope(h->device);
     const double bx = kx / (dx * dx), by = ky / (dy * dy), bz = h->g.nz > 1 ? kz / (dz * dz) : 0.0;
     const int64_t nblocks = (h->ntot + FDM_T - 1) / FDM_T;
     hipLaunchKernelGGL(k_fdm_fill<true>, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, h->d_presc, h->ntot, h->d_local, h->d_off_bar, h->d_off_chk,
