@@ -11,6 +11,8 @@ reference's Radau5 / Newton callers repeat, and the one the north_star compares 
 Beside the headline the same line carries (all measured in this run, outside the K timed steps):
   symmetric    the same matrix handed over as its lower triangle (Sym::YesLower, what russell_pde gives a GPU genie):
                L D L^T on the tiled fronts;
+  poisson3d    3D 7-point Poisson 100^3 as its lower triangle (one GPU, rank 0): factorize ms / LU-equivalent TFLOP/s, SpTRSV GB/s and
+               fraction of the HBM peak -- the regime where the level-to-level latency of the 2D headline amortises
   host_api     solver_hipmf_factorize / _solve with HOST pointers through the mirror of the Rust layer, i.e. including the
                COO -> CSR value refresh and the H2D / D2H copies the reference's boundary includes (interface_cudss.cu:424,524,553);
   many_rhs     the north_star split: 256 right-hand sides sharded over the ranks; one rank factorises, the factor travels over
@@ -138,6 +140,7 @@ def main():
     ap.add_argument("--cpu-tier", default="auto", choices=["auto", "umfpack", "superlu", "port"])
     ap.add_argument("--nrhs", type=int, default=NRHS_TOTAL, help="right-hand sides of the many-RHS section (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--grid3d", type=int, default=100, help="edge of the 3D 7-point Poisson problem of the `poisson3d` extra (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,6 +243,44 @@ def main():
             "max_abs_diff_vs_lu": float(np.max(np.abs(x2 - x)))}
         s2.dev_free(d_lv)
         s2.close()
+
+    # ---------------------------------------------------------------- a 3D problem beside the headline (where the latency floors amortise)
+    if not args.no_extras and rank == 0 and world == 1 and args.grid3d > 0:
+        try:
+            n3, rp3, ci3, v3 = P.poisson3d(args.grid3d)
+            b3 = P.csr_matvec(n3, rp3, ci3, v3, P.manufactured_solution(n3))
+            lrp3, lci3, lv3 = lower_triangle(n3, rp3, ci3, v3)
+            s3 = Hipmf()
+            t0 = time.perf_counter()
+            assert s3.initialize(n3, lrp3, lci3, general_symmetric=True) == 0
+            t_init3 = time.perf_counter() - t0
+            d_v3, d_b3, d_x3 = s3.dev_alloc(lv3.nbytes), s3.dev_alloc(b3.nbytes), s3.dev_alloc(b3.nbytes)
+            s3.h2d(d_v3, lv3), s3.h2d(d_b3, b3)
+            assert s3.factorize_device(d_v3) == 0
+            s3.solve_device(d_x3, d_b3)
+            s3.reset_timers()
+            for _ in range(3):
+                assert s3.factorize_device(d_v3) == 0
+                s3.solve_device(d_x3, d_b3)
+            lib.hipmf_device_synchronize()
+            st3 = s3.stats()
+            x3 = np.zeros(n3)
+            s3.d2h(x3, d_x3)
+            tri3 = (st3["acc_fwd_ms"] + st3["acc_bwd_ms"]) / max(st3["acc_tri_count"], 1.0)
+            fac3 = st3["acc_factor_ms"] / max(st3["acc_factor_count"], 1.0)
+            bytes3 = sptrsv_bytes(st3, n3)
+            extras["poisson3d"] = {
+                "workload": "3D 7-point Poisson %d^3 (n = %d) as its lower triangle (L D L^T on the tiled fronts), values and rhs resident in HBM"
+                            % (args.grid3d, n3),
+                "initialize_s": round(t_init3, 2), "factor_ms": round(fac3, 2), "lu_equivalent_tflops": round(st3["flops"] / (fac3 * 1e-3) / 1e12, 1),
+                "sptrsv_pair_ms": round(tri3, 3), "sptrsv_gbs": round(bytes3 / (tri3 * 1e-3) / 1e9, 1),
+                "sptrsv_frac_of_hbm_peak": round(bytes3 / (tri3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "pool_gb": round(st3["pool_bytes"] / 1e9, 2),
+                "relative_error": residual_metric(n3, rp3, ci3, v3, x3, b3)}
+            for ptr in (d_v3, d_b3, d_x3):
+                s3.dev_free(ptr)
+            s3.close()
+        except Exception as exc:  # never lose the headline to an extra
+            extras["poisson3d"] = {"error": repr(exc)}
 
     # ---------------------------------------------------------------- host-pointer boundary through the mirror of the Rust layer
     if not args.no_extras and rank == 0:
