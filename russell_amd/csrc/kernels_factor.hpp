@@ -310,6 +310,10 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
     }
     __syncthreads();
     lds_lu_blocked<NW, true>(sm, ld, f, p, lp, pivpos, eps, info);
+    // A front with a packed copy of its rows of U keeps L alone in its pivot block (zeros on and above the diagonal) and U alone in the
+    // copy (zeros below the diagonal of U11): the wave-subtree solves (kernels_solve_tree.hpp) then need no per-lane tests in their
+    // substitution steps; every other reader masks those entries anyway.
+    const bool split = fd.epoff >= 0;
     if (tid < f) {
         int c = grp;
         for (; c + 7 * NW < f; c += 8 * NW) {
@@ -317,13 +321,13 @@ __global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restr
 #pragma unroll
             for (int q = 0; q < 8; q++) a[q] = sm[tid + (c + q * NW) * ld];
 #pragma unroll
-            for (int q = 0; q < 8; q++) F[tid + (c + q * NW) * f] = a[q];
+            for (int q = 0; q < 8; q++) F[tid + (c + q * NW) * f] = (split && c + q * NW < p && tid <= c + q * NW) ? 0.0 : a[q];
         }
-        for (; c < f; c += NW) F[tid + c * f] = sm[tid + c * ld];
+        for (; c < f; c += NW) F[tid + c * f] = (split && c < p && tid <= c) ? 0.0 : sm[tid + c * ld];
     }
-    if (fd.epoff >= 0 && tid < p) { // packed rows of U for the backward solve (lane = row: p-entry contiguous pieces)
+    if (split && tid < p) { // packed rows of U for the backward solve (lane = row: p-entry contiguous pieces)
         double *Up = pool + fd.epoff;
-        for (int c = grp; c < f; c += NW) Up[tid + c * p] = sm[tid + c * ld];
+        for (int c = grp; c < f; c += NW) Up[tid + c * p] = (tid > c) ? 0.0 : sm[tid + c * ld];
     }
     if (grp == 0 && tid < p) {
         lperm[fd.first + tid] = lp[tid];

@@ -57,6 +57,26 @@ __device__ __forceinline__ bool sf_wait(const int *cnt, int need, int *err) {
     return true;
 }
 
+// Fronts of the top levels are cut into up to ~170 slabs, and up to ~170 slabs of the parent (forward) / of the children (backward)
+// wait for them: that many pollers on ONE counter word serialise with each other and with the arrivals (measured: 1.3 - 7.6 us from
+// the last publish of a level to the last wake-up of the next).  Such a front has SF_REP replicas of a "complete" word, one per 64-byte
+// line, written by whoever makes the counter reach its target; a waiting slab polls the replica its workgroup index selects.
+constexpr int SF_REP = 16;
+__device__ __forceinline__ void sf_wait_front(int s, const int32_t *__restrict__ need, const int *done, const int32_t *__restrict__ rep_idx,
+                                              const int *rep, int *err) {
+    const int ri = rep_idx ? rep_idx[s] : -1;
+    if (ri >= 0) sf_wait(rep + ((size_t)ri * SF_REP + (blockIdx.x % SF_REP)) * 16, 1, err);
+    else sf_wait(done + s, need[s], err);
+}
+__device__ __forceinline__ void sf_publish_front(int s, const int32_t *__restrict__ need, int *done, const int32_t *__restrict__ rep_idx, int *rep) {
+    const int old = flag_add(done + s, 1);
+    if (rep_idx) {
+        const int ri = rep_idx[s];
+        if (ri >= 0 && old + 1 == need[s])
+            for (int k = 0; k < SF_REP; k++) flag_store(rep + ((size_t)ri * SF_REP + k) * 16, 1);
+    }
+}
+
 // All kernels are templates on K = the number of right-hand sides a launch carries (1: the instances the
 // benchmark path uses; SF_KMAX: the many-RHS instances, which read every factor entry ONCE for K columns -- the
 // solves are HBM-bound, so K columns cost little more than one).  Column c of x lives at x + c * xstr, its solve
@@ -481,12 +501,21 @@ __device__ __forceinline__ double sf_mma_sum(const double *mt, int nsub, int rr,
 
 // Forward pass, one launch per band of levels.  sync[SF_SYNC_HEADER + s] = completed tasks of front s (zeroed before
 // every pass); *err is sticky: set when a wait timed out.
-template <bool SMALL_ONLY, int K>
+// STG (K = 1 only): the instance that runs ABOVE the wave-subtrees (kernels_solve_tree.hpp).  The upper levels of the tree are a chain
+// of dependent hand-offs with a few megabytes of E per level: what a slab does AFTER its children are complete must be short.  Every
+// thread parks the first `stage` entries of its share of its row of E (positions g, g + G, ... of row r) in dynamic LDS -- stage x 256
+// doubles, slot [u][tid]: private to the thread, no barrier, conflict-free -- BEFORE it waits; after the wait the dot product reads
+// them back in the same order and with the same two accumulators as sf_dot (bit-identical sums).  Registers cannot hold them: the
+// kernel also runs thousands of small fronts, whose occupancy pays for every VGPR (measured in round 2: 108 -> 152 VGPRs, slower).
+template <bool SMALL_ONLY, int K, bool STG = false>
 __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
                                                    const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int nk,
-                                                   int64_t xstr, int64_t wstr, unsigned long long *trace) {
+                                                   int64_t xstr, int64_t wstr, unsigned long long *trace, int stage,
+                                                   const int32_t *__restrict__ rep_idx, int *rep) {
+    static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
+    HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles
     constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK; // chunk of w1 per right-hand side
     // One LDS buffer, three uses that never overlap in time: a workgroup either runs four small fronts (wv: K x 64 doubles per wave)
     // or one slab of a big front (wc: the chunk of the K vectors; mt: the slab's MFMA tiles, written after the last chunk is consumed).
@@ -573,7 +602,7 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         return;
     }
     // ---- slab [r0, r1) of the big front t.a:  [y1; -delta] = E w1,  work[r] = y1[r] (r < p) or w2[r] + (E w1)[r] ----
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr_g = 0, tr_d = 0;
     if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
@@ -591,10 +620,24 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
     constexpr int NPRE = 8;
     double e_pre[K == 1 ? NPRE : 1];
     const int c1_first = jmax < CHK ? jmax : CHK;
-    const bool use_pre = K == 1 && r < r1 && (c1_first - g + G - 1) / G >= NPRE; // at least NPRE positions in the first chunk
+    const bool use_pre = K == 1 && !STG && r < r1 && (c1_first - g + G - 1) / G >= NPRE; // at least NPRE positions in the first chunk
     if (K == 1 && use_pre) {
 #pragma unroll
         for (int u = 0; u < NPRE; u++) e_pre[K == 1 ? u : 0] = E[r + (int64_t)(g + u * G) * ld];
+    }
+    if (STG) {
+        // (clamped addresses: unconditional loads, eight in flight; entries past the end of the row are never read back)
+        const double *Er = E + (r < r1 ? r : r1 - 1);
+        for (int u0 = 0; u0 < stage; u0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = g + (u0 + q) * G;
+                t[q] = Er[(int64_t)(j < jmax ? j : jmax - 1) * ld];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) els[(u0 + q) * 256 + tid] = t[q];
+        }
     }
     // ---- before the wait: everything that does not depend on the children ----
     //  * the children's descriptors, one child per lane of wave 0, parked in LDS for all waves
@@ -630,12 +673,12 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         if (lane == 0) cm_max_s = nch > 64 ? 0x7fffffff : mx;
         if (lane < ncd) {
             const int ch = child_idx[fd.child_begin + lane];
-            sf_wait(done + ch, need[ch], err);
+            sf_wait_front(ch, need, done, STG ? rep_idx : nullptr, rep, err);
         }
         for (int c0 = 64; c0 < nch; c0 += 64)
             if (c0 + lane < nch) {
                 const int ch = child_idx[fd.child_begin + c0 + lane];
-                sf_wait(done + ch, need[ch], err);
+                sf_wait_front(ch, need, done, STG ? rep_idx : nullptr, rep, err);
             }
     }
     __syncthreads();
@@ -657,11 +700,35 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         }
         if (cm_max <= 256)
             sf_children<(K == 1 ? 8 : 4), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
-        else
-            sf_children<2, (K == 1 ? 4 : 2), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+        else // (top-level instance: six entries per thread and child in one round trip -- 1 536 rows)
+            sf_children<2, (STG ? 6 : (K == 1 ? 4 : 2)), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         if (nch == 0) __syncthreads();
+        if (trace && tid == 0 && c0 == 0) tr_g = dev_clock();
         // the group's columns of this chunk: g, g + G, ... continue across chunks (CHK is a multiple of every G)
-        if (K == 1 && c0 == 0 && use_pre) {
+        if (STG && c0 == 0) {
+            if (r < r1) {
+                // this thread's positions of the chunk: g, g + G, ...; whole groups of eight alternate between the two accumulators,
+                // the last partial group goes into acc0 (sf_dot's order); the first `stage` of them come back from LDS
+                const int n0 = g < c1 ? (c1 - g + G - 1) / G : 0, nfull = n0 / 8 * 8, nst = stage < n0 ? stage : n0;
+                int sq = 0;
+                for (; sq + 8 <= nst && sq + 8 <= nfull; sq += 8) {
+                    double e[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) e[q] = els[(sq + q) * 256 + tid];
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        acc0[0] += e[q] * wc[g + (sq + q) * G];
+                        acc1[0] += e[q + 1] * wc[g + (sq + q + 1) * G];
+                    }
+                }
+                if (sq + 8 <= nfull) sf_dot<1, true>(acc0, acc1, E + r, ld, wc, CHK, 0, g + sq * G, c1, G);
+                else
+                    for (; sq < n0; sq++) {
+                        const double ev = sq < stage ? els[sq * 256 + tid] : E[r + (int64_t)(g + sq * G) * ld];
+                        acc0[0] += ev * wc[g + sq * G];
+                    }
+            }
+        } else if (K == 1 && c0 == 0 && use_pre) {
             // consume the prefetched entries exactly as sf_dot would (even positions into acc0, odd ones into acc1), then go on
 #pragma unroll
             for (int u = 0; u < NPRE; u += 2) {
@@ -675,6 +742,7 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
             sf_dot<1, true>(acc0, acc1, E + r, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
+    if (trace && tid == 0) tr_d = dev_clock();
     if (K > 1) {
         sf_mma_store(macc, mt, nsub, wave, lane);
         __syncthreads();
@@ -698,20 +766,23 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
     if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();
     __syncthreads();
-    if (tid == 0) flag_add(done + t.a, 1);
+    if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
     if (trace && tid == 0) {
-        unsigned long long *tr = trace + 4 * (size_t)blockIdx.x;
-        tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock();
+        unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;
+        tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock(), tr[4] = tr_g, tr[5] = tr_d;
     }
 }
 
 // Backward pass, one launch per band of levels (tasks ordered root first).
 // SYM: instance for factors whose big fronts are L D L^T (x1 = E^T [D^{-1} y1; x2], transposed GEMV); the LU instance carries none of it.
-template <bool SMALL_ONLY, int K, bool SYM>
+template <bool SMALL_ONLY, int K, bool SYM, bool STG = false>
 __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
-                                                   int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag) {
+                                                   int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag,
+                                                   int stage, const int32_t *__restrict__ rep_idx, int *rep) {
+    static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
+    HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles (see k_fwd_fused)
     constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK;
     // (one LDS buffer for the small fronts' vectors, the chunk of a big front's vectors and its MFMA tiles: see k_fwd_fused)
     constexpr int LDS_D = SMALL_ONLY ? 4 * K * 64 : (K * CHK > 4 * K * 64 ? K * CHK : 4 * K * 64);
@@ -730,7 +801,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     }
     if (SMALL_ONLY) return;
     // ---- pivot rows [r0, r1) of the big front t.a:  x1 = E' [y1; x2] ----
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr_g = 0, tr_d = 0;
     if (trace && tid == 0) tr0 = dev_clock();
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
@@ -762,7 +833,21 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
             }
         }
     }
-    if (fd.parent >= 0 && tid == 0) sf_wait(done + fd.parent, need[fd.parent], err);
+    if (STG && !sym) {
+        // the first `stage` entries of this thread's share of its row of E' (positions jmin + g, jmin + g + G, ...), parked in LDS
+        const double *Er = Ep + (i < r1 ? i : r1 - 1);
+        for (int u0 = 0; u0 < stage; u0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = jmin + g + (u0 + q) * G;
+                t[q] = Er[(int64_t)(j < f ? j : f - 1) * ld];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) els[(u0 + q) * 256 + tid] = t[q];
+        }
+    }
+    if (fd.parent >= 0 && tid == 0) sf_wait_front(fd.parent, need, done, STG ? rep_idx : nullptr, rep, err);
     __syncthreads();
     if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
@@ -774,6 +859,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
                 if (c < nk) wc[c * CHK + tid + 256 * k] = ld_agent(x + c * xstr + xrow[k]);
         }
     __syncthreads();
+    if (trace && tid == 0) tr_g = dev_clock();
     // (K = 1: scalar dot products; K > 1: MFMA tiles, see sf_mma_chunk)
     double acc0[1] = {0.0}, acc1[1] = {0.0};
     double sacc[(SYM && K == 1) ? SF_SYMC : 1][1];
@@ -826,10 +912,32 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
 #pragma unroll
                 for (int q = 0; q < SF_SYMC; q++) sacc[(SYM && K == 1) ? q : 0][0] += e[q] * wk[j];
             }
+        } else if (STG && c0 == jmin) {
+            if (i < r1) { // (same order of additions as sf_dot: see k_fwd_fused)
+                const int n0 = c0 + g < c1 ? (c1 - c0 - g + G - 1) / G : 0, nfull = n0 / 8 * 8, nst = stage < n0 ? stage : n0;
+                int sq = 0;
+                for (; sq + 8 <= nst && sq + 8 <= nfull; sq += 8) {
+                    double e[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) e[q] = els[(sq + q) * 256 + tid];
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        acc0[0] += e[q] * wc[g + (sq + q) * G];
+                        acc1[0] += e[q + 1] * wc[g + (sq + q + 1) * G];
+                    }
+                }
+                if (sq + 8 <= nfull) sf_dot<1>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g + sq * G, c1, G);
+                else
+                    for (; sq < n0; sq++) {
+                        const double ev = sq < stage ? els[sq * 256 + tid] : Ep[i + (int64_t)(c0 + g + sq * G) * ld];
+                        acc0[0] += ev * wc[g + sq * G];
+                    }
+            }
         } else if (i < r1)
             sf_dot<1>(acc0, acc1, Ep + i, ld, wc, CHK, c0, c0 + g, c1, G);
         __syncthreads();
     }
+    if (trace && tid == 0) tr_d = dev_clock();
     if (K > 1) {
         sf_mma_store(macc, mt, nsub, wave, lane);
         __syncthreads();
@@ -855,10 +963,10 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     if (trace && tid == 0) tr2 = dev_clock();
     drain_stores();
     __syncthreads();
-    if (tid == 0) flag_add(done + t.a, 1);
+    if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
     if (trace && tid == 0) {
-        unsigned long long *tr = trace + 4 * (size_t)blockIdx.x;
-        tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock();
+        unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;
+        tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock(), tr[4] = tr_g, tr[5] = tr_d;
     }
 }
 

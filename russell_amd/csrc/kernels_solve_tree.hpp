@@ -1,0 +1,342 @@
+// kernels_solve_tree.hpp -- the bottom of the assembly tree in the triangular solves: one WAVEFRONT per subtree, fed as a stream.
+//
+// The dependency-driven kernels (kernels_solve_fused.hpp) run every small front as a task of its own: task record -> descriptor ->
+// children's descriptors -> completion flags -> relative indices + update vectors -> panel, five to six dependent memory round trips
+// per front, 100 000 fronts for the 1M-DOF Poisson factor: the leaf band is bound by (resident waves) / (chain length), not by HBM.
+// Here a maximal subtree of small fronts (f <= 64, bounded size; planned at initialize, numeric.cpp) belongs to ONE wavefront, which
+// walks it in postorder (forward) / reverse postorder (backward):
+//   * dependencies inside the subtree are satisfied by program order: no flags, no waits, no agent-scope traffic;
+//   * the vectors that travel between the fronts of the subtree live in the wave's own LDS (forward: a parent's accumulator
+//     b1 + sum of the children's updates, children in ascending order -- the same sums in the same order as k_fwd / sf_fwd_small;
+//     backward: a front's solved vector [x1; x2], from which its children gather their x2); the subtree's part of the right-hand
+//     side (its pivot columns are one contiguous range) and of the interchanges is fetched once, at the start;
+//   * the factor comes in BATCHES of up to 8 fronts / 6 KB: a first version fetched one front per memory round trip (16 row loads in
+//     registers, the next front requested while the current one is computed) and measured 3 us per front -- a wave never had more than
+//     ~2 KB in flight.  Now the panels of a batch are read as FLAT 1 KB pieces (global_load_dwordx4: 16 bytes per lane, whatever the
+//     shape of the fronts), parked in LDS, and the fronts of the batch are computed out of LDS while the pieces of the next batch are
+//     in flight in the registers that staged this one.  Each batch comes with a header (where its pieces are) and a meta block (one
+//     16-word record per front + the index lists), both built at initialize: no descriptor chase at all.
+// Only the root of a subtree talks to the rest of the tree: forward, it publishes its update vector in `work` and bumps its
+// completion counter (the upper fronts run in a later launch on the same stream); backward, its ancestors are complete before the
+// launch starts.  Arithmetic and summation order are those of sf_fwd_small / sf_bwd_small: bit-identical results.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hipmf {
+
+#ifndef HIPMF_WT_NCH
+#define HIPMF_WT_NCH 6
+#endif
+#ifndef HIPMF_WT_X
+#define HIPMF_WT_X 256
+#endif
+#ifndef HIPMF_WT_STACK
+#define HIPMF_WT_STACK 320
+#endif
+#ifndef HIPMF_WT_WAVES
+#define HIPMF_WT_WAVES 2
+#endif
+constexpr int WT_NCH = HIPMF_WT_NCH;    // 1 KB pieces of factor per batch
+constexpr int WT_CHUNK = 128;           // doubles per piece (64 lanes x 16 bytes)
+constexpr int WT_NREC = 8;              // fronts per batch at most
+constexpr int WT_MI = 512;              // 32-bit words of a batch's meta block: WT_NREC records of 16 words, then the index lists
+constexpr int WT_X = HIPMF_WT_X;        // pivots of a wave-subtree at most (multiple of 256)
+constexpr int WT_STACK = HIPMF_WT_STACK; // doubles of LDS per wave for the stack of front vectors (5 levels x 64 rows)
+// (measured on the 1M-DOF Poisson factor, forward + backward pass pair: 8 pieces / 512 pivots / 384 stack doubles = 20 KB of LDS per
+//  wave, 8 waves per CU: 470 us; 6 / 256 / 320 = 14.8 KB, 10 waves per CU: 460 us; 4 / 256 / 320: 506 us -- fronts of more than 512
+//  panel entries then stay outside the wave-subtrees)
+// LDS of one wave, in doubles: [ panels | meta | x of the subtree | interchanges of the subtree | stack | gather scratch ]
+constexpr int WT_OFF_M = WT_NCH * WT_CHUNK, WT_OFF_X = WT_OFF_M + WT_MI / 2, WT_OFF_LP = WT_OFF_X + WT_X, WT_OFF_ST = WT_OFF_LP + WT_X / 2;
+constexpr int WT_OFF_XG = WT_OFF_ST + WT_STACK, WT_OFF_Z = WT_OFF_XG + 64, WT_LDS = WT_OFF_Z + 64; // (Z: 64 zeros)
+constexpr int WT_WAVES = HIPMF_WT_WAVES; // wavefronts (= subtrees) per workgroup
+
+struct WtRec {       // one front of a batch: 16 words at the head of the batch's meta block
+    int32_t pslot;   // offset (doubles) of the front's piece(s) in the panel area: forward [L11; L21] (f x p, stride f), backward the rows of U
+    int32_t pm;      // p | m << 16
+    int32_t xoff;    // first pivot column - first pivot column of the subtree
+    int32_t pxoff;   // parent's xoff (FIRST child: it initialises the parent's accumulator with the parent's b1)
+    int32_t ppf;     // parent's p | parent's f << 16
+    int32_t lds;     // (stack offset of the front's own vector + 1) | (stack offset of the parent's vector + 1) << 16; 0 = none
+    int32_t flags;   // bit 0: first child of its parent; bit 1 (backward): rows of U packed with stride p (else inside the f x f block);
+                     // bit 2: the front has the packed copy, i.e. zeros where the substitutions would otherwise test the lane (see wt_fwd_steps)
+    int32_t relo;    // word offset, inside the meta block, of the front's index list (rel; backward root: global row numbers)
+    int32_t first;   // first pivot column
+    int32_t s;       // front number (completion counter of the root)
+    int64_t woff;    // offset of the front's vector in the global solve workspace (root: its update vector goes there)
+    int32_t pad[4];
+};
+static_assert(sizeof(WtRec) == 64, "16 words");
+
+struct WtHdr {                 // one batch: 16 8-byte words, fetched by 16 lanes
+    int64_t src[WT_NCH];       // pool offsets of the batch's 1 KB pieces (unused ones repeat src[0])
+    int64_t meta;              // word offset of the batch's meta block
+    int32_t nrec, pad;
+    int64_t pad2[16 - WT_NCH - 2];
+};
+static_assert(sizeof(WtHdr) == 128, "16 words");
+
+struct WtWave {
+    int32_t b0, b1;  // batches of the wave
+    int32_t xfirst;  // first pivot column of the subtree
+    int32_t pad;
+};
+
+// the loads of one batch: 8 pieces of factor, 2 of meta (all unconditional: the batch after this one is requested before this one
+// is computed, and the compiler can only wait for "all but the last N loads" when N does not depend on predicates)
+__device__ __forceinline__ void wt_issue(long long hw, int lane, const double *__restrict__ pool, const int32_t *__restrict__ meta,
+                                         f64x2 (&pc)[WT_NCH], i32x4 (&mc)[2]) {
+#pragma unroll
+    for (int c = 0; c < WT_NCH; c++) pc[c] = ld_f64x2(pool + wave_bcast_i64(hw, c) + 2 * lane);
+    const int64_t mo = wave_bcast_i64(hw, WT_NCH);
+#pragma unroll
+    for (int c = 0; c < 2; c++) mc[c] = ld_i32x4(meta + mo + 256 * c + 4 * lane);
+}
+__device__ __forceinline__ void wt_park(double *L, int lane, const f64x2 (&pc)[WT_NCH], const i32x4 (&mc)[2]) {
+#pragma unroll
+    for (int c = 0; c < WT_NCH; c++) st_lds_f64x2(L + WT_CHUNK * c + 2 * lane, pc[c]);
+    int32_t *Mi = reinterpret_cast<int32_t *>(L + WT_OFF_M);
+#pragma unroll
+    for (int c = 0; c < 2; c++) st_lds_i32x4(Mi + 256 * c + 4 * lane, mc[c]);
+}
+
+// ------------------------------------------------------------------ forward: one front out of LDS
+// The wave-subtree kernels are bound by instruction issue (measured: ~1 500 cycles per front and SIMD, for f x p / 64 ~ 4 multiply-adds
+// per lane), so the substitution is straight-line code for P = 4, 8, 12 or 16 pivots (the class of the front; columns past p come from
+// a block of zeros) without per-step tests: k_small_factor leaves ZEROS on and above the diagonal of the pivot block of a front that
+// has a packed copy of its rows of U, so lane i <= j multiplies by zero where sf_fwd_small tests lane > j (same bits; the sign of
+// an exact zero may differ).  Fronts without the packed copy (no off-diagonal rows) take the tested form.
+template <int P>
+__device__ __forceinline__ double wt_fwd_steps(const double *L, int pslot, int lr, int p, int f, double v) {
+    double a[P];
+#pragma unroll
+    for (int c = 0; c < P; c++) a[c] = L[c < p ? pslot + lr + c * f : WT_OFF_Z];
+#pragma unroll
+    for (int c = 0; c < P; c++) {
+        const double vj = wave_bcast(v, c);
+        v -= a[c] * vj;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void wt_fwd_front(double *L, int q, int lane, double *x, double *work, int *done) {
+    const int32_t *Mi = reinterpret_cast<const int32_t *>(L + WT_OFF_M);
+    const int32_t *LPi = reinterpret_cast<const int32_t *>(L + WT_OFF_LP);
+    const double *X = L + WT_OFF_X;
+    double *ST = L + WT_OFF_ST;
+    const int ri = Mi[16 * q + (lane & 15)];
+    const int pslot = wave_bcast_i32(ri, 0), pm = wave_bcast_i32(ri, 1), xoff = wave_bcast_i32(ri, 2), ldsv = wave_bcast_i32(ri, 5);
+    const int flags = wave_bcast_i32(ri, 6), relo = wave_bcast_i32(ri, 7), first = wave_bcast_i32(ri, 8);
+    const int p = pm & 0xffff, m = pm >> 16, f = p + m;
+    const int lds_self = (ldsv & 0xffff) - 1, lds_par = (ldsv >> 16) - 1;
+    const int lr = lane < f ? lane : f - 1;
+    const int lp = LPi[xoff + (lane < p ? lane : 0)];
+    // w = b1 (pivot rows) + the children's updates: complete in the front's own stack slot when it has children
+    double v;
+    if (lds_self >= 0) v = ST[lds_self + (lane < p ? lp : lr)];
+    else v = (lane < p) ? X[xoff + lp] : 0.0;
+    // y1 = L11^{-1} (P w1) column by column, u = w2 - L21 y1 (sf_fwd_small's arithmetic)
+    if ((flags & 4) && p <= 16) { // (wave-uniform) zeros on and above the diagonal of the pivot block
+        if (p <= 4) v = wt_fwd_steps<4>(L, pslot, lr, p, f, v);
+        else if (p <= 8) v = wt_fwd_steps<8>(L, pslot, lr, p, f, v);
+        else if (p <= 12) v = wt_fwd_steps<12>(L, pslot, lr, p, f, v);
+        else v = wt_fwd_steps<16>(L, pslot, lr, p, f, v);
+    } else {
+        const double *Pn = L + pslot + lr;
+        for (int j0 = 0; j0 < p; j0 += 8) { // eight columns at a time
+            double a8[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) a8[c] = Pn[(j0 + c < p ? j0 + c : p - 1) * f];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int j = j0 + c;
+                if (j < p) {
+                    const double vj = wave_bcast(v, j & 63);
+                    if (lane > j && lane < f) v -= a8[c] * vj;
+                }
+            }
+        }
+    }
+    if (lane < p) x[first + lane] = v;
+    if (lds_par >= 0) {
+        double *ap = ST + lds_par;
+        if (flags & 1) {
+            const int pxoff = wave_bcast_i32(ri, 3), ppf = wave_bcast_i32(ri, 4);
+            if (lane < (ppf >> 16)) ap[lane] = (lane < (ppf & 0xffff)) ? X[pxoff + lane] : 0.0;
+            wave_sync();
+        }
+        if (lane >= p && lane < f) ap[Mi[relo + lane - p]] += v;
+        wave_sync();
+    } else {
+        const int s = wave_bcast_i32(ri, 9);
+        const int64_t woff = (int64_t)(((unsigned long long)(unsigned)wave_bcast_i32(ri, 11) << 32) | (unsigned)wave_bcast_i32(ri, 10));
+        if (lane >= p && lane < f) st_agent(work + woff + lane, v);
+        drain_stores();
+        if (lane == 0) flag_add(done + s, 1);
+    }
+}
+
+__global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restrict__ waves, const WtHdr *__restrict__ hdrs,
+                                                        const int32_t *__restrict__ meta, const double *__restrict__ pool,
+                                                        const int32_t *__restrict__ lperm, int *sync, double *work, double *x) {
+    __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    const WtWave wv = waves[blockIdx.x * WT_WAVES + wave];
+    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst);
+    if (b0 >= b1) return;
+    HIPMF_STAMP((int)blockIdx.x / 6, 0);
+    HIPMF_STAMP_VAL((int)blockIdx.x / 6, 4, b1 - b0);
+    double *L = lds[wave];
+    L[WT_OFF_Z + lane] = 0.0;
+    int *done = sync + 16; // (SF_SYNC_HEADER of kernels_solve_fused.hpp)
+    const long long *H = reinterpret_cast<const long long *>(hdrs);
+    long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
+    long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
+    // the subtree's part of the right-hand side and of the interchanges (the vectors are allocated with room for the over-read)
+    f64x2 xc[WT_X / WT_CHUNK];
+    i32x4 lc[WT_X / 256];
+#pragma unroll
+    for (int c = 0; c < WT_X / WT_CHUNK; c++) xc[c] = ld_f64x2(x + xfirst + WT_CHUNK * c + 2 * lane);
+#pragma unroll
+    for (int c = 0; c < WT_X / 256; c++) lc[c] = ld_i32x4(lperm + xfirst + 256 * c + 4 * lane);
+    f64x2 pc[WT_NCH];
+    i32x4 mc[2];
+    wt_issue(h0, lane, pool, meta, pc, mc);
+#pragma unroll
+    for (int c = 0; c < WT_X / WT_CHUNK; c++) st_lds_f64x2(L + WT_OFF_X + WT_CHUNK * c + 2 * lane, xc[c]);
+#pragma unroll
+    for (int c = 0; c < WT_X / 256; c++) st_lds_i32x4(reinterpret_cast<int32_t *>(L + WT_OFF_LP) + 256 * c + 4 * lane, lc[c]);
+    HIPMF_STAMP((int)blockIdx.x / 6, 1);
+    for (int j = b0; j < b1; j++) {
+        if (j == b0 + 1) HIPMF_STAMP((int)blockIdx.x / 6, 5);
+        wt_park(L, lane, pc, mc);
+        if (j == b0 + 1) HIPMF_STAMP((int)blockIdx.x / 6, 6);
+        const int nrec = wave_uniform((int)(unsigned)(unsigned long long)wave_bcast_i64(h0, WT_NCH + 1));
+        if (j + 1 < b1) wt_issue(h1, lane, pool, meta, pc, mc); // (wave-uniform)
+        const long long h2 = H[16 * (int64_t)(j + 2 < b1 ? j + 2 : b1 - 1) + (lane & 15)];
+        wave_sync();
+        if (j == b0 + 1) HIPMF_STAMP((int)blockIdx.x / 6, 7);
+        if (j == b0 + 1) HIPMF_STAMP_VAL((int)blockIdx.x / 6, 9, nrec);
+        for (int q = 0; q < nrec; q++) wt_fwd_front(L, q, lane, x, work, done);
+        if (j == b0 + 1) HIPMF_STAMP((int)blockIdx.x / 6, 8);
+        h0 = h1;
+        h1 = h2;
+        if (j == b0) HIPMF_STAMP((int)blockIdx.x / 6, 2);
+    }
+    HIPMF_STAMP((int)blockIdx.x / 6, 3);
+}
+
+// ------------------------------------------------------------------ backward: one front out of LDS
+// Straight-line substitution for P = 4, 8, 12, 16 pivots (see wt_fwd_steps): the packed rows of U come with ZEROS below the diagonal
+// of U11 (k_small_factor) and the diagonal entries are zeroed in LDS once the lane has its pivot, so step j is
+// v_i -= u_ij (v_j / u_jj) for every lane; lane j gets its own v_j / u_jj at the end (the same product as in its step: later steps
+// touch lanes < j only).
+template <int P>
+__device__ __forceinline__ double wt_bwd_steps(const double *L, int pslot, int lr, int p, int us, double v, double inv_d) {
+    double a[P];
+#pragma unroll
+    for (int c = 0; c < P; c++) a[c] = L[p - 1 - c >= 0 ? pslot + lr + (p - 1 - c) * us : WT_OFF_Z];
+#pragma unroll
+    for (int c = 0; c < P; c++) {
+        const int j = p - 1 - c >= 0 ? p - 1 - c : 0; // (columns past the first: a[c] = 0)
+        const double vm = v * inv_d;
+        const double vj = wave_bcast(vm, j);
+        v -= a[c] * vj;
+    }
+    return v * inv_d;
+}
+
+__device__ __forceinline__ void wt_bwd_front(double *L, int q, int lane, double *x) {
+    const int32_t *Mi = reinterpret_cast<const int32_t *>(L + WT_OFF_M);
+    const double *X = L + WT_OFF_X; // y1 of the subtree (forward launch)
+    double *ST = L + WT_OFF_ST, *xg = L + WT_OFF_XG;
+    const int ri = Mi[16 * q + (lane & 15)];
+    const int pslot = wave_bcast_i32(ri, 0), pm = wave_bcast_i32(ri, 1), xoff = wave_bcast_i32(ri, 2), ldsv = wave_bcast_i32(ri, 5);
+    const int flags = wave_bcast_i32(ri, 6), relo = wave_bcast_i32(ri, 7), first = wave_bcast_i32(ri, 8);
+    const int p = pm & 0xffff, m = pm >> 16, f = p + m;
+    const int lds_self = (ldsv & 0xffff) - 1, lds_par = (ldsv >> 16) - 1;
+    const int us = (flags & 2) ? p : f; // column stride of the rows of U
+    double *Ub = L + pslot;
+    const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
+    const int i = lane & ((1 << sh) - 1), jq = lane >> sh, ng = 64 >> sh;
+    const int lr = lane < p ? lane : p - 1;
+    // x2: from the parent's solved vector (inside the subtree) or from x (root: every ancestor is complete)
+    if (lane < m) {
+        const int idx = Mi[relo + lane];
+        xg[lane] = (lds_par >= 0) ? ST[lds_par + idx] : x[idx];
+    }
+    const bool fast = (flags & 4) && p <= 16; // (wave-uniform) zeros below the diagonal of U11
+    const double inv_d = 1.0 / Ub[lr + lr * us];
+    wave_sync();
+    if (fast && lane < p) Ub[lane + lane * us] = 0.0;
+    double acc = 0.0;
+    if (i < p) {
+        const double *Ui = Ub + i + p * us;
+        for (int j = jq; j < m; j += ng) acc += Ui[j * us] * xg[j];
+    }
+    for (int off = 1 << sh; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+    double v = (lane < p) ? X[xoff + lane] - acc : 0.0;
+    // x1 = U11^{-1} t, columns from right to left
+    if (fast) {
+        wave_sync();
+        if (p <= 4) v = wt_bwd_steps<4>(L, pslot, lr, p, us, v, inv_d);
+        else if (p <= 8) v = wt_bwd_steps<8>(L, pslot, lr, p, us, v, inv_d);
+        else if (p <= 12) v = wt_bwd_steps<12>(L, pslot, lr, p, us, v, inv_d);
+        else v = wt_bwd_steps<16>(L, pslot, lr, p, us, v, inv_d);
+    } else {
+        for (int jhi = p; jhi > 0; jhi -= 8) { // eight columns at a time
+            double a8[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) a8[c] = Ub[lr + (jhi - 1 - c >= 0 ? jhi - 1 - c : 0) * us];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int j = jhi - 1 - c;
+                if (j >= 0) {
+                    if (lane == j) v *= inv_d;
+                    const double vj = wave_bcast(v, j);
+                    if (lane < j) v -= a8[c] * vj;
+                }
+            }
+        }
+    }
+    if (lane < p) x[first + lane] = v;
+    if (lds_self >= 0) { // the children gather their x2 from [x1; x2]
+        const double keep = (lane >= p && lane < f) ? xg[lane - p] : 0.0;
+        wave_sync();
+        if (lane < f) ST[lds_self + lane] = (lane < p) ? v : keep;
+    }
+    wave_sync();
+}
+
+__global__ void __launch_bounds__(64 * WT_WAVES) k_wt_bwd(const WtWave *__restrict__ waves, const WtHdr *__restrict__ hdrs,
+                                                        const int32_t *__restrict__ meta, const double *__restrict__ pool, double *x) {
+    __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    const WtWave wv = waves[blockIdx.x * WT_WAVES + wave];
+    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst);
+    if (b0 >= b1) return;
+    double *L = lds[wave];
+    L[WT_OFF_Z + lane] = 0.0;
+    const long long *H = reinterpret_cast<const long long *>(hdrs);
+    long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
+    long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
+    f64x2 xc[WT_X / WT_CHUNK];
+#pragma unroll
+    for (int c = 0; c < WT_X / WT_CHUNK; c++) xc[c] = ld_f64x2(x + xfirst + WT_CHUNK * c + 2 * lane);
+    f64x2 pc[WT_NCH];
+    i32x4 mc[2];
+    wt_issue(h0, lane, pool, meta, pc, mc);
+#pragma unroll
+    for (int c = 0; c < WT_X / WT_CHUNK; c++) st_lds_f64x2(L + WT_OFF_X + WT_CHUNK * c + 2 * lane, xc[c]);
+    for (int j = b0; j < b1; j++) {
+        wt_park(L, lane, pc, mc);
+        const int nrec = wave_uniform((int)(unsigned)(unsigned long long)wave_bcast_i64(h0, WT_NCH + 1));
+        if (j + 1 < b1) wt_issue(h1, lane, pool, meta, pc, mc);
+        const long long h2 = H[16 * (int64_t)(j + 2 < b1 ? j + 2 : b1 - 1) + (lane & 15)];
+        wave_sync();
+        for (int q = 0; q < nrec; q++) wt_bwd_front(L, q, lane, x);
+        h0 = h1;
+        h1 = h2;
+    }
+}
+
+} // namespace hipmf

@@ -68,6 +68,11 @@ void Solver::release() {
         if (p) (void)hipFree(p);
     if (d_sd) (void)hipFree(d_sd);
     d_sd = nullptr;
+    for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep})
+        if (p) (void)hipFree(p);
+    d_wt_hdr = nullptr, d_wt_meta = nullptr, d_wt_wave = nullptr, d_sf2 = nullptr, d_need2 = nullptr, d_rep_idx = nullptr, d_rep = nullptr;
+    rep_words = 0;
+    wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
             if (p) (void)hipFree(p);
@@ -184,6 +189,14 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
+    if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
+    if (const char *e = getenv("HIPMF_UP_STAGE")) up_stage = std::max(0, std::min(64, atoi(e) / 8 * 8));
+    if (const char *e = getenv("HIPMF_UP_STAGE_BWD")) up_stage_bwd = std::max(8, std::min(64, atoi(e) / 8 * 8));
+    if (const char *e = getenv("HIPMF_UP_TOP_FRONTS")) up_top_fronts = std::max(1, atoi(e));
+    if (const char *e = getenv("HIPMF_UP_REPLICAS")) use_rep = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_UP_STAGE_MID")) up_stage_mid = std::max(0, std::min(32, atoi(e) / 8 * 8));
     if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
     if (const char *e = getenv("HIPMF_SF_BIG_FRONT")) sf_big_front = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_SF_ASM_FRONT")) sf_asm_front = atoi(e); // forward solve: fronts with at least this many rows assemble their vector once (0: never)
@@ -391,9 +404,12 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_vs, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
     if (sym_lower) HIPC(hipMalloc((void **)&d_vs2, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
-    for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * n), ERROR_HIP_MALLOC);
+    // (+ WT_X: a wave-subtree fetches its part of the vector / of the interchanges as WT_X entries from its first pivot column on)
+    for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
     if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
-    HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * n), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
+    HIPC(hipMemsetAsync(d_lperm, 0, sizeof(int32_t) * ((size_t)n + WT_X), STREAM), ERROR_HIP_MEMCPY);
+    for (double *p : {d_xp, d_du}) HIPC(hipMemsetAsync(p + n, 0, sizeof(double) * WT_X, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMalloc((void **)&d_diag, sizeof(double) * n), ERROR_HIP_MALLOC);
     if (S.sym_mode) d_cs = d_rs; // symmetric scaling S A S keeps the big fronts symmetric: column scale = row scale
     HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
@@ -604,6 +620,9 @@ int32_t Solver::upload_plan() {
         std::vector<int32_t> need((size_t)2 * ns, 1);
         // rows per slab by the length of the dot products (forward: p columns, backward: f columns): long ones get
         // narrow slabs, i.e. more column groups per workgroup and more workgroups per front
+        std::vector<char> in_w((size_t)ns, 0); // fronts that belong to a wave-subtree (kernels_solve_tree.hpp)
+        bool tree = false;                     // the task list being built is the one above the wave-subtrees
+        int32_t top_level = S.nlevels;         // ... its levels >= top_level run in a launch of their own (LDS-staged slabs)
         auto kind_of = [&](int32_t s, bool forward) {
             const int32_t len = forward ? S.npiv(s) : S.fsize(s);
             if (!forward && S.sym_mode) return 4; // transposed GEMV of the L D L^T fronts: 16 columns of E per workgroup
@@ -611,12 +630,23 @@ int32_t Solver::upload_plan() {
             // for 10 000 rows) re-read them hundreds of times; 64-row slabs still give >= 32 workgroups per front
             // (3D 100^3: pass pair 3.44 -> 3.33 ms, 64 right-hand sides 182 -> 160 ms)
             if (forward && sf_big_rows > 0 && S.fsize(s) >= sf_big_front) return sf_big_rows;
+            // above the wave-subtrees: a thread's share of its row of E / E' (len / G entries, G = 256 / rows column groups) is parked
+            // in LDS / registers BEFORE the wait, so the slabs are cut for <= ~40 entries per thread
+            // TOP levels above the wave-subtrees (few, large fronts: a chain of hand-offs): a thread's share of its row of E / E'
+            // (len / G entries, G = 256 / rows column groups) is parked in LDS BEFORE the wait, so the slabs are cut for <= 32 entries
+            // per thread where 8-row slabs (G = 32) allow it
+            if (tree && !slab64 && S.sn_level[s] >= top_level) {
+                int32_t G = 2;
+                while (G < 32 && len > 32 * G) G *= 2;
+                return G == 32 ? 3 : (G == 16 ? 4 : (G == 8 ? 5 : (G == 4 ? 6 : 7)));
+            }
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
         };
         auto emit_level = [&](int32_t l, bool forward) {
             std::vector<int32_t> small;
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                 int32_t s = S.level_sn[k];
+                if (tree && in_w[(size_t)s]) continue;
                 if (S.fsize(s) <= SMALL_F) {
                     small.push_back(s);
                     continue;
@@ -667,12 +697,208 @@ int32_t Solver::upload_plan() {
         sf_bwd_cnt = (int32_t)sf.size() - sf_fwd_cnt;
         if (getenv("HIPMF_SF_TRACE")) { // profiling aid: four device-clock stamps per task of the upper (mixed) launches
             const size_t ntr = (size_t)(sf_fwd_cnt - sf_fwd_band) + (size_t)sf_bwd_top;
-            HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 4 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
-            HIPC(hipMemset(d_trace, 0, sizeof(unsigned long long) * 4 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
+            HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 8 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
+            HIPC(hipMemset(d_trace, 0, sizeof(unsigned long long) * 8 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
             sf_host.clear();
             for (const SfTask &t : sf) sf_host.push_back(t.kind), sf_host.push_back(t.a);
         }
         HIPC(dev_upload(&d_sf, sf), ERROR_HIP_MALLOC);
+        // ---- bottom of the tree: one wavefront per subtree of small fronts (kernels_solve_tree.hpp) ----
+        // A front is "closed" when it and all its descendants are small fronts and the subtree stays within the caps (fronts, panel
+        // bytes, pivots = the part of x the wave keeps in LDS, LDS stack = sum of f over a root-to-leaf path of fronts with children);
+        // the wave-subtrees are the maximal closed ones.
+        wt_waves = wt_recs = 0;
+        sf2_fwd_cnt = sf2_bwd_cnt = 0;
+        bool tree_ok = use_tree && S.n >= 4;
+        if (tree_ok) {
+            std::vector<char> ok((size_t)ns, 0);
+            std::vector<int32_t> cnt((size_t)ns, 0), dl((size_t)ns, 0), piv((size_t)ns, 0);
+            std::vector<int64_t> bytes((size_t)ns, 0);
+            for (int32_t s = 0; s < ns && tree_ok; s++) { // (supernodes are numbered in postorder: children first)
+                const int32_t f = S.fsize(s), p = S.npiv(s);
+                bool good = f <= SMALL_F && (int64_t)f * p <= WT_NCH * WT_CHUNK && S.nrow(s) <= WT_MI - 16 * WT_NREC;
+                int32_t c = 1, d = 0, pv = p;
+                int64_t b = (int64_t)f * p * 8;
+                for (int32_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; q++) {
+                    const int32_t ch = S.child_idx[q];
+                    if (ch >= s) tree_ok = false;
+                    else good = good && ok[(size_t)ch], c += cnt[(size_t)ch], b += bytes[(size_t)ch], d = std::max(d, dl[(size_t)ch]), pv += piv[(size_t)ch];
+                }
+                if (S.child_ptr[s + 1] > S.child_ptr[s]) d += f;
+                cnt[(size_t)s] = c, bytes[(size_t)s] = b, dl[(size_t)s] = d, piv[(size_t)s] = pv;
+                ok[(size_t)s] = good && c <= wt_max_fronts && b <= (int64_t)wt_max_kb * 1024 && d <= WT_STACK && pv <= WT_X;
+            }
+            if (tree_ok) {
+                std::vector<int32_t> roots;
+                for (int32_t s = 0; s < ns; s++)
+                    if (ok[(size_t)s] && (S.sn_parent[s] < 0 || !ok[(size_t)S.sn_parent[s]])) roots.push_back(s);
+                // the longest subtrees first: workgroups start in index order, the short ones fill the tail
+                std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return bytes[(size_t)a] > bytes[(size_t)b]; });
+                std::vector<WtHdr> hdr_f, hdr_b;
+                std::vector<int32_t> meta_f, meta_b;
+                std::vector<WtWave> wav_f, wav_b;
+                std::vector<int32_t> off((size_t)ns, 0);
+                for (size_t ri = 0; ri < roots.size() && tree_ok; ri++) {
+                    const int32_t R = roots[ri], lo = R - cnt[(size_t)R] + 1;
+                    // the subtree is the supernode range [lo, R] (postorder numbering); its pivot columns are one contiguous range
+                    for (int32_t s = R; s >= lo; s--) {
+                        if (s != R && (S.sn_parent[s] < lo || S.sn_parent[s] > R)) tree_ok = false;
+                        if (s == R) off[(size_t)s] = 0;
+                        for (int32_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; q++) off[(size_t)S.child_idx[q]] = off[(size_t)s] + S.fsize(s);
+                    }
+                    if (!tree_ok) break;
+                    const int32_t xfirst = S.sn_first[lo];
+                    for (int dir = 0; dir < 2; dir++) { // 0: forward (postorder = ascending), 1: backward (descending)
+                        std::vector<WtHdr> &hdr = dir == 0 ? hdr_f : hdr_b;
+                        std::vector<int32_t> &meta = dir == 0 ? meta_f : meta_b;
+                        std::vector<WtWave> &wav = dir == 0 ? wav_f : wav_b;
+                        WtWave w;
+                        w.b0 = (int32_t)hdr.size(), w.xfirst = xfirst, w.pad = 0;
+                        int32_t s = dir == 0 ? lo : R;
+                        const int32_t send = dir == 0 ? R + 1 : lo - 1, step = dir == 0 ? 1 : -1;
+                        while (s != send) {
+                            // one batch: as many consecutive fronts as fit (records, 1 KB pieces, words of the meta block)
+                            int32_t nrec = 0, nch = 0, words = 0, e = s;
+                            while (e != send && nrec < WT_NREC) {
+                                const int32_t ck = (int32_t)(((int64_t)S.fsize(e) * S.npiv(e) + WT_CHUNK - 1) / WT_CHUNK);
+                                const bool lists = dir == 0 ? e != R : true; // (the forward root has no use for its relative indices)
+                                const int32_t wk = lists ? S.nrow(e) : 0;
+                                if (nrec > 0 && (nch + ck > WT_NCH || 16 * (nrec + 1) + words + wk > WT_MI)) break;
+                                nrec++, nch += ck, words += wk, e += step;
+                            }
+                            WtHdr h;
+                            memset(&h, 0, sizeof h);
+                            h.nrec = nrec;
+                            h.meta = (int64_t)meta.size();
+                            const size_t m0 = meta.size();
+                            meta.resize(m0 + (size_t)16 * nrec);
+                            int32_t ci = 0, lst = 16 * nrec;
+                            for (int32_t k = 0, t = s; k < nrec; k++, t += step) {
+                                WtRec r;
+                                memset(&r, 0, sizeof r);
+                                const int32_t par = S.sn_parent[t], pp = S.npiv(t), mm = S.nrow(t), ff = pp + mm;
+                                const bool has_children = S.child_ptr[t + 1] > S.child_ptr[t];
+                                const bool packed = dir == 1 && fd[(size_t)t].epoff >= 0;
+                                const int64_t src = dir == 0 ? fd[(size_t)t].off : (packed ? fd[(size_t)t].epoff : fd[(size_t)t].off);
+                                const int32_t ck = (int32_t)(((int64_t)ff * pp + WT_CHUNK - 1) / WT_CHUNK);
+                                r.pslot = WT_CHUNK * ci;
+                                for (int32_t c = 0; c < ck; c++) h.src[ci++] = src + (int64_t)WT_CHUNK * c;
+                                r.pm = pp | (mm << 16);
+                                r.xoff = S.sn_first[t] - xfirst;
+                                int32_t lds_self = has_children ? off[(size_t)t] + 1 : 0, lds_par = 0;
+                                if (t != R) {
+                                    lds_par = off[(size_t)par] + 1;
+                                    r.pxoff = S.sn_first[par] - xfirst, r.ppf = S.npiv(par) | (S.fsize(par) << 16);
+                                    if (S.child_idx[S.child_ptr[par]] == t) r.flags |= 1;
+                                }
+                                if (packed) r.flags |= 2;
+                                if (fd[(size_t)t].epoff >= 0) r.flags |= 4;
+                                r.lds = lds_self | (lds_par << 16);
+                                r.first = S.sn_first[t], r.s = t, r.woff = fd[(size_t)t].woff;
+                                const bool lists = dir == 0 ? t != R : true;
+                                r.relo = lst;
+                                if (lists && mm > 0) {
+                                    const int32_t *src_idx = (t != R ? S.rel.data() : S.sn_rows.data()) + S.sn_rowptr[t];
+                                    meta.insert(meta.end(), src_idx, src_idx + mm);
+                                    lst += mm;
+                                }
+                                memcpy(meta.data() + m0 + (size_t)16 * k, &r, sizeof r);
+                            }
+                            for (int32_t c = ci; c < WT_NCH; c++) h.src[c] = h.src[0];
+                            hdr.push_back(h);
+                            s = e;
+                        }
+                        w.b1 = (int32_t)hdr.size();
+                        wav.push_back(w);
+                    }
+                }
+                if (tree_ok) {
+                    for (size_t ri = 0; ri < roots.size(); ri++)
+                        for (int32_t s = roots[ri] - cnt[(size_t)roots[ri]] + 1; s <= roots[ri]; s++) in_w[(size_t)s] = 1, wt_recs++;
+                    wt_waves = (int32_t)roots.size();
+                    while (wav_f.size() % WT_WAVES != 0) wav_f.push_back({0, 0, 0, 0}), wav_b.push_back({0, 0, 0, 0});
+                    // one array each: forward part, then backward part (the backward headers / waves index their own parts)
+                    wt_hdr_fwd = (int32_t)hdr_f.size(), wt_hdr_bwd = (int32_t)hdr_b.size(), wt_meta_fwd = (int64_t)meta_f.size();
+                    hdr_f.insert(hdr_f.end(), hdr_b.begin(), hdr_b.end());
+                    meta_f.insert(meta_f.end(), meta_b.begin(), meta_b.end());
+                    meta_f.resize(meta_f.size() + WT_MI, 0); // (a batch's meta block is fetched as WT_MI words whatever it holds)
+                    wav_f.insert(wav_f.end(), wav_b.begin(), wav_b.end());
+                    HIPC(dev_upload(&d_wt_hdr, hdr_f), ERROR_HIP_MALLOC);
+                    HIPC(dev_upload(&d_wt_meta, meta_f), ERROR_HIP_MALLOC);
+                    HIPC(dev_upload(&d_wt_wave, wav_f), ERROR_HIP_MALLOC);
+                }
+            }
+            if (tree_ok) {
+                // the fronts above: the same task kinds as before, slabs cut for the LDS-staged instances
+                std::vector<SfTask> keep;
+                keep.swap(sf);
+                std::vector<int32_t> need_keep = need;
+                std::fill(need.begin(), need.end(), 1);
+                tree = true;
+                // the TOP levels: from the first level on above which no level has more than up_top_fronts tiled fronts
+                top_level = S.nlevels;
+                if (up_stage > 0) {
+                    while (top_level > 0) {
+                        int32_t nb = 0;
+                        for (int32_t k = S.level_ptr[top_level - 1]; k < S.level_ptr[top_level]; k++) nb += S.fsize(S.level_sn[k]) > SMALL_F;
+                        if (nb > up_top_fronts || nb == 0) break;
+                        top_level--;
+                    }
+                }
+                sf2_fwd_mid = 0;
+                for (int32_t l = 0; l < S.nlevels; l++) {
+                    if (l == top_level) sf2_fwd_mid = (int32_t)sf.size();
+                    emit_level(l, true);
+                }
+                sf2_fwd_cnt = (int32_t)sf.size();
+                if (top_level >= S.nlevels) sf2_fwd_mid = sf2_fwd_cnt;
+                sf2_bwd_top = 0;
+                for (int32_t l = S.nlevels - 1; l >= 0; l--) {
+                    emit_level(l, false);
+                    if (l == top_level) sf2_bwd_top = (int32_t)sf.size() - sf2_fwd_cnt;
+                }
+                sf2_bwd_cnt = (int32_t)sf.size() - sf2_fwd_cnt;
+                tree = false;
+                {
+                    // "complete" replicas of the tiled fronts of the top levels (kernels_solve_fused.hpp, sf_wait_front)
+                    std::vector<int32_t> ridx((size_t)ns, -1);
+                    int32_t ntop = 0;
+                    if (use_rep)
+                        for (int32_t l = top_level; l < S.nlevels; l++)
+                            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++)
+                                if (S.fsize(S.level_sn[k]) > SMALL_F) ridx[(size_t)S.level_sn[k]] = ntop++;
+                    rep_words = (int64_t)ntop * SF_REP * 16;
+                    if (ntop > 0) {
+                        HIPC(dev_upload(&d_rep_idx, ridx), ERROR_HIP_MALLOC);
+                        HIPC(hipMalloc((void **)&d_rep, sizeof(int32_t) * 2 * (size_t)rep_words), ERROR_HIP_MALLOC);
+                        HIPC(hipMemset(d_rep, 0, sizeof(int32_t) * 2 * (size_t)rep_words), ERROR_HIP_MALLOC);
+                    }
+                }
+                HIPC(dev_upload(&d_sf2, sf), ERROR_HIP_MALLOC);
+                HIPC(dev_upload(&d_need2, need), ERROR_HIP_MALLOC);
+                if (d_trace) { // (profiling aid: the stamps of THIS list's tasks)
+                    (void)hipFree(d_trace);
+                    d_trace = nullptr;
+                    HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 8 * std::max<size_t>(sf.size(), 1)), ERROR_HIP_MALLOC);
+                    HIPC(hipMemset(d_trace, 0, sizeof(unsigned long long) * 8 * std::max<size_t>(sf.size(), 1)), ERROR_HIP_MALLOC);
+                    sf_host.clear();
+                    for (const SfTask &t : sf) sf_host.push_back(t.kind), sf_host.push_back(t.a);
+                }
+                sf.swap(keep);
+                need.swap(need_keep);
+                if (opt.verbose)
+                    fprintf(stderr,
+                            "hipmf: initialize: %d wave-subtrees hold %d of %d fronts in %d + %d batches; %d + %d tasks above them, of which %d + %d "
+                            "on the top levels (%d..%d)\n",
+                            wt_waves, wt_recs, ns, wt_hdr_fwd, wt_hdr_bwd, sf2_fwd_cnt, sf2_bwd_cnt, sf2_fwd_cnt - sf2_fwd_mid, sf2_bwd_top, top_level,
+                            S.nlevels - 1);
+            }
+        }
+        tree_active = tree_ok && (wt_waves > 0 || sf2_fwd_cnt > 0);
+        if (tree_active && up_stage > 0) {
+            HIPMF_ALLOW_LDS((k_fwd_fused<false, 1, true>), sizeof(double) * 256 * (size_t)up_stage);
+            HIPMF_ALLOW_LDS((k_bwd_fused<false, 1, false, true>), sizeof(double) * 256 * (size_t)up_stage_bwd);
+        }
         HIPC(dev_upload(&d_need, need), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
         HIPC(hipMemset(d_sync, 0, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
@@ -690,7 +916,8 @@ int32_t Solver::upload_plan() {
     HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_rel, S.rel), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_child, S.child_idx), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_pool, sizeof(double) * std::max<int64_t>(pool_doubles, 1)), ERROR_HIP_MALLOC);
+    // (+ WT_CHUNK: the wave-subtree kernels read the factor in whole 1 KB pieces)
+    HIPC(hipMalloc((void **)&d_pool, sizeof(double) * (std::max<int64_t>(pool_doubles, 1) + WT_CHUNK)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_work, sizeof(double) * std::max<int64_t>(work_doubles, 1)), ERROR_HIP_MALLOC);
     return SUCCESSFUL_EXIT;
 }
@@ -939,15 +1166,65 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         int32_t *sync_f = lane_sync, *sync_b = lane_sync + SF_SYNC_HEADER + ns, *sync_err = lane_sync + 2 * (SF_SYNC_HEADER + ns);
         HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
+        if (tree_active && nk == 1) {
+            if (d_rep) HIPC(hipMemsetAsync(d_rep, 0, sizeof(int32_t) * 2 * (size_t)rep_words, LST), ERROR_HIP_MEMCPY);
+            // one wavefront per subtree of small fronts at the bottom (k_wt_fwd / k_wt_bwd), LDS-staged dependency-driven tasks above
+            const int32_t wg = (wt_waves + WT_WAVES - 1) / WT_WAVES;
+            const size_t dyn = sizeof(double) * 256 * (size_t)up_stage;
+            unsigned long long *no_tr = (timed && d_trace) ? d_trace : nullptr;
+            if (wg > 0)
+                hipLaunchKernelGGL(k_wt_fwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave, d_wt_hdr, d_wt_meta, d_pool, d_lperm, sync_f, wrk, xp);
+            // the fronts above the wave-subtrees: the many mid-level tasks at full occupancy, then the top levels (a chain of
+            // hand-offs between few, large fronts) with their shares of E / E' parked in LDS before the wait
+            const int32_t f_mid = sf2_fwd_mid, f_top = sf2_fwd_cnt - sf2_fwd_mid, b_top = sf2_bwd_top, b_mid = sf2_bwd_cnt - sf2_bwd_top;
+            if (f_mid > 0)
+                hipLaunchKernelGGL((k_fwd_fused<false, 1, false>), dim3(f_mid), dim3(256), 0, LST, d_sf2, d_fd, d_pool, d_lperm, d_child, d_rel, d_need2,
+                                   sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr, 0, (const int32_t *)nullptr, (int *)nullptr);
+            if (f_top > 0)
+                hipLaunchKernelGGL((k_fwd_fused<false, 1, true>), dim3(f_top), dim3(256), dyn, LST, d_sf2 + f_mid, d_fd, d_pool, d_lperm, d_child, d_rel,
+                                   d_need2, sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr ? no_tr + 8 * (size_t)f_mid : no_tr, up_stage,
+                                   (const int32_t *)d_rep_idx, d_rep);
+            if (timed) HIPC(hipEventRecord((hipEvent_t)ev[4], LST), ERROR_HIP_SYNCHRONIZE);
+            {
+                const SfTask *tb = d_sf2 + sf2_fwd_cnt;
+                unsigned long long *tr_b = no_tr ? no_tr + 8 * (size_t)sf2_fwd_cnt : nullptr;
+                const size_t dyn_b = sizeof(double) * 256 * (size_t)up_stage_bwd;
+                if (S.sym_mode) {
+                    if (sf2_bwd_cnt > 0)
+                        hipLaunchKernelGGL((k_bwd_fused<false, 1, true, false>), dim3(sf2_bwd_cnt), dim3(256), 0, LST, tb, d_fd, d_pool, d_rows,
+                                           d_need2 + ns, sync_b, sync_err, wrk, xp, 1, xstr, wstr, tr_b, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr);
+                } else {
+                    if (b_top > 0)
+                        hipLaunchKernelGGL((k_bwd_fused<false, 1, false, true>), dim3(b_top), dim3(256), dyn_b, LST, tb, d_fd, d_pool, d_rows, d_need2 + ns,
+                                           sync_b, sync_err, wrk, xp, 1, xstr, wstr, tr_b, d_diag, up_stage_bwd, (const int32_t *)d_rep_idx,
+                                           d_rep ? d_rep + rep_words : d_rep);
+                    if (b_mid > 0 && up_stage_mid > 0) // (the backward slabs have no register prefetch of E': a small parked share pays)
+                        hipLaunchKernelGGL((k_bwd_fused<false, 1, false, true>), dim3(b_mid), dim3(256), sizeof(double) * 256 * (size_t)up_stage_mid, LST,
+                                           tb + b_top, d_fd, d_pool, d_rows, d_need2 + ns, sync_b, sync_err, wrk, xp, 1, xstr, wstr,
+                                           tr_b ? tr_b + 8 * (size_t)b_top : tr_b, d_diag, up_stage_mid, (const int32_t *)nullptr, (int *)nullptr);
+                    else if (b_mid > 0)
+                        hipLaunchKernelGGL((k_bwd_fused<false, 1, false, false>), dim3(b_mid), dim3(256), 0, LST, tb + b_top, d_fd, d_pool, d_rows,
+                                           d_need2 + ns, sync_b, sync_err, wrk, xp, 1, xstr, wstr, tr_b ? tr_b + 8 * (size_t)b_top : tr_b, d_diag, 0,
+                                           (const int32_t *)nullptr, (int *)nullptr);
+                }
+            }
+            if (wg > 0)
+                hipLaunchKernelGGL(k_wt_bwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave + (size_t)wg * WT_WAVES, d_wt_hdr + wt_hdr_fwd,
+                                   d_wt_meta + wt_meta_fwd, d_pool, xp);
+            if (timed) HIPC(hipEventRecord((hipEvent_t)ev[5], LST), ERROR_HIP_SYNCHRONIZE);
+            times.n_kernel_launches_solve = 2 * (wg > 0) + (f_mid > 0) + (f_top > 0) + (S.sym_mode ? (sf2_bwd_cnt > 0) : (b_top > 0) + (b_mid > 0));
+            if (timed) tri_pending = true;
+            return SUCCESSFUL_EXIT;
+        }
         const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
         const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
         unsigned long long *no_trace = nullptr;
 #define HIPMF_FWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f, \
-                       sync_err, wrk, xp, nk, xstr, wstr, TRACE)
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, 0, (const int32_t *)nullptr, (int *)nullptr)
 #define HIPMF_BWD1(SMALL, KK, SYMM, CNT, TASKS, TRACE)                                                                                     \
     hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b,      \
-                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag)
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr)
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     do {                                                                                                                                  \
         if (!SMALL && S.sym_mode) HIPMF_BWD1(false, KK, true, CNT, TASKS, TRACE);                                                          \
@@ -962,10 +1239,10 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         }
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[4], LST), ERROR_HIP_SYNCHRONIZE);
         if (nk == 1) {
-            if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 4 * (size_t)fb : nullptr);
+            if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, 1, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         } else {
-            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 4 * (size_t)fb : nullptr);
+            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         }
 #undef HIPMF_FWD
@@ -1245,15 +1522,17 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     harvest_tri();
     if (use_fused && d_trace) {
         // dump: one line per task of the two upper launches: direction, level, front, kind, p, f, four stamps (10 ns units)
-        const size_t nf = (size_t)(sf_fwd_launch - std::min(sf_fwd_band, sf_fwd_launch)), nb = (size_t)sf_bwd_top;
-        std::vector<unsigned long long> tr(4 * (nf + nb));
+        const bool tr_tree = tree_active;
+        const size_t nf = tr_tree ? (size_t)sf2_fwd_cnt : (size_t)(sf_fwd_launch - std::min(sf_fwd_band, sf_fwd_launch));
+        const size_t nb = tr_tree ? (size_t)sf2_bwd_cnt : (size_t)sf_bwd_top;
+        std::vector<unsigned long long> tr(8 * (nf + nb));
         (void)hipMemcpy(tr.data(), d_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost);
         if (FILE *fp = fopen(getenv("HIPMF_SF_TRACE"), "w")) {
             for (size_t k = 0; k < nf + nb; k++) {
-                const size_t ti = k < nf ? (size_t)sf_fwd_band + k : (size_t)sf_fwd_cnt + (k - nf);
+                const size_t ti = tr_tree ? k : (k < nf ? (size_t)sf_fwd_band + k : (size_t)sf_fwd_cnt + (k - nf));
                 const int32_t kind = sf_host[2 * ti], a = sf_host[2 * ti + 1];
-                fprintf(fp, "%c %d %d %d %d %d %llu %llu %llu %llu\n", k < nf ? 'F' : 'B', S.sn_level[a], a, kind, S.npiv(a), S.fsize(a),
-                        tr[4 * k], tr[4 * k + 1], tr[4 * k + 2], tr[4 * k + 3]);
+                fprintf(fp, "%c %d %d %d %d %d %llu %llu %llu %llu %llu %llu\n", k < nf ? 'F' : 'B', S.sn_level[a], a, kind, S.npiv(a), S.fsize(a),
+                        tr[8 * k], tr[8 * k + 1], tr[8 * k + 2], tr[8 * k + 3], tr[8 * k + 4], tr[8 * k + 5]);
             }
             fclose(fp);
         }

@@ -14,6 +14,8 @@ struct EaTask;
 struct EaRange;
 struct SolveTask;
 struct SfTask;
+struct WtHdr;
+struct WtWave;
 struct ZeroTask;
 struct FactorInfo;
 
@@ -159,6 +161,30 @@ class Solver {
     int32_t sf_fwd_cnt = 0, sf_bwd_cnt = 0; // forward tasks first, then the backward tasks
     int32_t sf_fwd_band = 0, sf_bwd_top = 0; // tasks of the all-small bottom band (forward: first; backward: after sf_bwd_top)
     int32_t sf_fwd_launch = 0;              // == sf_fwd_cnt unless the profiling knob HIPMF_SF_FWD_LEVELS cuts the pass short
+    // bottom of the tree: one wavefront per subtree of small fronts (kernels_solve_tree.hpp); the tasks of everything above it
+    // (single right-hand side; the blocked many-RHS instances keep the task lists above)
+    bool use_tree = true;                   // HIPMF_TREE_SOLVE=0: the round-2 schedule (all-small band + upper band)
+    int32_t wt_max_fronts = 24;             // HIPMF_WT_FRONTS: fronts per wave-subtree at most
+    int32_t wt_max_kb = 64;                 // HIPMF_WT_KB: panel kilobytes per wave-subtree at most
+    int32_t up_stage = 32;                  // HIPMF_UP_STAGE: entries of E per thread of a TOP-level forward slab parked in LDS before the wait (multiple of 8; 0: no top launch)
+    int32_t up_stage_bwd = 48;              // HIPMF_UP_STAGE_BWD: the same for E' in the backward pass (the dot products run over f, not p)
+    int32_t up_stage_mid = 8;               // HIPMF_UP_STAGE_MID: the same for the backward slabs BELOW the top levels (0: none)
+    int32_t up_top_fronts = 40;             // HIPMF_UP_TOP_FRONTS: the top levels are those above which no level has more tiled fronts
+    WtHdr *d_wt_hdr = nullptr;              // batch headers: forward part, then backward part
+    int32_t *d_wt_meta = nullptr;           // meta blocks of the batches (records + index lists): forward part, then backward part
+    WtWave *d_wt_wave = nullptr;            // batch range and first pivot column of every wave-subtree: forward part, then backward part
+    int32_t wt_waves = 0, wt_recs = 0;      // wave-subtrees, fronts they hold
+    int32_t wt_hdr_fwd = 0, wt_hdr_bwd = 0; // batches of the forward / backward part
+    int64_t wt_meta_fwd = 0;                // words of the forward part of d_wt_meta
+    SfTask *d_sf2 = nullptr;                // tasks of the fronts above the wave-subtrees: forward, then backward
+    int32_t sf2_fwd_cnt = 0, sf2_bwd_cnt = 0;
+    int32_t sf2_fwd_mid = 0, sf2_bwd_top = 0; // forward: tasks below the top levels come first; backward: the top levels' tasks come first
+    int32_t *d_rep_idx = nullptr;           // per front: index of its "complete" replicas (tiled fronts of the top levels), else -1
+    int32_t *d_rep = nullptr;               // the replicas: forward part, then backward part (zeroed before every pass)
+    int64_t rep_words = 0;
+    bool use_rep = true;                    // HIPMF_UP_REPLICAS=0: every waiter polls the front's counter
+    int32_t *d_need2 = nullptr;             // completed-task counts of that list (the slabs are cut differently)
+    bool tree_active = false;               // the plan above exists for this matrix
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream

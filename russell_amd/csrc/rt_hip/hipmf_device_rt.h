@@ -14,6 +14,20 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// 16-byte accesses: global loads from 8-byte (4-byte) aligned addresses (global_load_dwordx4 takes them), LDS stores to 16-byte aligned ones
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x2 ld_f64x2(const double *p) {
+    typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+    return *(const f64x2u *)p;
+}
+__device__ __forceinline__ i32x4 ld_i32x4(const int *p) {
+    typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    return *(const i32x4u *)p;
+}
+__device__ __forceinline__ void st_lds_f64x2(double *p, f64x2 v) { *(f64x2 *)p = v; }
+__device__ __forceinline__ void st_lds_i32x4(int *p, i32x4 v) { *(i32x4 *)p = v; }
+
 // the value is needed (in a scalar register) at this point of the program: its load cannot sink below
 #define HIPMF_KEEP_SCALAR(x) asm volatile("" ::"s"(x))
 #define HIPMF_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]

@@ -42,7 +42,7 @@ def test_fused_equals_level_set_bitwise(grid):
     b = P.csr_matvec(n, rp, ci, v, xs)
     (ref,), st_l = _solve(n, rp, ci, v, b, fused=False, slab64=True)
     outs, st_f = _solve(n, rp, ci, v, b, fused=True, slab64=True, reps=8)
-    assert st_f["solve_launches"] <= 4 < st_l["solve_launches"] or grid < 64
+    assert st_f["solve_launches"] <= 6 < st_l["solve_launches"] or grid < 64
     for x in outs:
         assert np.array_equal(ref, x)
     assert np.max(np.abs(ref - xs)) < 1e-9

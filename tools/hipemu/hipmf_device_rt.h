@@ -5,6 +5,17 @@
 
 typedef double f64x4 __attribute__((vector_size(32)));
 
+struct f64x2 {
+    double x, y;
+};
+struct i32x4 {
+    int x, y, z, w;
+};
+inline f64x2 ld_f64x2(const double *p) { return {p[0], p[1]}; }
+inline i32x4 ld_i32x4(const int *p) { return {p[0], p[1], p[2], p[3]}; }
+inline void st_lds_f64x2(double *p, f64x2 v) { p[0] = v.x, p[1] = v.y; }
+inline void st_lds_i32x4(int *p, i32x4 v) { p[0] = v.x, p[1] = v.y, p[2] = v.z, p[3] = v.w; }
+
 inline double hipemu_mfma_a[16][64], hipemu_mfma_b[16][64];
 
 // same operand / result lane maps as v_mfma_f64_16x16x4_f64
