@@ -889,7 +889,8 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
         int32_t status = g_backend.initialize((InterfaceHIPMF *)solver, hipmf_ordering(par.ordering), hipmf_scaling(par.scaling),
                                               par.has_pivot_epsilon ? par.pivot_epsilon : -1.0,
                                               par.has_refinement_nstep ? par.refinement_nstep : -1, verbose,
-                                              mat.symmetric == Sym::YesLower ? 1 : 0, par.positive_definite ? 1 : 0, (int32_t)csr.nrow,
+                                              mat.symmetric == Sym::YesLower ? 1 : 0,
+                                              (par.positive_definite && mat.symmetric == Sym::YesLower) ? 1 : 0, (int32_t)csr.nrow,
                                               csr.row_pointers.data(), csr.col_indices.data(), csr.values.data());
         if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
         // value map for the repeat calls: CSR entry <- the COO triplets (duplicates in COO order) that sum into it
@@ -1096,8 +1097,13 @@ StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSol
         status = g_backend.zfactorize_mapped((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
                                              verbose, mat.values.data());
     } else {
-        StrError e = to_csr(mat, false);
+        // no value map (the backend refused it): the values go through a fresh conversion, and the pattern is checked on every call,
+        // as the real SolverHIPMF does -- summing through the segments of the first call's triplet order would be silently wrong
+        // for permuted triplets
+        const std::vector<int32_t> rp0 = zrp, ci0 = zci;
+        StrError e = to_csr(mat, true);
         if (e) return e;
+        if (zrp != rp0 || zci != ci0) return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
         status = g_backend.zfactorize((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate, 0,
                                       verbose, zvals.data());
     }

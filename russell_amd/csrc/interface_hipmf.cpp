@@ -48,8 +48,21 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int3
                                 int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
     // either flag promises the LOWER triangle of a symmetric matrix (interface_cudss.cu:324-333: SYMMETRIC / SPD + lower view); the
     // tiled fronts are then factorised as L D L^T (positive definite: D > 0, the same arithmetic)
-    const bool sym_lower = general_symmetric == 1 || positive_definite == 1;
     if (!h || !row_pointers || !col_indices) return ERROR_NULL_POINTER;
+    bool sym_lower = general_symmetric == 1 || positive_definite == 1;
+    if (sym_lower && general_symmetric != 1 && ndim >= 1 && row_pointers[0] == 0) {
+        // positive_definite alone: LinSolParams::positive_definite is independent of the storage (lin_sol_params.rs:41-42), and the
+        // reference's GPU plug-in accepts it with FULL storage (Sym::No) by taking the lower view (solver_cudss.rs:260-261).  A CSR
+        // with entries above the diagonal is therefore factorised as the general matrix it is (LU), not refused.
+        bool upper = false;
+        for (int32_t i = 0; i < ndim && !upper; i++)
+            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++)
+                if (col_indices[k] > i) {
+                    upper = true;
+                    break;
+                }
+        if (upper) sym_lower = false;
+    }
     if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
     if (ndim < 1) return ERROR_HIPMF_INVALID_MATRIX;
     SymbolicOptions so;
@@ -225,8 +238,9 @@ int32_t solver_hipmf_factor_parts(struct InterfaceHIPMF *h, int32_t max_parts, v
 }
 
 int32_t solver_hipmf_adopt_factor(struct InterfaceHIPMF *h, const double *d_values) {
-    // the peer wrote pool / lperm / row-scale through the pointers of solver_hipmf_factor_buffers;
-    // the values are still needed for the refinement SpMV
+    // the peer wrote the four parts of the factor (persistent part of the pool, interchanges, row scaling, pivots) through the
+    // pointers of solver_hipmf_factor_parts -- with a matching in force also the column scaling; the values are still needed for
+    // the refinement SpMV.  A re-matching factorize on the sending side (HIPMF_COUNTER_REMATCH) invalidates those pointers.
     if (!h || !d_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     return h->solver.adopt_factor(d_values);
@@ -250,6 +264,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
     bool tried = false, ok = false;
 };
 Rccl g_rccl;
@@ -267,7 +282,8 @@ bool rccl_load() {
     g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(g_rccl.dl, "ncclCommInitRank");
     g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(g_rccl.dl, "ncclCommDestroy");
     g_rccl.broadcast = (decltype(g_rccl.broadcast))dlsym(g_rccl.dl, "ncclBroadcast");
-    g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.broadcast;
+    g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(g_rccl.dl, "ncclAllReduce");
+    g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.broadcast && g_rccl.all_reduce;
     return g_rccl.ok;
 }
 } // namespace
@@ -301,16 +317,57 @@ int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *h, void *comm, int3
     if (rank == root && !h->solver.factorized) return ERROR_NEED_FACTORIZATION;
     if (!rccl_load()) return ERROR_NOT_AVAILABLE;
     Solver &s = h->solver;
-    void *ptrs[5];
-    int64_t nb[5];
-    if (solver_hipmf_factor_parts(h, 4, ptrs, nb) != 4) return ERROR_HIPMF_INVALID_VALUE;
-    ptrs[4] = s.d_vals_ptr(), nb[4] = s.S.nnz_a * 8; // the matrix values: the refinement SpMV of every rank needs them
+    // the handle's device for the duration of the call (handles are Send), the caller's device afterwards
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     if (hipSetDevice(s.device) != hipSuccess) return ERROR_HIPMF_NO_DEVICE;
+    struct Restore {
+        int dev, mine;
+        ~Restore() {
+            if (dev >= 0 && dev != mine) (void)hipSetDevice(dev);
+        }
+    } restore{caller_device, s.device};
+    // 1. every rank must hold the SAME plan as the root (same structure, same ordering, same matching): the root's plan signature
+    //    travels first, every rank compares it with its own, and the ranks agree on the outcome (MIN over the ranks) before any
+    //    factor data moves -- mismatched buffer sizes would otherwise hang the collective or, worse, be adopted into another plan.
+    //    A root that re-matched inside factorize (rematch_count) has another plan than peers that did not: they must be initialised
+    //    again from the root's values.
     const auto t0 = std::chrono::steady_clock::now();
+    {
+        int64_t mine[8] = {s.S.n, s.S.nnz_a, s.persist_bytes(), s.matched ? 1 : 0, (int64_t)s.plan_signature(), s.S.nsuper, s.S.sym_mode ? 1 : 0, 0};
+        int64_t *d_hdr = nullptr;
+        if (hipMalloc((void **)&d_hdr, sizeof(mine) + sizeof(int32_t) * 2) != hipSuccess) return ERROR_HIP_MALLOC;
+        int32_t *d_ok = (int32_t *)(d_hdr + 8);
+        bool fail = hipMemcpyAsync(d_hdr, mine, sizeof(mine), hipMemcpyHostToDevice, (hipStream_t)s.stream) != hipSuccess;
+        fail = fail || g_rccl.broadcast(d_hdr, d_hdr, sizeof(mine), ncclChar, root, (ncclComm_t)comm, (hipStream_t)s.stream) != ncclSuccess;
+        int64_t got[8];
+        fail = fail || hipMemcpyAsync(got, d_hdr, sizeof(got), hipMemcpyDeviceToHost, (hipStream_t)s.stream) != hipSuccess;
+        fail = fail || hipStreamSynchronize((hipStream_t)s.stream) != hipSuccess;
+        int32_t ok = (!fail && memcmp(got, mine, sizeof(mine)) == 0) ? 1 : 0, all_ok = 0;
+        fail = fail || hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, (hipStream_t)s.stream) != hipSuccess;
+        fail = fail || g_rccl.all_reduce(d_ok, d_ok + 1, 1, ncclInt32, ncclMin, (ncclComm_t)comm, (hipStream_t)s.stream) != ncclSuccess;
+        fail = fail || hipMemcpyAsync(&all_ok, d_ok + 1, sizeof(all_ok), hipMemcpyDeviceToHost, (hipStream_t)s.stream) != hipSuccess;
+        fail = fail || hipStreamSynchronize((hipStream_t)s.stream) != hipSuccess;
+        (void)hipFree(d_hdr);
+        if (fail) return ERROR_HIPMF_COMM;
+        if (all_ok != 1) {
+            s.last_error = ok == 1 ? "broadcast_factor: another rank holds a different plan than the root"
+                                   : "broadcast_factor: this rank's plan differs from the root's (structure, ordering or matching); initialize it "
+                                     "from the same structure and values as the root";
+            return ERROR_HIPMF_INVALID_VALUE;
+        }
+    }
+    // 2. the factor: persistent part of the pool, interchanges, row scaling, pivots; the column scaling of a matching; the matrix
+    //    values (the refinement SpMV of every rank needs them)
+    void *ptrs[6];
+    int64_t nb[6];
+    if (solver_hipmf_factor_parts(h, 4, ptrs, nb) != 4) return ERROR_HIPMF_INVALID_VALUE;
+    ptrs[4] = s.d_vals_ptr(), nb[4] = s.S.nnz_a * 8;
+    ptrs[5] = (s.matched && s.d_cs) ? (void *)s.d_cs : nullptr, nb[5] = ptrs[5] ? (int64_t)s.S.n * 8 : 0;
     // ring / tree collectives over xGMI are per-link bound: large messages (256 MB) keep every link busy
     const int64_t chunk = 256ll << 20;
     int64_t total = 0;
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 6; i++)
         for (int64_t off = 0; off < nb[i]; off += chunk) {
             const int64_t len = std::min(chunk, nb[i] - off);
             char *p = (char *)ptrs[i] + off;

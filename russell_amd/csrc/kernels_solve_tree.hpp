@@ -12,7 +12,7 @@
 //     side (its pivot columns are one contiguous range) and of the interchanges is fetched once, at the start;
 //   * the factor comes in BATCHES of up to 8 fronts / 6 KB: a first version fetched one front per memory round trip (16 row loads in
 //     registers, the next front requested while the current one is computed) and measured 3 us per front -- a wave never had more than
-//     ~2 KB in flight.  Now the panels of a batch are read as FLAT 1 KB pieces (global_load_dwordx4: 16 bytes per lane, whatever the
+//     ~2 KB in flight.  Now the panels of a batch are read as FLAT 512-byte pieces (64 lanes x 8 bytes, whatever the
 //     shape of the fronts), parked in LDS, and the fronts of the batch are computed out of LDS while the pieces of the next batch are
 //     in flight in the registers that staged this one.  Each batch comes with a header (where its pieces are) and a meta block (one
 //     16-word record per front + the index lists), both built at initialize: no descriptor chase at all.
@@ -25,7 +25,7 @@
 namespace hipmf {
 
 #ifndef HIPMF_WT_NCH
-#define HIPMF_WT_NCH 6
+#define HIPMF_WT_NCH 12
 #endif
 #ifndef HIPMF_WT_X
 #define HIPMF_WT_X 256
@@ -36,15 +36,16 @@ namespace hipmf {
 #ifndef HIPMF_WT_WAVES
 #define HIPMF_WT_WAVES 2
 #endif
-constexpr int WT_NCH = HIPMF_WT_NCH;    // 1 KB pieces of factor per batch
-constexpr int WT_CHUNK = 128;           // doubles per piece (64 lanes x 16 bytes)
+constexpr int WT_NCH = HIPMF_WT_NCH;    // 512-byte pieces of factor per batch
+constexpr int WT_CHUNK = 64;            // doubles per piece (64 lanes x 8 bytes; with 1 KB pieces the pass fetched 1.25x the algorithmic bytes:
+                                        // a piece is read whole, and what follows a front's panel in the pool is its contribution block)
 constexpr int WT_NREC = 8;              // fronts per batch at most
 constexpr int WT_MI = 512;              // 32-bit words of a batch's meta block: WT_NREC records of 16 words, then the index lists
 constexpr int WT_X = HIPMF_WT_X;        // pivots of a wave-subtree at most (multiple of 256)
 constexpr int WT_STACK = HIPMF_WT_STACK; // doubles of LDS per wave for the stack of front vectors (5 levels x 64 rows)
 // (measured on the 1M-DOF Poisson factor, forward + backward pass pair: 8 pieces / 512 pivots / 384 stack doubles = 20 KB of LDS per
 //  wave, 8 waves per CU: 470 us; 6 / 256 / 320 = 14.8 KB, 10 waves per CU: 460 us; 4 / 256 / 320: 506 us -- fronts of more than 512
-//  panel entries then stay outside the wave-subtrees)
+//  panel entries then stay outside the wave-subtrees; those runs used 1 KB pieces, the counts are now in 512-byte pieces)
 // LDS of one wave, in doubles: [ panels | meta | x of the subtree | interchanges of the subtree | stack | gather scratch ]
 constexpr int WT_OFF_M = WT_NCH * WT_CHUNK, WT_OFF_X = WT_OFF_M + WT_MI / 2, WT_OFF_LP = WT_OFF_X + WT_X, WT_OFF_ST = WT_OFF_LP + WT_X / 2;
 constexpr int WT_OFF_XG = WT_OFF_ST + WT_STACK, WT_OFF_Z = WT_OFF_XG + 64, WT_LDS = WT_OFF_Z + 64; // (Z: 64 zeros)
@@ -68,7 +69,7 @@ struct WtRec {       // one front of a batch: 16 words at the head of the batch'
 static_assert(sizeof(WtRec) == 64, "16 words");
 
 struct WtHdr {                 // one batch: 16 8-byte words, fetched by 16 lanes
-    int64_t src[WT_NCH];       // pool offsets of the batch's 1 KB pieces (unused ones repeat src[0])
+    int64_t src[WT_NCH];       // pool offsets of the batch's pieces (unused ones repeat src[0])
     int64_t meta;              // word offset of the batch's meta block
     int32_t nrec, pad;
     int64_t pad2[16 - WT_NCH - 2];
@@ -84,16 +85,16 @@ struct WtWave {
 // the loads of one batch: 8 pieces of factor, 2 of meta (all unconditional: the batch after this one is requested before this one
 // is computed, and the compiler can only wait for "all but the last N loads" when N does not depend on predicates)
 __device__ __forceinline__ void wt_issue(long long hw, int lane, const double *__restrict__ pool, const int32_t *__restrict__ meta,
-                                         f64x2 (&pc)[WT_NCH], i32x4 (&mc)[2]) {
+                                         double (&pc)[WT_NCH], i32x4 (&mc)[2]) {
 #pragma unroll
-    for (int c = 0; c < WT_NCH; c++) pc[c] = ld_f64x2(pool + wave_bcast_i64(hw, c) + 2 * lane);
+    for (int c = 0; c < WT_NCH; c++) pc[c] = pool[wave_bcast_i64(hw, c) + lane];
     const int64_t mo = wave_bcast_i64(hw, WT_NCH);
 #pragma unroll
     for (int c = 0; c < 2; c++) mc[c] = ld_i32x4(meta + mo + 256 * c + 4 * lane);
 }
-__device__ __forceinline__ void wt_park(double *L, int lane, const f64x2 (&pc)[WT_NCH], const i32x4 (&mc)[2]) {
+__device__ __forceinline__ void wt_park(double *L, int lane, const double (&pc)[WT_NCH], const i32x4 (&mc)[2]) {
 #pragma unroll
-    for (int c = 0; c < WT_NCH; c++) st_lds_f64x2(L + WT_CHUNK * c + 2 * lane, pc[c]);
+    for (int c = 0; c < WT_NCH; c++) L[WT_CHUNK * c + lane] = pc[c];
     int32_t *Mi = reinterpret_cast<int32_t *>(L + WT_OFF_M);
 #pragma unroll
     for (int c = 0; c < 2; c++) st_lds_i32x4(Mi + 256 * c + 4 * lane, mc[c]);
@@ -192,17 +193,17 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restri
     long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
     long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
     // the subtree's part of the right-hand side and of the interchanges (the vectors are allocated with room for the over-read)
-    f64x2 xc[WT_X / WT_CHUNK];
+    f64x2 xc[WT_X / 128];
     i32x4 lc[WT_X / 256];
 #pragma unroll
-    for (int c = 0; c < WT_X / WT_CHUNK; c++) xc[c] = ld_f64x2(x + xfirst + WT_CHUNK * c + 2 * lane);
+    for (int c = 0; c < WT_X / 128; c++) xc[c] = ld_f64x2(x + xfirst + 128 * c + 2 * lane);
 #pragma unroll
     for (int c = 0; c < WT_X / 256; c++) lc[c] = ld_i32x4(lperm + xfirst + 256 * c + 4 * lane);
-    f64x2 pc[WT_NCH];
+    double pc[WT_NCH];
     i32x4 mc[2];
     wt_issue(h0, lane, pool, meta, pc, mc);
 #pragma unroll
-    for (int c = 0; c < WT_X / WT_CHUNK; c++) st_lds_f64x2(L + WT_OFF_X + WT_CHUNK * c + 2 * lane, xc[c]);
+    for (int c = 0; c < WT_X / 128; c++) st_lds_f64x2(L + WT_OFF_X + 128 * c + 2 * lane, xc[c]);
 #pragma unroll
     for (int c = 0; c < WT_X / 256; c++) st_lds_i32x4(reinterpret_cast<int32_t *>(L + WT_OFF_LP) + 256 * c + 4 * lane, lc[c]);
     HIPMF_STAMP((int)blockIdx.x / 6, 1);
@@ -319,14 +320,14 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_bwd(const WtWave *__restri
     const long long *H = reinterpret_cast<const long long *>(hdrs);
     long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
     long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
-    f64x2 xc[WT_X / WT_CHUNK];
+    f64x2 xc[WT_X / 128];
 #pragma unroll
-    for (int c = 0; c < WT_X / WT_CHUNK; c++) xc[c] = ld_f64x2(x + xfirst + WT_CHUNK * c + 2 * lane);
-    f64x2 pc[WT_NCH];
+    for (int c = 0; c < WT_X / 128; c++) xc[c] = ld_f64x2(x + xfirst + 128 * c + 2 * lane);
+    double pc[WT_NCH];
     i32x4 mc[2];
     wt_issue(h0, lane, pool, meta, pc, mc);
 #pragma unroll
-    for (int c = 0; c < WT_X / WT_CHUNK; c++) st_lds_f64x2(L + WT_OFF_X + WT_CHUNK * c + 2 * lane, xc[c]);
+    for (int c = 0; c < WT_X / 128; c++) st_lds_f64x2(L + WT_OFF_X + 128 * c + 2 * lane, xc[c]);
     for (int j = b0; j < b1; j++) {
         wt_park(L, lane, pc, mc);
         const int nrec = wave_uniform((int)(unsigned)(unsigned long long)wave_bcast_i64(h0, WT_NCH + 1));

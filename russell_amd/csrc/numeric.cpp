@@ -290,6 +290,15 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     }
     HIPC(dev_upload(&d_perm, S.perm), ERROR_HIP_MALLOC);
     d_rperm = d_perm;
+    {
+        uint64_t hsh = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) {
+            for (int b = 0; b < 8; b++) hsh = (hsh ^ ((v >> (8 * b)) & 0xff)) * 1099511628211ull;
+        };
+        for (int32_t k = 0; k < n; k++) mix((uint64_t)(uint32_t)S.perm[k] | ((uint64_t)(matched ? (uint32_t)mrow[S.perm[k]] : 0u) << 32));
+        mix((uint64_t)S.persist_doubles), mix((uint64_t)S.temp_doubles), mix((uint64_t)S.nsuper);
+        plan_sig = hsh & 0x7fffffffffffffffull;
+    }
     if (matched) {
         std::vector<int32_t> rperm((size_t)n);
         for (int32_t k = 0; k < n; k++) rperm[k] = mrow[S.perm[k]];
@@ -931,7 +940,7 @@ int32_t Solver::factorize(const double *values, bool on_device) {
          ERROR_HIP_MEMCPY);
     int32_t code = run_factor();
     if (code != SUCCESSFUL_EXIT) return code;
-    if (n_weak_diag > 0 && !rematching) return rematch_and_factorize();
+    if (n_weak_diag > 0 && !rematching && !rematch_futile) return rematch_and_factorize();
     factorized = true;
     return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
 }
@@ -967,6 +976,9 @@ int32_t Solver::rematch_and_factorize() {
     fused_fallbacks = keep_fallbacks;
     code = factorize(hv.data(), false); // (rematching is still set: one re-analysis per call)
     rematching = false;
+    // a new matching that leaves the diagonal weak (structurally singular matrix, no perfect matching, the boundary case of the
+    // criterion) cannot be improved by another one: later factorizes keep this order instead of redoing the analysis every time
+    if (n_weak_diag > 0) rematch_futile = true;
     if (opt.verbose) fprintf(stderr, "hipmf: factorize: weak diagonal for these values: maximum-product matching recomputed, analysis redone\n");
     return code;
 }
@@ -1015,7 +1027,7 @@ int32_t Solver::factorize_mapped(const double *input, bool on_device) {
                        src, d_vals);
     int32_t code = run_factor();
     if (code != SUCCESSFUL_EXIT) return code;
-    if (n_weak_diag > 0 && !rematching) return rematch_and_factorize();
+    if (n_weak_diag > 0 && !rematching && !rematch_futile) return rematch_and_factorize();
     factorized = true;
     return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
 }

@@ -99,6 +99,10 @@ class Solver {
     int32_t adopt_factor(const double *d_values); // factor buffers were filled by a peer (many-RHS multi-GPU path)
     void mark_factor_adopted() { n_perturbed = n_zero_pivot = 0, factorized = true; } // ... including the matrix values
     void *d_diag_ptr() const { return d_diag; }
+    // FNV-1a over what two handles must share to exchange a factor: the fill-reducing permutation, the matching's row permutation, the
+    // layout of the pool (computed at initialize / after a re-matching factorize)
+    uint64_t plan_signature() const { return plan_sig; }
+    uint64_t plan_sig = 0;
     int64_t nnz_in_values() const { return nnz_in; } // inputs the installed value map reads (0: none)
     void *d_vals_ptr() const { return d_vals; }
     void release();
@@ -139,6 +143,7 @@ class Solver {
     std::vector<int32_t> h_rp_keep, h_ci_keep, h_seg_ptr, h_seg_idx;
     SymbolicOptions sopt_keep;
     bool sym_lower_keep = false, rematching = false;
+    bool rematch_futile = false; // the last re-matching left a weak diagonal: no further attempts for this handle
     int32_t *d_dcol = nullptr; // column of the (matched) diagonal entry of every row of A (nullptr: identity)
     int32_t run_factor();
     // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)

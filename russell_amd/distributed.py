@@ -24,8 +24,9 @@ def _as_tensor(ptr, nbytes, device):
 
 def broadcast_factor(solver, d_values, dist, src=0, device=None, chunk_bytes=256 << 20):
     """Numeric factor of `solver` (rank `src` has factorised; every rank has run `initialize` on the same structure, which
-    is deterministic) -> all ranks, in place, straight between the solvers' own device buffers: the front pool, the local
-    row interchanges and the row scaling, in chunks of `chunk_bytes` (ring collectives over xGMI are per-link bound, large
+    is deterministic) -> all ranks, in place, straight between the solvers' own device buffers -- the FOUR parts of
+    solver_hipmf_factor_parts: persistent part of the front pool, local row interchanges, row scaling, pivots (the D of the
+    L D L^T fronts, the determinant and rcond come from them) -- in chunks of `chunk_bytes` (ring collectives over xGMI are per-link bound, large
     messages keep the links busy).  Afterwards the other ranks adopt the factor; `d_values` = device pointer of the matrix
     values of the calling rank (for the refinement SpMV).  Returns the number of bytes broadcast."""
     total = 0
