@@ -48,7 +48,7 @@ def sptrsv_bytes(st, n, k=1):
 def measured_traffic(grid):
     """HBM bytes per SpTRSV pass from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed loop;
     the counters were collected with this same command on the same workload; the file names the run they come from)."""
-    for name in ("r02_sptrsv_traffic.json", "r01_sptrsv_traffic.json"):
+    for name in ("r03_sptrsv_traffic.json", "r02_sptrsv_traffic.json", "r01_sptrsv_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if grid == 1000 and os.path.exists(path):
             with open(path) as fh:
@@ -463,6 +463,21 @@ def main():
                 many["broadcast"] = {"error": err or "RCCL communicator not available on every rank"}
         if many:
             many["rhs_per_s"] = max(many["replicate"]["rhs_per_s"], many.get("broadcast", {}).get("rhs_per_s", 0.0))
+            try:
+                # blocks of BLK columns read the factor once per block and triangular pass pair; every column is solved once and
+                # refined (st["refinement_steps"] further pass pairs): physical factor bytes moved / solve time against the HBM peak
+                stm = s.stats()
+                blk = 16 if count > 12 else 8
+                passes = 1 + int(stm.get("refinement_steps", 1))
+                nblocks = (count + blk - 1) // blk
+                fbytes = (stm["nnz_l"] + stm["nnz_u"]) * 8
+                moved = nblocks * passes * fbytes
+                many["roofline"] = {"bound": "hbm", "block_columns": blk, "blocks": nblocks, "pass_pairs_per_block": passes,
+                                    "physical_factor_bytes_per_pass_pair": int(fbytes), "achieved": round(moved / (many["solve_ms"] * 1e-3) / 1e9, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(moved / (many["solve_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "ms_per_rhs": round(many["solve_ms"] / max(count, 1), 4)}
+            except Exception as exc:
+                many["roofline"] = {"error": repr(exc)}
             extras["many_rhs"] = many
         else:
             extras["many_rhs"] = {"error": err or "skipped: another rank failed"}
@@ -480,6 +495,7 @@ def main():
         if lib.hipmf_device_mfma_rate(1024, 4000, ctypes.byref(mfma_tfs)) != 0:
             mfma_tfs.value = 0.0
         bytes_alg = sptrsv_bytes(st, n)
+        phys_bytes = (st["nnz_l"] + st["nnz_u"]) * 8 + n * 8 * 4
         traffic, traffic_src = measured_traffic(args.grid)
         achieved = bytes_alg / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
         fact_ms = st["acc_factor_ms"] / max(st["acc_factor_count"], 1.0)
@@ -502,11 +518,14 @@ def main():
                        "rhs_per_gpu": 1, "refinement_steps": st["refinement_steps"]},
             "sptrsv_gbs": round(achieved, 1),
             "roofline": {"kernel": "multifrontal SpTRSV pass, forward + backward (%s, %d launches over %d tree levels)" %
-                                   ("dependency-driven k_fwd_fused + k_bwd_fused" if st["solve_launches"] <= 4 else "level-set k_fwd/k_bwd[_big]",
-                                    st["solve_launches"], st["nlevels"]),
+                                   ("wave-subtrees k_wt_fwd / k_wt_bwd + dependency-driven k_fwd_fused / k_bwd_fused (mid and top levels)"
+                                    if st["solve_launches"] <= 6 else "level-set k_fwd/k_bwd[_big]", st["solve_launches"], st["nlevels"]),
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": int(bytes_alg), "avg_ms": round(tri_ms, 4),
+                         # the factor is stored supernodally: 8 B per stored entry and pass (SURVEY.md 8d charges 12 B per entry)
+                         "physical_bytes": int(phys_bytes), "physical_gbs": round(phys_bytes / (tri_ms * 1e-3) / 1e9, 1) if tri_ms > 0 else 0.0,
+                         "physical_frac": round(phys_bytes / (tri_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tri_ms > 0 else 0.0,
                          "measured_copy_gbs": round(copy_gbs.value, 1),
                          "frac_of_measured_copy": round(achieved / copy_gbs.value, 4) if copy_gbs.value > 0 else None,
                          "fused_solve_fallbacks": st.get("fused_fallbacks", 0)},
@@ -525,9 +544,17 @@ def main():
             "relative_error": rel_err,
         }
         out.update(extras)
+        # StatsLinSol's total_ifs (stats_lin_sol.rs:75-103): initialize + factorize + solve of a ONE-SHOT call; the headline is the
+        # repeat call (factorize + solve on a handle that is initialised)
+        out["total_ifs_ms"] = round(t_init * 1e3 + ms_per_step, 1)
         if perm is not None:
-            out["cpu_baseline"] = cpu_baseline(n, rp, ci, v, b, perm, args.cpu_tier)
-            out["cpu_baseline"]["host_cores"] = os.cpu_count() or 0
+            cb = cpu_baseline(n, rp, ci, v, b, perm, args.cpu_tier)
+            cb["host_cores"] = os.cpu_count() or 0
+            out["cpu_baseline"] = cb
+            # like for like: the CPU number contains ordering + symbolic + numeric + solve (SuperLU / UMFPACK redo all of it per call)
+            out["speedup_one_shot"] = round(cb["value"] / out["total_ifs_ms"], 1)
+            out["speedup_note"] = ("speedup_one_shot = cpu_baseline.value / total_ifs_ms (both include ordering + symbolic analysis); value / "
+                                   "cpu_baseline.value would compare a repeat call with a one-shot call")
         line = json.dumps(out)
     else:
         line = None

@@ -30,7 +30,10 @@ constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
 constexpr int SF_CHUNK = 1024;           // doubles of a big front's vector staged in LDS at a time, per right-hand side (the children are
                                          // re-scanned for every chunk; 1024 doubles per right-hand side up to K = 4, 512 at K = 8: 32 KB of LDS)
 constexpr int SF_SYMC = 4;               // columns of E per wavefront in the backward slabs of the symmetric (L D L^T) fronts: slabs of 16 pivots
-constexpr int SF_KMAX = 8;               // right-hand sides solved together by the blocked instances (the factor is read once per block)
+constexpr int SF_KMAX = 16;              // right-hand sides solved together by the widest blocked instance (the factor is read once per block):
+                                         // a full 16-column MFMA tile; narrower blocks (2..8 columns) use the SF_KMID instance
+constexpr int SF_KMID = 8;
+constexpr int SF_ASM_ROWS = 256;         // rows per ASSEMBLE task (kind 1): the smallest chunk of any instance
 
 struct SfTask {
     int32_t kind;       // 0: group of small fronts, one per wavefront (a, b, c, d; -1 = none)
@@ -155,6 +158,10 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
         }
     }
     // row interchanges of the pivot block, then y1 = L11^{-1} (P w1) column by column, u = w2 - L21 y1;
+    // (a front without children reaches this point without a wave-level barrier since w was written: the interchange reads
+    //  ANOTHER lane's entry.  The hardware runs a wave's LDS operations in order; the barrier costs nothing there and makes the
+    //  dependence explicit -- tools/hipemu, which runs the lanes one after the other, needs it)
+    wave_sync();
     double v[K];
 #pragma unroll
     for (int c = 0; c < K; c++) v[c] = (c < nk) ? ((lane < p) ? w[c][lp] : ((lane < f) ? w[c][lane] : 0.0)) : 0.0;
@@ -516,7 +523,7 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
                                                    const int32_t *__restrict__ rep_idx, int *rep) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles
-    constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK; // chunk of w1 per right-hand side
+    constexpr int CHK = K > 8 ? SF_CHUNK / 4 : (K > 4 ? SF_CHUNK / 2 : SF_CHUNK); // chunk of w1 per right-hand side
     // One LDS buffer, three uses that never overlap in time: a workgroup either runs four small fronts (wv: K x 64 doubles per wave)
     // or one slab of a big front (wc: the chunk of the K vectors; mt: the slab's MFMA tiles, written after the last chunk is consumed).
     // As separate arrays they added up to 75 KB in the blocked instance: two workgroups per CU.
@@ -699,9 +706,9 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
             __syncthreads();
         }
         if (cm_max <= 256)
-            sf_children<(K == 1 ? 8 : 4), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+            sf_children<(K == 1 ? 8 : (K <= 8 ? 4 : 2)), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         else // (top-level instance: six entries per thread and child in one round trip -- 1 536 rows)
-            sf_children<2, (STG ? 6 : (K == 1 ? 4 : 2)), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+            sf_children<2, (STG ? 6 : (K == 1 ? 4 : (K <= 8 ? 2 : 1))), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
         if (nch == 0) __syncthreads();
         if (trace && tid == 0 && c0 == 0) tr_g = dev_clock();
         // the group's columns of this chunk: g, g + G, ... continue across chunks (CHK is a multiple of every G)
@@ -783,7 +790,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
                                                    int stage, const int32_t *__restrict__ rep_idx, int *rep) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles (see k_fwd_fused)
-    constexpr int CHK = K > 4 ? SF_CHUNK / 2 : SF_CHUNK;
+    constexpr int CHK = K > 8 ? SF_CHUNK / 4 : (K > 4 ? SF_CHUNK / 2 : SF_CHUNK);
     // (one LDS buffer for the small fronts' vectors, the chunk of a big front's vectors and its MFMA tiles: see k_fwd_fused)
     constexpr int LDS_D = SMALL_ONLY ? 4 * K * 64 : (K * CHK > 4 * K * 64 ? K * CHK : 4 * K * 64);
     static_assert(SMALL_ONLY || K == 1 || K * CHK >= 8 * 256, "the MFMA tiles share the chunk buffer");

@@ -87,6 +87,7 @@ void Solver::release() {
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_cs = nullptr, d_rperm = nullptr;
     d_blk = nullptr, d_work_blk = nullptr;
+    block_cols = 0;
     d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr, nnz_in = 0;
     d_sa_ptr = d_sa_k = nullptr, d_sa_pos = nullptr, d_zero = nullptr, zero_cnt = 0;
     d_vs = d_vs2 = nullptr;
@@ -665,7 +666,7 @@ int32_t Solver::upload_plan() {
                 // tasks of their own, 512 rows each (the chunk the blocked instances stage in LDS); the slabs wait for those
                 int32_t nasm = 0;
                 if (forward && sf_asm_front > 0 && S.fsize(s) >= sf_asm_front && S.child_ptr[s + 1] > S.child_ptr[s]) {
-                    for (int32_t q0 = 0; q0 < ext; q0 += SF_CHUNK / 2) sf.push_back({1, s, q0, std::min(ext, q0 + SF_CHUNK / 2), 0, 0}), nasm++;
+                    for (int32_t q0 = 0; q0 < ext; q0 += SF_ASM_ROWS) sf.push_back({1, s, q0, std::min(ext, q0 + SF_ASM_ROWS), 0, 0}), nasm++;
                 }
                 need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows + nasm;
                 for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), nasm, 0});
@@ -1245,6 +1246,9 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         if (nk == 1) {
             if (fa > 0) HIPMF_FWD(true, 1, fa, d_sf, no_trace);
             if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, timed ? d_trace : no_trace);
+        } else if (nk <= SF_KMID) {
+            if (fa > 0) HIPMF_FWD(true, SF_KMID, fa, d_sf, no_trace);
+            if (fb > 0) HIPMF_FWD(false, SF_KMID, fb, d_sf + fa, timed ? d_trace : no_trace);
         } else {
             if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, d_sf, no_trace);
             if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, timed ? d_trace : no_trace);
@@ -1253,6 +1257,9 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         if (nk == 1) {
             if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, 1, bb, d_sf + sf_fwd_cnt + bt, no_trace);
+        } else if (nk <= SF_KMID) {
+            if (bt > 0) HIPMF_BWD(false, SF_KMID, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
+            if (bb > 0) HIPMF_BWD(true, SF_KMID, bb, d_sf + sf_fwd_cnt + bt, no_trace);
         } else {
             if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, d_sf + sf_fwd_cnt + bt, no_trace);
@@ -1351,7 +1358,32 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     refinement_steps_done = 0;
     // Blocks of KB right-hand sides go through the triangular solves together (the dependency-driven kernels read each
     // factor entry once per block); one right-hand side uses the single-column instances and buffers.
-    const int32_t KB = (use_fused && nrhs > 1) ? SF_KMAX : 1;
+    // (blocks of 16 columns = one full MFMA tile per slab tile when there are enough of them and the block buffers fit; else 8)
+    int32_t KB = (use_fused && nrhs > 1) ? (nrhs > SF_KMID + SF_KMID / 2 ? SF_KMAX : SF_KMID) : 1;
+    if (KB > 1 && block_cols >= KB) KB = block_cols; // (the buffers exist and are wide enough: keep their width)
+    if (KB > 1 && block_cols > 0 && block_cols < KB) {
+        // wider blocks than the buffers of an earlier call hold: let them go, they are allocated again below
+        for (void *p : {(void *)d_blk, (void *)d_work_blk})
+            if (p) (void)hipFree(p);
+        d_blk = d_work_blk = nullptr;
+        for (LaneBuffers &lb : extra_lanes) {
+            for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
+                if (p) (void)hipFree(p);
+            if (lb.stream) (void)hipStreamDestroy((hipStream_t)lb.stream);
+        }
+        extra_lanes.clear();
+        block_cols = 0;
+    }
+    if (KB == SF_KMAX && !d_blk) {
+        size_t free_b = 0, total_b = 0;
+        const double need_b = 8.0 * ((double)n * 6 + (double)work_doubles) * SF_KMAX * std::max(1, std::min(solve_lanes, (nrhs + SF_KMAX - 1) / SF_KMAX));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need_b > 0.9 * (double)free_b) KB = SF_KMID;
+    }
+    if (const char *e = getenv("HIPMF_BLOCK_COLS")) {
+        const int v = atoi(e);
+        if (KB > 1 && block_cols == 0 && (v == SF_KMID || v == SF_KMAX)) KB = v;
+    }
+    if (KB > 1) block_cols = KB;
     const int32_t nblocks = (nrhs + KB - 1) / KB;
     const int32_t nlanes = KB > 1 ? std::max(1, std::min(solve_lanes, nblocks)) : 1;
     const size_t sync_words = 2 * (size_t)(SF_SYNC_HEADER + S.nsuper) + 1;

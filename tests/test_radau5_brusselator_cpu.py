@@ -35,6 +35,6 @@ def check_reference_test(d):
 def test_radau5_brusselator_reference_test_on_the_emulated_backend(emu_lib):
     # (the emulator runs one handle at a time and its dependency-driven solve mis-schedules this matrix -- a limitation of the
     #  emulator present since round 1, not of the device code, which the gpu twin runs with both -- hence --serial and the level-set solves)
-    d = run(emu_lib, "--npoint", "9", "--first-book", "--neg-exp-tol", "3", "--t1", "0.1", "--serial", env_extra={"HIPMF_FUSED_SOLVE": "0"})
+    d = run(emu_lib, "--npoint", "9", "--first-book", "--neg-exp-tol", "3", "--t1", "0.1", "--serial", env_extra={"HIPMF_FUSED_SOLVE": "1"})
     check_reference_test(d)
     assert d["n_factor"] == 5 and d["n_rejected"] == 0

@@ -1,0 +1,163 @@
+"""Round 3 on the device: the configurations VERDICT r02 listed as untested (config 4's matrix in full on one GPU with a block of
+right-hand sides; a convection-dominated, non-diagonally-dominant config-3 stand-in that needs the matching), the 16-column blocked
+solves, positive_definite with full storage, and the schedule knobs of the wave-subtree solves."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_device_gb():
+    free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        if hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) != 0:
+            return 0.0
+    except OSError:
+        return 0.0
+    return free_b.value / 1e9
+
+
+@pytest.mark.parametrize("grid,nrhs", [(150, 32), (120, 33), (90, 13)])
+def test_blocks_of_16_and_8_columns_agree_with_single_solves(grid, nrhs):
+    # 13 columns: one block of 16 (partly filled); 32: two full blocks on two lanes; 33: a last block with one column
+    n, rp, ci, v = P.poisson2d(grid)
+    rng = np.random.default_rng(grid)
+    XS = rng.standard_normal((nrhs, n))
+    B = np.array([P.csr_matvec(n, rp, ci, v, XS[j]) for j in range(nrhs)])
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    X = s.solve_many(B)
+    for j in range(nrhs):
+        xj = s.solve(B[j])
+        assert np.max(np.abs(X[j] - xj)) <= 1e-12 * np.max(np.abs(xj))
+    assert np.max(np.abs(X - XS)) / np.max(np.abs(XS)) < 1e-10
+    # a narrower call afterwards re-uses the 16-column buffers; a column's result does not depend on its block
+    X5 = s.solve_many(B[:5])
+    assert np.max(np.abs(X5 - X[:5])) <= 1e-12 * np.max(np.abs(X[:5]))
+    s.close()
+
+
+def test_positive_definite_with_full_storage_is_factorised_as_lu():
+    # LinSolParams::positive_definite is independent of the storage (lin_sol_params.rs:41-42); with Sym::No (full storage) the
+    # reference's GPU plug-in takes the lower view (solver_cudss.rs:260-261): the flag alone must not make the C-ABI refuse the matrix
+    n, rp, ci, v = P.poisson2d(70, 64)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci, positive_definite=True) == 0
+    assert s.counter("symmetric_ldlt") == 0
+    assert s.factorize(v) == 0
+    x = s.solve(b)
+    s.close()
+    assert np.max(np.abs(x - xs)) < 1e-10
+    # the lower triangle with the same flag: L D L^T, same solution
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    s2 = Hipmf()
+    assert s2.initialize(n, lrp, lci, positive_definite=True) == 0
+    assert s2.counter("symmetric_ldlt") == 1
+    assert s2.factorize(lv) == 0
+    assert np.max(np.abs(s2.solve(b) - xs)) < 1e-10
+    s2.close()
+
+
+def test_wave_subtree_knobs_do_not_change_a_bit(monkeypatch):
+    # fronts move between the wave-subtrees, the mid launch and the top launch: the sums and their order stay (same slab shapes)
+    n, rp, ci, v = P.convection_diffusion2d(220, peclet=30.0, scale_decades=0.0)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    monkeypatch.setenv("HIPMF_SOLVE_SLAB64", "1")
+    got = []
+    for env in ({"HIPMF_FUSED_SOLVE": "0"}, {}, {"HIPMF_TREE_SOLVE": "0"}, {"HIPMF_WT_FRONTS": "5", "HIPMF_UP_STAGE": "0"},
+                {"HIPMF_WT_KB": "200", "HIPMF_WT_FRONTS": "200", "HIPMF_UP_TOP_FRONTS": "400", "HIPMF_UP_STAGE": "16", "HIPMF_UP_STAGE_BWD": "24"},
+                {"HIPMF_UP_REPLICAS": "0", "HIPMF_UP_STAGE_MID": "0"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci, refinement_nstep=0) == 0
+        assert s.factorize(v) == 0
+        outs = [s.solve(b) for _ in range(4)]
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        for x in outs:
+            assert np.array_equal(outs[0], x)
+        got.append(outs[0])
+    for x in got[1:]:
+        assert np.array_equal(got[0], x)
+    assert np.max(np.abs(got[0] - xs)) / np.max(np.abs(xs)) < 1e-10
+
+
+def test_config3_bbmat_like_convection_dominated_needs_the_matching():
+    # bbmat is a CFD Jacobian: convection-dominated, NOT diagonally dominant, badly scaled.  Stand-in at its published size
+    # (n = 38 720 ~ 38 744): 5 x 5 node blocks whose diagonal is WEAK (shift 0.02: the diagonal entry is 2 % of the row's
+    # off-diagonal sum), rows scaled over twelve decades, and the rows of every second node shuffled inside the node so that large
+    # entries sit off the diagonal -- static pivoting alone perturbs pivots here; the maximum-product matching + scaling (applied at
+    # initialize because the values are handed over, as the reference's shims do) must bring the system back
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, rp, ci, v = P.fe_block2d(88, 88, 5, symmetric=False, scale_decades=6.0, shift=0.02)
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n)).tolil()
+    rng = np.random.default_rng(38744)
+    perm = np.arange(n)
+    for node in range(0, n // 5, 2):
+        perm[5 * node:5 * node + 5] = 5 * node + rng.permutation(5)
+    A = sp.csr_matrix(A)[perm, :].tocsr()
+    A.sort_indices()
+    rp2, ci2, v2 = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    xs = P.manufactured_solution(n)
+    b = A @ xs
+    s = Hipmf()
+    assert s.initialize(n, rp2, ci2, values=v2) == 0
+    assert s.stats()["matched"] == 1
+    assert s.factorize(v2) == 0
+    x = s.solve(b)
+    st = s.stats()
+    s.close()
+    xo = spla.splu(A.tocsc(), permc_spec="COLAMD").solve(b)
+    err, err_slu = np.max(np.abs(x - xs)), np.max(np.abs(xo - xs))
+    assert err <= max(100.0 * err_slu, 1e-9 * np.max(np.abs(xs))), (err, err_slu, st["n_perturbed"])
+    r = A @ x - b
+    assert np.max(np.abs(r)) / (np.max(np.abs(v2)) + 1.0) <= 1e-10
+
+
+def test_config4_matrix_200_cubed_with_a_block_of_32_right_hand_sides_on_one_gpu():
+    # BASELINE config 4's matrix itself: 3D 7-point Poisson 200^3 = 8 M unknowns as its lower triangle (L D L^T), 32 right-hand sides
+    # = the shard one of eight GPUs gets from the 256, resident in HBM, solved in two blocks of 16 columns.  The
+    # 8-GPU split itself is the driver's run (bench.py --gpus 8); what one rank does is all here.  Needs ~215 GB of HBM.
+    if _free_device_gb() < 240.0:
+        pytest.skip("needs an otherwise empty 288 GB device")
+    N, nrhs = 200, 32
+    n, rp, ci, v = P.poisson3d(N)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    s = Hipmf()
+    assert s.initialize(n, lrp, lci, general_symmetric=True) == 0
+    assert s.stats()["pool_bytes"] < 205e9
+    assert s.factorize(lv) == 0
+    B = np.empty((nrhs, n))
+    for j in range(nrhs):
+        B[j] = b * (1.0 + 0.125 * j)
+    d_b, d_x = s.dev_alloc(B.nbytes), s.dev_alloc(B.nbytes)
+    s.h2d(d_b, B)
+    s.solve_device(d_x, d_b, nrhs=nrhs)
+    X = np.empty_like(B)
+    s.d2h(X, d_x)
+    s.dev_free(d_b), s.dev_free(d_x)
+    s.close()
+    worst_fwd, worst_res = 0.0, 0.0
+    for j in (0, 7, 15, 16, 31):  # (the host-side residual of all 32 columns would take longer than the solves)
+        xj = X[j]
+        worst_fwd = max(worst_fwd, float(np.max(np.abs(xj - xs * (1.0 + 0.125 * j))) / (1.0 + 0.125 * j)))
+        r = P.csr_matvec(n, rp, ci, v, xj) - B[j]
+        worst_res = max(worst_res, float(np.max(np.abs(r)) / (np.max(np.abs(v)) + 1.0)))
+    assert worst_res <= 1e-10
+    assert worst_fwd < 1e-9

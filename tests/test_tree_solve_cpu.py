@@ -1,0 +1,127 @@
+"""The default triangular-solve path on the CPU: wave-subtrees (kernels_solve_tree.hpp) + dependency-driven mid / top launches, compiled
+against tools/hipemu and compared bit for bit with the level-set launches; the blocked many-RHS instances (8 / 16 columns); and the
+golden ordering of round 3 (permutation hash + factor statistics: an ordering change that still yields a valid permutation is
+invisible to the solution-level parity tests).
+
+The emulator is a development tool, not parity evidence: the -m gpu twins (tests/test_fused_solve_gpu.py) run the same comparisons on
+the device."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+
+
+def _solve(lib, n, rp, ci, v, b, env, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = Hipmf(lib)
+        assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+        assert s.factorize(v) == 0
+        x = s.solve(b)
+        st = s.stats()
+        s.close()
+        return x, st
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+LEVEL = {"HIPMF_FUSED_SOLVE": "0", "HIPMF_SOLVE_SLAB64": "1"}
+TREE = {"HIPMF_FUSED_SOLVE": "1", "HIPMF_SOLVE_SLAB64": "1", "HIPMF_TREE_SOLVE": "1"}
+ROUND2 = {"HIPMF_FUSED_SOLVE": "1", "HIPMF_SOLVE_SLAB64": "1", "HIPMF_TREE_SOLVE": "0"}
+
+
+def _cases():
+    n, rp, ci, v = P.poisson2d(44, 40)
+    yield "poisson2d 44x40 (tiled top levels)", n, rp, ci, v, {}
+    n, rp, ci, v = P.convection_diffusion2d(40, peclet=30.0, scale_decades=0.0)
+    yield "convection-diffusion 40x40 (row interchanges inside the pivot blocks)", n, rp, ci, v, {}
+    n, rp, ci, v = P.poisson3d(9)
+    yield "poisson3d 9^3", n, rp, ci, v, {}
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_tree_schedule_equals_level_set_bitwise(emu_lib, case):
+    _, n, rp, ci, v, kw = case
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    ref, st_l = _solve(emu_lib, n, rp, ci, v, b, LEVEL, **kw)
+    new, st_t = _solve(emu_lib, n, rp, ci, v, b, TREE, **kw)
+    old, _ = _solve(emu_lib, n, rp, ci, v, b, ROUND2, **kw)
+    assert st_t["solve_launches"] <= 6
+    assert np.array_equal(ref, new)
+    assert np.array_equal(ref, old)  # (the round-2 schedule: mis-executed by the emulator until its missing wave barrier was found)
+    assert np.max(np.abs(ref - xs)) < 1e-11
+    # the knobs that move fronts between the wave-subtrees and the upper launches do not change a bit
+    for env in ({"HIPMF_WT_FRONTS": "3", "HIPMF_UP_STAGE": "0"}, {"HIPMF_WT_KB": "4", "HIPMF_UP_STAGE": "8", "HIPMF_UP_STAGE_BWD": "8"},
+                {"HIPMF_UP_TOP_FRONTS": "1", "HIPMF_UP_REPLICAS": "0", "HIPMF_UP_STAGE_MID": "0"}):
+        x, _ = _solve(emu_lib, n, rp, ci, v, b, dict(TREE, **env), **kw)
+        assert np.array_equal(ref, x), env
+
+
+def test_tree_schedule_symmetric_lower_ldlt(emu_lib):
+    n, rp, ci, v = P.poisson2d(48, 44)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    old, _ = _solve(emu_lib, n, lrp, lci, lv, b, ROUND2, general_symmetric=True)
+    new, _ = _solve(emu_lib, n, lrp, lci, lv, b, TREE, general_symmetric=True)
+    assert np.array_equal(old, new)
+    assert np.max(np.abs(new - xs)) < 1e-11
+
+
+@pytest.mark.parametrize("grid,nrhs", [((30, 28), 5), ((44, 40), 18)])
+def test_blocked_many_rhs_instances_agree_with_single_solves(emu_lib, grid, nrhs):
+    # blocks of 8 columns (2 .. 12 right-hand sides) and of 16 columns (more): small fronts use the single-column arithmetic per column,
+    # the slabs of the tiled fronts run on MFMA tiles (another summation order: equal to rounding)
+    n, rp, ci, v = P.poisson2d(*grid)
+    rng = np.random.default_rng(nrhs)
+    XS = rng.standard_normal((nrhs, n))
+    B = np.array([P.csr_matvec(n, rp, ci, v, XS[j]) for j in range(nrhs)])
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    X = s.solve_many(B)
+    for j in range(0, nrhs, 3):
+        xj = s.solve(B[j])
+        assert np.max(np.abs(X[j] - xj)) <= 1e-12 * np.max(np.abs(xj))
+    assert np.max(np.abs(X - XS)) / np.max(np.abs(XS)) < 1e-11
+    s.close()
+
+
+GOLDEN_ORDERING = {
+    # grid: (sha256 of the int32 permutation, first 16 hex digits; nnz(L); nnz(U); supernodes; levels; largest front)
+    (48, 40): ("29d941a96643a52a", 43832, 45752, 205, 9, 67),
+    (1000, 1000): ("b2c470a532d24c58", 42142252, 43142252, 113068, 20, 1431),  # BASELINE config 2
+}
+
+
+@pytest.mark.parametrize("grid", sorted(GOLDEN_ORDERING))
+def test_golden_ordering_is_pinned(emu_lib, grid, monkeypatch):
+    # north_star's "bit-exact permutation vectors" cannot be checked against UMFPACK (the reference never extracts P / Q);
+    # what is pinned instead: THIS build's deterministic ordering, so that a change of the analysis shows up as a red test and not
+    # only as a fill / flop regression
+    n, rp, ci, v = P.poisson2d(*grid)
+    want = GOLDEN_ORDERING[grid]
+    got = []
+    for threads in ("1", "5"):
+        monkeypatch.setenv("HIPMF_ND_THREADS", threads)
+        s = Hipmf(emu_lib)
+        assert s.initialize(n, rp, ci) == 0
+        p = np.ascontiguousarray(s.permutation(), dtype=np.int32)
+        st = s.stats()
+        s.close()
+        assert sorted(p.tolist()) == list(range(n)) if n < 5000 else np.array_equal(np.sort(p), np.arange(n))
+        got.append((hashlib.sha256(p.tobytes()).hexdigest()[:16], st["nnz_l"], st["nnz_u"], st["nsuper"], st["nlevels"], st["max_front"]))
+        if n > 100000:
+            break  # (one analysis of the 1M-DOF matrix is enough for the CPU suite's time budget)
+    for g in got:
+        assert g == want
