@@ -172,6 +172,28 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 #define HIPMF_COUNTER_SYMMETRIC_LDLT 5     /* 1: the tiled fronts are factorised as L D L^T */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
+/* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only
+ * arguments) does not carry: set them BEFORE solver_hipmf_initialize (ERROR_ALREADY_INITIALIZED afterwards).
+ *   HIPMF_OPTION_MATCHING            lin_sol_params.rs:13 / enums.rs Matching: 0 = None (never), 1 = Auto (default: when values are
+ *                                    handed to initialize and the diagonal is weak), 2 = always; every reference variant other than
+ *                                    None / Auto selects THE matching this backend has (maximum product + scaling, MC64 job 5)
+ *   HIPMF_OPTION_PIVOTING            lin_sol_params.rs:16 / enums.rs Pivoting: 1 = Auto / LocalBlock (partial pivoting inside the pivot
+ *                                    block of a small front / the 32-row diagonal tile of a tiled one, tiny pivots perturbed and counted);
+ *                                    None / GlobalCol / GlobalRow / Diagonal are not available: ERROR_NOT_AVAILABLE
+ *   HIPMF_OPTION_HYBRID_MEMORY       lin_sol_params.rs:39 (cuDSS hybrid memory, factor 0.01 .. 0.99): accepted and recorded; this
+ *                                    backend has no out-of-core path, a factor that does not fit HBM is refused by initialize with the
+ *                                    "Not enough memory" string the reference's harness recognises (stats_lin_sol.rs:334-340)
+ *   HIPMF_OPTION_ERROR_ESTIMATES     lin_sol_params.rs:50: the componentwise backward error omega of the last solve is always kept
+ *   HIPMF_OPTION_CONDITION_NUMBERS   lin_sol_params.rs:55: min|u_ii| / max|u_ii| is always reported by factorize (rcond_estimate)
+ * (both readable with solver_hipmf_get_option after solve / factorize: the value, not the flag). */
+#define HIPMF_OPTION_MATCHING 0
+#define HIPMF_OPTION_PIVOTING 1
+#define HIPMF_OPTION_HYBRID_MEMORY 2
+#define HIPMF_OPTION_ERROR_ESTIMATES 3
+#define HIPMF_OPTION_CONDITION_NUMBERS 4
+int32_t solver_hipmf_set_option(struct InterfaceHIPMF *solver, int32_t option, double value);
+int32_t solver_hipmf_get_option(struct InterfaceHIPMF *solver, int32_t option, double *value);
+
 /* ---- many right-hand sides over the GPUs of one node (the reference has no counterpart: lin_solver.rs:51,
  * interface_cudss.cu:275,281 create b and x with ONE column).  One process (or thread) per GPU, every rank runs
  * solver_hipmf_initialize on the same structure (the analysis is deterministic), ONE rank factorises, the factor travels over

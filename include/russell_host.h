@@ -25,6 +25,11 @@ struct RhParams { /* lin_sol_params.rs:5-107, the fields this backend honours */
     double pivot_epsilon;
     int32_t has_refinement_nstep, refinement_nstep;
     int32_t positive_definite, compute_determinant, verbose;
+    /* round 3 (appended): lin_sol_params.rs:13-16,39,50,55 */
+    int32_t matching, pivoting; /* enums.rs Matching (0 None, 1 Auto, 2.. named variants), Pivoting (0 Auto, 1 None, 2 GlobalCol, 3 GlobalRow, 4 Diagonal, 5 LocalBlock) */
+    int32_t has_hybrid_memory_factor;
+    double hybrid_memory_factor;
+    int32_t compute_error_estimates, compute_condition_numbers;
 };
 
 void rh_set_hipmf_library(const char *path);

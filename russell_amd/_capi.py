@@ -52,6 +52,8 @@ SYMBOLS = {
     "complex_solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
     "complex_solver_hipmf_last_error": (C.c_char_p, [C.c_void_p]),
     "solver_hipmf_get_counter": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "solver_hipmf_set_option": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double]),
+    "solver_hipmf_get_option": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "solver_hipmf_factor_parts": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "hipmf_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "hipmf_comm_init_rank": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32]),

@@ -733,6 +733,8 @@ struct Backend {
     decltype(&solver_hipmf_set_value_map) set_value_map = nullptr;
     decltype(&solver_hipmf_factorize_mapped) factorize_mapped = nullptr;
     decltype(&solver_hipmf_get_stats) get_stats = nullptr;
+    decltype(&solver_hipmf_set_option) set_option = nullptr;
+    decltype(&solver_hipmf_get_option) get_option = nullptr;
     decltype(&complex_solver_hipmf_new) znew = nullptr;
     decltype(&complex_solver_hipmf_drop) zdrop = nullptr;
     decltype(&complex_solver_hipmf_initialize) zinitialize = nullptr;
@@ -779,6 +781,8 @@ bool load_backend() {
     BIND(set_value_map, "solver_hipmf_set_value_map")
     BIND(factorize_mapped, "solver_hipmf_factorize_mapped")
     BIND(get_stats, "solver_hipmf_get_stats")
+    BIND(set_option, "solver_hipmf_set_option")
+    BIND(get_option, "solver_hipmf_get_option")
     BIND(znew, "complex_solver_hipmf_new")
     BIND(zdrop, "complex_solver_hipmf_drop")
     BIND(zinitialize, "complex_solver_hipmf_initialize")
@@ -886,6 +890,15 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
     if (!initialized) {
         compute_determinant = par.compute_determinant;
         uint64_t t0 = now_ns();
+        // the parameters the initialize signature does not carry (lin_sol_params.rs:13-16,39)
+        if (par.pivoting != Pivoting::Auto && par.pivoting != Pivoting::LocalBlock)
+            return "HIPMF pivots inside the pivot block only (Pivoting::Auto or Pivoting::LocalBlock)";
+        const double mval = par.matching == Matching::None ? 0.0 : (par.matching == Matching::Auto ? 1.0 : 2.0);
+        if (g_backend.set_option((InterfaceHIPMF *)solver, HIPMF_OPTION_MATCHING, mval) != SUCCESSFUL_EXIT) return "HIPMF: invalid matching option";
+        if (par.has_hybrid_memory_factor) {
+            if (!(par.hybrid_memory_factor >= 0.01 && par.hybrid_memory_factor <= 0.99)) return "hybrid_memory_factor must satisfy: 0.01 ≤ factor ≤ 0.99";
+            (void)g_backend.set_option((InterfaceHIPMF *)solver, HIPMF_OPTION_HYBRID_MEMORY, par.hybrid_memory_factor);
+        }
         int32_t status = g_backend.initialize((InterfaceHIPMF *)solver, hipmf_ordering(par.ordering), hipmf_scaling(par.scaling),
                                               par.has_pivot_epsilon ? par.pivot_epsilon : -1.0,
                                               par.has_refinement_nstep ? par.refinement_nstep : -1, verbose,
@@ -1338,6 +1351,10 @@ struct RhParams {
     double pivot_epsilon;
     int32_t has_refinement_nstep, refinement_nstep;
     int32_t positive_definite, compute_determinant, verbose;
+    int32_t matching, pivoting;
+    int32_t has_hybrid_memory_factor;
+    double hybrid_memory_factor;
+    int32_t compute_error_estimates, compute_condition_numbers;
 };
 
 static LinSolParams to_params(const RhParams *p) {
@@ -1351,6 +1368,12 @@ static LinSolParams to_params(const RhParams *p) {
     q.positive_definite = p->positive_definite != 0;
     q.compute_determinant = p->compute_determinant != 0;
     q.verbose = p->verbose != 0;
+    q.matching = (Matching)p->matching;
+    q.pivoting = (Pivoting)p->pivoting;
+    q.has_hybrid_memory_factor = p->has_hybrid_memory_factor != 0;
+    q.hybrid_memory_factor = p->hybrid_memory_factor;
+    q.compute_error_estimates = p->compute_error_estimates != 0;
+    q.compute_condition_numbers = p->compute_condition_numbers != 0;
     return q;
 }
 

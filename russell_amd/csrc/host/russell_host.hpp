@@ -34,15 +34,35 @@ const char *genie_to_string(Genie g);
 Genie genie_from(const std::string &name); // default Hipmf here (the reference defaults to umfpack, enums.rs:336-343)
 Sym genie_get_sym(Genie g, bool symmetric); // enums.rs:355-365; Hipmf follows the cuDSS rule (YesLower)
 
+// enums.rs:159-332 (the variants the GPU plug-ins read)
+enum class Matching : int32_t { None = 0, Auto, MaxDiagCount, MaxMinDiag, MaxMinDiagAlt, MaxDiagSum, MaxDiagProduct };
+enum class Pivoting : int32_t { Auto = 0, None, GlobalCol, GlobalRow, Diagonal, LocalBlock };
+
+// lin_sol_params.rs:5-82; the MUMPS / UMFPACK-only fields have no meaning for this backend and are not mirrored.
+//   ordering   Ordering::No -> natural order; every other variant (Auto, Amd, Amf, Cholmod, Colamd, Metis, Pord, Qamd, Scotch, Best)
+//              -> this backend's nested dissection with dense leaves (the reference maps unknown variants to the backend's default
+//              the same way, solver_umfpack.rs:457-472); the effective ordering is reported by update_stats
+//   matching   None -> never; Auto -> when the diagonal is weak; any named variant -> always (there is one matching: maximum product
+//              + scaling, what cuDSS calls MaxDiagProduct)
+//   pivoting   Auto / LocalBlock -> partial pivoting inside the pivot block (the only strategy); others: factorize returns an error
+//   hybrid_memory_factor  recorded; a factor that does not fit HBM is refused with the "Not enough memory" string the reference's
+//              harness recognises (stats_lin_sol.rs:334-340)
+//   compute_error_estimates / compute_condition_numbers  always available from the actual solver (get_error_estimate / rcond_estimate)
 struct LinSolParams {
     Ordering ordering = Ordering::Auto;
     Scaling scaling = Scaling::Auto;
+    Matching matching = Matching::Auto;
+    Pivoting pivoting = Pivoting::Auto;
     bool has_pivot_epsilon = false;
     double pivot_epsilon = 0.0;
     bool has_refinement_nstep = false;
     int32_t refinement_nstep = 0;
+    bool has_hybrid_memory_factor = false;
+    double hybrid_memory_factor = 0.0;
     bool positive_definite = false;
     bool compute_determinant = false;
+    bool compute_error_estimates = false;
+    bool compute_condition_numbers = false;
     bool verbose = false;
 };
 

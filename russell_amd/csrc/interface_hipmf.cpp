@@ -27,6 +27,9 @@ struct InterfaceHIPMF {
     Solver solver;
     int32_t ordering_requested = 0;
     int32_t effective_ordering = 0;
+    // solver_hipmf_set_option (before initialize)
+    int32_t opt_matching = 1, opt_pivoting = 1;
+    double opt_hybrid = 0.0;
 };
 
 extern "C" {
@@ -72,6 +75,7 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int3
     if (pivot_epsilon >= 0.0) no.pivot_epsilon = pivot_epsilon;
     if (refinement_nstep >= 0) no.refinement_nstep = refinement_nstep;
     no.verbose = verbose == 1;
+    no.matching = h->opt_matching;
     h->ordering_requested = ordering;
     h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
     int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, sym_lower, so, no, values);
@@ -83,6 +87,43 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int3
                S.seconds_total);
     }
     return code;
+}
+
+int32_t solver_hipmf_set_option(struct InterfaceHIPMF *h, int32_t option, double value) {
+    if (!h) return ERROR_NULL_POINTER;
+    if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
+    switch (option) {
+    case HIPMF_OPTION_MATCHING:
+        if (value < 0.0 || value > 2.0) return ERROR_HIPMF_INVALID_VALUE;
+        h->opt_matching = (int32_t)value;
+        return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_PIVOTING:
+        if (value != 1.0) return ERROR_NOT_AVAILABLE; // (the only strategy of the kernels: partial pivoting inside the pivot block)
+        h->opt_pivoting = 1;
+        return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_HYBRID_MEMORY:
+        if (!(value > 0.0 && value < 1.0)) return ERROR_HIPMF_INVALID_VALUE;
+        h->opt_hybrid = value;
+        return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_ERROR_ESTIMATES:
+    case HIPMF_OPTION_CONDITION_NUMBERS: return SUCCESSFUL_EXIT; // (always computed)
+    default: return ERROR_HIPMF_INVALID_VALUE;
+    }
+}
+
+int32_t solver_hipmf_get_option(struct InterfaceHIPMF *h, int32_t option, double *value) {
+    if (!h || !value) return ERROR_NULL_POINTER;
+    switch (option) {
+    case HIPMF_OPTION_MATCHING: *value = h->solver.initialized ? h->solver.opt.matching : h->opt_matching; return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_PIVOTING: *value = h->opt_pivoting; return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_HYBRID_MEMORY: *value = h->opt_hybrid; return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_ERROR_ESTIMATES: *value = h->solver.last_omega; return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_CONDITION_NUMBERS: {
+        if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+        return h->solver.rcond_estimate(value);
+    }
+    default: return ERROR_HIPMF_INVALID_VALUE;
+    }
 }
 
 static int32_t finish_factorize(struct InterfaceHIPMF *h, int32_t code, int32_t *effective_ordering, int32_t *effective_scaling,

@@ -68,10 +68,12 @@ void Solver::release() {
         if (p) (void)hipFree(p);
     if (d_sd) (void)hipFree(d_sd);
     d_sd = nullptr;
-    for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep})
+    for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep, (void *)d_sf3,
+                    (void *)d_need3})
         if (p) (void)hipFree(p);
     d_wt_hdr = nullptr, d_wt_meta = nullptr, d_wt_wave = nullptr, d_sf2 = nullptr, d_need2 = nullptr, d_rep_idx = nullptr, d_rep = nullptr;
     rep_words = 0;
+    d_sf3 = nullptr, d_need3 = nullptr;
     wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
@@ -604,22 +606,11 @@ int32_t Solver::upload_plan() {
         L.bwd_cnt = (int32_t)stasks.size() - L.bwd_off;
         if (L.big_pmax > MAX_LDS_DOUBLES || L.big_fmax > MAX_LDS_DOUBLES) {
             // the level-set solve kernels stage a whole p- / f-vector in LDS; the dependency-driven ones work in chunks
+            // (without in-launch hand-offs such a factor is solved by the same kernels launched level by level: run_triangular)
             level_path_ok = false;
-            if (!use_fused) {
-                last_error = "a frontal matrix exceeds the LDS staging limit of the level-set solves (f = " + std::to_string(L.big_fmax) +
-                             "); enable the dependency-driven solves (HIPMF_FUSED_SOLVE=1)";
-                return ERROR_NOT_AVAILABLE;
-            }
         }
     }
-    if (S.sym_mode && !allbig.empty()) {
-        // the level-set solve kernels have no L D L^T instance
-        level_path_ok = false;
-        if (!use_fused) {
-            last_error = "the symmetric (L D L^T) factorisation needs the dependency-driven solves (HIPMF_FUSED_SOLVE=1)";
-            return ERROR_NOT_AVAILABLE;
-        }
-    }
+    if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
     allbig_off = (int32_t)lists.size();
     allbig_cnt = (int32_t)allbig.size();
     lists.insert(lists.end(), allbig.begin(), allbig.end());
@@ -1273,6 +1264,42 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         return SUCCESSFUL_EXIT;
     }
     if (nk != 1 || wrk != d_work) return ERROR_HIPMF_INVALID_VALUE; // the level-set launches carry one right-hand side
+    if (!level_path_ok) {
+        // L D L^T fronts / fronts beyond the LDS staging of the level-set kernels: the dependency-driven kernels, ONE LAUNCH PER LEVEL.
+        // A task then only depends on tasks of earlier launches (the list carries no assemble-once tasks): the in-launch hand-offs,
+        // and with them the reliance on the order in which the hardware places workgroups, are gone; same arithmetic.
+        int32_t code = build_level_tasks();
+        if (code != SUCCESSFUL_EXIT) return code;
+        const int32_t ns = S.nsuper;
+        int32_t *sync_f = lane_sync, *sync_b = lane_sync + SF_SYNC_HEADER + ns, *sync_err = lane_sync + 2 * (SF_SYNC_HEADER + ns);
+        HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), STREAM), ERROR_HIP_MEMCPY);
+        HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
+        unsigned long long *no_tr = nullptr;
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            const int32_t t0 = sf3_lvl[(size_t)l], cnt = sf3_lvl[(size_t)l + 1] - t0;
+            if (cnt <= 0) continue;
+            hipLaunchKernelGGL((k_fwd_fused<false, 1, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_lperm, d_child, d_rel, d_need3,
+                               sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr, 0, (const int32_t *)nullptr, (int *)nullptr);
+            launches++;
+        }
+        HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
+        const int32_t nb0 = sf3_lvl[(size_t)S.nlevels];
+        for (int32_t l = S.nlevels - 1; l >= 0; l--) {
+            const int32_t t0 = nb0 + sf3_lvl_b[(size_t)(S.nlevels - 1 - l)], cnt = sf3_lvl_b[(size_t)(S.nlevels - l)] - sf3_lvl_b[(size_t)(S.nlevels - 1 - l)];
+            if (cnt <= 0) continue;
+            if (S.sym_mode)
+                hipLaunchKernelGGL((k_bwd_fused<false, 1, true, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr);
+            else
+                hipLaunchKernelGGL((k_bwd_fused<false, 1, false, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr);
+            launches++;
+        }
+        HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
+        times.n_kernel_launches_solve = launches;
+        tri_pending = true;
+        return SUCCESSFUL_EXIT;
+    }
     HIPC(hipEventRecord((hipEvent_t)ev[3], STREAM), ERROR_HIP_SYNCHRONIZE);
     for (const LevelPlan &L : levels) {
         if (L.small_cnt > 0) {
@@ -1311,6 +1338,49 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
     HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
     times.n_kernel_launches_solve = launches;
     tri_pending = true;
+    return SUCCESSFUL_EXIT;
+}
+
+// Task list of the level-by-level launches of the dependency-driven kernels (built at the first solve that needs it): the tasks of
+// level l are sf3[sf3_lvl[l], sf3_lvl[l + 1]) in the forward part, the backward part follows with the levels from the root down.
+int32_t Solver::build_level_tasks() {
+    if (d_sf3) return SUCCESSFUL_EXIT;
+    const int32_t ns = S.nsuper;
+    std::vector<SfTask> sf;
+    std::vector<int32_t> need((size_t)2 * ns, 1);
+    auto kind_of = [&](int32_t s, bool forward) {
+        const int32_t len = forward ? S.npiv(s) : S.fsize(s);
+        if (!forward && S.sym_mode) return 4; // transposed GEMV of the L D L^T fronts: 16 columns of E per workgroup
+        if (forward && sf_big_rows > 0 && S.fsize(s) >= sf_big_front) return sf_big_rows;
+        return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
+    };
+    auto emit_level = [&](int32_t l, bool forward) {
+        std::vector<int32_t> small;
+        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            const int32_t s = S.level_sn[k];
+            if (S.fsize(s) <= SMALL_F) {
+                small.push_back(s);
+                continue;
+            }
+            const int32_t kind = kind_of(s, forward), rows = 1 << kind, ext = forward ? S.fsize(s) : S.npiv(s);
+            need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows;
+            for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), 0, 0});
+        }
+        for (size_t k = 0; k < small.size(); k += 4) {
+            SfTask t = {0, small[k], -1, -1, -1, 0};
+            if (k + 1 < small.size()) t.b = small[k + 1];
+            if (k + 2 < small.size()) t.c = small[k + 2];
+            if (k + 3 < small.size()) t.d = small[k + 3];
+            sf.push_back(t);
+        }
+    };
+    sf3_lvl.assign(1, 0);
+    for (int32_t l = 0; l < S.nlevels; l++) emit_level(l, true), sf3_lvl.push_back((int32_t)sf.size());
+    const int32_t nf = (int32_t)sf.size();
+    sf3_lvl_b.assign(1, 0);
+    for (int32_t l = S.nlevels - 1; l >= 0; l--) emit_level(l, false), sf3_lvl_b.push_back((int32_t)sf.size() - nf);
+    HIPC(dev_upload(&d_sf3, sf), ERROR_HIP_MALLOC);
+    HIPC(dev_upload(&d_need3, need), ERROR_HIP_MALLOC);
     return SUCCESSFUL_EXIT;
 }
 
@@ -1583,11 +1653,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     }
     if (use_fused && (sf_err[0] != 0 || sf_err[1] != 0)) {
         // a hand-off wait timed out (never expected): the result is not trusted; redo with the level-set launches
-        if (!level_path_ok) {
-            last_error = "dependency-driven solve timed out and the fronts are too large for the level-set fallback";
-            return ERROR_NOT_AVAILABLE;
-        }
-        use_fused = false;
+        use_fused = false; // (level-set kernels, or -- L D L^T fronts, fronts beyond their LDS staging -- the same kernels level by level)
         fused_fallbacks++;
         sf_err[0] = sf_err[1] = 0;
         (void)hipMemset(d_sync + sync_words - 1, 0, sizeof(int32_t));

@@ -150,6 +150,10 @@ class Solver {
     struct SolveLane;
     int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed);
     void harvest_tri();
+    int32_t build_level_tasks();
+    SfTask *d_sf3 = nullptr;   // tasks of the level-by-level launches of the dependency-driven kernels (fallback of L D L^T / very large fronts)
+    int32_t *d_need3 = nullptr;
+    std::vector<int32_t> sf3_lvl, sf3_lvl_b; // task offsets per level: forward (leaves first), backward (root first)
     bool tri_pending = false;
     std::vector<LevelPlan> levels;
     int64_t work_doubles = 0;

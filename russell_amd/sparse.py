@@ -87,7 +87,9 @@ class MMsym(enum.IntEnum):
 class _RhParams(C.Structure):
     _fields_ = [("ordering", C.c_int32), ("scaling", C.c_int32), ("has_pivot_epsilon", C.c_int32), ("pivot_epsilon", C.c_double),
                 ("has_refinement_nstep", C.c_int32), ("refinement_nstep", C.c_int32), ("positive_definite", C.c_int32),
-                ("compute_determinant", C.c_int32), ("verbose", C.c_int32)]
+                ("compute_determinant", C.c_int32), ("verbose", C.c_int32), ("matching", C.c_int32), ("pivoting", C.c_int32),
+                ("has_hybrid_memory_factor", C.c_int32), ("hybrid_memory_factor", C.c_double), ("compute_error_estimates", C.c_int32),
+                ("compute_condition_numbers", C.c_int32)]
 
 
 class LinSolParams:
@@ -101,11 +103,18 @@ class LinSolParams:
         self.positive_definite = False
         self.compute_determinant = False
         self.verbose = False
+        self.matching = 1                 # enums.rs Matching: 0 None, 1 Auto, 2.. the named variants (all select the maximum-product matching)
+        self.pivoting = 0                 # enums.rs Pivoting: 0 Auto, 5 LocalBlock; the others are refused
+        self.hybrid_memory_factor = None  # lin_sol_params.rs:39 (recorded; no out-of-core path)
+        self.compute_error_estimates = False
+        self.compute_condition_numbers = False
 
     def _c(self):
         return _RhParams(int(self.ordering), int(self.scaling), int(self.pivot_epsilon is not None), float(self.pivot_epsilon or 0.0),
                          int(self.refinement_nstep is not None), int(self.refinement_nstep or 0), int(self.positive_definite),
-                         int(self.compute_determinant), int(self.verbose))
+                         int(self.compute_determinant), int(self.verbose), int(self.matching), int(self.pivoting),
+                         int(self.hybrid_memory_factor is not None), float(self.hybrid_memory_factor or 0.0),
+                         int(self.compute_error_estimates), int(self.compute_condition_numbers))
 
 
 def _L():

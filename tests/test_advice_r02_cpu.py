@@ -1,0 +1,101 @@
+"""Regression tests for the round-2 advisor findings and the LinSolParams surface added in round 3 (host logic + emulated kernels)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from russell_amd import problems as P
+from russell_amd import sparse as RS
+from russell_amd.backend import Hipmf
+
+
+@pytest.fixture()
+def host_on_emu(emu_lib):
+    lib = RS._L()
+    lib.rh_set_hipmf_library.argtypes = [C.c_char_p]
+    lib.rh_set_hipmf_library(emu_lib.encode())
+    yield lib
+    lib.rh_set_hipmf_library(b"")
+
+
+def _coo(n, rows, cols, vals, sym=None):
+    coo = RS.CooMatrix(n, n, len(vals), sym) if sym is not None else RS.CooMatrix(n, n, len(vals))
+    coo.put_many(rows.astype(np.int32), cols.astype(np.int32), vals.astype(np.float64))
+    return coo
+
+
+def test_positive_definite_with_full_storage_is_not_refused(emu_lib, host_on_emu):
+    # positive_definite alone used to mean "the CSR is the lower triangle"; Sym::No + positive_definite was refused with
+    # "invalid CSR structure".  LinSolParams::positive_definite is independent of the storage (lin_sol_params.rs:41-42).
+    n, rp, ci, v = P.poisson2d(11, 9)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci, positive_definite=True) == 0  # C-ABI: entries above the diagonal -> general matrix, LU
+    assert s.counter("symmetric_ldlt") == 0
+    assert s.factorize(v) == 0
+    assert np.max(np.abs(s.solve(b) - xs)) < 1e-12
+    s.close()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    solver = RS.LinSolver(RS.Genie.Hipmf)  # host mirror: the flag only travels with Sym::YesLower
+    par = RS.LinSolParams()
+    par.positive_definite = True
+    solver.actual.factorize(_coo(n, rows, ci, v), par)
+    assert np.max(np.abs(solver.actual.solve(b) - xs)) < 1e-12
+
+
+def test_lin_sol_params_matching_pivoting_hybrid(host_on_emu):
+    # lin_sol_params.rs:13-16,39: carried by the mirror; Matching::None switches the maximum-product matching off, the pivoting
+    # strategies this backend does not have are refused with a message, hybrid_memory_factor is range-checked like the reference's
+    rng = np.random.default_rng(7)
+    n = 40
+    A = np.zeros((n, n))
+    for i in range(n):  # weak diagonal: the large entries sit on a shifted diagonal
+        A[i, (i + 3) % n] = 5.0 + rng.random()
+        A[i, i] = 1e-3
+        A[i, (i + 7) % n] = 0.5 * rng.random()
+    r, c = np.nonzero(A)
+    xs = P.manufactured_solution(n)
+    b = A @ xs
+    par = RS.LinSolParams()
+    solver = RS.LinSolver(RS.Genie.Hipmf)
+    solver.actual.factorize(_coo(n, r, c, A[r, c]), par)  # Matching::Auto: weak diagonal -> matching applied
+    assert np.max(np.abs(solver.actual.solve(b) - xs)) < 1e-10
+    par2 = RS.LinSolParams()
+    par2.matching = 0  # Matching::None
+    par2.refinement_nstep = 10
+    solver2 = RS.LinSolver(RS.Genie.Hipmf)
+    solver2.actual.factorize(_coo(n, r, c, A[r, c]), par2)  # static pivoting alone: still a solution after refinement, or perturbed pivots
+    x2 = solver2.actual.solve(b)
+    assert np.all(np.isfinite(x2))
+    par3 = RS.LinSolParams()
+    par3.pivoting = 2  # Pivoting::GlobalCol
+    with pytest.raises(Exception, match="pivots inside the pivot block"):
+        RS.LinSolver(RS.Genie.Hipmf).actual.factorize(_coo(n, r, c, A[r, c]), par3)
+    par4 = RS.LinSolParams()
+    par4.hybrid_memory_factor = 1.5
+    with pytest.raises(Exception, match="hybrid_memory_factor"):
+        RS.LinSolver(RS.Genie.Hipmf).actual.factorize(_coo(n, r, c, A[r, c]), par4)
+    par5 = RS.LinSolParams()
+    par5.hybrid_memory_factor = 0.5  # accepted and recorded (no out-of-core path: a factor that does not fit is refused at initialize)
+    RS.LinSolver(RS.Genie.Hipmf).actual.factorize(_coo(n, r, c, A[r, c]), par5)
+
+
+def test_set_option_before_and_after_initialize(emu_lib):
+    n, rp, ci, v = P.poisson2d(6, 5)
+    s = Hipmf(emu_lib)
+    lib = s.lib
+    val = C.c_double(0.0)
+    assert lib.solver_hipmf_set_option(s.h, 0, 0.0) == 0          # matching off
+    assert lib.solver_hipmf_set_option(s.h, 1, 2.0) == 400000     # Pivoting::GlobalCol: ERROR_NOT_AVAILABLE
+    assert lib.solver_hipmf_set_option(s.h, 2, 1.5) == 803        # hybrid factor out of range: invalid value
+    assert lib.solver_hipmf_set_option(s.h, 2, 0.25) == 0
+    assert lib.solver_hipmf_get_option(s.h, 4, C.byref(val)) == 600000  # condition number: needs a factorisation
+    assert s.initialize(n, rp, ci) == 0
+    assert lib.solver_hipmf_set_option(s.h, 0, 1.0) == 700000     # ERROR_ALREADY_INITIALIZED
+    assert lib.solver_hipmf_get_option(s.h, 0, C.byref(val)) == 0 and val.value == 0.0
+    assert s.factorize(v) == 0
+    s.solve(P.csr_matvec(n, rp, ci, v, P.manufactured_solution(n)))
+    assert lib.solver_hipmf_get_option(s.h, 4, C.byref(val)) == 0 and 0.0 < val.value <= 1.0
+    assert lib.solver_hipmf_get_option(s.h, 3, C.byref(val)) == 0 and 0.0 <= val.value < 1e-10
+    s.close()

@@ -161,3 +161,45 @@ def test_config4_matrix_200_cubed_with_a_block_of_32_right_hand_sides_on_one_gpu
         worst_res = max(worst_res, float(np.max(np.abs(r)) / (np.max(np.abs(v)) + 1.0)))
     assert worst_res <= 1e-10
     assert worst_fwd < 1e-9
+
+
+@pytest.mark.parametrize("kind,size", [("2d", 300), ("3d", 40)])
+def test_symmetric_mode_without_in_launch_hand_offs(kind, size, monkeypatch):
+    # L D L^T factors had no fallback when the dependency-driven launch times out (the level-set kernels have no
+    # L D L^T instance).  HIPMF_FUSED_SOLVE=0 now runs the dependency-driven kernels one launch per level (no task waits for a task of
+    # its own launch): same arithmetic, bit-identical to the single-launch schedule with the same slab shapes.
+    n, rp, ci, v = P.poisson2d(size) if kind == "2d" else P.poisson3d(size)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HIPMF_FUSED_SOLVE", fused)
+        monkeypatch.setenv("HIPMF_TREE_SOLVE", "0")  # (the round-2 slab shapes on both sides)
+        s = Hipmf()
+        assert s.initialize(n, lrp, lci, general_symmetric=True, refinement_nstep=0) == 0
+        assert s.counter("symmetric_ldlt") == 1
+        assert s.factorize(lv) == 0
+        got[fused] = s.solve(b)
+        st = s.stats()
+        s.close()
+        assert (st["solve_launches"] <= 4) == (fused == "1")
+    assert np.array_equal(got["0"], got["1"])
+    assert np.max(np.abs(got["0"] - xs)) / np.max(np.abs(xs)) < 1e-10
+
+
+def test_fronts_beyond_the_lds_staging_limit_without_in_launch_hand_offs(monkeypatch):
+    # 88^3 (general storage, LU): the root front has > 7 936 rows, more than the level-set kernels stage in LDS; with
+    # HIPMF_FUSED_SOLVE=0 the chunked dependency-driven kernels run level by level instead of refusing the matrix (~26 GB of HBM)
+    monkeypatch.setenv("HIPMF_FUSED_SOLVE", "0")
+    n, rp, ci, v = P.poisson3d(88)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.stats()["max_front"] > 7936
+    assert s.factorize(v) == 0
+    x = s.solve(b)
+    assert s.stats()["solve_launches"] > 6
+    s.close()
+    assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-11
