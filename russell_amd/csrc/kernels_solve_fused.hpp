@@ -26,7 +26,9 @@
 namespace hipmf {
 
 constexpr int SF_SYNC_HEADER = 16;       // ints in front of the completion counters (reserved)
-constexpr unsigned SF_SPIN_LIMIT = 1u << 19;
+constexpr unsigned long long SF_WAIT_TICKS = 10ull * 100000000ull; // a wait gives up after 10 s of the constant 100 MHz device clock
+// (a poll COUNT was the limit until round 3: 2^19 polls are ~0.2 s, which the upper levels of a 200^3 factor exceed when two blocks of
+//  16 right-hand sides share the GPU -- the timeout sent that solve to the one-column fallback, 26 s instead of 3 s)
 constexpr int SF_CHUNK = 1024;           // doubles of a big front's vector staged in LDS at a time, per right-hand side (the children are
                                          // re-scanned for every chunk; 1024 doubles per right-hand side up to K = 4, 512 at K = 8: 32 KB of LDS)
 constexpr int SF_SYMC = 4;               // columns of E per wavefront in the backward slabs of the symmetric (L D L^T) fronts: slabs of 16 pivots
@@ -48,14 +50,19 @@ struct SfTask {
 // wait until *cnt >= need (relaxed agent-scope polls); false on timeout or when another waiter timed out
 __device__ __forceinline__ bool sf_wait(const int *cnt, int need, int *err) {
     unsigned spins = 0;
+    unsigned long long t0 = 0;
     while (flag_load(cnt) < need) {
         poll_nap();
         spins++;
-        if (spins > SF_SPIN_LIMIT) {
-            flag_store(err, 1);
-            return false;
+        if ((spins & 1023u) == 0) {
+            if (flag_load(err) != 0) return false;
+            const unsigned long long now = dev_clock();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > SF_WAIT_TICKS) {
+                flag_store(err, 1);
+                return false;
+            }
         }
-        if ((spins & 1023u) == 0 && flag_load(err) != 0) return false;
     }
     return true;
 }

@@ -40,7 +40,10 @@ constexpr int WT_NCH = HIPMF_WT_NCH;    // 512-byte pieces of factor per batch
 constexpr int WT_CHUNK = 64;            // doubles per piece (64 lanes x 8 bytes; with 1 KB pieces the pass fetched 1.25x the algorithmic bytes:
                                         // a piece is read whole, and what follows a front's panel in the pool is its contribution block)
 constexpr int WT_NREC = 8;              // fronts per batch at most
-constexpr int WT_MI = 512;              // 32-bit words of a batch's meta block: WT_NREC records of 16 words, then the index lists
+#ifndef HIPMF_WT_MI
+#define HIPMF_WT_MI 512
+#endif
+constexpr int WT_MI = HIPMF_WT_MI;      // 32-bit words of a batch's meta block: WT_NREC records of 16 words, then the index lists
 constexpr int WT_X = HIPMF_WT_X;        // pivots of a wave-subtree at most (multiple of 256)
 constexpr int WT_STACK = HIPMF_WT_STACK; // doubles of LDS per wave for the stack of front vectors (5 levels x 64 rows)
 // (measured on the 1M-DOF Poisson factor, forward + backward pass pair: 8 pieces / 512 pivots / 384 stack doubles = 20 KB of LDS per

@@ -69,11 +69,12 @@ void Solver::release() {
     if (d_sd) (void)hipFree(d_sd);
     d_sd = nullptr;
     for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep, (void *)d_sf3,
-                    (void *)d_need3})
+                    (void *)d_need3, (void *)d_sfk, (void *)d_needk})
         if (p) (void)hipFree(p);
     d_wt_hdr = nullptr, d_wt_meta = nullptr, d_wt_wave = nullptr, d_sf2 = nullptr, d_need2 = nullptr, d_rep_idx = nullptr, d_rep = nullptr;
     rep_words = 0;
     d_sf3 = nullptr, d_need3 = nullptr;
+    d_sfk = nullptr, d_needk = nullptr;
     wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
@@ -199,6 +200,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_UP_STAGE_BWD")) up_stage_bwd = std::max(8, std::min(64, atoi(e) / 8 * 8));
     if (const char *e = getenv("HIPMF_UP_TOP_FRONTS")) up_top_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_UP_REPLICAS")) use_rep = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_BLOCKED_SLABS")) blocked_slabs = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_UP_STAGE_MID")) up_stage_mid = std::max(0, std::min(32, atoi(e) / 8 * 8));
     if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
     if (const char *e = getenv("HIPMF_SF_BIG_FRONT")) sf_big_front = std::max(65, atoi(e));
@@ -623,9 +625,15 @@ int32_t Solver::upload_plan() {
         // narrow slabs, i.e. more column groups per workgroup and more workgroups per front
         std::vector<char> in_w((size_t)ns, 0); // fronts that belong to a wave-subtree (kernels_solve_tree.hpp)
         bool tree = false;                     // the task list being built is the one above the wave-subtrees
+        bool blocked = false;                  // ... the one of the blocked (many-RHS) instances
         int32_t top_level = S.nlevels;         // ... its levels >= top_level run in a launch of their own (LDS-staged slabs)
         auto kind_of = [&](int32_t s, bool forward) {
             const int32_t len = forward ? S.npiv(s) : S.fsize(s);
+            // Blocked instances (K columns on MFMA tiles): every slab stages the WHOLE vector block of its front (len x K doubles) chunk by
+            // chunk, so narrow slabs re-read it as often as there are slabs -- at K = 16 and 16-row slabs as many bytes as the factor
+            // itself (config 4 on one GPU: 16 columns cost 1.9x what 8 cost).  64 rows (four 16-output tiles per workgroup, forward 128
+            // for the long dot products) read it a quarter / an eighth as often.
+            if (blocked) return forward ? (S.fsize(s) >= sf_big_front || len >= 512 ? 7 : 6) : 6;
             if (!forward && S.sym_mode) return 4; // transposed GEMV of the L D L^T fronts: 16 columns of E per workgroup
             // fronts of thousands of rows: every slab workgroup gathers ALL children's update vectors, so 16-row slabs (625 of them
             // for 10 000 rows) re-read them hundreds of times; 64-row slabs still give >= 32 workgroups per front
@@ -696,6 +704,32 @@ int32_t Solver::upload_plan() {
         }
         if (band == 0) sf_bwd_top = (int32_t)sf.size() - sf_fwd_cnt;
         sf_bwd_cnt = (int32_t)sf.size() - sf_fwd_cnt;
+        if (blocked_slabs) {
+            // the same levels once more with the slab shapes of the blocked instances (the small fronts' tasks are the same)
+            std::vector<SfTask> keep;
+            keep.swap(sf);
+            std::vector<int32_t> need_keep = need;
+            std::fill(need.begin(), need.end(), 1);
+            blocked = true;
+            sfk_fwd_band = 0;
+            for (int32_t l = 0; l < S.nlevels; l++) {
+                emit_level(l, true);
+                if (l + 1 == band) sfk_fwd_band = (int32_t)sf.size();
+            }
+            sfk_fwd_cnt = (int32_t)sf.size();
+            sfk_bwd_top = 0;
+            for (int32_t l = S.nlevels - 1; l >= 0; l--) {
+                if (l + 1 == band) sfk_bwd_top = (int32_t)sf.size() - sfk_fwd_cnt;
+                emit_level(l, false);
+            }
+            if (band == 0) sfk_bwd_top = (int32_t)sf.size() - sfk_fwd_cnt;
+            sfk_bwd_cnt = (int32_t)sf.size() - sfk_fwd_cnt;
+            blocked = false;
+            HIPC(dev_upload(&d_sfk, sf), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_needk, need), ERROR_HIP_MALLOC);
+            sf.swap(keep);
+            need.swap(need_keep);
+        }
         if (getenv("HIPMF_SF_TRACE")) { // profiling aid: four device-clock stamps per task of the upper (mixed) launches
             const size_t ntr = (size_t)(sf_fwd_cnt - sf_fwd_band) + (size_t)sf_bwd_top;
             HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 8 * std::max<size_t>(ntr, 1)), ERROR_HIP_MALLOC);
@@ -1220,14 +1254,18 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             if (timed) tri_pending = true;
             return SUCCESSFUL_EXIT;
         }
-        const int32_t fa = std::min(sf_fwd_band, sf_fwd_launch), fb = sf_fwd_launch - fa;
-        const int32_t bt = sf_bwd_top, bb = sf_bwd_cnt - sf_bwd_top;
+        const bool use_k = nk > 1 && d_sfk != nullptr; // the blocked instances have their own slab shapes
+        const SfTask *T = use_k ? d_sfk : d_sf;
+        const int32_t *NEED = use_k ? d_needk : d_need;
+        const int32_t t_fwd = use_k ? sfk_fwd_cnt : sf_fwd_cnt;
+        const int32_t fa = use_k ? sfk_fwd_band : std::min(sf_fwd_band, sf_fwd_launch), fb = (use_k ? sfk_fwd_cnt : sf_fwd_launch) - fa;
+        const int32_t bt = use_k ? sfk_bwd_top : sf_bwd_top, bb = (use_k ? sfk_bwd_cnt : sf_bwd_cnt) - bt;
         unsigned long long *no_trace = nullptr;
 #define HIPMF_FWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
-    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need, sync_f, \
+    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, NEED, sync_f, \
                        sync_err, wrk, xp, nk, xstr, wstr, TRACE, 0, (const int32_t *)nullptr, (int *)nullptr)
 #define HIPMF_BWD1(SMALL, KK, SYMM, CNT, TASKS, TRACE)                                                                                     \
-    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, d_need + ns, sync_b,      \
+    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, NEED + ns, sync_b,        \
                        sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr)
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     do {                                                                                                                                  \
@@ -1235,25 +1273,25 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         else HIPMF_BWD1(SMALL, KK, false, CNT, TASKS, TRACE);                                                                              \
     } while (0)
         if (nk == 1) {
-            if (fa > 0) HIPMF_FWD(true, 1, fa, d_sf, no_trace);
-            if (fb > 0) HIPMF_FWD(false, 1, fb, d_sf + fa, timed ? d_trace : no_trace);
+            if (fa > 0) HIPMF_FWD(true, 1, fa, T, no_trace);
+            if (fb > 0) HIPMF_FWD(false, 1, fb, T + fa, timed ? d_trace : no_trace);
         } else if (nk <= SF_KMID) {
-            if (fa > 0) HIPMF_FWD(true, SF_KMID, fa, d_sf, no_trace);
-            if (fb > 0) HIPMF_FWD(false, SF_KMID, fb, d_sf + fa, timed ? d_trace : no_trace);
+            if (fa > 0) HIPMF_FWD(true, SF_KMID, fa, T, no_trace);
+            if (fb > 0) HIPMF_FWD(false, SF_KMID, fb, T + fa, timed ? d_trace : no_trace);
         } else {
-            if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, d_sf, no_trace);
-            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, d_sf + fa, timed ? d_trace : no_trace);
+            if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, T, no_trace);
+            if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, T + fa, timed ? d_trace : no_trace);
         }
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[4], LST), ERROR_HIP_SYNCHRONIZE);
         if (nk == 1) {
-            if (bt > 0) HIPMF_BWD(false, 1, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
-            if (bb > 0) HIPMF_BWD(true, 1, bb, d_sf + sf_fwd_cnt + bt, no_trace);
+            if (bt > 0) HIPMF_BWD(false, 1, bt, T + t_fwd, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
+            if (bb > 0) HIPMF_BWD(true, 1, bb, T + t_fwd + bt, no_trace);
         } else if (nk <= SF_KMID) {
-            if (bt > 0) HIPMF_BWD(false, SF_KMID, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
-            if (bb > 0) HIPMF_BWD(true, SF_KMID, bb, d_sf + sf_fwd_cnt + bt, no_trace);
+            if (bt > 0) HIPMF_BWD(false, SF_KMID, bt, T + t_fwd, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
+            if (bb > 0) HIPMF_BWD(true, SF_KMID, bb, T + t_fwd + bt, no_trace);
         } else {
-            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, d_sf + sf_fwd_cnt, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
-            if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, d_sf + sf_fwd_cnt + bt, no_trace);
+            if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, T + t_fwd, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
+            if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, T + t_fwd + bt, no_trace);
         }
 #undef HIPMF_FWD
 #undef HIPMF_BWD

@@ -151,6 +151,13 @@ class Solver {
     int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed);
     void harvest_tri();
     int32_t build_level_tasks();
+    // optional task list of the blocked (many-RHS) instances with wider slabs (HIPMF_BLOCKED_SLABS=1).  Measured and NOT the default:
+    // 64 / 128-row slabs re-read the vector block of a front less often, but lose more in parallelism -- 144^3, 64 right-hand sides:
+    // 4.92 -> 7.06 ms per right-hand side; 200^3, 256 right-hand sides: 4.58 -> 6.86 s (profiles/r03_rejected_experiments.txt)
+    bool blocked_slabs = false;
+    SfTask *d_sfk = nullptr;
+    int32_t *d_needk = nullptr;
+    int32_t sfk_fwd_cnt = 0, sfk_bwd_cnt = 0, sfk_fwd_band = 0, sfk_bwd_top = 0;
     SfTask *d_sf3 = nullptr;   // tasks of the level-by-level launches of the dependency-driven kernels (fallback of L D L^T / very large fronts)
     int32_t *d_need3 = nullptr;
     std::vector<int32_t> sf3_lvl, sf3_lvl_b; // task offsets per level: forward (leaves first), backward (root first)
