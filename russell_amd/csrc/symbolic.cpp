@@ -831,10 +831,13 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             S.e_off[s] = pers, pers += round16((int64_t)S.front_ld[s] * p);
             if (!S.sym_mode) S.ep_off[s] = pers, pers += round16(p * f);
         } else {
+            // (both blocks start on a 128-byte line: the wave-subtree solves fetch them as flat 512-byte pieces, and a piece that
+            //  straddles lines costs a fifth line -- measured as HBM fetch bytes of k_wt_fwd / k_wt_bwd; +64 bytes per front on average)
+            pers = round16(pers);
             S.front_off[s] = pers, pers += f * f;
             // the rows of U of a small front once more, packed (p x f, stride p): the backward solve reads [U11 | U12] as one
             // contiguous block instead of p-entry pieces of f columns (which drags the whole f x f block through the cache lines)
-            if (p > 0 && m > 0) S.ep_off[s] = pers, pers += p * f;
+            if (p > 0 && m > 0) pers = round16(pers), S.ep_off[s] = pers, pers += p * f;
         }
         S.nnz_l += p * (p - 1) / 2 + p * m;
         S.nnz_u += p * (p + 1) / 2 + p * m;
