@@ -80,7 +80,9 @@ void solver_hipmf_drop(struct InterfaceHIPMF *solver);
  * umfpack_di_symbolic(Ap, Ai, Ax) at interface_umfpack.c:109, cudssExecute(ANALYSIS) at interface_cudss.cu:361)
  * and the diagonal is weak (missing, zero or < 1 % of the row's largest entry somewhere), general-storage matrices
  * get a maximum-product matching + row/column scaling pre-permutation, which stays in force for every later
- * factorisation with this handle. */
+ * factorisation with this handle.  A symmetric-lower matrix with such a diagonal (indefinite: the Lagrange rows of
+ * CooMatrix::put_lagrange_block, coo_matrix.rs:823-857) is mirrored to general storage inside the handle and takes the same
+ * path (HIPMF_COUNTER_SYM_EXPANDED); the caller keeps passing lower-triangle values and lower-triangle value maps. */
 int32_t solver_hipmf_initialize(struct InterfaceHIPMF *solver,
                                 int32_t ordering,
                                 int32_t scaling,
@@ -170,6 +172,9 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 #define HIPMF_COUNTER_PERSISTENT_BYTES 3   /* pool: the factor proper (small fronts, E / E' panels) */
 #define HIPMF_COUNTER_ARENA_BYTES 4        /* pool: arena of the tiled fronts' working blocks */
 #define HIPMF_COUNTER_SYMMETRIC_LDLT 5     /* 1: the tiled fronts are factorised as L D L^T */
+#define HIPMF_COUNTER_SYM_EXPANDED 6       /* 1: symmetric-lower input with a weak diagonal (indefinite / saddle-point): mirrored to general
+                                            * storage at initialize, factorised by LU with the maximum-product matching; the caller keeps
+                                            * handing over lower-triangle values */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

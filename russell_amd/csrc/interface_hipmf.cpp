@@ -30,6 +30,10 @@ struct InterfaceHIPMF {
     // solver_hipmf_set_option (before initialize)
     int32_t opt_matching = 1, opt_pivoting = 1;
     double opt_hybrid = 0.0;
+    // a symmetric-lower matrix with a weak diagonal is analysed and factorised as the mirrored GENERAL matrix (with the matching):
+    // the caller keeps handing over lower-triangle values, entry k of the handle's CSR is entry emap[k] of the caller's
+    bool expanded = false;
+    int64_t nnz_lower = 0;
 };
 
 extern "C" {
@@ -78,7 +82,69 @@ int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int3
     no.matching = h->opt_matching;
     h->ordering_requested = ordering;
     h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
-    int32_t code = h->solver.initialize(ndim, row_pointers, col_indices, sym_lower, so, no, values);
+    int32_t code;
+    // Symmetric INDEFINITE input (saddle-point / KKT matrices: put_lagrange_block, coo_matrix.rs:823-857): the L D L^T fronts never
+    // interchange rows and the matching needs general storage, so a weak diagonal used to rest on perturbed pivots + refinement.  When
+    // the values are handed over and the diagonal of the symmetric matrix is weak somewhere (missing, zero or < 1 % of the row's
+    // largest entry: the criterion of the general path), the matrix is mirrored to general storage HERE and takes the general path:
+    // maximum-product matching + scaling, LU with pivoting inside the pivot blocks.  Twice the factor of L D L^T, no perturbed pivots.
+    // The caller's interface does not change: it keeps passing lower-triangle values (HIPMF_COUNTER_SYM_EXPANDED tells).
+    bool expand = false;
+    if (sym_lower && values && ndim > 1 && no.matching > 0 && row_pointers[0] == 0 && validate_csr(ndim, row_pointers, col_indices) == 0) {
+        const char *e = getenv("HIPMF_SYM_EXPAND");
+        if (!e || atoi(e) != 0) {
+            std::vector<double> rmax((size_t)ndim, 0.0), dg((size_t)ndim, 0.0);
+            bool lower_only = true;
+            for (int32_t i = 0; i < ndim && lower_only; i++)
+                for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+                    const int32_t j = col_indices[k];
+                    if (j > i) {
+                        lower_only = false;
+                        break;
+                    }
+                    const double a = std::fabs(values[k]);
+                    rmax[(size_t)i] = std::max(rmax[(size_t)i], a), rmax[(size_t)j] = std::max(rmax[(size_t)j], a);
+                    if (j == i) dg[(size_t)i] = a;
+                }
+            if (lower_only)
+                for (int32_t i = 0; i < ndim && !expand; i++) expand = dg[(size_t)i] < 0.01 * rmax[(size_t)i] || rmax[(size_t)i] == 0.0;
+        }
+    }
+    if (expand) {
+        const int64_t nl = row_pointers[ndim];
+        std::vector<int64_t> cnt((size_t)ndim + 1, 0);
+        for (int32_t i = 0; i < ndim; i++)
+            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+                cnt[(size_t)i + 1]++;
+                if (col_indices[k] != i) cnt[(size_t)col_indices[k] + 1]++;
+            }
+        for (int32_t i = 0; i < ndim; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
+        if (cnt[(size_t)ndim] > 0x7fffffffLL) return ERROR_HIPMF_INVALID_MATRIX;
+        std::vector<int32_t> rpf((size_t)ndim + 1), cif((size_t)cnt[(size_t)ndim]), emap((size_t)cnt[(size_t)ndim]);
+        std::vector<double> vf((size_t)cnt[(size_t)ndim]);
+        for (int32_t i = 0; i <= ndim; i++) rpf[(size_t)i] = (int32_t)cnt[(size_t)i];
+        // row i of the full matrix: its stored lower entries (columns ascending, <= i), then the mirrored ones (rows r > i ascending):
+        // filling row by row in ascending order of the source row keeps every row's columns ascending
+        std::vector<int64_t> w(cnt.begin(), cnt.end() - 1);
+        for (int32_t i = 0; i < ndim; i++)
+            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+                const int64_t q = w[(size_t)i]++;
+                cif[(size_t)q] = col_indices[k], vf[(size_t)q] = values[k], emap[(size_t)q] = k;
+            }
+        for (int32_t i = 0; i < ndim; i++)
+            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+                const int32_t j = col_indices[k];
+                if (j == i) continue;
+                const int64_t q = w[(size_t)j]++;
+                cif[(size_t)q] = i, vf[(size_t)q] = values[k], emap[(size_t)q] = k;
+            }
+        code = h->solver.initialize(ndim, rpf.data(), cif.data(), false, so, no, vf.data());
+        if (code == SUCCESSFUL_EXIT) code = h->solver.set_expansion(nl, emap);
+        if (code == SUCCESSFUL_EXIT) h->expanded = true, h->nnz_lower = nl;
+        else h->solver.release();
+    } else {
+        code = h->solver.initialize(ndim, row_pointers, col_indices, sym_lower, so, no, values);
+    }
     if (verbose == 1 && code == SUCCESSFUL_EXIT) {
         const Symbolic &S = h->solver.S;
         printf("solver_hipmf_initialize: n=%d nnz=%lld supernodes=%d levels=%d nnz(L)=%lld nnz(U)=%lld flops=%.3e "
@@ -161,7 +227,30 @@ int32_t solver_hipmf_factorize(struct InterfaceHIPMF *h, int32_t *effective_orde
 
 int32_t solver_hipmf_set_value_map(struct InterfaceHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
     if (!h) return ERROR_NULL_POINTER;
-    return h->solver.set_value_map(nnz_in, seg_ptr, seg_idx);
+    if (!h->expanded) return h->solver.set_value_map(nnz_in, seg_ptr, seg_idx);
+    // the caller's map speaks of ITS CSR (the lower triangle): entry k of the handle's general CSR takes the segment of entry emap[k]
+    if (!seg_ptr || !seg_idx) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    const int64_t nl = h->nnz_lower;
+    if (seg_ptr[0] != 0) return ERROR_HIPMF_INVALID_VALUE;
+    for (int64_t j = 0; j < nl; j++)
+        if (seg_ptr[j + 1] < seg_ptr[j]) return ERROR_HIPMF_INVALID_VALUE;
+    if (seg_ptr[nl] != nnz_in) return ERROR_HIPMF_INVALID_VALUE;
+    const std::vector<int32_t> &emap = h->solver.expansion_map();
+    std::vector<int32_t> sp(emap.size() + 1, 0), si;
+    int64_t tot = 0;
+    for (size_t k = 0; k < emap.size(); k++) tot += seg_ptr[emap[k] + 1] - seg_ptr[emap[k]];
+    if (tot > 0x7fffffffLL) return ERROR_HIPMF_INVALID_VALUE;
+    si.reserve((size_t)tot);
+    for (size_t k = 0; k < emap.size(); k++) {
+        for (int32_t q = seg_ptr[emap[k]]; q < seg_ptr[emap[k] + 1]; q++) {
+            if (seg_idx[q] < 0 || seg_idx[q] >= nnz_in) return ERROR_HIPMF_INVALID_VALUE;
+            si.push_back(seg_idx[q]);
+        }
+        sp[k + 1] = (int32_t)si.size();
+    }
+    // (signed-map form: seg_ptr[nnz] entries, every input used once per mirrored entry)
+    return h->solver.set_value_map(nnz_in, sp.data(), si.data(), true);
 }
 
 int32_t solver_hipmf_factorize_mapped(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
@@ -263,6 +352,7 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
     case HIPMF_COUNTER_PERSISTENT_BYTES: return s.S.persist_doubles * 8;
     case HIPMF_COUNTER_ARENA_BYTES: return s.S.temp_doubles * 8;
     case HIPMF_COUNTER_SYMMETRIC_LDLT: return s.S.sym_mode ? 1 : 0;
+    case HIPMF_COUNTER_SYM_EXPANDED: return h->expanded ? 1 : 0;
     default: return -1;
     }
 }

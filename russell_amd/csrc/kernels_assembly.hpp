@@ -43,6 +43,12 @@ __global__ void k_gather_values(int64_t nnz, const int32_t *__restrict__ seg_ptr
     }
 }
 
+// Expansion of a symmetric-lower value array to the general storage the handle was analysed with (interface_hipmf.cpp: a symmetric
+// matrix with a weak diagonal is factorised as a general one, with the matching): out[k] = in[emap[k]].
+__global__ void k_expand_values(int64_t nnz, const int32_t *__restrict__ emap, const double *__restrict__ in, double *__restrict__ out) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x) out[j] = in[emap[j]];
+}
+
 // Scaled values vs[k] = rs[row(k)] * a_k * cs[col(k)] (and, for symmetric-lower storage, the mirrored entry's
 // vs2[k] = rs[col(k)] * a_k) for the assembly kernels, and max |vs| -> *out (as ordered bits of a non-negative double).
 __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int32_t *__restrict__ arow, const int32_t *__restrict__ acol,

@@ -75,6 +75,9 @@ void Solver::release() {
     rep_words = 0;
     d_sf3 = nullptr, d_need3 = nullptr;
     d_sfk = nullptr, d_needk = nullptr;
+    for (void *p : {(void *)d_emap, (void *)d_vlow})
+        if (p) (void)hipFree(p);
+    d_emap = nullptr, d_vlow = nullptr, nnz_low = 0;
     wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
@@ -961,10 +964,9 @@ int32_t Solver::factorize(const double *values, bool on_device) {
     if (!initialized) return ERROR_NEED_INITIALIZATION;
     if (!values) return ERROR_NULL_POINTER;
     DeviceScope dev_scope(device);
-    const int64_t nnz = S.nnz_a;
-    HIPC(hipMemcpyAsync(d_vals, values, sizeof(double) * nnz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, STREAM),
-         ERROR_HIP_MEMCPY);
-    int32_t code = run_factor();
+    int32_t code = load_values(values, on_device);
+    if (code != SUCCESSFUL_EXIT) return code;
+    code = run_factor();
     if (code != SUCCESSFUL_EXIT) return code;
     if (n_weak_diag > 0 && !rematching && !rematch_futile) return rematch_and_factorize();
     factorized = true;
@@ -986,10 +988,13 @@ int32_t Solver::rematch_and_factorize() {
     const int64_t nin = nnz_in;
     const PhaseTimes keep_times = times;
     const int64_t keep_rematch = rematch_count, keep_fallbacks = fused_fallbacks;
+    const std::vector<int32_t> keep_emap = h_emap;
+    const int64_t keep_low = nnz_low;
     release();
     rematching = true;
     int32_t code = initialize_impl(n, h_rp_keep.data(), h_ci_keep.data(), sym_lower_keep, sopt_keep, nopt, hv.data());
     if (code == SUCCESSFUL_EXIT && nin > 0) code = set_value_map(nin, seg_ptr.data(), seg_idx.data(), true);
+    const bool had_expansion = keep_low > 0;
     if (code != SUCCESSFUL_EXIT) {
         rematching = false;
         const std::string keep = last_error;
@@ -1000,7 +1005,9 @@ int32_t Solver::rematch_and_factorize() {
     times = keep_times;
     rematch_count = keep_rematch + 1;
     fused_fallbacks = keep_fallbacks;
+    // (hv holds the EXPANDED values of the handle's own CSR: they are factorised as they are, the expansion map comes back afterwards)
     code = factorize(hv.data(), false); // (rematching is still set: one re-analysis per call)
+    if (had_expansion && initialized) (void)set_expansion(keep_low, keep_emap);
     rematching = false;
     // a new matching that leaves the diagonal weak (structurally singular matrix, no perfect matching, the boundary case of the
     // criterion) cannot be improved by another one: later factorizes keep this order instead of redoing the analysis every time
@@ -1726,11 +1733,41 @@ int32_t Solver::spmv(double *y, const double *x, double alpha, bool on_device) {
     return SUCCESSFUL_EXIT;
 }
 
+int32_t Solver::load_values(const double *values, bool on_device) {
+    const int64_t nnz = S.nnz_a;
+    if (!d_emap) {
+        HIPC(hipMemcpyAsync(d_vals, values, sizeof(double) * nnz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
+        return SUCCESSFUL_EXIT;
+    }
+    const double *src = values;
+    if (!on_device) {
+        HIPC(hipMemcpyAsync(d_vlow, values, sizeof(double) * nnz_low, hipMemcpyHostToDevice, STREAM), ERROR_HIP_MEMCPY);
+        src = d_vlow;
+    }
+    hipLaunchKernelGGL(k_expand_values, dim3((unsigned)std::min<int64_t>(4096, (nnz + 255) / 256)), dim3(256), 0, STREAM, nnz, d_emap, src, d_vals);
+    return SUCCESSFUL_EXIT;
+}
+
+int32_t Solver::set_expansion(int64_t nnz_lower, const std::vector<int32_t> &emap) {
+    if (!initialized) return ERROR_NEED_INITIALIZATION;
+    if (nnz_lower < 1 || (int64_t)emap.size() != S.nnz_a) return ERROR_HIPMF_INVALID_VALUE;
+    DeviceScope dev_scope(device);
+    for (void *p : {(void *)d_emap, (void *)d_vlow})
+        if (p) (void)hipFree(p);
+    d_emap = nullptr, d_vlow = nullptr;
+    HIPC(dev_upload(&d_emap, emap), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_vlow, sizeof(double) * (size_t)nnz_lower), ERROR_HIP_MALLOC);
+    nnz_low = nnz_lower;
+    if (&emap != &h_emap) h_emap = emap;
+    return SUCCESSFUL_EXIT;
+}
+
 int32_t Solver::adopt_factor(const double *d_values) {
     if (!initialized) return ERROR_NEED_INITIALIZATION;
     if (!d_values) return ERROR_NULL_POINTER;
     DeviceScope dev_scope(device);
-    HIPC(hipMemcpyAsync(d_vals, d_values, sizeof(double) * S.nnz_a, hipMemcpyDeviceToDevice, STREAM), ERROR_HIP_MEMCPY);
+    int32_t lc = load_values(d_values, true);
+    if (lc != SUCCESSFUL_EXIT) return lc;
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     n_perturbed = n_zero_pivot = 0;
     factorized = true;

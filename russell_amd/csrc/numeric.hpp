@@ -97,6 +97,12 @@ class Solver {
     int32_t determinant(double *mantissa, double *exponent, double *rcond);
     int32_t rcond_estimate(double *rcond); // min |u_ii| / max |u_ii| by a device reduction
     int32_t adopt_factor(const double *d_values); // factor buffers were filled by a peer (many-RHS multi-GPU path)
+    // The caller's value arrays hold nnz_lower entries (the lower triangle it handed to the C-ABI) while the handle was analysed with
+    // the mirrored general matrix: entry k of the handle's CSR is entry emap[k] of the caller's.  Every entry point that takes CSR
+    // values expands them on the device.
+    int32_t set_expansion(int64_t nnz_lower, const std::vector<int32_t> &emap);
+    int64_t expansion_inputs() const { return nnz_low; }
+    const std::vector<int32_t> &expansion_map() const { return h_emap; }
     void mark_factor_adopted() { n_perturbed = n_zero_pivot = 0, factorized = true; } // ... including the matrix values
     void *d_diag_ptr() const { return d_diag; }
     // FNV-1a over what two handles must share to exchange a factor: the fill-reducing permutation, the matching's row permutation, the
@@ -224,6 +230,11 @@ class Solver {
     double *d_vs = nullptr, *d_vs2 = nullptr; // scaled values (and the mirrored ones of symmetric-lower storage)
     int32_t zero_cnt = 0;
     int32_t *d_seg_ptr = nullptr, *d_seg_idx = nullptr; // value map (set_value_map)
+    int32_t *d_emap = nullptr;      // expansion of symmetric-lower values to the analysed general storage (set_expansion)
+    double *d_vlow = nullptr;       // staging of the caller's lower-triangle values
+    int64_t nnz_low = 0;
+    std::vector<int32_t> h_emap;
+    int32_t load_values(const double *values, bool on_device); // values (CSR order of the caller) -> d_vals
     double *d_vin = nullptr;
     int64_t nnz_in = 0;
     int64_t n_lists = 0;            // entries of d_lists

@@ -203,3 +203,45 @@ def test_fronts_beyond_the_lds_staging_limit_without_in_launch_hand_offs(monkeyp
     assert s.stats()["solve_launches"] > 6
     s.close()
     assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-11
+
+
+def test_saddle_point_through_the_symmetric_lower_boundary_has_no_perturbed_pivots(monkeypatch):
+    # [[K, B^T], [B, 0]] (CooMatrix::put_lagrange_block, coo_matrix.rs:823-857) handed over as a lower triangle
+    # with general_symmetric = 1.  The C-ABI mirrors it to general storage and takes the matched LU path (HIPMF_COUNTER_SYM_EXPANDED):
+    # error <= 1e-10 with ZERO perturbed pivots; the L D L^T route (HIPMF_SYM_EXPAND=0) needs perturbed pivots for the same matrix.
+    from test_sym_indefinite_cpu import saddle_point
+
+    A, L = saddle_point(150, 3000, seed=11)
+    n = A.shape[0]
+    rp, ci, v = L.indptr.astype(np.int32), L.indices.astype(np.int32), L.data.astype(np.float64)
+    rng = np.random.default_rng(2)
+    xs = rng.standard_normal(n)
+    b = A @ xs
+    s = Hipmf()
+    assert s.initialize(n, rp, ci, general_symmetric=True, values=v) == 0
+    assert s.counter("sym_expanded") == 1 and s.counter("symmetric_ldlt") == 0
+    assert s.stats()["matched"] == 1
+    assert s.factorize(v) == 0
+    assert s.num_perturbed == 0
+    x = s.solve(b)
+    assert np.max(np.abs(x - xs)) <= 1e-10 * np.max(np.abs(xs))
+    # second factorize with other values (a Newton step) and a block of right-hand sides
+    v2 = v * (1.0 + 0.1 * np.cos(np.arange(v.size)))
+    L2 = L.copy()
+    L2.data = v2
+    import scipy.sparse as sp
+
+    A2 = (L2 + sp.tril(L2, -1).T).tocsr()
+    assert s.factorize(v2) == 0
+    assert s.num_perturbed == 0
+    XS = rng.standard_normal((5, n))
+    X = s.solve_many(np.array([A2 @ XS[j] for j in range(5)]))
+    assert np.max(np.abs(X - XS)) <= 1e-10 * np.max(np.abs(XS))
+    s.close()
+    monkeypatch.setenv("HIPMF_SYM_EXPAND", "0")
+    s = Hipmf()
+    assert s.initialize(n, rp, ci, general_symmetric=True, values=v) == 0
+    assert s.counter("sym_expanded") == 0
+    s.factorize(v)  # (static pivoting: a singular-matrix warning is allowed here)
+    assert s.num_perturbed > 0  # what the expansion avoids
+    s.close()
