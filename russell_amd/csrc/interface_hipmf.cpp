@@ -353,6 +353,7 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
     case HIPMF_COUNTER_ARENA_BYTES: return s.S.temp_doubles * 8;
     case HIPMF_COUNTER_SYMMETRIC_LDLT: return s.S.sym_mode ? 1 : 0;
     case HIPMF_COUNTER_SYM_EXPANDED: return h->expanded ? 1 : 0;
+    case HIPMF_COUNTER_CHAIN_FALLBACKS: return s.chain_fallbacks;
     default: return -1;
     }
 }

@@ -6,5 +6,6 @@
 #include "kernels_factor.hpp"
 #include "kernels_solve.hpp"
 #include "kernels_solve_fused.hpp"
+#include "kernels_factor_chain.hpp"
 #include "kernels_solve_tree.hpp"
 #include "kernels_vector.hpp"

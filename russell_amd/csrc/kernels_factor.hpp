@@ -430,25 +430,56 @@ __global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD,
 // SYM: the L tiles cover the rows of F below the tile only (and leave U12 = D L21^T in the upper triangle for the trailing update),
 // the U tiles the columns of E only;
 // the tile is factorised without interchanges from its lower triangle.
-template <bool SYM>
-__global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
-                                                   int32_t k0, double *__restrict__ pool,
-                                                   int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
-                                                   const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                   double *__restrict__ diag, int32_t pre_lu) {
-    // D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
-    // ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
-    __shared__ __attribute__((aligned(16))) double D[NB][NB + 2];
-    __shared__ __attribute__((aligned(16))) double DT[NB][NB + 2];
-    __shared__ double T[NB][PANEL_T + 1];
-    __shared__ double dinv[NB];
-    __shared__ int32_t lp[NB];
+// Memory access of the tiled kernels' bodies.  COH = false: plain loads and stores (one launch per step: the launch boundary orders
+// everything).  COH = true: agent-scope (sc1) accesses for the chained launch (k_chain, kernels_factor_chain.hpp), whose workgroups
+// consume what other workgroups of the SAME launch produced -- the eight XCDs' L2s are not coherent with each other inside a launch.
+// Loads whose address is only valid under a condition come in two forms: `cond ? *p : 0` (the compiler predicates the load) and an
+// unconditional load from a clamped address followed by a select.  An agent-scope load is never speculated, so the chained instance
+// (COH) needs the second form everywhere -- one load per branch would wait for its own round trip (measured: 18 us instead of 8 for a
+// panel tile).  For the plain instances, measured at 1000 x 1000 (profiles/r03_rejected_experiments.txt): the clamped form makes the panel
+// solve of the L D L^T fronts faster (factorisation 6.68 -> 6.31 ms) and leaves LU where it was; in the look-ahead piece it costs
+// 0.06 ms, in the tiles of the trailing update 15 % at 100^3 (address arithmetic in a throughput-bound loop).
+#define HIPMF_CLAMP_PANEL 1
+#define HIPMF_CLAMP_LA 0
+template <bool COH> struct TileMem {
+    static __device__ __forceinline__ double ld(const double *p) { return COH ? ld_agent(p) : *p; }
+    static __device__ __forceinline__ void st(double *p, double v) {
+        if (COH) st_agent(p, v);
+        else *p = v;
+    }
+    static __device__ __forceinline__ int32_t ldi(const int32_t *p) { return COH ? flag_load(p) : *p; }
+    static __device__ __forceinline__ void sti(int32_t *p, int32_t v) {
+        if (COH) flag_store(p, v);
+        else *p = v;
+    }
+};
+
+// LDS of a panel workgroup.  D: L\U of the tile, row-major rows (16-byte aligned so that a thread can fetch a whole row of U with
+// ds_read_b128 broadcasts); DT: its transpose (rows of DT = columns of L for the U-tile substitution)
+struct PanelLds {
+    __attribute__((aligned(16))) double D[NB][NB + 2];
+    __attribute__((aligned(16))) double DT[NB][NB + 2];
+    double T[NB][PANEL_T + 1];
+    double dinv[NB];
+    int32_t lp[NB];
+};
+
+// One panel tile (tile t of the front in `slot`) of step k0.  NT = threads of the workgroup: PANEL_T of them work (k_chain's
+// workgroups have 256: the others only take part in the barriers).
+template <bool SYM, bool COH, int NT>
+__device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const int t, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
+                                           int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
+                                           const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                           double *__restrict__ diag, int32_t pre_lu) {
+    typedef TileMem<COH> M;
+    constexpr bool CLP = COH || HIPMF_CLAMP_PANEL;
+    double(&D)[NB][NB + 2] = sh.D;
+    double(&DT)[NB][NB + 2] = sh.DT;
+    double(&T)[NB][PANEL_T + 1] = sh.T;
+    double(&dinv)[NB] = sh.dinv;
+    int32_t(&lp)[NB] = sh.lp;
     const int tid = threadIdx.x;
-    int pfx_slot;
-    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
-    const int t = blockIdx.x - pfx_slot;
-    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
-    fd_resident(fd);
+    const bool act = NT == PANEL_T || tid < PANEL_T;
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
@@ -472,46 +503,70 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     //  the factorised diagonal tile of steps k0 > 0 and its row interchanges are requested first, in the same round trip)
     double tv[NB * NB / PANEL_T];
     int32_t lpv = 0;
-    if (from_dws) {
+    if (from_dws && act) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
 #pragma unroll
         for (int u = 0; u < NB * NB / PANEL_T; u++) {
             const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
-            tv[u] = (r < nb && c < nb) ? dw[r + c * nb] : (r == c ? 1.0 : 0.0); // identity padding
+            // (unconditional loads from clamped addresses, here and below: an agent-scope load is not speculated by the compiler, a
+            //  load per branch would wait for its own round trip)
+            const bool in = r < nb && c < nb;
+            if (CLP) {
+                const double dv = M::ld(dw + (in ? r + c * nb : 0));
+                tv[u] = in ? dv : (r == c ? 1.0 : 0.0); // identity padding
+            } else
+                tv[u] = in ? dw[r + c * nb] : (r == c ? 1.0 : 0.0);
         }
-        if (tid < nb) lpv = lperm[fd.first + k0 + tid];
+        if (CLP) lpv = M::ldi(lperm + fd.first + k0 + (tid < nb ? tid : 0));
+        else if (tid < nb) lpv = lperm[fd.first + k0 + tid];
     }
     if (ltile) {
         if (tid < ext) {
             double v[NB];
             if (lmixed) { // (the one tile per front that straddles row f: per-thread stride)
 #pragma unroll
-                for (int u = 0; u < NB; u++) v[u] = (u < nb) ? Lrow[(int64_t)u * lstr] : 0.0;
+                for (int u = 0; u < NB; u++) {
+                    const double lv = M::ld(Lrow + (int64_t)(u < nb ? u : 0) * lstr);
+                    v[u] = (u < nb) ? lv : 0.0;
+                }
             } else { // workgroup-uniform stride: the address arithmetic stays on the scalar unit
 #pragma unroll
-                for (int u = 0; u < NB; u++) v[u] = (u < nb) ? Lrow[(int64_t)u * lstr_u] : 0.0;
+                for (int u = 0; u < NB; u++) {
+                    const double lv = M::ld(Lrow + (int64_t)(u < nb ? u : 0) * lstr_u);
+                    v[u] = (u < nb) ? lv : 0.0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < NB; u++) T[u][tid] = v[u];
         }
-    } else {
+    } else if (act && ext > 0) {
         const int k = tid & (NB - 1), cq = tid >> 5; // 4 columns x 32 rows per pass
         double v[PANEL_T / 4];
-        const double *sF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *sE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
+        const int kc = k < nb ? k : 0; // (clamped row: the load is unconditional, the value is dropped)
+        const double *sF = A.F + (k0 + kc) + (int64_t)o0 * A.ld, *sE = A.Esh + (k0 + kc) + (int64_t)o0 * A.ld;
         // (a per-element choice between the two arrays costs ~1.2 us per launch in this latency chain -- measured: only the one tile
         //  per front that straddles column f pays it)
         if (o0 < f && o0 + ext > f) {
 #pragma unroll
             for (int u = 0; u < PANEL_T / 4; u++) {
                 const int cc = 4 * u + cq;
-                v[u] = (k < nb && cc < ext) ? (o0 + cc >= f ? sE : sF)[(int64_t)cc * A.ld] : 0.0;
+                if (CLP) {
+                    const int ccl = cc < ext ? cc : 0;
+                    const double uv = M::ld((o0 + ccl >= f ? sE : sF) + (int64_t)ccl * A.ld);
+                    v[u] = (k < nb && cc < ext) ? uv : 0.0;
+                } else
+                    v[u] = (k < nb && cc < ext) ? (o0 + cc >= f ? sE : sF)[(int64_t)cc * A.ld] : 0.0;
             }
         } else {
             const double *sU = o0 >= f ? sE : sF;
 #pragma unroll
             for (int u = 0; u < PANEL_T / 4; u++) {
                 const int cc = 4 * u + cq;
-                v[u] = (k < nb && cc < ext) ? sU[(int64_t)cc * A.ld] : 0.0;
+                if (CLP) {
+                    const double uv = M::ld(sU + (int64_t)(cc < ext ? cc : 0) * A.ld);
+                    v[u] = (k < nb && cc < ext) ? uv : 0.0;
+                } else
+                    v[u] = (k < nb && cc < ext) ? sU[(int64_t)cc * A.ld] : 0.0;
             }
         }
 #pragma unroll
@@ -520,12 +575,14 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     // 2. the factorised diagonal tile.  Steps k0 > 0 find it in dws: workgroup 0 of the previous k_update factorised
     //    it right after updating it (look-ahead: that LU overlaps with the rest of the trailing update).
     if (from_dws) {
+        if (act) {
 #pragma unroll
-        for (int u = 0; u < NB * NB / PANEL_T; u++) {
-            const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
-            D[r][c] = tv[u];
-            DT[c][r] = tv[u];
-            if (r == c) dinv[r] = 1.0 / tv[u];
+            for (int u = 0; u < NB * NB / PANEL_T; u++) {
+                const int e = tid + u * PANEL_T, r = e % NB, c = e / NB;
+                D[r][c] = tv[u];
+                DT[c][r] = tv[u];
+                if (r == c) dinv[r] = 1.0 / tv[u];
+            }
         }
         if (tid < NB) lp[tid] = (tid < nb) ? lpv - k0 : tid;
     } else if (tid < 64) {
@@ -535,7 +592,9 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         for (int c = 0; c < NB; c++) {
             // (SYM: only the lower triangle of F is assembled)
             const int rr = (SYM && tid < c) ? c : tid, cc = (SYM && tid < c) ? tid : c;
-            a[c] = (tid < nb && c < nb) ? F[(k0 + rr) + (int64_t)(k0 + cc) * A.ld] : (tid == c ? 1.0 : 0.0);
+            const bool in = tid < nb && c < nb;
+            const double fv = M::ld(F + (k0 + (in ? rr : 0)) + (int64_t)(k0 + (in ? cc : 0)) * A.ld);
+            a[c] = in ? fv : (tid == c ? 1.0 : 0.0);
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
@@ -559,10 +618,10 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
         }
     }
     __syncthreads();
-    if (t == 0 && !from_dws) {
+    if (t == 0 && !from_dws && act) {
         double *dw = dws + (int64_t)slot * NB * NB; // step 0 uses buffer 0
-        for (int e = tid; e < nb * nb; e += PANEL_T) dw[e] = D[e % nb][e / nb];
-        if (tid < nb) lperm[fd.first + k0 + tid] = k0 + lp[tid];
+        for (int e = tid; e < nb * nb; e += PANEL_T) M::st(dw + e, D[e % nb][e / nb]);
+        if (tid < nb) M::sti(lperm + fd.first + k0 + tid, k0 + lp[tid]);
     }
     if (ext <= 0) return;
     // 3. substitution, right-looking, one row / column per thread, branch-free over the padded 32 steps
@@ -604,14 +663,14 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
             if (lmixed) {
 #pragma unroll
                 for (int k = 0; k < NB; k++)
-                    if (k < nb) Lrow[(int64_t)k * lstr] = T[k][tid];
+                    if (k < nb) M::st(Lrow + (int64_t)k * lstr, T[k][tid]);
             } else {
 #pragma unroll
                 for (int k = 0; k < NB; k++)
-                    if (k < nb) Lrow[(int64_t)k * lstr_u] = T[k][tid];
+                    if (k < nb) M::st(Lrow + (int64_t)k * lstr_u, T[k][tid]);
             }
         }
-        if (SYM) {
+        if (SYM && act) {
             // the rows of U the trailing update multiplies with: U12(k, c) = d_k L21(c, k) into the (otherwise unused) upper triangle
             // of F, rows k0 .. k0 + nb, columns of this tile (32-row segments of a column: the store pattern of the U tiles)
             const int k = tid & (NB - 1), cq = tid >> 5;
@@ -620,27 +679,42 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 #pragma unroll
             for (int cb = 0; cb < PANEL_T; cb += 4) {
                 const int cc = cb + cq;
-                if (k < nb && cc < ext) dst[(int64_t)cc * A.ld] = dk * T[k][cc];
+                if (k < nb && cc < ext) M::st(dst + (int64_t)cc * A.ld, dk * T[k][cc]);
             }
         }
-    } else {
+    } else if (act) {
         const int k = tid & (NB - 1), cq = tid >> 5;
         double *dF = A.F + (k0 + k) + (int64_t)o0 * A.ld, *dE = A.Esh + (k0 + k) + (int64_t)o0 * A.ld;
         if (o0 < f && o0 + ext > f) {
 #pragma unroll
             for (int cb = 0; cb < PANEL_T; cb += 4) {
                 const int cc = cb + cq;
-                if (k < nb && cc < ext) (o0 + cc >= f ? dE : dF)[(int64_t)cc * A.ld] = T[k][cc];
+                if (k < nb && cc < ext) M::st((o0 + cc >= f ? dE : dF) + (int64_t)cc * A.ld, T[k][cc]);
             }
         } else {
             double *dU = o0 >= f ? dE : dF;
 #pragma unroll
             for (int cb = 0; cb < PANEL_T; cb += 4) {
                 const int cc = cb + cq;
-                if (k < nb && cc < ext) dU[(int64_t)cc * A.ld] = T[k][cc];
+                if (k < nb && cc < ext) M::st(dU + (int64_t)cc * A.ld, T[k][cc]);
             }
         }
     }
+}
+
+template <bool SYM>
+__global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+                                                   int32_t k0, double *__restrict__ pool,
+                                                   int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
+                                                   const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                   double *__restrict__ diag, int32_t pre_lu) {
+    __shared__ PanelLds sh;
+    int pfx_slot;
+    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    const int t = blockIdx.x - pfx_slot;
+    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
+    fd_resident(fd);
+    panel_body<SYM, false, PANEL_T>(sh, slot, t, fd, k0, pool, lperm, dws, dws_stride, anorm_bits, pivot_eps, info, diag, pre_lu);
 }
 
 // Tiled path, step k0: trailing update  A22 -= L21 * U12  on v_mfma_f64_16x16x4_f64 over the active
@@ -671,27 +745,29 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // exactly as the LU instance does; rows of E are read as they are.
 // (Tried and rejected: 128 x 128 tiles, four 64 x 64 waves -- 204 VGPRs + 128 AGPRs, one workgroup per CU: 962 ms instead of
 // 924 ms for the 128^3 Poisson factorisation.)
-template <bool SYM>
-__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
-                                                int32_t k0, double *__restrict__ pool,
-                                                double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
-                                                const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                double *__restrict__ diag) {
+// LDS of an update workgroup (the look-ahead workgroup's tile buffer shares the space of Ls: it never touches Ls / Us)
+struct UpdateLds {
+    static constexpr int LSLD = UPD_T + 16; // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
+    __attribute__((aligned(16))) double LsUM[(NB * LSLD > NB * (NB + 2)) ? NB * LSLD : NB * (NB + 2)];
+    double Us[UPD_T * US_LD];
+};
+
+// One tile (t < ntiles) or the look-ahead piece (t == ntiles) of the trailing update of step k0 of the front in `slot`.
+template <bool SYM, bool COH>
+__device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const int t, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
+                                            double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
+                                            const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                            double *__restrict__ diag) {
+    typedef TileMem<COH> M;
+    constexpr bool CLA = COH || HIPMF_CLAMP_LA;
     constexpr int TS = UPD_T;
-    constexpr int LSLD = TS + 16;  // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
+    constexpr int LSLD = UpdateLds::LSLD;
     constexpr int MT = TS / 32;    // MFMA tiles per wave and dimension
     constexpr int NE = TS / 8;     // panel entries per thread and 32-column slice (L and U each)
-    // the look-ahead workgroup's tile buffer shares the space of Ls (it never touches Ls / Us)
-    __shared__ __attribute__((aligned(16))) double LsUM[(NB * LSLD > NB * (NB + 2)) ? NB * LSLD : NB * (NB + 2)];
-    __shared__ double Us[TS * US_LD];
-    double *Ls = LsUM;
-    double(*UM)[NB + 2] = reinterpret_cast<double(*)[NB + 2]>(LsUM);
+    double *Ls = sh.LsUM;
+    double *Us = sh.Us;
+    double(*UM)[NB + 2] = reinterpret_cast<double(*)[NB + 2]>(sh.LsUM);
     const int tid = threadIdx.x;
-    int pfx_slot;
-    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
-    const int t = blockIdx.x - pfx_slot;
-    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
-    fd_resident(fd);
     const int f = fd.p + fd.m;
     const int nb = (fd.p - k0) < NB ? (fd.p - k0) : NB;
     const int base = k0 + nb, limit = f + base;
@@ -714,7 +790,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     const AugView A = aug_view(fd, pool);
     double *F = A.F;
     if (t == ntiles) {
-        // ---- look-ahead workgroup: only wave 0 works ----
+        // ---- look-ahead workgroup: only wave 0 works (its LDS phases are ordered by wave_sync: no workgroup barrier in here) ----
         if (tid >= 64) return;
         const int r = tid & 31, half = tid >> 5; // row, column half (16 columns each)
         double acc[16];
@@ -722,11 +798,16 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         for (int c = 0; c < 16; c++) {
             const int cc = half * 16 + c;
             const int rr = (SYM && r < cc) ? cc : r, c2 = (SYM && r < cc) ? r : cc; // (SYM: lower triangle)
-            acc[c] = (r < nb2 && cc < nb2) ? F[(base + rr) + (int64_t)(base + c2) * A.ld] : (r == cc ? 1.0 : 0.0);
+            const bool in = r < nb2 && cc < nb2;
+            if (CLA) {
+                const double fv = M::ld(F + (base + (in ? rr : 0)) + (int64_t)(base + (in ? c2 : 0)) * A.ld);
+                acc[c] = in ? fv : (r == cc ? 1.0 : 0.0);
+            } else
+                acc[c] = in ? F[(base + rr) + (int64_t)(base + c2) * A.ld] : (r == cc ? 1.0 : 0.0);
         }
         for (int h = 0; h < nhalf; h++) {
             const int kh = kfirst + h * NB, nbh = (h == nhalf - 1) ? nb : NB;
-            if (h > 0) __syncthreads();
+            if (h > 0) wave_sync();
             // U block (rows kh.., columns base..base+32) -> LDS, 16 elements per lane; the lane's row of L is requested in the same
             // round trip (the LDS stores wait for the U loads: everything this slice needs from memory is in flight before them)
             double um[16];
@@ -734,17 +815,29 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u;
                 const int kk = e & 31, c = e >> 5; // (SYM: k_panel left U12 = D L21^T in the upper triangle of the panel rows)
-                um[u] = (kk < nbh && c < nb2) ? F[(kh + kk) + (int64_t)(base + c) * A.ld] : 0.0;
+                const bool in = kk < nbh && c < nb2;
+                if (CLA) {
+                    const double fv = M::ld(F + (kh + (in ? kk : 0)) + (int64_t)(base + (in ? c : 0)) * A.ld);
+                    um[u] = in ? fv : 0.0;
+                } else
+                    um[u] = in ? F[(kh + kk) + (int64_t)(base + c) * A.ld] : 0.0;
             }
             double lrow[NB];
 #pragma unroll
-            for (int kk = 0; kk < NB; kk++) lrow[kk] = (r < nb2 && kk < nbh) ? F[(base + r) + (int64_t)(kh + kk) * A.ld] : 0.0;
+            for (int kk = 0; kk < NB; kk++) {
+                const bool in = r < nb2 && kk < nbh;
+                if (CLA) {
+                    const double fv = M::ld(F + (base + (in ? r : 0)) + (int64_t)(kh + (in ? kk : 0)) * A.ld);
+                    lrow[kk] = in ? fv : 0.0;
+                } else
+                    lrow[kk] = in ? F[(base + r) + (int64_t)(kh + kk) * A.ld] : 0.0;
+            }
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 64 * u;
                 UM[e & 31][e >> 5] = um[u];
             }
-            __syncthreads(); // (only wave 0 is left in this workgroup)
+            wave_sync();
 #pragma unroll
             for (int kk = 0; kk < NB; kk++) {
                 double u[16];
@@ -770,10 +863,10 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
             double dgv = 1.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                if (c < nb2) dwo[step + c * nb2] = a2[c];
+                if (c < nb2) M::st(dwo + step + c * nb2, a2[c]);
                 if (c == step) dgv = a2[c];
             }
-            lperm[fd.first + base + step] = base + tid;
+            M::sti(lperm + fd.first + base + step, base + tid);
             diag[fd.first + base + step] = dgv;
         }
         if (tid == 0 && npert > 0) {
@@ -817,11 +910,11 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
         double dv[NB * NB / 256];
 #pragma unroll
-        for (int u = 0; u < NB * NB / 256; u++) dv[u] = (tid + 256 * u < nb * nb) ? dw[tid + 256 * u] : 0.0;
+        for (int u = 0; u < NB * NB / 256; u++) dv[u] = M::ld(dw + (tid + 256 * u < nb * nb ? tid + 256 * u : 0));
 #pragma unroll
         for (int u = 0; u < NB * NB / 256; u++) {
             const int e = tid + 256 * u;
-            if (e < nb * nb) F[(k0 + e % nb) + (int64_t)(k0 + e / nb) * A.ld] = dv[u];
+            if (e < nb * nb) M::st(F + (k0 + e % nb) + (int64_t)(k0 + e / nb) * A.ld, dv[u]);
         }
     }
     if (r0 >= rend || c0 >= cend) return;          // no such tile
@@ -848,9 +941,16 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
             const int e = tid + 256 * u;                                                                               \
             const int r = e % TS, kk = e / TS;                                                                         \
-            lreg[u] = (r0 + r < rend && kk < nbh) ? Lb[(r0 + r) + (int64_t)(kh + kk) * lstr] : 0.0;                    \
             const int k2 = e % NB, c = c0 + e / NB;                                                                    \
-            ureg[u] = (c < cend && k2 < nbh) ? Ub[(kh + k2) + (int64_t)c * A.ld] : 0.0;                                \
+            const bool lin = r0 + r < rend && kk < nbh, uin = c < cend && k2 < nbh;                                    \
+            if (COH) { /* (agent-scope loads are not speculated: unconditional, from clamped addresses) */            \
+                const double lv = M::ld(Lb + (r0 + (lin ? r : 0)) + (int64_t)(kh + (lin ? kk : 0)) * lstr);            \
+                const double uv = M::ld(Ub + (kh + (uin ? k2 : 0)) + (int64_t)(uin ? c : c0) * A.ld);                  \
+                lreg[u] = lin ? lv : 0.0, ureg[u] = uin ? uv : 0.0;                                                    \
+            } else { /* (the throughput-bound instance: the clamped form costs 15 % at 100^3) */                      \
+                lreg[u] = lin ? Lb[(r0 + r) + (int64_t)(kh + kk) * lstr] : 0.0;                                        \
+                ureg[u] = uin ? Ub[(kh + k2) + (int64_t)c * A.ld] : 0.0;                                               \
+            }                                                                                                          \
         }                                                                                                              \
     }
 #define HIPMF_STORE_SLICE()                                                                                            \
@@ -880,7 +980,12 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                cur[a][b][g] = is_live(a, b, g) ? Cb[r + (int64_t)c * cstr] : 0.0;
+                const bool live = is_live(a, b, g);
+                if (COH) {
+                    const double cv = M::ld(Cb + (live ? r : r0) + (int64_t)(live ? c : c0) * cstr);
+                    cur[a][b][g] = live ? cv : 0.0;
+                } else
+                    cur[a][b][g] = live ? Cb[r + (int64_t)c * cstr] : 0.0;
             }
     HIPMF_STORE_SLICE()
     __syncthreads();
@@ -925,8 +1030,24 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + wr + b * 16 + l15, c = c0 + wc + a * 16 + l4 + 4 * g;
-                if (is_live(a, b, g)) Cb[r + (int64_t)c * cstr] = cur[a][b][g] - acc[a][b][g];
+                if (is_live(a, b, g)) M::st(Cb + r + (int64_t)c * cstr, cur[a][b][g] - acc[a][b][g]);
             }
+}
+
+
+template <bool SYM>
+__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+                                                int32_t k0, double *__restrict__ pool,
+                                                double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
+                                                const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                double *__restrict__ diag) {
+    __shared__ UpdateLds sh;
+    int pfx_slot;
+    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    const int t = blockIdx.x - pfx_slot;
+    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
+    fd_resident(fd);
+    update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
 }
 
 } // namespace hipmf

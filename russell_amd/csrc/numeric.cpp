@@ -68,6 +68,9 @@ void Solver::release() {
         if (p) (void)hipFree(p);
     if (d_sd) (void)hipFree(d_sd);
     d_sd = nullptr;
+    if (d_chain) (void)hipFree(d_chain);
+    if (d_chain_cnt) (void)hipFree(d_chain_cnt);
+    d_chain = nullptr, d_chain_cnt = nullptr, chain_words = 0;
     for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep, (void *)d_sf3,
                     (void *)d_need3, (void *)d_sfk, (void *)d_needk})
         if (p) (void)hipFree(p);
@@ -208,6 +211,11 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
     if (const char *e = getenv("HIPMF_SF_BIG_FRONT")) sf_big_front = std::max(65, atoi(e));
     if (const char *e = getenv("HIPMF_SF_ASM_FRONT")) sf_asm_front = atoi(e); // forward solve: fronts with at least this many rows assemble their vector once (0: never)
+    if (const char *e = getenv("HIPMF_FACTOR_CHAIN")) use_chain = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_CHAIN_FINE")) chain_fine = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_CHAIN_MAX_WGS")) chain_max_update = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_CHAIN_MIN_WGS")) chain_min_update = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_CHAIN_MAX_STEPS")) chain_max_steps = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -466,6 +474,8 @@ int32_t Solver::upload_plan() {
     pool_doubles = S.persist_doubles + S.temp_doubles;
 
     std::vector<int32_t> lists, tasks, allbig;
+    std::vector<ChainTask> chain;
+    chain_words = 0;
     std::vector<FrontDesc> bigfd;
     std::vector<EaTask> ea;
     std::vector<EaRange> ear;
@@ -547,6 +557,68 @@ int32_t Solver::upload_plan() {
             if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
             st.n_update = (int32_t)acc;
             L.steps.push_back(st);
+        }
+        // the same steps as tasks of ONE launch (k_chain) for the levels near the root: panel tiles and update pieces in the order of the
+        // launches, each with the counters it waits for and the ones it bumps (kernels_factor_chain.hpp)
+        {
+            int64_t maxu = 0;
+            for (const StepPlan &st : L.steps) maxu = std::max<int64_t>(maxu, st.n_update);
+            if (use_chain && !L.steps.empty() && maxu <= chain_max_update && maxu >= chain_min_update && (int32_t)L.steps.size() <= chain_max_steps) {
+                const int32_t nsteps = (int32_t)L.steps.size();
+                const int64_t cbase = chain_words;
+                auto cidx = [&](int32_t a, int32_t si, int32_t j) { return (int32_t)(cbase + ((int64_t)a * nsteps + si) * 3 + j); };
+                chain_words += (int64_t)L.big_cnt * nsteps * 3;
+                std::vector<int32_t> prevC((size_t)L.big_cnt, 0), prevU((size_t)L.big_cnt, 0);
+                L.chain_off = (int64_t)chain.size();
+                for (int32_t si = 0; si < nsteps; si++) {
+                    const StepPlan &st = L.steps[(size_t)si];
+                    const int32_t k0 = si * NB;
+                    for (int32_t a = 0; a < st.nactive; a++) {
+                        const int32_t npan = 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
+                        for (int32_t t = 0; t < npan; t++) {
+                            ChainTask c{};
+                            c.slot = a, c.k0 = k0, c.t = t, c.kind = 0;
+                            c.w0 = si > 0 ? cidx(a, si - 1, chain_fine ? 1 : 2) : -1, c.n0 = si > 0 ? (chain_fine ? prevC[a] : prevU[a]) : 0;
+                            c.w1 = -1, c.n1 = 0, c.pub0 = cidx(a, si, 0), c.pub1 = -1;
+                            chain.push_back(c);
+                        }
+                    }
+                    for (int32_t a = 0; a < st.nactive; a++) {
+                        const int32_t npan = 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
+                        const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
+                        const int32_t ntF = (int32_t)((fa - basea + UPD_T - 1) / UPD_T), ntE = (int32_t)((basea + UPD_T - 1) / UPD_T), nt = ntF + ntE;
+                        const bool follow = S.npiv(big[a]) > k0 + NB;
+                        const int32_t G = update_group(S.fsize(big[a]));
+                        const bool narrow = follow && ((k0 / NB) % G) != G - 1;
+                        const int32_t ntri = ntF * (ntF + 1) / 2;
+                        const int32_t ntiles = S.sym_mode ? (narrow ? nt : ntri + ntF * ntE) : (narrow ? 2 * nt : nt * nt);
+                        // critical pieces: the look-ahead piece and the tiles that hold the next panel's block column (first tile column)
+                        // or block row (first tile row); a narrow step consists of them
+                        auto critical = [&](int32_t t) {
+                            if (t == ntiles || narrow) return true;
+                            if (!S.sym_mode) return t % nt == 0 || t / nt == 0;
+                            return t < ntF || (t >= ntri && (t - ntri) % ntF == 0);
+                        };
+                        int32_t nC = 0;
+                        auto emit = [&](int32_t t) {
+                            ChainTask c{};
+                            c.slot = a, c.k0 = k0, c.t = t, c.kind = 1;
+                            c.w0 = cidx(a, si, 0), c.n0 = npan;
+                            c.w1 = si > 0 ? cidx(a, si - 1, 2) : -1, c.n1 = si > 0 ? prevU[a] : 0;
+                            c.pub0 = cidx(a, si, 2), c.pub1 = critical(t) ? cidx(a, si, 1) : -1;
+                            if (c.pub1 >= 0) nC++;
+                            chain.push_back(c);
+                        };
+                        if (follow) emit(ntiles); // the look-ahead piece first: the longest serial piece of the step
+                        for (int32_t t = 0; t < ntiles; t++)
+                            if (critical(t)) emit(t);
+                        for (int32_t t = 0; t < ntiles; t++)
+                            if (!critical(t)) emit(t);
+                        prevC[a] = nC, prevU[a] = ntiles + (follow ? 1 : 0);
+                    }
+                }
+                L.chain_cnt = (int32_t)((int64_t)chain.size() - L.chain_off);
+            }
         }
         // extend-add tasks: 32-column x 256-row tiles of the parent
         L.ea_off = (int32_t)ea.size();
@@ -951,6 +1023,13 @@ int32_t Solver::upload_plan() {
     HIPC(dev_upload(&d_lists, lists), ERROR_HIP_MALLOC);
     n_lists = (int64_t)lists.size();
     HIPC(dev_upload(&d_tasks, tasks), ERROR_HIP_MALLOC);
+    if (!chain.empty()) {
+        ChainTask *dc = nullptr;
+        HIPC(dev_upload(&dc, chain), ERROR_HIP_MALLOC);
+        d_chain = dc;
+        chain_words += 1; // the error word
+        HIPC(hipMalloc((void **)&d_chain_cnt, sizeof(int32_t) * (size_t)chain_words), ERROR_HIP_MALLOC);
+    }
     HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_rel, S.rel), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_child, S.child_idx), ERROR_HIP_MALLOC);
@@ -1075,6 +1154,8 @@ int32_t Solver::run_factor() {
         hipLaunchKernelGGL(k_row_scale, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_vals, d_tptr, d_tidx, opt.scaling, S.sym_mode ? 1 : 0, d_rs);
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
+    const bool chained = use_chain && d_chain_cnt != nullptr;
+    if (chained) HIPC(hipMemsetAsync(d_chain_cnt, 0, sizeof(int32_t) * (size_t)chain_words, STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
     hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar, d_info);
     launches += 2;
@@ -1146,6 +1227,25 @@ int32_t Solver::run_factor() {
         if (fill_next) fill_level(*Lnext, forked ? (hipStream_t)stream2 : STREAM);
         if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
         int32_t k0 = 0;
+        if (chained && L.chain_cnt > 0) {
+            // all tiled steps of the level in one launch (kernels_factor_chain.hpp)
+            const FrontDesc *lfd = d_bigfd + L.bigfd_off;
+            const StepPlan &st0 = L.steps[0];
+            const int32_t pre_lu = 1; // (the first diagonal tiles always get their launch here: a panel task that factorises the tile itself is 10 us longer)
+            if (pre_lu) {
+                if (S.sym_mode) hipLaunchKernelGGL(k_diag0<true>, dim3(st0.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else hipLaunchKernelGGL(k_diag0<false>, dim3(st0.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                launches++;
+            }
+            const ChainTask *ct = (const ChainTask *)d_chain + L.chain_off;
+            if (S.sym_mode)
+                hipLaunchKernelGGL(k_chain<true>, dim3(L.chain_cnt), dim3(256), 0, STREAM, ct, lfd, d_pool, d_lperm, d_dws, dws_stride, d_scalar,
+                                   opt.pivot_epsilon, d_info, d_diag, pre_lu, d_chain_cnt, d_chain_cnt + (chain_words - 1));
+            else
+                hipLaunchKernelGGL(k_chain<false>, dim3(L.chain_cnt), dim3(256), 0, STREAM, ct, lfd, d_pool, d_lperm, d_dws, dws_stride, d_scalar,
+                                   opt.pivot_epsilon, d_info, d_diag, pre_lu, d_chain_cnt, d_chain_cnt + (chain_words - 1));
+            launches++;
+        } else
         for (const StepPlan &st : L.steps) {
             const FrontDesc *lfd = d_bigfd + L.bigfd_off; // descriptors of the level's tiled fronts, in slot order
             // step 0 of a level with many tiled fronts: the first diagonal tiles are factorised once, by a launch of their own (k_diag0)
@@ -1177,9 +1277,19 @@ int32_t Solver::run_factor() {
     }
     HIPC(hipEventRecord((hipEvent_t)ev[2], STREAM), ERROR_HIP_SYNCHRONIZE);
     FactorInfo hinfo;
+    int32_t chain_err = 0;
     HIPC(hipMemcpyAsync(&hinfo, d_info, sizeof(FactorInfo), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    if (chained) HIPC(hipMemcpyAsync(&chain_err, d_chain_cnt + (chain_words - 1), sizeof(int32_t), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
+    if (chain_err != 0) {
+        // a hand-off inside a chained launch timed out (workgroups not dispatched in index order?): the factor is incomplete.  The scaled
+        // values are still there: this handle goes back to one launch per step, for this factorisation and all later ones.
+        use_chain = false;
+        chain_fallbacks++;
+        if (opt.verbose) fprintf(stderr, "hipmf: factorize: a hand-off of the chained tiled steps timed out; repeating with one launch per step\n");
+        return run_factor();
+    }
     n_perturbed = hinfo.n_perturbed;
     n_zero_pivot = hinfo.n_zero_pivot;
     n_weak_diag = hinfo.n_weak_diag;

@@ -78,6 +78,8 @@ struct LevelPlan {
     int32_t big_pmax = 0, big_fmax = 0;
     bool wide = false; // solve with 32-row slabs x 32 column groups (few large fronts)
     std::vector<StepPlan> steps;
+    int64_t chain_off = 0;  // the level's tiled steps as ONE launch (k_chain): its tasks in d_chain, chain_cnt of them (0: one launch per step)
+    int32_t chain_cnt = 0;
 };
 
 class Solver {
@@ -122,6 +124,7 @@ class Solver {
     int64_t rematch_count = 0; // factorisations that recomputed the maximum-product matching (and the analysis) for new values
     int32_t refinement_steps_done = 0;
     int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
+    int64_t chain_fallbacks = 0; // factorisations repeated with one launch per tiled step after a hand-off timeout of a chained launch (never expected)
     int64_t persist_bytes() const { return S.persist_doubles * 8; }
     double last_residual_inf = 0.0, last_omega = 0.0;
     int device = 0;
@@ -212,6 +215,16 @@ class Solver {
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream
     int32_t sf_big_rows = 6, sf_big_front = 2048; // forward solve: fronts with at least sf_big_front rows use slabs of 2^sf_big_rows rows
     int32_t sf_asm_front = 2048;                  // forward solve: fronts with at least this many rows assemble their vector once, in tasks of their own (0: never; then sf_big_rows applies)
+    // levels with few tiled steps (the middle of the tree): all steps of a level in one launch with in-launch hand-offs (kernels_factor_chain.hpp)
+    bool use_chain = true;                  // HIPMF_FACTOR_CHAIN=0: one launch per step everywhere
+    bool chain_fine = false;                // HIPMF_CHAIN_FINE=1: a panel waits only for the critical pieces of the update before (measured: no gain)
+    int32_t chain_max_steps = 8;            // a level is chained when it has at most this many steps (HIPMF_CHAIN_MAX_STEPS) ...
+    int32_t chain_max_update = 16384;       // ... no step of it has more update workgroups than this (HIPMF_CHAIN_MAX_WGS: wide steps are bound by throughput, and
+                                            //     the 8-byte agent-scope accesses of the chained form cost more per byte) ...
+    int32_t chain_min_update = 0;           // ... and its widest step has at least this many (HIPMF_CHAIN_MIN_WGS)
+    void *d_chain = nullptr;                // ChainTask records of all chained levels
+    int32_t *d_chain_cnt = nullptr;         // their counters (3 per front and step) + the error word (last); zeroed before every factorisation
+    int64_t chain_words = 0;
     int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)

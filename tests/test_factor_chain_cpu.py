@@ -1,0 +1,54 @@
+"""Chained tiled steps (k_chain, kernels_factor_chain.hpp: all steps of a level in one launch, in-launch hand-offs) against one launch per
+step, on the CPU emulator: the tile bodies are shared, so factors, pivots and determinants must agree bit for bit -- for LU (row
+interchanges inside the tiles), for L D L^T, with the fine-grained waits, and whatever levels the knobs select.  The emulator runs the
+workgroups of a launch one after the other: this checks the task lists (every piece present once, right front / step / tile), not the
+hand-offs -- tests/test_round3_gpu.py repeats it on the device."""
+import os
+
+import numpy as np
+import pytest
+
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+
+
+def _run(lib, n, rp, ci, v, env, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = Hipmf(lib)
+        assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+        assert s.factorize(v, compute_determinant=True) == 0
+        x = s.solve(np.cos(np.arange(n)))
+        out = (x, s.det_coefficient, s.det_exponent, s.permutation(), s.stats()["factor_launches"], s.counter("chain_fallbacks"))
+        s.close()
+        return out
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+def _cases():
+    yield "poisson2d 52x48", P.poisson2d(52, 48), {}
+    yield "convection-diffusion 46 (interchanges)", P.convection_diffusion2d(46, peclet=30.0, scale_decades=0.0), {}
+    n, rp, ci, v = P.poisson3d(10)
+    yield "poisson3d 10 lower (L D L^T)", (n,) + tuple(P.lower_triangle(n, rp, ci, v)), {"general_symmetric": True}
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_chained_steps_give_the_same_factor_bit_for_bit(emu_lib, case):
+    _, (n, rp, ci, v), kw = case
+    ref = _run(emu_lib, n, rp, ci, v, {"HIPMF_FACTOR_CHAIN": "0"}, **kw)
+    variants = [{"HIPMF_FACTOR_CHAIN": "1"},  # defaults: levels with at most 8 steps
+                {"HIPMF_FACTOR_CHAIN": "1", "HIPMF_CHAIN_MAX_STEPS": "1000", "HIPMF_CHAIN_FINE": "1"},  # every level, fine-grained waits
+                {"HIPMF_FACTOR_CHAIN": "1", "HIPMF_CHAIN_MAX_STEPS": "1", "HIPMF_CHAIN_MAX_WGS": "100000"}]
+    for env in variants:
+        got = _run(emu_lib, n, rp, ci, v, env, **kw)
+        assert np.array_equal(ref[0], got[0]), env
+        assert ref[1:3] == got[1:3], env
+        assert np.array_equal(ref[3], got[3])
+        assert got[5] == 0
+    assert _run(emu_lib, n, rp, ci, v, variants[1], **kw)[4] <= ref[4]  # (fewer launches as soon as a level has more than one step)

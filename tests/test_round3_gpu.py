@@ -245,3 +245,44 @@ def test_saddle_point_through_the_symmetric_lower_boundary_has_no_perturbed_pivo
     s.factorize(v)  # (static pivoting: a singular-matrix warning is allowed here)
     assert s.num_perturbed > 0  # what the expansion avoids
     s.close()
+
+
+@pytest.mark.parametrize("kind", ["lu", "ldlt"])
+def test_chained_tiled_steps_equal_one_launch_per_step_bitwise(kind, monkeypatch):
+    # kernels_factor_chain.hpp: all tiled steps of a level in one launch with in-launch hand-offs (agent-scope accesses, counters).  The
+    # tile bodies are the ones of the per-step launches: the factor must be the same bit for bit -- a stale or early read of another
+    # workgroup's tile shows up as a difference; repeated, with every level chained and with the default selection.
+    n, rp, ci, v = P.poisson2d(400, 380)
+    rng = np.random.default_rng(5)
+    v = v * (1.0 + 0.2 * rng.uniform(-1, 1, v.size))
+    kw = {}
+    if kind == "ldlt":
+        n, rp, ci, v = P.poisson2d(400, 380)
+        rp, ci, v = P.lower_triangle(n, rp, ci, v)
+        kw = {"general_symmetric": True}
+    b = np.cos(np.arange(n))
+
+    def run(env, reps):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+        outs = []
+        for _ in range(reps):
+            assert s.factorize(v, compute_determinant=True) == 0
+            outs.append((s.solve(b), s.det_coefficient, s.det_exponent))
+        launches, fb = s.stats()["factor_launches"], s.counter("chain_fallbacks")
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return outs, launches, fb
+
+    (ref,), l0, _ = run({"HIPMF_FACTOR_CHAIN": "0"}, 1)
+    for env in ({"HIPMF_FACTOR_CHAIN": "1"}, {"HIPMF_FACTOR_CHAIN": "1", "HIPMF_CHAIN_MAX_STEPS": "1000", "HIPMF_CHAIN_MAX_WGS": "1000000"},
+                {"HIPMF_FACTOR_CHAIN": "1", "HIPMF_CHAIN_MAX_STEPS": "1000", "HIPMF_CHAIN_FINE": "1"}):
+        outs, l1, fb = run(env, 6)
+        assert fb == 0
+        assert l1 < l0
+        for x, dc, de in outs:
+            assert np.array_equal(ref[0], x), env
+            assert (dc, de) == ref[1:], env
