@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -143,6 +144,14 @@ int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool
 int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
                                 const NumericOptions &nopt, const double *values) {
     opt = nopt;
+    // (verbose: wall-clock of the host-side pieces of initialize, printed at the end)
+    auto lap_t = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char *, double>> laps;
+    auto lap = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        laps.emplace_back(what, std::chrono::duration<double>(now - lap_t).count());
+        lap_t = now;
+    };
     // the structure is validated once, before the matching / the analysis read through the indices
     if (const int vc = validate_csr(n, rp, ci)) {
         last_error = vc == -1 ? "invalid CSR: row pointers must start at 0 and be non-decreasing"
@@ -173,6 +182,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         sopt_keep = sopt;
         sym_lower_keep = sym_lower;
     }
+    lap("validate + streams + keep");
     SymbolicOptions so = sopt;
     so.augment_above = SMALL_F;
     // symmetric-lower input (general_symmetric / positive_definite, interface_cudss.cu:324-333): the big fronts are factorised
@@ -244,7 +254,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) so.pool_limit_bytes = 0.95 * (double)free_b;
         if (const char *e = getenv("HIPMF_POOL_LIMIT_GB")) so.pool_limit_bytes = 0.95e9 * atof(e); // (tests: force the refusal)
     }
+    lap("matching test");
     int rc = matched ? analyse(n, rpB.data(), ciB.data(), false, so, S) : analyse(n, rp, ci, sym_lower, so, S);
+    lap("analyse");
     if (rc == -40) {
         char msg[256];
         snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free)", S.pool_estimate_bytes / 1e9,
@@ -263,9 +275,97 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         S.amap.swap(am);
         S.amap_sn.swap(as);
     }
+    // The assembly lists only read the analysis: they are computed on a host thread of their own beside upload_plan (which builds the
+    // launch plans and talks to the device).
+    //   The entries of A that land in small fronts are gathered by k_small_factor itself (per-front lists: entry index,
+    //   position inside the front); the entries of the big fronts are scattered level by level (their working blocks share
+    //   an arena: a block is zero-filled and filled when its level starts).
+    struct AsmLists {
+        std::vector<int32_t> sa_ptr, sa_k, sc_k, zero_off, zero_n;
+        std::vector<uint16_t> sa_pos;
+        std::vector<int64_t> sc_cnt, sc_at;
+        std::vector<ZeroTask> zt;
+        int32_t zero_cnt = 0, status = 0;
+    } AL;
+    struct Joiner { // (every early return below must not leave the thread running)
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    };
+    std::thread asm_thread([this, &AL]() {
+        const int32_t ns = S.nsuper;
+        std::vector<int32_t> &sa_ptr = AL.sa_ptr;
+        std::vector<int64_t> &sc_cnt = AL.sc_cnt;
+        sa_ptr.assign((size_t)ns + 1, 0);
+        sc_cnt.assign((size_t)S.nlevels + 1, 0);
+        for (int pass = 0; pass < 2; pass++) {
+            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
+            for (int64_t k = 0; k < (int64_t)am.size(); k++)
+                if (am[k] >= 0) {
+                    const int32_t s = S.amap_sn[(size_t)k];
+                    if (S.fsize(s) <= SMALL_F) sa_ptr[(size_t)s + 1]++;
+                    else sc_cnt[(size_t)S.sn_level[s] + 1]++;
+                }
+        }
+        for (int32_t s = 0; s < ns; s++) sa_ptr[(size_t)s + 1] += sa_ptr[s];
+        for (int32_t l = 0; l < S.nlevels; l++) sc_cnt[(size_t)l + 1] += sc_cnt[l];
+        if (sc_cnt[(size_t)S.nlevels] > 0x7fffffffLL) {
+            AL.status = 1;
+            return;
+        }
+        AL.sa_k.resize((size_t)sa_ptr[ns]);
+        AL.sa_pos.resize((size_t)sa_ptr[ns]);
+        AL.sc_k.resize((size_t)sc_cnt[(size_t)S.nlevels]);
+        AL.sc_at.resize((size_t)sc_cnt[(size_t)S.nlevels]);
+        std::vector<int32_t> w(sa_ptr.begin(), sa_ptr.end() - 1);
+        std::vector<int64_t> wl(sc_cnt.begin(), sc_cnt.end() - 1);
+        for (int pass = 0; pass < 2; pass++) {
+            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
+            for (int64_t k = 0; k < (int64_t)am.size(); k++)
+                if (am[k] >= 0) {
+                    const int32_t s = S.amap_sn[(size_t)k];
+                    if (S.fsize(s) > SMALL_F) {
+                        const size_t q = (size_t)wl[(size_t)S.sn_level[s]]++;
+                        AL.sc_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
+                        AL.sc_at[q] = am[k];
+                        continue;
+                    }
+                    const int64_t off = am[k] - S.front_off[s], f = S.fsize(s);
+                    const size_t q = (size_t)w[s]++;
+                    AL.sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
+                    AL.sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
+                }
+        }
+        // zero-fill tasks, 16 Ki doubles per workgroup: first the persistent E / E' panels of all big fronts (one launch per
+        // factorisation), then the working blocks level by level
+        std::vector<ZeroTask> &zt = AL.zt;
+        auto zero_range = [&](int64_t o0, int64_t len) {
+            for (int64_t o = o0; o < o0 + len; o += 16384) zt.push_back({o, (int32_t)std::min<int64_t>(16384, o0 + len - o), 0});
+        };
+        for (int32_t s = 0; s < ns; s++) {
+            if (S.fsize(s) <= SMALL_F) continue;
+            const int64_t f = S.fsize(s), p = S.npiv(s);
+            zero_range(S.e_off[s], (int64_t)S.front_ld[s] * p);
+            if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * p);
+        }
+        AL.zero_cnt = (int32_t)zt.size();
+        AL.zero_off.assign((size_t)S.nlevels, 0), AL.zero_n.assign((size_t)S.nlevels, 0);
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            AL.zero_off[(size_t)l] = (int32_t)zt.size();
+            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+                const int32_t s = S.level_sn[k];
+                if (S.fsize(s) > SMALL_F) zero_range(S.front_off[s], (int64_t)S.front_ld[s] * S.fsize(s));
+            }
+            AL.zero_n[(size_t)l] = (int32_t)zt.size() - AL.zero_off[(size_t)l];
+        }
+        if (zt.size() > 0x7fffffffULL) AL.status = 2;
+    });
+    Joiner asm_joiner{asm_thread};
     const auto t_plan = std::chrono::steady_clock::now();
     int32_t code = upload_plan();
     if (code != SUCCESSFUL_EXIT) return code;
+    lap("plan + upload");
     if (opt.verbose)
         fprintf(stderr,
                 "hipmf: initialize: graph %.3f s, ordering %.3f s, etree %.3f s, supernodes %.3f s, row structures %.3f s, layout %.3f s, "
@@ -304,6 +404,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         HIPC(dev_upload(&d_tptr, tptr), ERROR_HIP_MALLOC);
         HIPC(dev_upload(&d_tidx, tidx), ERROR_HIP_MALLOC);
     }
+    lap("matrix structure + transpose index");
     HIPC(dev_upload(&d_perm, S.perm), ERROR_HIP_MALLOC);
     d_rperm = d_perm;
     {
@@ -333,51 +434,25 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             if ((len & 1) == 0) match_parity ^= 1;
         }
     }
+    lap("perm + signature");
     {
-        // The entries of A that land in small fronts are gathered by k_small_factor itself (per-front lists: entry index,
-        // position inside the front); the entries of the big fronts are scattered level by level (their working blocks share
-        // an arena: a block is zero-filled and filled when its level starts).
-        const int32_t ns = S.nsuper;
-        std::vector<int32_t> sa_ptr((size_t)ns + 1, 0);
-        std::vector<int64_t> sc_cnt((size_t)S.nlevels + 1, 0);
-        for (int pass = 0; pass < 2; pass++) {
-            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
-            for (int64_t k = 0; k < (int64_t)am.size(); k++)
-                if (am[k] >= 0) {
-                    const int32_t s = S.amap_sn[(size_t)k];
-                    if (S.fsize(s) <= SMALL_F) sa_ptr[(size_t)s + 1]++;
-                    else sc_cnt[(size_t)S.sn_level[s] + 1]++;
-                }
-        }
-        for (int32_t s = 0; s < ns; s++) sa_ptr[(size_t)s + 1] += sa_ptr[s];
-        for (int32_t l = 0; l < S.nlevels; l++) sc_cnt[(size_t)l + 1] += sc_cnt[l];
-        if (sc_cnt[(size_t)S.nlevels] > 0x7fffffffLL) {
+        // (joined below: the lists were computed beside upload_plan)
+        if (asm_thread.joinable()) asm_thread.join();
+        if (AL.status == 1) {
             last_error = "too many entries in the tiled fronts";
             return ERROR_HIPMF_SYMBOLIC;
         }
-        std::vector<int32_t> sa_k((size_t)sa_ptr[ns]), w(sa_ptr.begin(), sa_ptr.end() - 1);
-        std::vector<uint16_t> sa_pos((size_t)sa_ptr[ns]);
-        std::vector<int32_t> sc_k((size_t)sc_cnt[(size_t)S.nlevels]);
-        std::vector<int64_t> sc_at((size_t)sc_cnt[(size_t)S.nlevels]), wl(sc_cnt.begin(), sc_cnt.end() - 1);
-        for (int pass = 0; pass < 2; pass++) {
-            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
-            for (int64_t k = 0; k < (int64_t)am.size(); k++)
-                if (am[k] >= 0) {
-                    const int32_t s = S.amap_sn[(size_t)k];
-                    if (S.fsize(s) > SMALL_F) {
-                        const size_t q = (size_t)wl[(size_t)S.sn_level[s]]++;
-                        sc_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
-                        sc_at[q] = am[k];
-                        continue;
-                    }
-                    const int64_t off = am[k] - S.front_off[s], f = S.fsize(s);
-                    const size_t q = (size_t)w[s]++;
-                    sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
-                    sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
-                }
+        if (AL.status == 2) {
+            last_error = "too many zero-fill tasks";
+            return ERROR_HIPMF_SYMBOLIC;
         }
-        for (int32_t l = 0; l < S.nlevels; l++) levels[(size_t)l].sc_off = (int32_t)sc_cnt[(size_t)l], levels[(size_t)l].sc_cnt = (int32_t)(sc_cnt[(size_t)l + 1] - sc_cnt[(size_t)l]);
-        HIPC(dev_upload(&d_sa_ptr, sa_ptr), ERROR_HIP_MALLOC);
+        const int32_t ns = S.nsuper;
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            levels[(size_t)l].sc_off = (int32_t)AL.sc_cnt[(size_t)l], levels[(size_t)l].sc_cnt = (int32_t)(AL.sc_cnt[(size_t)l + 1] - AL.sc_cnt[(size_t)l]);
+            levels[(size_t)l].zero_off = AL.zero_off[(size_t)l], levels[(size_t)l].zero_cnt = AL.zero_n[(size_t)l];
+        }
+        zero_cnt = AL.zero_cnt;
+        HIPC(dev_upload(&d_sa_ptr, AL.sa_ptr), ERROR_HIP_MALLOC);
         {
             // descriptors in launch order (the plan is on the device already: read it back rather than keep host copies around)
             std::vector<FrontDesc> h_fd((size_t)ns);
@@ -388,41 +463,17 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             for (size_t q = 0; q < h_lists.size(); q++) {
                 const int32_t s = h_lists[q];
                 sd[q].fd = h_fd[(size_t)s];
-                sd[q].e0 = sa_ptr[(size_t)s], sd[q].e1 = sa_ptr[(size_t)s + 1]; // (empty ranges for the big fronts, which never read them)
+                sd[q].e0 = AL.sa_ptr[(size_t)s], sd[q].e1 = AL.sa_ptr[(size_t)s + 1]; // (empty ranges for the big fronts, which never read them)
             }
             HIPC(dev_upload(&d_sd, sd), ERROR_HIP_MALLOC);
         }
-        HIPC(dev_upload(&d_sa_k, sa_k), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_sa_pos, sa_pos), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_sc_k, sc_k), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_sc_at, sc_at), ERROR_HIP_MALLOC);
-        // zero-fill tasks, 16 Ki doubles per workgroup: first the persistent E / E' panels of all big fronts (one launch per
-        // factorisation), then the working blocks level by level
-        std::vector<ZeroTask> zt;
-        auto zero_range = [&](int64_t o0, int64_t len) {
-            for (int64_t o = o0; o < o0 + len; o += 16384) zt.push_back({o, (int32_t)std::min<int64_t>(16384, o0 + len - o), 0});
-        };
-        for (int32_t s = 0; s < ns; s++) {
-            if (S.fsize(s) <= SMALL_F) continue;
-            const int64_t f = S.fsize(s), p = S.npiv(s);
-            zero_range(S.e_off[s], (int64_t)S.front_ld[s] * p);
-            if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * p);
-        }
-        zero_cnt = (int32_t)zt.size();
-        for (int32_t l = 0; l < S.nlevels; l++) {
-            levels[(size_t)l].zero_off = (int32_t)zt.size();
-            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
-                const int32_t s = S.level_sn[k];
-                if (S.fsize(s) > SMALL_F) zero_range(S.front_off[s], (int64_t)S.front_ld[s] * S.fsize(s));
-            }
-            levels[(size_t)l].zero_cnt = (int32_t)zt.size() - levels[(size_t)l].zero_off;
-        }
-        if (zt.size() > 0x7fffffffULL) {
-            last_error = "too many zero-fill tasks";
-            return ERROR_HIPMF_SYMBOLIC;
-        }
-        HIPC(dev_upload(&d_zero, zt), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sa_k, AL.sa_k), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sa_pos, AL.sa_pos), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sc_k, AL.sc_k), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_sc_at, AL.sc_at), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_zero, AL.zt), ERROR_HIP_MALLOC);
     }
+    lap("assembly lists + zero tasks");
     std::vector<int64_t>().swap(S.amap);
     std::vector<int64_t>().swap(S.amap2);
     std::vector<int32_t>().swap(S.amap_sn);
@@ -445,6 +496,12 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         e = he;
     }
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    lap("value / vector buffers");
+    if (opt.verbose) {
+        fprintf(stderr, "hipmf: initialize: host pieces:");
+        for (const auto &l : laps) fprintf(stderr, " %s %.3f s;", l.first, l.second);
+        fprintf(stderr, "\n");
+    }
     initialized = true;
     return SUCCESSFUL_EXIT;
 }

@@ -115,16 +115,22 @@ static void permute_graph(const Graph &g, const std::vector<int32_t> &perm, cons
 // The result does not depend on the number of threads or on the schedule: a region's outcome is a function
 // of its own vertex list only; region ids and visit stamps are merely unique, never compared for order.
 // ------------------------------------------------------------------------------------------------
+// per-vertex state of the dissection in ONE record: a breadth-first search tests the region and the visit stamp of every neighbour
+// and writes stamp and level of the ones it takes -- one cache line per neighbour instead of three
+struct NDVertex {
+    std::atomic<int32_t> part; // region id, -1 once numbered (read across regions: atomic, relaxed)
+    int32_t stamp;             // visit stamp (vertices of the own region only)
+    int32_t lev;               // BFS level / local index (vertices of the own region only)
+    int32_t pad;
+};
 struct NDShared {
     const Graph &g;
-    std::unique_ptr<std::atomic<int32_t>[]> part; // region id per vertex, -1 once numbered (read across regions: atomic, relaxed)
+    std::unique_ptr<NDVertex[]> vx;
     std::vector<int32_t> verts;                   // region vertex lists (disjoint segments)
-    std::vector<int32_t> lev;                     // BFS level / local index (vertices of the own region only)
-    std::vector<int32_t> stamp;                   // visit stamps (vertices of the own region only)
     std::atomic<int32_t> cur_stamp{0}, next_id{1};
     explicit NDShared(const Graph &gr) : g(gr) {}
-    int32_t region_of(int32_t v) const { return part[v].load(std::memory_order_relaxed); }
-    void set_region(int32_t v, int32_t id) { part[v].store(id, std::memory_order_relaxed); }
+    int32_t region_of(int32_t v) const { return vx[v].part.load(std::memory_order_relaxed); }
+    void set_region(int32_t v, int32_t id) { vx[v].part.store(id, std::memory_order_relaxed); }
 };
 
 // per-thread scratch, sized by the largest region the thread has seen
@@ -149,25 +155,28 @@ static int32_t bfs_region(NDShared &w, NDScratch &t, int32_t root, int32_t id, i
     const Graph &g = w.g;
     const int32_t st = w.cur_stamp.fetch_add(1, std::memory_order_relaxed) + 1;
     int32_t head = 0, tail = 0;
-    t.queue[tail++] = root;
-    w.stamp[root] = st;
-    w.lev[root] = 0;
+    NDVertex *vx = w.vx.get();
+    int32_t *queue = t.queue.data();
+    queue[tail++] = root;
+    vx[root].stamp = st;
+    vx[root].lev = 0;
     t.lvl_ptr.clear();
     t.lvl_ptr.push_back(0);
-    int32_t curlev = 0;
+    int32_t curlev = 0, lev_end = 1; // the current level is queue[lvl_ptr.back(), lev_end)
     while (head < tail) {
-        int32_t v = t.queue[head];
-        if (w.lev[v] != curlev) {
-            curlev = w.lev[v];
+        if (head == lev_end) { // first vertex of the next level
+            curlev++;
             t.lvl_ptr.push_back(head);
+            lev_end = tail;
         }
-        head++;
-        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
-            int32_t u = g.adj[p];
-            if (w.region_of(u) == id && w.stamp[u] != st) {
-                w.stamp[u] = st;
-                w.lev[u] = curlev + 1;
-                t.queue[tail++] = u;
+        const int32_t v = queue[head++];
+        for (int64_t p = g.ptr[v], pe = g.ptr[v + 1]; p < pe; p++) {
+            const int32_t u = g.adj[p];
+            NDVertex &x = vx[u];
+            if (x.part.load(std::memory_order_relaxed) == id && x.stamp != st) {
+                x.stamp = st;
+                x.lev = curlev + 1;
+                queue[tail++] = u;
             }
         }
     }
@@ -181,14 +190,14 @@ static void leaf_min_degree(NDShared &w, int32_t begin, int32_t end, int32_t id,
     int32_t s = end - begin;
     uint64_t a[64];
     int32_t ext[64];
-    for (int32_t i = 0; i < s; i++) w.lev[w.verts[begin + i]] = i; // local index
+    for (int32_t i = 0; i < s; i++) w.vx[w.verts[begin + i]].lev = i; // local index
     for (int32_t i = 0; i < s; i++) {
         int32_t v = w.verts[begin + i];
         a[i] = 0;
         ext[i] = 0;
         for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
             int32_t u = g.adj[p];
-            if (w.region_of(u) == id) a[i] |= (uint64_t)1 << w.lev[u];
+            if (w.region_of(u) == id) a[i] |= (uint64_t)1 << w.vx[u].lev;
             else ext[i]++;
         }
     }
@@ -225,6 +234,15 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
     const int32_t size = R.end - R.begin;
     if (size <= 0) return;
     t.reserve(size);
+    // A region that is not known to be connected and is going to be split: the first breadth-first search of the pseudo-peripheral
+    // iteration (from the region's first vertex) visits exactly what the component sweep below would visit first, in the same order.
+    // When it reaches every vertex the region is connected and the sweep -- one more pass over the region's adjacency -- is skipped.
+    bool have_bfs = false;
+    int32_t count0 = 0, ecc0 = 0;
+    if (!R.connected && size > leaf) {
+        ecc0 = bfs_region(w, t, w.verts[R.begin], R.id, count0);
+        if (count0 == size) R.connected = true, have_bfs = true;
+    }
     if (!R.connected) {
         // connected components of the region (discovery order, deterministic)
         const int32_t st = w.cur_stamp.fetch_add(1, std::memory_order_relaxed) + 1;
@@ -233,16 +251,16 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
         t.comp_ptr.push_back(0);
         for (int32_t k = R.begin; k < R.end; k++) {
             int32_t r = w.verts[k];
-            if (w.stamp[r] == st) continue;
+            if (w.vx[r].stamp == st) continue;
             int32_t head = outn;
             t.tmp[outn++] = r;
-            w.stamp[r] = st;
+            w.vx[r].stamp = st;
             while (head < outn) {
                 int32_t v = t.tmp[head++];
                 for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
                     int32_t u = g.adj[p];
-                    if (w.region_of(u) == R.id && w.stamp[u] != st) {
-                        w.stamp[u] = st;
+                    if (w.region_of(u) == R.id && w.vx[u].stamp != st) {
+                        w.vx[u].stamp = st;
                         t.tmp[outn++] = u;
                     }
                 }
@@ -269,8 +287,8 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
         return;
     }
     // pseudo-peripheral vertex: repeat BFS from a minimum-degree vertex of the last level
-    int32_t root = w.verts[R.begin], count = 0;
-    int32_t ecc = bfs_region(w, t, root, R.id, count);
+    int32_t root = w.verts[R.begin], count = count0;
+    int32_t ecc = have_bfs ? ecc0 : bfs_region(w, t, root, R.id, count);
     for (int32_t it = 0; it < 4; it++) {
         int32_t lb = t.lvl_ptr[t.lvl_ptr.size() - 2], le = t.lvl_ptr.back();
         int32_t cand = t.queue[lb];
@@ -331,7 +349,7 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
         bool up = false;
         for (int64_t p = g.ptr[v]; p < g.ptr[v + 1] && !up; p++) {
             int32_t u = g.adj[p];
-            up = (w.region_of(u) == R.id && w.lev[u] == best + 1);
+            up = (w.region_of(u) == R.id && w.vx[u].lev == best + 1);
         }
         if (up) {
             t.tmp[--sep_begin] = v;
@@ -361,8 +379,11 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
     perm.assign((size_t)n, -1);
     leaf_of.assign((size_t)n, -1);
     NDShared w(g);
-    w.part.reset(new std::atomic<int32_t>[(size_t)n]);
-    for (int32_t v = 0; v < n; v++) w.part[v].store(0, std::memory_order_relaxed);
+    w.vx.reset(new NDVertex[(size_t)n]);
+    for (int32_t v = 0; v < n; v++) {
+        w.vx[v].part.store(0, std::memory_order_relaxed);
+        w.vx[v].stamp = 0, w.vx[v].lev = 0, w.vx[v].pad = 0;
+    }
     // Dense rows / columns (hub vertices: the supply nets of circuit matrices, Lagrange multipliers tied to many unknowns) are
     // taken out first and numbered last, as AMD / COLAMD do: left inside, one hub makes every breadth-first level structure three
     // levels deep with its whole neighbourhood as the "separator".  Threshold: degree > max(32, min(10 sqrt(n), 40 x the average
@@ -391,8 +412,6 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
         ndense = 0;
     }
     const int32_t nsparse = n - ndense;
-    w.lev.assign((size_t)n, 0);
-    w.stamp.assign((size_t)n, 0);
     const int32_t leaf = std::min<int32_t>(64, std::max<int32_t>(1, opt.nd_leaf));
 
     int nthreads = host_threads(opt);
@@ -767,25 +786,53 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     }
     // relative indices into the parent's front
     S.rel.assign(S.sn_rows.size(), -1);
-    for (int32_t s = 0; s < S.nsuper; s++) {
-        int32_t t = S.sn_parent[s];
-        if (t < 0) {
-            if (S.nrow(s) != 0) return -20; // a root must have an empty off-diagonal structure
-            continue;
-        }
-        int32_t tf = S.sn_first[t], tl = S.sn_first[t + 1] - 1, tp = S.npiv(t);
-        int64_t q = S.sn_rowptr[t], qe = S.sn_rowptr[t + 1];
-        for (int64_t p = S.sn_rowptr[s]; p < S.sn_rowptr[s + 1]; p++) {
-            int32_t i = S.sn_rows[p];
-            if (i <= tl) {
-                if (i < tf) return -21;
-                S.rel[p] = i - tf;
-            } else {
-                while (q < qe && S.sn_rows[q] < i) q++;
-                if (q >= qe || S.sn_rows[q] != i) return -22;
-                S.rel[p] = tp + (int32_t)(q - S.sn_rowptr[t]);
+    {
+        // (every supernode writes its own range of rel and reads its parent's rows: independent, spread over the host threads)
+        std::atomic<int> rel_err{0};
+        auto rel_range = [&](int32_t s0, int32_t s1) {
+            for (int32_t s = s0; s < s1; s++) {
+                int32_t t = S.sn_parent[s];
+                if (t < 0) {
+                    if (S.nrow(s) != 0) rel_err.store(-20); // a root must have an empty off-diagonal structure
+                    continue;
+                }
+                int32_t tf = S.sn_first[t], tl = S.sn_first[t + 1] - 1, tp = S.npiv(t);
+                int64_t q = S.sn_rowptr[t], qe = S.sn_rowptr[t + 1];
+                for (int64_t p = S.sn_rowptr[s]; p < S.sn_rowptr[s + 1]; p++) {
+                    int32_t i = S.sn_rows[p];
+                    if (i <= tl) {
+                        if (i < tf) {
+                            rel_err.store(-21);
+                            break;
+                        }
+                        S.rel[p] = i - tf;
+                    } else {
+                        while (q < qe && S.sn_rows[q] < i) q++;
+                        if (q >= qe || S.sn_rows[q] != i) {
+                            rel_err.store(-22);
+                            break;
+                        }
+                        S.rel[p] = tp + (int32_t)(q - S.sn_rowptr[t]);
+                    }
+                }
             }
-        }
+        };
+        if (S.sn_rows.size() > (size_t)1 << 20 && threads > 1) {
+            // ranges of supernodes with about the same number of rows
+            const int nt = threads;
+            std::vector<std::thread> pool;
+            int32_t s0 = 0;
+            for (int t = 0; t < nt; t++) {
+                const int64_t target = (int64_t)S.sn_rows.size() * (t + 1) / nt;
+                int32_t s1 = (int32_t)(std::upper_bound(S.sn_rowptr.begin(), S.sn_rowptr.end(), target) - S.sn_rowptr.begin()) - 1;
+                s1 = t == nt - 1 ? S.nsuper : std::max(s0, std::min(s1, S.nsuper));
+                if (s1 > s0) pool.emplace_back([=]() { rel_range(s0, s1); });
+                s0 = s1;
+            }
+            for (auto &th : pool) th.join();
+        } else
+            rel_range(0, S.nsuper);
+        if (rel_err.load() != 0) return rel_err.load();
     }
 
     S.seconds_phase[4] = since(t_phase), t_phase = clk::now();
