@@ -534,7 +534,10 @@ def main():
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(st["flops"] / (fact_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if fact_ms > 0 else 0.0,
                                 "flops": st["flops"], "avg_ms": round(fact_ms, 3), "assemble_ms": round(asm_ms, 3),
-                                "measured_mfma_tflops": round(mfma_tfs.value, 1)},
+                                "measured_mfma_tflops": round(mfma_tfs.value, 1),
+                                # against what v_mfma_f64_16x16x4_f64 delivers on THIS device (tools/microbench/mfma_peak.hip through the
+                                # library's probe), not the data-sheet figure: profiles/r03_mfma_ceiling.txt
+                                "frac_of_measured": round(st["flops"] / (fact_ms * 1e-3) / 1e12 / mfma_tfs.value, 5) if fact_ms > 0 and mfma_tfs.value > 0 else None},
             "phases_ms": {"initialize_once": round(t_init * 1e3, 1), "ordering_s": st["ordering_s"], "symbolic_s": st["symbolic_s"],
                           "assemble": round(asm_ms, 3), "factor": round(fact_ms, 3), "sptrsv_pair": round(tri_ms, 4),
                           "solve_total_last": round(st["solve_total_ms"], 3)},
@@ -550,6 +553,10 @@ def main():
         if perm is not None:
             cb = cpu_baseline(n, rp, ci, v, b, perm, args.cpu_tier)
             cb["host_cores"] = os.cpu_count() or 0
+            #  a threaded tier exists only where a threaded sparse direct solver can be loaded: UMFPACK with a threaded
+            # BLAS is the first tier above (cores = its thread count); SuperLU through scipy is sequential, the port is scalar
+            cb["threads"] = cb.get("cores", 1)
+            cb["threaded_tier"] = "none importable on this box (scipy's SuperLU is sequential)" if cb.get("kind") != "reference" else "UMFPACK + threaded BLAS"
             out["cpu_baseline"] = cb
             # like for like: the CPU number contains ordering + symbolic + numeric + solve (SuperLU / UMFPACK redo all of it per call)
             out["speedup_one_shot"] = round(cb["value"] / out["total_ifs_ms"], 1)

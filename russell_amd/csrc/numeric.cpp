@@ -1623,6 +1623,7 @@ struct Solver::SolveLane {
     // the block in flight
     bool busy = false;
     int32_t j0 = 0, nk = 0, it = 0;
+    int64_t cstr = 0; // stride between the block's columns of b and x
     double prev[SF_KMAX];
     bool active[SF_KMAX];
     const double *bj[SF_KMAX];
@@ -1722,10 +1723,17 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     // residual + norms of the active columns of the lane's block, and their way to the host
     auto enqueue_norms = [&](SolveLane &L) -> int32_t {
         HIPC(hipMemsetAsync(L.norms, 0, (size_t)RES_NORM_WORDS * L.nk * sizeof(unsigned long long), L.st), ERROR_HIP_MEMCPY);
-        for (int32_t c = 0; c < L.nk; c++) {
-            if (!L.active[c]) continue;
-            hipLaunchKernelGGL(k_spmv_stream<true>, dim3(spmv_blocks), b, 0, L.st, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, 1.0, L.xj[c], L.bj[c],
-                               L.RR + (size_t)c * n, L.norms + (size_t)RES_NORM_WORDS * c);
+        if (L.nk == 1) {
+            if (L.active[0])
+                hipLaunchKernelGGL(k_spmv_stream<true>, dim3(spmv_blocks), b, 0, L.st, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, 1.0, L.xj[0], L.bj[0],
+                                   L.RR, L.norms);
+        } else {
+            uint32_t amask = 0;
+            for (int32_t c = 0; c < L.nk; c++)
+                if (L.active[c]) amask |= 1u << c;
+            if (amask)
+                hipLaunchKernelGGL(k_residual_cols, dim3(spmv_blocks), b, 0, L.st, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, L.xj[0], L.cstr, L.bj[0],
+                                   L.cstr, L.RR, (int64_t)n, L.norms, L.nk, amask);
         }
         HIPC(hipMemcpyAsync(L.h_nrm, L.norms, (size_t)RES_NORM_WORDS * L.nk * sizeof(double), hipMemcpyDeviceToHost, L.st), ERROR_HIP_MEMCPY);
         return SUCCESSFUL_EXIT;
@@ -1753,11 +1761,16 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
                 L.bj[c] = L.BB + (size_t)c * n;
                 L.xj[c] = L.XX + (size_t)c * n;
             }
-            hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.bj[c], L.XP + (size_t)c * n);
+            if (L.nk == 1) hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.bj[c], L.XP + (size_t)c * n);
         }
+        // (the columns of a block sit at a regular stride -- ldx on the device, n in the staging block: one launch for all of them)
+        L.cstr = on_device ? ldx : (int64_t)n;
+        const uint32_t all = L.nk >= 32 ? 0xffffffffu : ((1u << L.nk) - 1u);
+        if (L.nk > 1) hipLaunchKernelGGL(k_perm_in_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_rperm, d_rs, L.bj[0], L.cstr, L.XP, (int64_t)n, all);
         int32_t code = run_triangular(L.XP, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed);
         if (code != SUCCESSFUL_EXIT) return code;
-        for (int32_t c = 0; c < L.nk; c++) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.XP + (size_t)c * n, L.xj[c], 0);
+        if (L.nk == 1) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.XP, L.xj[0], 0);
+        else hipLaunchKernelGGL(k_perm_out_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_perm, d_cs, L.XP, (int64_t)n, L.xj[0], L.cstr, 0, all);
         for (int32_t c = 0; c < L.nk; c++) L.prev[c] = INFINITY, L.active[c] = true;
         if (opt.refinement_nstep <= 0) return finish(L);
         return enqueue_norms(L);
@@ -1778,7 +1791,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
                 omega = std::max(omega, L.h_nrm[(size_t)RES_NORM_WORDS * c + (size_t)sl * RES_SLOT_WORDS + 1]);
             }
             if (L.it > 0 && !(omega < L.prev[c])) {
-                hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 2); // take the last correction back
+                hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 2); // take the last correction back (rare: one launch per such column)
                 L.active[c] = false;
                 continue;
             }
@@ -1792,14 +1805,15 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             any = true;
         }
         if (!any) return finish(L);
-        for (int32_t c = 0; c < L.nk; c++) {
-            if (L.active[c]) hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.RR + (size_t)c * n, L.DU + (size_t)c * n);
-            else HIPC(hipMemsetAsync(L.DU + (size_t)c * n, 0, sizeof(double) * n, L.st), ERROR_HIP_MEMCPY); // finished columns ride along as zeros
-        }
+        uint32_t amask = 0;
+        for (int32_t c = 0; c < L.nk; c++)
+            if (L.active[c]) amask |= 1u << c;
+        if (L.nk == 1) hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.RR, L.DU);
+        else hipLaunchKernelGGL(k_perm_in_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_rperm, d_rs, L.RR, (int64_t)n, L.DU, (int64_t)n, amask); // finished columns ride along as zeros
         int32_t code = run_triangular(L.DU, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed);
         if (code != SUCCESSFUL_EXIT) return code;
-        for (int32_t c = 0; c < L.nk; c++)
-            if (L.active[c]) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 1);
+        if (L.nk == 1) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU, L.xj[0], 1);
+        else hipLaunchKernelGGL(k_perm_out_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_perm, d_cs, L.DU, (int64_t)n, L.xj[0], L.cstr, 1, amask);
         if (L.j0 == 0 && L.active[0]) refinement_steps_done++;
         // a column whose backward error was already within 64 eps is done after this correction: no further residual /
         // norm / host round trip just to confirm it

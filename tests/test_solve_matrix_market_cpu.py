@@ -162,3 +162,22 @@ def test_out_of_memory_is_refused_before_any_allocation(emu_lib, tmp_path):
     assert rc == 0, err
     d = json.loads(out)
     assert d["main"]["out_of_memory"] is True and d["matrix"]["nrow"] == n
+
+
+def test_sweep_runner_consumes_whatever_mtx_is_present(emu_lib, tmp_path):
+    # tools/sweep_matrix_market.py: the reference's benchmark sweep (tools/sweep.txt = the matrices its download script names) over
+    # any *.mtx found in a directory; there is no network, so the listed matrices are reported absent and whatever IS there is solved
+    import shutil
+    import sys
+
+    src = os.path.join(ROOT, "tests", "golden", "mtx")
+    for name in ("ok_general.mtx", "ok_symmetric.mtx", "ok_complex_general.mtx"):
+        shutil.copy(os.path.join(src, name), tmp_path / name)
+    env = dict(os.environ, RUSSELL_HIPMF_LIB=emu_lib)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_matrix_market.py"), str(tmp_path)], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    last = p.stdout.strip().splitlines()[-1]
+    assert last.startswith("3 solved, 0 failed, 43 of the list absent: bbmat af_shell10"), last
+    for name in ("ok_general", "ok_symmetric", "ok_complex_general"):
+        assert os.path.exists(os.path.join(ROOT, "gpurun_out", "sweep", name + ".json"))
