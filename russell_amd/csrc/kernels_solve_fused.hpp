@@ -87,6 +87,16 @@ __device__ __forceinline__ void sf_publish_front(int s, const int32_t *__restric
     }
 }
 
+// One entry per column of a block of right-hand sides, column c < nk at base + c * cstr + off: K agent-scope loads issued back to back.
+// The compiler never speculates an agent-scope load: written as `cond ? ld_agent(p) : 0` (or under `if (c < nk)`) every load sits in a
+// branch of its own and waits for its own round trip -- sixteen columns cost sixteen round trips (measured on the blocked small-front
+// step: 9 us from entry to the last of its sixteen loads, 8.5 us per child gathered; tools/ab stamps, round 3).  Callers clamp `off` to
+// an address that is always valid and drop what they do not need; the columns >= nk re-read column 0.
+template <int K> __device__ __forceinline__ void ld_cols(double (&v)[K], const double *base, int64_t cstr, int64_t off, int nk) {
+#pragma unroll
+    for (int c = 0; c < K; c++) v[c] = ld_agent(base + (int64_t)(c < nk ? c : 0) * cstr + off);
+}
+
 // All kernels are templates on K = the number of right-hand sides a launch carries (1: the instances the
 // benchmark path uses; SF_KMAX: the many-RHS instances, which read every factor entry ONCE for K columns -- the
 // solves are HBM-bound, so K columns cost little more than one).  Column c of x lives at x + c * xstr, its solve
@@ -104,9 +114,13 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
     const double *F = pool + fd.off;
     double *W = work + fd.woff;
     double *xs = x + fd.first;
+    {
+        double xv[K];
+        ld_cols<K>(xv, xs, xstr, lane < p ? lane : 0, nk);
 #pragma unroll
-    for (int c = 0; c < K; c++)
-        if (c < nk) w[c][lane] = (lane < p) ? ld_agent(xs + c * xstr + lane) : 0.0;
+        for (int c = 0; c < K; c++)
+            if (c < nk) w[c][lane] = (lane < p) ? xv[c] : 0.0;
+    }
     const int lp = (lane < p) ? lperm[fd.first + lane] : 0;
     // the lane's row of [L11; L21], first 8 columns: on their way before the waits (the panel is read-only)
     constexpr int CH = 8;
@@ -132,8 +146,9 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             // them in child order (fixed order: reproducible sums)
             const int myr = (lane < nbatch && c_m == 1) ? rel[c_rowptr] : -1;
             double myv[K];
+            ld_cols<K>(myv, work, wstr, myr >= 0 ? c_woff + c_p : 0, nk);
 #pragma unroll
-            for (int c = 0; c < K; c++) myv[c] = (c < nk && myr >= 0) ? ld_agent(work + c * wstr + c_woff + c_p) : 0.0;
+            for (int c = 0; c < K; c++) myv[c] = (c < nk && myr >= 0) ? myv[c] : 0.0;
             double add[K]; // starts from the row's current value: the same association order as adding child after child
 #pragma unroll
             for (int c = 0; c < K; c++) add[c] = (c < nk) ? w[c][lane] : 0.0;
@@ -155,11 +170,18 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             // (cl is wave-uniform: v_readlane, not a trip through the LDS crossbar)
             const int64_t woff = wave_bcast_i64(c_woff, cl), rowptr = wave_bcast_i64(c_rowptr, cl);
             const int cp = wave_bcast_i32(c_p, cl), cm = wave_bcast_i32(c_m, cl);
-            if (lane < cm) { // cm <= f <= 64
-                const int r = rel[rowptr + lane];
+            if constexpr (K == 1) {
+                if (lane < cm) w[0][rel[rowptr + lane]] += ld_agent(work + woff + cp + lane); // cm <= f <= 64
+            } else if (cm > 0) { // (wave-uniform)
+                const int gl = lane < cm ? lane : 0;
+                const int r = rel[rowptr + gl];
+                double gv[K];
+                ld_cols<K>(gv, work, wstr, woff + cp + gl, nk);
+                if (lane < cm) {
 #pragma unroll
-                for (int c = 0; c < K; c++)
-                    if (c < nk) w[c][r] += ld_agent(work + c * wstr + woff + cp + lane);
+                    for (int c = 0; c < K; c++)
+                        if (c < nk) w[c][r] += gv[c];
+                }
             }
             wave_sync();
         }
@@ -210,8 +232,9 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     const int32_t *rws = rows + fd.rowptr;
     const int myrow = (lane < m) ? rws[lane] : 0;
     double y1[K]; // from the forward launch
+    ld_cols<K>(y1, xs, xstr, lane < p ? lane : 0, nk);
 #pragma unroll
-    for (int c = 0; c < K; c++) y1[c] = (c < nk && lane < p) ? ld_agent(xs + c * xstr + lane) : 0.0;
+    for (int c = 0; c < K; c++) y1[c] = (c < nk && lane < p) ? y1[c] : 0.0;
     const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
     const int i = lane & ((1 << sh) - 1), jq = lane >> sh, ng = 64 >> sh;
     // read-only factor data on their way before the wait: the first 8 of this lane's U12 entries and the
@@ -233,10 +256,14 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     const double inv_d = (lane < p) ? 1.0 / Ub[lane + (int64_t)lane * us] : 1.0;
     if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
     wave_sync();
-    if (lane < m) {
+    {
+        double xv[K];
+        ld_cols<K>(xv, x, xstr, myrow, nk); // (myrow = 0 for the lanes past the front's rows: a valid address, the value is dropped)
+        if (lane < m) {
 #pragma unroll
-        for (int c = 0; c < K; c++)
-            if (c < nk) xg[c][lane] = ld_agent(x + c * xstr + myrow);
+            for (int c = 0; c < K; c++)
+                if (c < nk) xg[c][lane] = xv[c];
+        }
     }
     wave_sync();
     double acc[K];
@@ -372,13 +399,20 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
                 }
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
+                    // (clamped index: the loads are unconditional -- see ld_cols; `work` and `rel` are padded by 64 entries, so
+                    //  index 0 of a child without update rows is still inside the allocation)
                     const int i = tid + 256 * e;
-                    qv[k][e] = -1;
-                    if (i < cm[k]) {
-                        qv[k][e] = rel[relo + i];
-#pragma unroll
-                        for (int cc = 0; cc < K; cc++)
-                            if (cc < nk) uv[k][e][cc] = ld_agent(work + cc * wstr + woff + i);
+                    if constexpr (K == 1) { // (one load per child and entry: the single-column instances keep the predicated form they were tuned with)
+                        qv[k][e] = -1;
+                        if (i < cm[k]) {
+                            qv[k][e] = rel[relo + i];
+                            uv[k][e][0] = ld_agent(work + woff + i);
+                        }
+                    } else {
+                        const int ic = i < cm[k] ? i : 0;
+                        const int qq = rel[relo + ic];
+                        qv[k][e] = i < cm[k] ? qq : -1;
+                        ld_cols<K>(uv[k][e], work, wstr, woff + ic, nk);
                     }
                 }
                 if (cm[k] > 256 * NE) cm[k] = -cm[k]; // the rest of this child's list goes through the plain loop below
@@ -411,14 +445,16 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
                     }
                     for (int i = tid + 256 * NE; i < -cm[k]; i += 256) {
                         const int q = rel[relo + i];
+                        double tv[K];
+                        ld_cols<K>(tv, work, wstr, woff + i, nk);
                         if (q >= c0 && q < c1) {
 #pragma unroll
                             for (int cc = 0; cc < K; cc++)
-                                if (cc < nk) wc[cc * wld + q - c0] += ld_agent(work + cc * wstr + woff + i);
+                                if (cc < nk) wc[cc * wld + q - c0] += tv[cc];
                         } else if (c0 == 0 && q >= p && q >= r0 && q < r1) {
 #pragma unroll
                             for (int cc = 0; cc < K; cc++)
-                                if (cc < nk) wsl[cc * 128 + q - r0] += ld_agent(work + cc * wstr + woff + i);
+                                if (cc < nk) wsl[cc * 128 + q - r0] += tv[cc];
                         }
                     }
                 }
@@ -564,9 +600,11 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         double *W = work + fd.woff;
         const int nch = fd.child_end - fd.child_begin;
         for (int i = tid; i < nq; i += 256) {
+            double xv[K];
+            ld_cols<K>(xv, x, xstr, fd.first + (q0 + i < p ? q0 + i : 0), nk);
 #pragma unroll
             for (int c = 0; c < K; c++)
-                if (c < nk) wc[c * CHK + i] = (q0 + i < p) ? ld_agent(x + c * xstr + fd.first + q0 + i) : 0.0;
+                if (c < nk) wc[c * CHK + i] = (q0 + i < p) ? xv[c] : 0.0;
         }
         for (int cb = 0; cb < nch; cb += 256) { // wait for the children (one per thread)
             if (cb + tid < nch) {
@@ -595,9 +633,11 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
                 const int64_t woff = a_woff[k], relo = a_rel[k];
                 for (int i = lo + tid; i < hi; i += 256) {
                     const int q = rel[relo + i] - q0;
+                    double tv[K];
+                    ld_cols<K>(tv, work, wstr, woff + i, nk);
 #pragma unroll
                     for (int c = 0; c < K; c++)
-                        if (c < nk) wc[c * CHK + q] += ld_agent(work + c * wstr + woff + i);
+                        if (c < nk) wc[c * CHK + q] += tv[c];
                 }
                 __syncthreads();
             }
@@ -663,15 +703,27 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         if (tid == 0) sf_wait(done + t.a, nasm, err);
         __syncthreads();
     }
-#pragma unroll
-    for (int c = 0; c < K; c++)
-        if (c < nk)
-            for (int i = tid; i < (jmax < CHK ? jmax : CHK); i += 256) wc[c * CHK + i] = ld_agent(x + c * xstr + fd.first + i);
-    if (nasm > 0 && r0 + (tid & 127) < r1 && r0 + (tid & 127) >= p && tid < 128) {
-        // the assembled update part of the slab's own rows (what the children sweep leaves in wsl otherwise)
+    for (int i = tid; i < (jmax < CHK ? jmax : CHK); i += 256) {
+        double xv[K];
+        ld_cols<K>(xv, x, xstr, fd.first + i, nk);
 #pragma unroll
         for (int c = 0; c < K; c++)
-            if (c < nk) wsl[c * 128 + tid] = ld_agent(W + c * wstr + r0 + tid);
+            if (c < nk) wc[c * CHK + i] = xv[c];
+    }
+    if (nasm > 0) { // (workgroup-uniform)
+        // the assembled update part of the slab's own rows (what the children sweep leaves in wsl otherwise)
+        const bool mine = r0 + (tid & 127) < r1 && r0 + (tid & 127) >= p && tid < 128;
+        if constexpr (K == 1) {
+            if (mine) wsl[tid] = ld_agent(W + r0 + tid);
+        } else {
+            double av[K];
+            ld_cols<K>(av, W, wstr, r0 + (mine ? tid : 0), nk);
+            if (mine) {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) wsl[c * 128 + tid] = av[c];
+            }
+        }
     }
     if (wave == 0) {
         int mym = 0;
@@ -706,10 +758,13 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         const int c1 = c0 + CHK < jmax ? c0 + CHK : jmax;
         // w1[c0, c1) = b1 + the children's updates to these pivot rows (children in ascending order)
         if (c0 > 0) {
+            for (int i = c0 + tid; i < c1; i += 256) {
+                double xv[K];
+                ld_cols<K>(xv, x, xstr, fd.first + i, nk);
 #pragma unroll
-            for (int c = 0; c < K; c++)
-                if (c < nk)
-                    for (int i = c0 + tid; i < c1; i += 256) wc[c * CHK + i - c0] = ld_agent(x + c * xstr + fd.first + i);
+                for (int c = 0; c < K; c++)
+                    if (c < nk) wc[c * CHK + i - c0] = xv[c];
+            }
             __syncthreads();
         }
         if (cm_max <= 256)
@@ -865,13 +920,36 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     __syncthreads();
     if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
+    if constexpr (K == 1) {
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (xrow[k] >= 0) {
+        for (int k = 0; k < 4; k++)
+            if (xrow[k] >= 0) wc[tid + 256 * k] = ld_agent(x + xrow[k]);
+    } else if constexpr (K <= 4) {
+        // (all loads first, unconditional -- see ld_cols: up to four rows of x2 per thread and column)
+        double xv[4][K];
 #pragma unroll
-            for (int c = 0; c < K; c++)
-                if (c < nk) wc[c * CHK + tid + 256 * k] = ld_agent(x + c * xstr + xrow[k]);
+        for (int k = 0; k < 4; k++) ld_cols<K>(xv[k], x, xstr, xrow[k] >= 0 ? xrow[k] : 0, nk);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (xrow[k] >= 0) {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) wc[c * CHK + tid + 256 * k] = xv[k][c];
+            }
+    } else {
+        // (the K columns of one row together; the wider blocks cannot hold 4 K values in registers)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (jmin + 256 * k >= e1) break; // (workgroup-uniform: no thread has a row in this group)
+            double xv[K];
+            ld_cols<K>(xv, x, xstr, xrow[k] >= 0 ? xrow[k] : 0, nk);
+            if (xrow[k] >= 0) {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c < nk) wc[c * CHK + tid + 256 * k] = xv[c];
+            }
         }
+    }
     __syncthreads();
     if (trace && tid == 0) tr_g = dev_clock();
     // (K = 1: scalar dot products; K > 1: MFMA tiles, see sf_mma_chunk)
@@ -887,9 +965,11 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
             for (int j = c0 + tid; j < c1; j += 256) {
                 const int row = (j < p) ? 0 : rws[j - p];
                 const double dj = (sym && j < p) ? diag[fd.first + j] : 1.0;
+                double xv[K];
+                ld_cols<K>(xv, x, xstr, row, nk);
 #pragma unroll
                 for (int c = 0; c < K; c++)
-                    if (c < nk) wc[c * CHK + j - c0] = (j < p) ? (sym ? W[c * wstr + j] / dj : W[c * wstr + j]) : ld_agent(x + c * xstr + row);
+                    if (c < nk) wc[c * CHK + j - c0] = (j < p) ? (sym ? W[c * wstr + j] / dj : W[c * wstr + j]) : xv[c];
             }
             __syncthreads();
         }

@@ -1088,11 +1088,16 @@ int32_t Solver::upload_plan() {
         HIPC(hipMalloc((void **)&d_chain_cnt, sizeof(int32_t) * (size_t)chain_words), ERROR_HIP_MALLOC);
     }
     HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
-    HIPC(dev_upload(&d_rel, S.rel), ERROR_HIP_MALLOC);
+    {
+        // (+ 64 entries: the solve kernels read relative indices and workspace entries from clamped addresses, unconditionally)
+        std::vector<int32_t> relp(S.rel);
+        relp.resize(S.rel.size() + 64, 0);
+        HIPC(dev_upload(&d_rel, relp), ERROR_HIP_MALLOC);
+    }
     HIPC(dev_upload(&d_child, S.child_idx), ERROR_HIP_MALLOC);
     // (+ WT_CHUNK: the wave-subtree kernels read the factor in whole 1 KB pieces)
     HIPC(hipMalloc((void **)&d_pool, sizeof(double) * (std::max<int64_t>(pool_doubles, 1) + WT_CHUNK)), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_work, sizeof(double) * std::max<int64_t>(work_doubles, 1)), ERROR_HIP_MALLOC);
+    HIPC(hipMalloc((void **)&d_work, sizeof(double) * (std::max<int64_t>(work_doubles, 1) + 64)), ERROR_HIP_MALLOC);
     return SUCCESSFUL_EXIT;
 }
 
@@ -1673,7 +1678,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     if (KB > 1 && !d_blk) {
         // xp | du | r | den | b | x: six n x KB blocks, plus KB solve workspaces
         HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * ((size_t)std::max<int64_t>(work_doubles, 1) * KB + 64)), ERROR_HIP_MALLOC);
     }
     if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * RES_NORM_WORDS * SF_KMAX * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
     while ((int32_t)extra_lanes.size() < nlanes - 1) {
@@ -1684,7 +1689,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         extra_lanes.push_back(lb); // (registered first: release() frees whatever a failed allocation leaves behind)
         LaneBuffers &r = extra_lanes.back();
         HIPC(hipMalloc((void **)&r.blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&r.work, sizeof(double) * (size_t)std::max<int64_t>(work_doubles, 1) * KB), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.work, sizeof(double) * ((size_t)std::max<int64_t>(work_doubles, 1) * KB + 64)), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&r.sync, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
         HIPC(hipMemset(r.sync, 0, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&r.norms, (size_t)RES_NORM_WORDS * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
