@@ -216,7 +216,8 @@ class Solver {
     int32_t sf_big_rows = 6, sf_big_front = 2048; // forward solve: fronts with at least sf_big_front rows use slabs of 2^sf_big_rows rows
     int32_t sf_asm_front = 2048;                  // forward solve: fronts with at least this many rows assemble their vector once, in tasks of their own (0: never; then sf_big_rows applies)
     // levels with few tiled steps (the middle of the tree): all steps of a level in one launch with in-launch hand-offs (kernels_factor_chain.hpp)
-    bool use_chain = true;                  // HIPMF_FACTOR_CHAIN=0: one launch per step everywhere
+    bool use_chain = false;                 // HIPMF_FACTOR_CHAIN=1 switches it on.  Off by default: measured at the end of round 3 it is neutral for LU at
+                                            // 1000 x 1000 (7.35 -> 7.34 ms), -1.6 % for L D L^T there and +1 ... +3 % on smaller problems (profiles/r03_chain_check.txt)
     bool chain_fine = false;                // HIPMF_CHAIN_FINE=1: a panel waits only for the critical pieces of the update before (measured: no gain)
     int32_t chain_max_steps = 8;            // a level is chained when it has at most this many steps (HIPMF_CHAIN_MAX_STEPS) ...
     int32_t chain_max_update = 16384;       // ... no step of it has more update workgroups than this (HIPMF_CHAIN_MAX_WGS: wide steps are bound by throughput, and

@@ -51,7 +51,7 @@ for name, (n, rp, ci, v), kw in cases:
         continue
     (ref,), st0, t0 = run(n, rp, ci, v, {"HIPMF_FACTOR_CHAIN": "0"}, **kw)
     print("%-26s per-step launches: %4d launches, factor %.3f ms" % (name, st0["factor_launches"], t0), flush=True)
-    for mx in ("16384",):
+    for mx in ("16384",):  # (the default)
         for fine in ("0",):
             outs, st1, t1 = run(n, rp, ci, v, {"HIPMF_FACTOR_CHAIN": "1", "HIPMF_CHAIN_FINE": fine, "HIPMF_CHAIN_MAX_WGS": mx}, reps=4, **kw)
             same = all(np.array_equal(ref[0], o[0]) and ref[1:] == o[1:] for o in outs)

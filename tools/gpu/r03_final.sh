@@ -40,3 +40,8 @@ timeout 900 python tools/config4_one_gpu.py 200 256 > $OUT/config4_one_gpu.txt 2
 tail -5 $OUT/config4_one_gpu.txt
 # 7. MFMA ceiling
 ./tools/microbench/mfma_peak > $OUT/mfma_ceiling.txt 2>&1
+# 8. host phases of initialize, chained tiled steps against one launch per step
+python tools/init_phases.py 1000 2>&1 | grep -v "^solver_hipmf" | tail -3 > $OUT/init_phases.txt
+python tools/init_phases.py 100 3d sym 2>&1 | grep -v "^solver_hipmf" | tail -3 >> $OUT/init_phases.txt
+timeout 600 python tools/chain_check.py > $OUT/chain_check.txt 2>&1
+tail -4 $OUT/chain_check.txt

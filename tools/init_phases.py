@@ -1,4 +1,5 @@
 """Phase times of solver_hipmf_initialize (verbose printout of the handle) for a Poisson matrix: python tools/init_phases.py [N] [2d|3d] [sym]."""
+import os
 import sys
 import time
 
@@ -12,7 +13,7 @@ n, rp, ci, v = P.poisson2d(N) if kind == "2d" else P.poisson3d(N)
 sym = len(sys.argv) > 3
 if sym:
     rp, ci, v = P.lower_triangle(n, rp, ci, v)
-for rep in range(3):
+for rep in range(int(os.environ.get("INIT_REPS", "3"))):
     s = Hipmf()
     t = time.time()
     assert s.initialize(n, rp, ci, verbose=True, general_symmetric=sym) == 0
