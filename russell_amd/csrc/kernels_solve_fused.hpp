@@ -402,7 +402,8 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
                     // (clamped index: the loads are unconditional -- see ld_cols; `work` and `rel` are padded by 64 entries, so
                     //  index 0 of a child without update rows is still inside the allocation)
                     const int i = tid + 256 * e;
-                    if constexpr (K == 1) { // (one load per child and entry: the single-column instances keep the predicated form they were tuned with)
+                    if constexpr (K == 1) { // (one load per child and entry: the single-column instances keep the predicated form they were tuned with;
+                                            //  the unconditional form costs 20 registers and an occupancy step there: forward 230 -> 250 us)
                         qv[k][e] = -1;
                         if (i < cm[k]) {
                             qv[k][e] = rel[relo + i];

@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 os.environ["HIPMF_SF_TRACE"] = sys.argv[1]
 from russell_amd import problems as P
 from russell_amd.backend import Hipmf
-n, rp, ci, v = P.poisson2d(int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+n, rp, ci, v = P.poisson3d(N) if os.environ.get("TRACE_3D") else P.poisson2d(N)  # (TRACE_3D=1: the N^3 7-point matrix)
 b = P.csr_matvec(n, rp, ci, v, P.manufactured_solution(n))
 s = Hipmf()
 assert s.initialize(n, rp, ci, refinement_nstep=0) == 0
