@@ -687,6 +687,17 @@ int32_t Solver::upload_plan() {
             if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
             int32_t f = S.fsize(s);
             const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
+            // where every child's (ascending) relative indices cross the tile boundaries: computed once per child, not per tile (a front of
+            // 76 000 rows has 716 000 tiles; four binary searches per tile and child made `initialize` of such a matrix take minutes)
+            const int32_t nch_s = S.child_ptr[s + 1] - S.child_ptr[s];
+            const int32_t ncc = (f + cstep - 1) / cstep + 1, nrc = (f + rstep - 1) / rstep + 1;
+            std::vector<int32_t> ccut((size_t)nch_s * ncc), rcut((size_t)nch_s * nrc);
+            for (int32_t q = 0; q < nch_s; q++) {
+                const int32_t ch = S.child_idx[S.child_ptr[s] + q];
+                const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
+                for (int32_t k = 0; k < ncc; k++) ccut[(size_t)q * ncc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * cstep)) - rb);
+                for (int32_t k = 0; k < nrc; k++) rcut[(size_t)q * nrc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * rstep)) - rb);
+            }
             for (int32_t c0 = 0; c0 < f; c0 += cstep)
                 for (int32_t r0 = 0; r0 < f; r0 += rstep) {
                     EaTask tk;
@@ -698,12 +709,12 @@ int32_t Solver::upload_plan() {
                     if (S.sym_mode && r1 <= c0) continue; // tile strictly above the diagonal
                     for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
                         int32_t ch = S.child_idx[c];
-                        const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
+                        const int32_t q = c - S.child_ptr[s];
                         EaRange rg;
-                        rg.jlo = (int32_t)(std::lower_bound(rb, re, c0) - rb);
-                        rg.jhi = (int32_t)(std::lower_bound(rb, re, c1) - rb);
-                        rg.ilo = (int32_t)(std::lower_bound(rb, re, r0) - rb);
-                        rg.ihi = (int32_t)(std::lower_bound(rb, re, r1) - rb);
+                        rg.jlo = ccut[(size_t)q * ncc + c0 / cstep];
+                        rg.jhi = ccut[(size_t)q * ncc + c0 / cstep + 1];
+                        rg.ilo = rcut[(size_t)q * nrc + r0 / rstep];
+                        rg.ihi = rcut[(size_t)q * nrc + r0 / rstep + 1];
                         if (rg.jlo >= rg.jhi || rg.ilo >= rg.ihi) continue;
                         rg.ldc = S.front_ld[ch];
                         rg.cb_off = S.front_off[ch] + S.npiv(ch) + (int64_t)S.npiv(ch) * rg.ldc;
