@@ -10,7 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <iterator>
+#include <map>
 #include <mutex>
+#include <set>
 #include <numeric>
 #include <thread>
 
@@ -756,7 +759,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.sn_rows.clear();
     {
         std::vector<int32_t> mark((size_t)n, -1);
-        std::vector<int32_t> rows;
+        std::vector<int32_t> rows, merged;
         for (int32_t s = 0; s < S.nsuper; s++) {
             int32_t last = S.sn_first[s + 1] - 1;
             rows.clear();
@@ -769,17 +772,35 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
                         rows.push_back(i);
                     }
                 }
-            for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
-                int32_t ch = S.child_idx[c];
-                for (int64_t p = S.sn_rowptr[ch]; p < S.sn_rowptr[ch + 1]; p++) {
-                    int32_t i = S.sn_rows[p];
-                    if (i > last && mark[i] != s) {
-                        mark[i] = s;
-                        rows.push_back(i);
+            const int32_t nchild = S.child_ptr[s + 1] - S.child_ptr[s];
+            if (nchild >= 1 && nchild <= 8) {
+                // Few children (the separators of a dissection have two): their row lists are sorted, so the union is a merge --
+                // the entries of A first (few, sorted here), then child after child; no sort of the whole list (the sorts of the
+                // large supernodes were most of this phase: 0.8 s at 200^3).
+                std::sort(rows.begin(), rows.end());
+                for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
+                    const int32_t ch = S.child_idx[c];
+                    const int32_t *cb = S.sn_rows.data() + S.sn_rowptr[ch], *ce = S.sn_rows.data() + S.sn_rowptr[ch + 1];
+                    cb = std::upper_bound(cb, ce, last); // the child's rows beyond this supernode's pivots
+                    if (cb == ce) continue;
+                    merged.clear();
+                    merged.reserve(rows.size() + (size_t)(ce - cb));
+                    std::set_union(rows.begin(), rows.end(), cb, ce, std::back_inserter(merged));
+                    rows.swap(merged);
+                }
+            } else {
+                for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
+                    int32_t ch = S.child_idx[c];
+                    for (int64_t p = S.sn_rowptr[ch]; p < S.sn_rowptr[ch + 1]; p++) {
+                        int32_t i = S.sn_rows[p];
+                        if (i > last && mark[i] != s) {
+                            mark[i] = s;
+                            rows.push_back(i);
+                        }
                     }
                 }
+                std::sort(rows.begin(), rows.end());
             }
-            std::sort(rows.begin(), rows.end());
             S.sn_rows.insert(S.sn_rows.end(), rows.begin(), rows.end());
             S.sn_rowptr[s + 1] = (int64_t)S.sn_rows.size();
         }
@@ -898,43 +919,55 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.persist_doubles = pers;
     {
         // arena plan: best fit over a coalescing free list, levels in execution order
-        struct Blk {
-            int64_t off, size;
-        };
-        std::vector<Blk> freeb; // ascending by offset
+        // (free blocks by offset for coalescing and by (size, offset) for the best-fit search: the same choices as a linear scan over a
+        //  list sorted by offset -- smallest sufficient block, lowest offset among equals -- in O(log) per request; the scan took
+        //  0.6 - 0.8 s of the analysis of the 200^3 matrix, 190 000 tiled fronts)
+        std::map<int64_t, int64_t> by_off;             // offset -> size
+        std::set<std::pair<int64_t, int64_t>> by_size; // (size, offset)
         int64_t top = 0;
         auto take = [&](int64_t sz) -> int64_t {
-            int best = -1;
-            for (int i = 0; i < (int)freeb.size(); i++)
-                if (freeb[i].size >= sz && (best < 0 || freeb[i].size < freeb[best].size)) best = i;
-            if (best >= 0) {
-                const int64_t off = freeb[best].off;
-                freeb[best].off += sz, freeb[best].size -= sz;
-                if (freeb[best].size == 0) freeb.erase(freeb.begin() + best);
+            auto it = by_size.lower_bound(std::make_pair(sz, (int64_t)INT64_MIN));
+            if (it != by_size.end()) {
+                const int64_t bsz = it->first, off = it->second;
+                by_size.erase(it);
+                by_off.erase(off);
+                if (bsz > sz) {
+                    by_off.emplace(off + sz, bsz - sz);
+                    by_size.emplace(bsz - sz, off + sz);
+                }
                 return off;
             }
-            if (!freeb.empty() && freeb.back().off + freeb.back().size == top) { // grow the free block at the end of the arena
-                const int64_t off = freeb.back().off;
-                freeb.pop_back();
-                top = off + sz;
-                return off;
+            if (!by_off.empty()) { // grow the free block at the end of the arena
+                auto last = std::prev(by_off.end());
+                if (last->first + last->second == top) {
+                    const int64_t off = last->first;
+                    by_size.erase(std::make_pair(last->second, last->first));
+                    by_off.erase(last);
+                    top = off + sz;
+                    return off;
+                }
             }
             const int64_t off = top;
             top += sz;
             return off;
         };
         auto give = [&](int64_t off, int64_t sz) {
-            size_t i = 0;
-            while (i < freeb.size() && freeb[i].off < off) i++;
-            freeb.insert(freeb.begin() + (std::ptrdiff_t)i, Blk{off, sz});
-            if (i + 1 < freeb.size() && freeb[i].off + freeb[i].size == freeb[i + 1].off) {
-                freeb[i].size += freeb[i + 1].size;
-                freeb.erase(freeb.begin() + (std::ptrdiff_t)i + 1);
+            auto nx = by_off.lower_bound(off);
+            if (nx != by_off.end() && off + sz == nx->first) { // merge with the block behind
+                sz += nx->second;
+                by_size.erase(std::make_pair(nx->second, nx->first));
+                nx = by_off.erase(nx);
             }
-            if (i > 0 && freeb[i - 1].off + freeb[i - 1].size == freeb[i].off) {
-                freeb[i - 1].size += freeb[i].size;
-                freeb.erase(freeb.begin() + (std::ptrdiff_t)i);
+            if (nx != by_off.begin()) {
+                auto pv = std::prev(nx);
+                if (pv->first + pv->second == off) { // merge with the block in front
+                    off = pv->first, sz += pv->second;
+                    by_size.erase(std::make_pair(pv->second, pv->first));
+                    by_off.erase(pv);
+                }
             }
+            by_off.emplace(off, sz);
+            by_size.emplace(sz, off);
         };
         std::vector<std::vector<int32_t>> expire((size_t)S.nlevels);
         std::vector<int32_t> bigs;
