@@ -26,7 +26,7 @@ keep = ci <= rows
 rpl = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=n))]).astype(np.int32)
 cil, vl = ci[keep], v[keep]
 del rows, keep
-s = Hipmf()
+s = Hipmf(os.environ.get("HIPMF_LIB") or None)
 t0 = time.perf_counter()
 code = s.initialize(n, rpl, cil, general_symmetric=True)
 t_init = time.perf_counter() - t0
