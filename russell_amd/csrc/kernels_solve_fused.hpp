@@ -97,32 +97,6 @@ template <int K> __device__ __forceinline__ void ld_cols(double (&v)[K], const d
     for (int c = 0; c < K; c++) v[c] = ld_agent(base + (int64_t)(c < nk ? c : 0) * cstr + off);
 }
 
-// The K columns of one row per lane (v[c] = entry (row `lane`, column c)) go out as 16-byte stores: lanes 2i and 2i + 1 trade values so
-// that the even lane holds rows (2i, 2i + 1) of column c and the odd lane the same rows of column c + 1 -- K / 2 stores of two consecutive
-// doubles per lane instead of K single ones (the stores + their drain were 7 - 9 of the 16 - 22 us of a blocked small-front step).
-// Column c, row r lives at dst(c) + r; row r is stored when lo <= r < hi.  A pair of rows that straddles lo or hi, and K = 1, use 8-byte stores.
-template <int K, typename Dst> __device__ __forceinline__ void st_cols_paired(const double (&v)[K], int lane, int lo, int hi, int nk, Dst dst) {
-    if constexpr (K == 1) {
-        if (lane >= lo && lane < hi) st_agent(dst(0) + lane, v[0]);
-    } else {
-        const int r0 = lane & ~1;                           // first row of this lane's pair
-        const bool whole = r0 >= lo && r0 + 1 < hi;         // both rows inside: one 16-byte store per column pair and lane
-        const bool mine = lane >= lo && lane < hi;
-#pragma unroll
-        for (int c = 0; c < K; c += 2) {
-            const double oa = __shfl_xor(v[c], 1), ob = __shfl_xor(v[c + 1], 1);
-            if (c >= nk) continue; // (wave-uniform)
-            if (whole) {
-                if (!(lane & 1)) st_agent2(dst(c) + r0, v[c], oa);
-                else if (c + 1 < nk) st_agent2(dst(c + 1) + r0, ob, v[c + 1]);
-            } else if (mine) {
-                st_agent(dst(c) + lane, v[c]);
-                if (c + 1 < nk) st_agent(dst(c + 1) + lane, v[c + 1]);
-            }
-        }
-    }
-}
-
 // All kernels are templates on K = the number of right-hand sides a launch carries (1: the instances the
 // benchmark path uses; SF_KMAX: the many-RHS instances, which read every factor entry ONCE for K columns -- the
 // solves are HBM-bound, so K columns cost little more than one).  Column c of x lives at x + c * xstr, its solve
@@ -236,8 +210,12 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
 #pragma unroll
         for (int q = 0; q < CH; q++) a[q] = an[q];
     }
-    st_cols_paired<K>(v, lane, 0, p, nk, [&](int c) { return xs + (int64_t)c * xstr; }); // y1: rows [0, p) of x
-    st_cols_paired<K>(v, lane, p, f, nk, [&](int c) { return W + (int64_t)c * wstr; });  // the update: rows [p, f) of the work vector
+#pragma unroll
+    for (int c = 0; c < K; c++)
+        if (c < nk) {
+            if (lane < p) st_agent(xs + c * xstr + lane, v[c]);
+            else if (lane < f) st_agent(W + c * wstr + lane, v[c]);
+        }
     drain_stores();
     if (lane == 0) flag_add(done + s, 1);
 }
@@ -334,7 +312,11 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
             }
         }
     }
-    st_cols_paired<K>(v, lane, 0, p, nk, [&](int c) { return xs + (int64_t)c * xstr; });
+    if (lane < p) {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+            if (c < nk) st_agent(xs + c * xstr + lane, v[c]);
+    }
     drain_stores();
     if (lane == 0) flag_add(done + s, 1);
 }

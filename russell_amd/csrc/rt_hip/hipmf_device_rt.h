@@ -114,13 +114,6 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
 __device__ __forceinline__ int flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int flag_add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// two consecutive doubles in ONE write-through (sc1) store.  An 8-byte agent-scope store is one fabric transaction per lane
-// (MI355X_MICROARCH.md: 2.7x the time per byte of a 16-byte one); the address needs 8-byte alignment only.  The instruction is written
-// in assembly (the atomic-store builtins stop at 8 bytes); drain_stores() waits for it like for any other store (vmcnt).
-__device__ __forceinline__ void st_agent2(double *p, double v0, double v1) {
-    f64x2 v = {v0, v1};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
 // every wave that stored hand-off data drains its stores before the flag is raised (inline asm: the compiler
 // must not drop or move this wait)
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

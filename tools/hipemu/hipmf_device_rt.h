@@ -70,10 +70,6 @@ inline unsigned __float_as_uint(float f) {
 // dependency is always satisfied before its consumer starts; these keep the protocol's code path alive)
 inline double ld_agent(const double *p) { return *(const volatile double *)p; }
 inline void st_agent(double *p, double v) { *(volatile double *)p = v; }
-inline void st_agent2(double *p, double v0, double v1) {
-    ((volatile double *)p)[0] = v0;
-    ((volatile double *)p)[1] = v1;
-}
 inline int flag_load(const int *p) { return *(const volatile int *)p; }
 inline int flag_add(int *p, int v) {
     int o = *p;
