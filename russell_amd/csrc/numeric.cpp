@@ -198,7 +198,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         so.dense_leaves = v > 0;
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
-    if (const char *e = getenv("HIPMF_SOLVE_LANES")) solve_lanes = std::max(1, std::min(MAX_SOLVE_LANES, atoi(e)));
+    solve_lanes_auto = true;
+    if (const char *e = getenv("HIPMF_SOLVE_LANES")) solve_lanes = std::max(1, std::min(MAX_SOLVE_LANES, atoi(e))), solve_lanes_auto = false;
     if (const char *e = getenv("HIPMF_SMALL_WIDE")) small_wide_max = atoi(e);
     if (const char *e = getenv("HIPMF_SMALL_SPLIT")) small_split = atoi(e);
     if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
@@ -1684,7 +1685,12 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     }
     if (KB > 1) block_cols = KB;
     const int32_t nblocks = (nrhs + KB - 1) / KB;
-    const int32_t nlanes = KB > 1 ? std::max(1, std::min(solve_lanes, nblocks)) : 1;
+    // Two blocks in flight hide the host round trips of the refinement (residual norms) behind the other block's kernels: worth 10 - 20 %
+    // while a pass lasts a millisecond.  When the factor is tens of gigabytes a pass lasts 0.1 s, the round trips vanish, and two
+    // launches full of waiting workgroups only get in each other's way (200^3, 256 right-hand sides: 3.0 - 3.7 s on two lanes from run
+    // to run, 3.3 s on one; each lane also holds its own block and workspace buffers, 25 GB there): one lane from 64 GB of factor on.
+    const int32_t lanes_here = (solve_lanes_auto && 8.0 * (double)S.persist_doubles > 64e9) ? 1 : solve_lanes;
+    const int32_t nlanes = KB > 1 ? std::max(1, std::min(lanes_here, nblocks)) : 1;
     const size_t sync_words = 2 * (size_t)(SF_SYNC_HEADER + S.nsuper) + 1;
     if (KB > 1 && !d_blk) {
         // xp | du | r | den | b | x: six n x KB blocks, plus KB solve workspaces

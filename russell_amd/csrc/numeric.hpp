@@ -267,6 +267,7 @@ class Solver {
     double *h_nrm = nullptr;   // pinned: norms of every lane
     double *h_stage = nullptr; // pinned: rhs | x of a single host-pointer solve
     int32_t solve_lanes = 2;   // HIPMF_SOLVE_LANES (1..4)
+    bool solve_lanes_auto = true; // no HIPMF_SOLVE_LANES given: one lane when the factor exceeds 64 GB (solve())
     int32_t block_cols = 0;    // columns per block of the many-RHS driver once its buffers exist (8 or 16; HIPMF_BLOCK_COLS forces one)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
