@@ -509,6 +509,15 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
 
 int32_t Solver::upload_plan() {
     const int32_t ns = S.nsuper;
+    auto pl_t = std::chrono::steady_clock::now();
+    std::string pl_log;
+    auto pl_lap = [&](const char *what) { // (verbose: where the plan + upload time of initialize goes)
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.3f s;", what, std::chrono::duration<double>(now - pl_t).count());
+        pl_log += buf;
+        pl_t = now;
+    };
     std::vector<FrontDesc> fd((size_t)ns);
     work_doubles = 0;
     for (int32_t s = 0; s < ns; s++) {
@@ -757,6 +766,7 @@ int32_t Solver::upload_plan() {
         }
     }
     if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
+    pl_lap("factor launch plans");
     allbig_off = (int32_t)lists.size();
     allbig_cnt = (int32_t)allbig.size();
     lists.insert(lists.end(), allbig.begin(), allbig.end());
@@ -1082,6 +1092,7 @@ int32_t Solver::upload_plan() {
         HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
         HIPC(hipMemset(d_sync, 0, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
     }
+    pl_lap("solve task lists + their uploads");
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_bigfd, bigfd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
@@ -1107,9 +1118,14 @@ int32_t Solver::upload_plan() {
         HIPC(dev_upload(&d_rel, relp), ERROR_HIP_MALLOC);
     }
     HIPC(dev_upload(&d_child, S.child_idx), ERROR_HIP_MALLOC);
+    pl_lap("descriptor / index uploads");
     // (+ WT_CHUNK: the wave-subtree kernels read the factor in whole 1 KB pieces)
+    // (tried: these two allocations on a host thread of their own beside the planning -- the runtime serialises the plan uploads behind
+    //  the large allocation, initialize of the 200^3 matrix 6.0 -> 6.9 s)
     HIPC(hipMalloc((void **)&d_pool, sizeof(double) * (std::max<int64_t>(pool_doubles, 1) + WT_CHUNK)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_work, sizeof(double) * (std::max<int64_t>(work_doubles, 1) + 64)), ERROR_HIP_MALLOC);
+    pl_lap("pool + workspace allocation");
+    if (opt.verbose) fprintf(stderr, "hipmf: initialize: plan pieces:%s\n", pl_log.c_str());
     return SUCCESSFUL_EXIT;
 }
 
