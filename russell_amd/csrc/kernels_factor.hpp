@@ -419,17 +419,6 @@ __global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD,
     }
 }
 
-// Tiled path, step k0 (base = k0 + nb, active range [base, f + base)):
-//   every workgroup factorises the diagonal tile itself (wave 0, registers) while all its threads prefetch
-//   the workgroup's own tile;  then
-//   L tiles  (rows of the range, columns of the tile):   X <- X * U_kk^{-1}       (covers L21 and E')
-//   U tiles  (columns of the range, rows of the tile):   X <- L_kk^{-1} * (P X)   (covers U12 and E)
-// One thread owns one row (L) / one column (U) and runs a right-looking substitution in registers.
-// The factorised tile is NOT written into F here (other workgroups still read the original): workgroup 0
-// of each front parks it in dws, k_update moves it into place.
-// SYM: the L tiles cover the rows of F below the tile only (and leave U12 = D L21^T in the upper triangle for the trailing update),
-// the U tiles the columns of E only;
-// the tile is factorised without interchanges from its lower triangle.
 // Memory access of the tiled kernels' bodies.  COH = false: plain loads and stores (one launch per step: the launch boundary orders
 // everything).  COH = true: agent-scope (sc1) accesses for the chained launch (k_chain, kernels_factor_chain.hpp), whose workgroups
 // consume what other workgroups of the SAME launch produced -- the eight XCDs' L2s are not coherent with each other inside a launch.
@@ -464,6 +453,17 @@ struct PanelLds {
     int32_t lp[NB];
 };
 
+// Tiled path, step k0 (base = k0 + nb, active range [base, f + base)):
+//   every workgroup factorises the diagonal tile itself (wave 0, registers) while all its threads prefetch
+//   the workgroup's own tile;  then
+//   L tiles  (rows of the range, columns of the tile):   X <- X * U_kk^{-1}       (covers L21 and E')
+//   U tiles  (columns of the range, rows of the tile):   X <- L_kk^{-1} * (P X)   (covers U12 and E)
+// One thread owns one row (L) / one column (U) and runs a right-looking substitution in registers.
+// The factorised tile is NOT written into F here (other workgroups still read the original): workgroup 0
+// of each front parks it in dws, k_update moves it into place.
+// SYM: the L tiles cover the rows of F below the tile only (and leave U12 = D L21^T in the upper triangle for the trailing update),
+// the U tiles the columns of E only;
+// the tile is factorised without interchanges from its lower triangle.
 // One panel tile (tile t of the front in `slot`) of step k0.  NT = threads of the workgroup: PANEL_T of them work (k_chain's
 // workgroups have 256: the others only take part in the barriers).
 template <bool SYM, bool COH, int NT>
@@ -745,6 +745,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // exactly as the LU instance does; rows of E are read as they are.
 // (Tried and rejected: 128 x 128 tiles, four 64 x 64 waves -- 204 VGPRs + 128 AGPRs, one workgroup per CU: 962 ms instead of
 // 924 ms for the 128^3 Poisson factorisation.)
+//
 // LDS of an update workgroup (the look-ahead workgroup's tile buffer shares the space of Ls: it never touches Ls / Us)
 struct UpdateLds {
     static constexpr int LSLD = UPD_T + 16; // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
