@@ -747,24 +747,31 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
 // 924 ms for the 128^3 Poisson factorisation.)
 //
 // LDS of an update workgroup (the look-ahead workgroup's tile buffer shares the space of Ls: it never touches Ls / Us)
-struct UpdateLds {
-    static constexpr int LSLD = UPD_T + 16; // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
+// TS: tile edge.  64: a 256-thread workgroup, four waves of 32 x 32 (the large fronts); 32 (UPD_T_SMALL): ONE wave per tile -- the
+// levels in the middle of the tree hold thousands of fronts of 65 - 200 rows, where a 64 x 64 grid wastes up to 44 % of every edge and
+// three of a tile's four waves often have nothing live (k_update32).  A wave's work is the same in both: 2 x 2 MFMA tiles, same
+// k order -- the two instances give bit-identical trailing matrices.
+constexpr int UPD_T_SMALL = 32;
+template <int TS> struct UpdateLdsT {
+    static constexpr int LSLD = TS + 16; // (TS + 16) mod 32 == 16: the two kk rows of a ds_read_b64 pass fall into disjoint banks
     __attribute__((aligned(16))) double LsUM[(NB * LSLD > NB * (NB + 2)) ? NB * LSLD : NB * (NB + 2)];
-    double Us[UPD_T * US_LD];
+    double Us[TS * US_LD];
 };
+typedef UpdateLdsT<UPD_T> UpdateLds;
 
 // One tile (t < ntiles) or the look-ahead piece (t == ntiles) of the trailing update of step k0 of the front in `slot`.
-template <bool SYM, bool COH>
-__device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const int t, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
+template <bool SYM, bool COH, int TS = UPD_T>
+__device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, const int t, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
                                             double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                             const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
                                             double *__restrict__ diag) {
     typedef TileMem<COH> M;
     constexpr bool CLA = COH || HIPMF_CLAMP_LA;
-    constexpr int TS = UPD_T;
-    constexpr int LSLD = UpdateLds::LSLD;
-    constexpr int MT = TS / 32;    // MFMA tiles per wave and dimension
-    constexpr int NE = TS / 8;     // panel entries per thread and 32-column slice (L and U each)
+    static_assert(TS == 64 || TS == 32, "tile edge");
+    constexpr int NT = TS == 64 ? 256 : 64; // threads of the workgroup
+    constexpr int LSLD = UpdateLdsT<TS>::LSLD;
+    constexpr int MT = 2;                   // MFMA tiles per wave and dimension (a wave owns 32 x 32)
+    constexpr int NE = TS * NB / NT;        // panel entries per thread and 32-column slice (L and U each)
     double *Ls = sh.LsUM;
     double *Us = sh.Us;
     double(*UM)[NB + 2] = reinterpret_cast<double(*)[NB + 2]>(sh.LsUM);
@@ -909,12 +916,12 @@ __device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const
     const int rend = rowsE ? limit : f, cend = colsE ? limit : f;
     if (t == 0) {
         const double *dw = dws + ((int64_t)((k0 / NB) & 1) * dws_stride + slot) * NB * NB;
-        double dv[NB * NB / 256];
+        double dv[NB * NB / NT];
 #pragma unroll
-        for (int u = 0; u < NB * NB / 256; u++) dv[u] = M::ld(dw + (tid + 256 * u < nb * nb ? tid + 256 * u : 0));
+        for (int u = 0; u < NB * NB / NT; u++) dv[u] = M::ld(dw + (tid + NT * u < nb * nb ? tid + NT * u : 0));
 #pragma unroll
-        for (int u = 0; u < NB * NB / 256; u++) {
-            const int e = tid + 256 * u;
+        for (int u = 0; u < NB * NB / NT; u++) {
+            const int e = tid + NT * u;
             if (e < nb * nb) M::st(F + (k0 + e % nb) + (int64_t)(k0 + e / nb) * A.ld, dv[u]);
         }
     }
@@ -927,7 +934,7 @@ __device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const
     const int cmin = rowstrip ? base + nb2 : 0;
     if (SYM && rowstrip && !colsE) return;         // row strip of a symmetric front: only the columns of E are live
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave & 1) * (TS / 2), wc = (wave >> 1) * (TS / 2);
+    const int wr = TS == 64 ? (wave & 1) * 32 : 0, wc = TS == 64 ? (wave >> 1) * 32 : 0; // this wave's 32 x 32 part of the tile
     const int l15 = lane & 15, l4 = lane >> 4;
     double lreg[NE], ureg[NE];
     const double *Lb = rowsE ? A.Epsh : F;             // rows of the L slice: (r, k) at Lb[r + k * lstr]
@@ -940,7 +947,7 @@ __device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const
     {                                                                                                                  \
         const int kh = kfirst + (h) * NB, nbh = ((h) == nhalf - 1) ? nb : NB;                                          \
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
-            const int e = tid + 256 * u;                                                                               \
+            const int e = tid + NT * u;                                                                                \
             const int r = e % TS, kk = e / TS;                                                                         \
             const int k2 = e % NB, c = c0 + e / NB;                                                                    \
             const bool lin = r0 + r < rend && kk < nbh, uin = c < cend && k2 < nbh;                                    \
@@ -957,7 +964,7 @@ __device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const
 #define HIPMF_STORE_SLICE()                                                                                            \
     {                                                                                                                  \
         _Pragma("unroll") for (int u = 0; u < NE; u++) {                                                               \
-            const int e = tid + 256 * u;                                                                               \
+            const int e = tid + NT * u;                                                                                \
             Ls[(e / TS) * LSLD + e % TS] = lreg[u];                                                                    \
             Us[(e / NB) * US_LD + e % NB] = ureg[u];                                                                   \
         }                                                                                                              \
@@ -992,8 +999,7 @@ __device__ __forceinline__ void update_body(UpdateLds &sh, const int slot, const
     __syncthreads();
     if (nhalf > 1) HIPMF_FETCH_SLICE(1) // in flight while the first slice is multiplied
     // strips of a narrow step: a wave whose quarter of the tile holds no live entry has nothing to multiply
-    const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + TS / 2 <= cmin) || (r0 + wr >= rmax) ||
-                           (SYM && !colsE && r0 + wr + TS / 2 <= c0 + wc);
+    const bool wave_idle = (c0 + wc >= cmax) || (c0 + wc + 32 <= cmin) || (r0 + wr >= rmax) || (SYM && !colsE && r0 + wr + 32 <= c0 + wc);
     f64x4 acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; a++)
@@ -1049,6 +1055,22 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
     FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
     fd_resident(fd);
     update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
+}
+
+// the same with 32 x 32 tiles, one wavefront per tile (levels whose largest tiled front has at most Solver::upd32_max_front rows)
+template <bool SYM>
+__global__ void __launch_bounds__(64) k_update32(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+                                                 int32_t k0, double *__restrict__ pool,
+                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
+                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                 double *__restrict__ diag) {
+    __shared__ UpdateLdsT<UPD_T_SMALL> sh;
+    int pfx_slot;
+    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    const int t = blockIdx.x - pfx_slot;
+    FrontDesc fd = LFD[slot];
+    fd_resident(fd);
+    update_body<SYM, false, UPD_T_SMALL>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
 }
 
 } // namespace hipmf

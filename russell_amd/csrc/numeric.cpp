@@ -227,6 +227,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_CHAIN_MAX_WGS")) chain_max_update = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_CHAIN_MIN_WGS")) chain_min_update = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_CHAIN_MAX_STEPS")) chain_max_steps = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_UPD32_MAXF")) upd32_max_front = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -594,6 +595,13 @@ int32_t Solver::upload_plan() {
         max_big = std::max(max_big, L.big_cnt);
         // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
         int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
+        {
+            int32_t fmax_big = 0;
+            for (int32_t a : big) fmax_big = std::max(fmax_big, S.fsize(a));
+            const bool forced = getenv("HIPMF_UPD32_MAXF") != nullptr; // (an explicit setting also applies to the symmetric fronts)
+            L.upd_ts = (!big.empty() && fmax_big <= upd32_max_front && (!S.sym_mode || forced)) ? UPD_T_SMALL : UPD_T;
+        }
+        const int64_t UT = L.upd_ts;
         for (int32_t k0 = 0; k0 < pmax; k0 += NB) {
             StepPlan st;
             while (st.nactive < L.big_cnt && S.npiv(big[st.nactive]) > k0) st.nactive++;
@@ -611,7 +619,7 @@ int32_t Solver::upload_plan() {
                 tasks.push_back((int32_t)acc);
                 // tiles per dimension of k_update at this step: [base, f) and [f, f + base) are tiled separately (base = k0 + nb)
                 const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
-                const int64_t ntF = (fa - basea + UPD_T - 1) / UPD_T, ntE = (basea + UPD_T - 1) / UPD_T;
+                const int64_t ntF = (fa - basea + UT - 1) / UT, ntE = (basea + UT - 1) / UT;
                 int64_t nt = ntF + ntE;
                 const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
                 const int32_t G = update_group(S.fsize(big[a]));
@@ -630,7 +638,7 @@ int32_t Solver::upload_plan() {
         {
             int64_t maxu = 0;
             for (const StepPlan &st : L.steps) maxu = std::max<int64_t>(maxu, st.n_update);
-            if (use_chain && !L.steps.empty() && maxu <= chain_max_update && maxu >= chain_min_update && (int32_t)L.steps.size() <= chain_max_steps) {
+            if (use_chain && L.upd_ts == UPD_T && !L.steps.empty() && maxu <= chain_max_update && maxu >= chain_min_update && (int32_t)L.steps.size() <= chain_max_steps) {
                 const int32_t nsteps = (int32_t)L.steps.size();
                 const int64_t cbase = chain_words;
                 auto cidx = [&](int32_t a, int32_t si, int32_t j) { return (int32_t)(cbase + ((int64_t)a * nsteps + si) * 3 + j); };
@@ -1348,13 +1356,21 @@ int32_t Solver::run_factor() {
             if (S.sym_mode) {
                 hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
-                if (st.n_update > 0) hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                   d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                if (st.n_update > 0 && L.upd_ts == UPD_T)
+                    hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else if (st.n_update > 0)
+                    hipLaunchKernelGGL(k_update32<true>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             } else {
                 hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
-                hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                   d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                if (L.upd_ts == UPD_T)
+                    hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else
+                    hipLaunchKernelGGL(k_update32<false>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             }
             launches += 2;
             k0 += NB;

@@ -78,6 +78,7 @@ struct LevelPlan {
     int32_t big_pmax = 0, big_fmax = 0;
     bool wide = false; // solve with 32-row slabs x 32 column groups (few large fronts)
     std::vector<StepPlan> steps;
+    int32_t upd_ts = 64;    // edge of the trailing-update tiles on this level (32: k_update32, one wave per tile)
     int64_t chain_off = 0;  // the level's tiled steps as ONE launch (k_chain): its tasks in d_chain, chain_cnt of them (0: one launch per step)
     int32_t chain_cnt = 0;
 };
@@ -226,6 +227,9 @@ class Solver {
     void *d_chain = nullptr;                // ChainTask records of all chained levels
     int32_t *d_chain_cnt = nullptr;         // their counters (3 per front and step) + the error word (last); zeroed before every factorisation
     int64_t chain_words = 0;
+    int32_t upd32_max_front = 256;          // LU: levels whose largest tiled front has at most this many rows update with 32 x 32 tiles, one wave per tile
+                                            // (HIPMF_UPD32_MAXF; 0: never).  Bit-identical to the 64 x 64 instance; 1000 x 1000: 7.30 -> 7.23 ms.  The L D L^T
+                                            // fronts keep the 64 x 64 tiles (measured: 6.32 -> 6.35 ms with the small ones)
     int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)

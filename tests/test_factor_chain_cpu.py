@@ -52,3 +52,16 @@ def test_chained_steps_give_the_same_factor_bit_for_bit(emu_lib, case):
         assert np.array_equal(ref[3], got[3])
         assert got[5] == 0
     assert _run(emu_lib, n, rp, ci, v, variants[1], **kw)[4] <= ref[4]  # (fewer launches as soon as a level has more than one step)
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_small_update_tiles_give_the_same_factor_bit_for_bit(emu_lib, case):
+    # k_update32: 32 x 32 trailing-update tiles, one wavefront per tile, on the levels of mid-size fronts (default for LU up to 256
+    # rows; HIPMF_UPD32_MAXF).  A wavefront does the same 2 x 2 MFMA tiles in the same k order as a quarter of a 64 x 64 tile.
+    _, (n, rp, ci, v), kw = case
+    ref = _run(emu_lib, n, rp, ci, v, {"HIPMF_UPD32_MAXF": "0"}, **kw)
+    for mf in ("80", "100000"):
+        got = _run(emu_lib, n, rp, ci, v, {"HIPMF_UPD32_MAXF": mf}, **kw)
+        assert np.array_equal(ref[0], got[0]), mf
+        assert ref[1:3] == got[1:3], mf
+        assert np.array_equal(ref[3], got[3])

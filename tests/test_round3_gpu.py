@@ -286,3 +286,26 @@ def test_chained_tiled_steps_equal_one_launch_per_step_bitwise(kind, monkeypatch
         for x, dc, de in outs:
             assert np.array_equal(ref[0], x), env
             assert (dc, de) == ref[1:], env
+
+
+@pytest.mark.parametrize("kind", ["lu", "ldlt"])
+def test_small_update_tiles_equal_the_large_ones_bitwise(kind, monkeypatch):
+    # k_update32 (32 x 32 tiles, one wavefront each; the default for LU levels with fronts of at most 256 rows) against the 64 x 64 tiles
+    n, rp, ci, v = P.poisson2d(400, 380)
+    kw = {}
+    if kind == "ldlt":
+        rp, ci, v = P.lower_triangle(n, rp, ci, v)
+        kw = {"general_symmetric": True}
+    else:
+        v = v * (1.0 + 0.2 * np.random.default_rng(5).uniform(-1, 1, v.size))
+    b = np.cos(np.arange(n))
+    outs = []
+    for mf in ("0", "256", "100000"):
+        monkeypatch.setenv("HIPMF_UPD32_MAXF", mf)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+        assert s.factorize(v, compute_determinant=True) == 0
+        outs.append((s.solve(b), s.det_coefficient, s.det_exponent))
+        s.close()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and outs[0][1:] == o[1:]
