@@ -36,6 +36,21 @@ struct InterfaceHIPMF {
     int64_t nnz_lower = 0;
 };
 
+// No C++ exception crosses the C boundary: a failed host allocation (the analysis of a large matrix takes gigabytes) comes back as
+// ERROR_MALLOC, the code of the reference's shims for the same event (c_code/constants.h:6), with a message the reference's harness
+// recognises as a memory error (stats_lin_sol.rs:334-340); anything else as ERROR_HIPMF_SYMBOLIC.
+template <typename Fn> static int32_t guarded(struct InterfaceHIPMF *h, Fn fn) {
+    try {
+        return fn();
+    } catch (const std::bad_alloc &) {
+        if (h) h->solver.last_error = "Not enough memory: a host allocation failed";
+        return ERROR_MALLOC;
+    } catch (const std::exception &e) {
+        if (h) h->solver.last_error = std::string("internal error: ") + e.what();
+        return ERROR_HIPMF_SYMBOLIC;
+    }
+}
+
 extern "C" {
 
 struct InterfaceHIPMF *solver_hipmf_new(void) {
@@ -50,7 +65,7 @@ void solver_hipmf_drop(struct InterfaceHIPMF *h) {
     delete h;
 }
 
-int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
+static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
                                 int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, C_BOOL positive_definite,
                                 int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
     // either flag promises the LOWER triangle of a symmetric matrix (interface_cudss.cu:324-333: SYMMETRIC / SPD + lower view); the
@@ -212,7 +227,7 @@ static int32_t finish_factorize(struct InterfaceHIPMF *h, int32_t code, int32_t 
     return code;
 }
 
-int32_t solver_hipmf_factorize(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+static int32_t factorize_body(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
                                int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
                                double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *values) {
     if (!h || !values) return ERROR_NULL_POINTER;
@@ -225,7 +240,7 @@ int32_t solver_hipmf_factorize(struct InterfaceHIPMF *h, int32_t *effective_orde
                             determinant_coefficient, determinant_exponent, compute_determinant);
 }
 
-int32_t solver_hipmf_set_value_map(struct InterfaceHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
+static int32_t set_value_map_body(struct InterfaceHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
     if (!h) return ERROR_NULL_POINTER;
     if (!h->expanded) return h->solver.set_value_map(nnz_in, seg_ptr, seg_idx);
     // the caller's map speaks of ITS CSR (the lower triangle): entry k of the handle's general CSR takes the segment of entry emap[k]
@@ -253,7 +268,7 @@ int32_t solver_hipmf_set_value_map(struct InterfaceHIPMF *h, int32_t nnz_in, con
     return h->solver.set_value_map(nnz_in, sp.data(), si.data(), true);
 }
 
-int32_t solver_hipmf_factorize_mapped(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+static int32_t factorize_mapped_body(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
                                       int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
                                       double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *input_values) {
     if (!h || !input_values) return ERROR_NULL_POINTER;
@@ -264,19 +279,19 @@ int32_t solver_hipmf_factorize_mapped(struct InterfaceHIPMF *h, int32_t *effecti
                             determinant_exponent, compute_determinant);
 }
 
-int32_t solver_hipmf_factorize_mapped_device(struct InterfaceHIPMF *h, const double *d_input_values) {
+static int32_t factorize_mapped_device_body(struct InterfaceHIPMF *h, const double *d_input_values) {
     if (!h || !d_input_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     return h->solver.factorize_mapped(d_input_values, true);
 }
 
-int32_t solver_hipmf_factorize_device(struct InterfaceHIPMF *h, const double *d_values) {
+static int32_t factorize_device_body(struct InterfaceHIPMF *h, const double *d_values) {
     if (!h || !d_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     return h->solver.factorize(d_values, true);
 }
 
-int32_t solver_hipmf_solve(struct InterfaceHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
+static int32_t solve_body(struct InterfaceHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
     if (!h || !x || !rhs) return ERROR_NULL_POINTER;
     if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
     h->solver.opt.verbose = verbose == 1;
@@ -287,17 +302,60 @@ int32_t solver_hipmf_solve(struct InterfaceHIPMF *h, double *x, const double *rh
     return code;
 }
 
-int32_t solver_hipmf_solve_many(struct InterfaceHIPMF *h, double *x, const double *rhs, int32_t nrhs, int32_t ld, C_BOOL verbose) {
+static int32_t solve_many_body(struct InterfaceHIPMF *h, double *x, const double *rhs, int32_t nrhs, int32_t ld, C_BOOL verbose) {
     if (!h || !x || !rhs) return ERROR_NULL_POINTER;
     if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
     h->solver.opt.verbose = verbose == 1;
     return h->solver.solve(x, rhs, nrhs, ld, false);
 }
 
-int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *h, double *d_x, const double *d_rhs, int32_t nrhs, int32_t ld) {
+static int32_t solve_device_body(struct InterfaceHIPMF *h, double *d_x, const double *d_rhs, int32_t nrhs, int32_t ld) {
     if (!h || !d_x || !d_rhs) return ERROR_NULL_POINTER;
     if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
     return h->solver.solve(d_x, d_rhs, nrhs, ld, true);
+}
+
+
+int32_t solver_hipmf_initialize(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
+                                int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, C_BOOL positive_definite,
+                                int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
+    return guarded(h, [&]() { return initialize_body(h, ordering, scaling, pivot_epsilon, refinement_nstep, verbose, general_symmetric, positive_definite, ndim, row_pointers, col_indices, values); });
+}
+
+int32_t solver_hipmf_factorize(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+                               int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
+                               double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *values) {
+    return guarded(h, [&]() { return factorize_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, determinant_coefficient, determinant_exponent, compute_determinant, verbose, values); });
+}
+
+int32_t solver_hipmf_set_value_map(struct InterfaceHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
+    return guarded(h, [&]() { return set_value_map_body(h, nnz_in, seg_ptr, seg_idx); });
+}
+
+int32_t solver_hipmf_factorize_mapped(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+                                      int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
+                                      double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *input_values) {
+    return guarded(h, [&]() { return factorize_mapped_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, determinant_coefficient, determinant_exponent, compute_determinant, verbose, input_values); });
+}
+
+int32_t solver_hipmf_factorize_mapped_device(struct InterfaceHIPMF *h, const double *d_input_values) {
+    return guarded(h, [&]() { return factorize_mapped_device_body(h, d_input_values); });
+}
+
+int32_t solver_hipmf_factorize_device(struct InterfaceHIPMF *h, const double *d_values) {
+    return guarded(h, [&]() { return factorize_device_body(h, d_values); });
+}
+
+int32_t solver_hipmf_solve(struct InterfaceHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
+    return guarded(h, [&]() { return solve_body(h, x, rhs, verbose); });
+}
+
+int32_t solver_hipmf_solve_many(struct InterfaceHIPMF *h, double *x, const double *rhs, int32_t nrhs, int32_t ld, C_BOOL verbose) {
+    return guarded(h, [&]() { return solve_many_body(h, x, rhs, nrhs, ld, verbose); });
+}
+
+int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *h, double *d_x, const double *d_rhs, int32_t nrhs, int32_t ld) {
+    return guarded(h, [&]() { return solve_device_body(h, d_x, d_rhs, nrhs, ld); });
 }
 
 int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *h, double *v, double alpha, const double *u) {

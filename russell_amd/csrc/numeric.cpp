@@ -296,6 +296,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         }
     };
     std::thread asm_thread([this, &AL]() {
+      try {
         const int32_t ns = S.nsuper;
         std::vector<int32_t> &sa_ptr = AL.sa_ptr;
         std::vector<int64_t> &sc_cnt = AL.sc_cnt;
@@ -362,6 +363,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             AL.zero_n[(size_t)l] = (int32_t)zt.size() - AL.zero_off[(size_t)l];
         }
         if (zt.size() > 0x7fffffffULL) AL.status = 2;
+      } catch (const std::bad_alloc &) { // (an exception must not leave the thread)
+        AL.status = 3;
+      }
     });
     Joiner asm_joiner{asm_thread};
     const auto t_plan = std::chrono::steady_clock::now();
@@ -447,6 +451,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         if (AL.status == 2) {
             last_error = "too many zero-fill tasks";
             return ERROR_HIPMF_SYMBOLIC;
+        }
+        if (AL.status == 3) {
+            last_error = "Not enough memory: a host allocation failed";
+            return ERROR_MALLOC;
         }
         const int32_t ns = S.nsuper;
         for (int32_t l = 0; l < S.nlevels; l++) {
