@@ -549,246 +549,13 @@ int32_t Solver::upload_plan() {
     }
     pool_doubles = S.persist_doubles + S.temp_doubles;
 
-    std::vector<int32_t> lists, tasks, allbig;
-    std::vector<ChainTask> chain;
-    chain_words = 0;
-    std::vector<FrontDesc> bigfd;
-    std::vector<EaTask> ea;
-    std::vector<EaRange> ear;
-    int32_t max_big = 0;
-    std::vector<SolveTask> stasks;
-    levels.assign((size_t)S.nlevels, LevelPlan());
-    for (int32_t l = 0; l < S.nlevels; l++) {
-        LevelPlan &L = levels[l];
-        std::vector<int32_t> small, big;
-        int32_t fmax_small = 1;
-        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
-            int32_t s = S.level_sn[k];
-            if (S.fsize(s) <= SMALL_F) {
-                small.push_back(s);
-                fmax_small = std::max(fmax_small, S.fsize(s));
-                L.small_pmax = std::max(L.small_pmax, S.npiv(s));
-            } else {
-                big.push_back(s);
-            }
-        }
-        std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
-        // symmetric mode: the tiled fronts of this level whose parent is a small front (it pulls a FULL contribution block)
-        std::vector<int32_t> mirror;
-        if (S.sym_mode)
-            for (int32_t a : big)
-                if (S.sn_parent[a] >= 0 && S.nrow(a) > 0 && S.fsize(S.sn_parent[a]) <= SMALL_F) mirror.push_back(a);
-        // the small fronts of a level go in two launches by size: the LDS a workgroup reserves is that of the largest front of
-        // its launch, and the assembly phases of k_small_factor are latency-bound, i.e. they live on the number of resident waves
-        std::stable_partition(small.begin(), small.end(), [&](int32_t a) { return S.fsize(a) <= small_split; });
-        L.small_cnt_a = 0;
-        int32_t fmax_a = 1;
-        for (int32_t a : small)
-            if (S.fsize(a) <= small_split) L.small_cnt_a++, fmax_a = std::max(fmax_a, S.fsize(a));
-        if (L.small_cnt_a < 2048 || (int32_t)small.size() - L.small_cnt_a < 2048) L.small_cnt_a = 0; // not worth a second launch
-        L.small_ld_a = fmax_a | 1;
-        L.small_off = (int32_t)lists.size();
-        L.small_cnt = (int32_t)small.size();
-        L.small_ld = fmax_small | 1;
-        lists.insert(lists.end(), small.begin(), small.end());
-        L.big_off = (int32_t)lists.size();
-        L.big_cnt = (int32_t)big.size();
-        lists.insert(lists.end(), big.begin(), big.end());
-        L.mirror_off = (int32_t)lists.size();
-        L.mirror_cnt = (int32_t)mirror.size();
-        lists.insert(lists.end(), mirror.begin(), mirror.end());
-        L.bigfd_off = (int32_t)bigfd.size();
-        for (int32_t a : big) bigfd.push_back(fd[(size_t)a]);
-        allbig.insert(allbig.end(), big.begin(), big.end());
-        max_big = std::max(max_big, L.big_cnt);
-        // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
-        int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
-        {
-            int32_t fmax_big = 0;
-            for (int32_t a : big) fmax_big = std::max(fmax_big, S.fsize(a));
-            const bool forced = getenv("HIPMF_UPD32_MAXF") != nullptr; // (an explicit setting also applies to the symmetric fronts)
-            L.upd_ts = (!big.empty() && fmax_big <= upd32_max_front && (!S.sym_mode || forced)) ? UPD_T_SMALL : UPD_T;
-        }
-        const int64_t UT = L.upd_ts;
-        for (int32_t k0 = 0; k0 < pmax; k0 += NB) {
-            StepPlan st;
-            while (st.nactive < L.big_cnt && S.npiv(big[st.nactive]) > k0) st.nactive++;
-            st.pfx_panel = (int64_t)tasks.size();
-            int64_t acc = 0;
-            for (int32_t a = 0; a < st.nactive; a++) {
-                tasks.push_back((int32_t)acc);
-                acc += 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
-            }
-            tasks.push_back((int32_t)acc);
-            st.n_panel = (int32_t)acc;
-            st.pfx_update = (int64_t)tasks.size();
-            acc = 0;
-            for (int32_t a = 0; a < st.nactive; a++) {
-                tasks.push_back((int32_t)acc);
-                // tiles per dimension of k_update at this step: [base, f) and [f, f + base) are tiled separately (base = k0 + nb)
-                const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
-                const int64_t ntF = (fa - basea + UT - 1) / UT, ntE = (basea + UT - 1) / UT;
-                int64_t nt = ntF + ntE;
-                const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
-                const int32_t G = update_group(S.fsize(big[a]));
-                const bool narrow = follow && ((k0 / NB) % G) != G - 1; // not the last step of a group: block column + block row only
-                // (symmetric fronts enumerate only the tiles with live entries: lower triangle of F, rows of F x columns of E)
-                if (S.sym_mode) acc += (narrow ? nt : ntF * (ntF + 1) / 2 + ntF * ntE) + (follow ? 1 : 0);
-                else acc += (narrow ? 2 * nt : nt * nt) + (follow ? 1 : 0);
-            }
-            tasks.push_back((int32_t)acc);
-            if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
-            st.n_update = (int32_t)acc;
-            L.steps.push_back(st);
-        }
-        // the same steps as tasks of ONE launch (k_chain) for the levels near the root: panel tiles and update pieces in the order of the
-        // launches, each with the counters it waits for and the ones it bumps (kernels_factor_chain.hpp)
-        {
-            int64_t maxu = 0;
-            for (const StepPlan &st : L.steps) maxu = std::max<int64_t>(maxu, st.n_update);
-            if (use_chain && L.upd_ts == UPD_T && !L.steps.empty() && maxu <= chain_max_update && maxu >= chain_min_update && (int32_t)L.steps.size() <= chain_max_steps) {
-                const int32_t nsteps = (int32_t)L.steps.size();
-                const int64_t cbase = chain_words;
-                auto cidx = [&](int32_t a, int32_t si, int32_t j) { return (int32_t)(cbase + ((int64_t)a * nsteps + si) * 3 + j); };
-                chain_words += (int64_t)L.big_cnt * nsteps * 3;
-                std::vector<int32_t> prevC((size_t)L.big_cnt, 0), prevU((size_t)L.big_cnt, 0);
-                L.chain_off = (int64_t)chain.size();
-                for (int32_t si = 0; si < nsteps; si++) {
-                    const StepPlan &st = L.steps[(size_t)si];
-                    const int32_t k0 = si * NB;
-                    for (int32_t a = 0; a < st.nactive; a++) {
-                        const int32_t npan = 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
-                        for (int32_t t = 0; t < npan; t++) {
-                            ChainTask c{};
-                            c.slot = a, c.k0 = k0, c.t = t, c.kind = 0;
-                            c.w0 = si > 0 ? cidx(a, si - 1, chain_fine ? 1 : 2) : -1, c.n0 = si > 0 ? (chain_fine ? prevC[a] : prevU[a]) : 0;
-                            c.w1 = -1, c.n1 = 0, c.pub0 = cidx(a, si, 0), c.pub1 = -1;
-                            chain.push_back(c);
-                        }
-                    }
-                    for (int32_t a = 0; a < st.nactive; a++) {
-                        const int32_t npan = 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
-                        const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
-                        const int32_t ntF = (int32_t)((fa - basea + UPD_T - 1) / UPD_T), ntE = (int32_t)((basea + UPD_T - 1) / UPD_T), nt = ntF + ntE;
-                        const bool follow = S.npiv(big[a]) > k0 + NB;
-                        const int32_t G = update_group(S.fsize(big[a]));
-                        const bool narrow = follow && ((k0 / NB) % G) != G - 1;
-                        const int32_t ntri = ntF * (ntF + 1) / 2;
-                        const int32_t ntiles = S.sym_mode ? (narrow ? nt : ntri + ntF * ntE) : (narrow ? 2 * nt : nt * nt);
-                        // critical pieces: the look-ahead piece and the tiles that hold the next panel's block column (first tile column)
-                        // or block row (first tile row); a narrow step consists of them
-                        auto critical = [&](int32_t t) {
-                            if (t == ntiles || narrow) return true;
-                            if (!S.sym_mode) return t % nt == 0 || t / nt == 0;
-                            return t < ntF || (t >= ntri && (t - ntri) % ntF == 0);
-                        };
-                        int32_t nC = 0;
-                        auto emit = [&](int32_t t) {
-                            ChainTask c{};
-                            c.slot = a, c.k0 = k0, c.t = t, c.kind = 1;
-                            c.w0 = cidx(a, si, 0), c.n0 = npan;
-                            c.w1 = si > 0 ? cidx(a, si - 1, 2) : -1, c.n1 = si > 0 ? prevU[a] : 0;
-                            c.pub0 = cidx(a, si, 2), c.pub1 = critical(t) ? cidx(a, si, 1) : -1;
-                            if (c.pub1 >= 0) nC++;
-                            chain.push_back(c);
-                        };
-                        if (follow) emit(ntiles); // the look-ahead piece first: the longest serial piece of the step
-                        for (int32_t t = 0; t < ntiles; t++)
-                            if (critical(t)) emit(t);
-                        for (int32_t t = 0; t < ntiles; t++)
-                            if (!critical(t)) emit(t);
-                        prevC[a] = nC, prevU[a] = ntiles + (follow ? 1 : 0);
-                    }
-                }
-                L.chain_cnt = (int32_t)((int64_t)chain.size() - L.chain_off);
-            }
-        }
-        // extend-add tasks: 32-column x 256-row tiles of the parent
-        L.ea_off = (int32_t)ea.size();
-        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
-            int32_t s = S.level_sn[k];
-            bool any = false;
-            for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
-            if (!any) continue;
-            if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
-            int32_t f = S.fsize(s);
-            const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
-            // where every child's (ascending) relative indices cross the tile boundaries: computed once per child, not per tile (a front of
-            // 76 000 rows has 716 000 tiles; four binary searches per tile and child made `initialize` of such a matrix take minutes)
-            const int32_t nch_s = S.child_ptr[s + 1] - S.child_ptr[s];
-            const int32_t ncc = (f + cstep - 1) / cstep + 1, nrc = (f + rstep - 1) / rstep + 1;
-            std::vector<int32_t> ccut((size_t)nch_s * ncc), rcut((size_t)nch_s * nrc);
-            for (int32_t q = 0; q < nch_s; q++) {
-                const int32_t ch = S.child_idx[S.child_ptr[s] + q];
-                const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
-                for (int32_t k = 0; k < ncc; k++) ccut[(size_t)q * ncc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * cstep)) - rb);
-                for (int32_t k = 0; k < nrc; k++) rcut[(size_t)q * nrc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * rstep)) - rb);
-            }
-            for (int32_t c0 = 0; c0 < f; c0 += cstep)
-                for (int32_t r0 = 0; r0 < f; r0 += rstep) {
-                    EaTask tk;
-                    tk.f_off = S.front_off[s];
-                    tk.ld = S.front_ld[s];
-                    tk.piece_begin = (int32_t)ear.size();
-                    tk.sym = S.sym_mode ? 1 : 0; // L D L^T parent: lower triangle only
-                    const int32_t c1 = std::min(f, c0 + cstep), r1 = std::min(f, r0 + rstep);
-                    if (S.sym_mode && r1 <= c0) continue; // tile strictly above the diagonal
-                    for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
-                        int32_t ch = S.child_idx[c];
-                        const int32_t q = c - S.child_ptr[s];
-                        EaRange rg;
-                        rg.jlo = ccut[(size_t)q * ncc + c0 / cstep];
-                        rg.jhi = ccut[(size_t)q * ncc + c0 / cstep + 1];
-                        rg.ilo = rcut[(size_t)q * nrc + r0 / rstep];
-                        rg.ihi = rcut[(size_t)q * nrc + r0 / rstep + 1];
-                        if (rg.jlo >= rg.jhi || rg.ilo >= rg.ihi) continue;
-                        rg.ldc = S.front_ld[ch];
-                        rg.cb_off = S.front_off[ch] + S.npiv(ch) + (int64_t)S.npiv(ch) * rg.ldc;
-                        rg.rel_off = S.sn_rowptr[ch];
-                        rg.pad = 0;
-                        ear.push_back(rg);
-                    }
-                    tk.piece_end = (int32_t)ear.size();
-                    if (tk.piece_end > tk.piece_begin) ea.push_back(tk);
-                }
-        }
-        L.ea_cnt = (int32_t)ea.size() - L.ea_off;
-        // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
-        L.fwd_off = (int32_t)stasks.size();
-        int64_t nslab = 0;
-        for (int32_t s : big) {
-            L.big_pmax = std::max(L.big_pmax, S.npiv(s));
-            L.big_fmax = std::max(L.big_fmax, S.fsize(s));
-            nslab += (S.fsize(s) + SOLVE_SLAB - 1) / SOLVE_SLAB;
-        }
-        // few, large fronts (the levels near the root): narrow slabs and 32 column groups per workgroup
-        L.wide = !slab64 && nslab < 256 && L.big_pmax >= 128;
-        const int32_t slab = L.wide ? SOLVE_SLAB_WIDE : SOLVE_SLAB;
-        for (int32_t s : big) {
-            int32_t f = S.fsize(s);
-            for (int32_t r0 = 0; r0 < f; r0 += slab) stasks.push_back({s, r0, std::min(f, r0 + slab)});
-        }
-        L.fwd_cnt = (int32_t)stasks.size() - L.fwd_off;
-        L.bwd_off = (int32_t)stasks.size();
-        for (int32_t s : big) {
-            int32_t p = S.npiv(s);
-            for (int32_t r0 = 0; r0 < p; r0 += slab) stasks.push_back({s, r0, std::min(p, r0 + slab)});
-        }
-        L.bwd_cnt = (int32_t)stasks.size() - L.bwd_off;
-        if (L.big_pmax > MAX_LDS_DOUBLES || L.big_fmax > MAX_LDS_DOUBLES) {
-            // the level-set solve kernels stage a whole p- / f-vector in LDS; the dependency-driven ones work in chunks
-            // (without in-launch hand-offs such a factor is solved by the same kernels launched level by level: run_triangular)
-            level_path_ok = false;
-        }
-    }
-    if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
-    pl_lap("factor launch plans");
-    allbig_off = (int32_t)lists.size();
-    allbig_cnt = (int32_t)allbig.size();
-    lists.insert(lists.end(), allbig.begin(), allbig.end());
+    // The task lists of the solves (wave-subtrees, slabs, blocked instances: a third of the time of this function) depend on the
+    // analysis and on `fd` only: they are built and uploaded on a host thread of their own while this one builds the launch plans of
+    // the factorisation (no other HIP call runs here until the join).
     // dependency-driven solve: tasks in level order (forward: leaves first; backward: root first); small fronts
     // four to a workgroup (one per wavefront), big fronts one workgroup per slab of 2^kind rows
-    {
+    int32_t sp_code = SUCCESSFUL_EXIT;
+    auto solve_plans = [&]() -> int32_t {
         std::vector<SfTask> sf;
         std::vector<int32_t> need((size_t)2 * ns, 1);
         // rows per slab by the length of the dot products (forward: p columns, backward: f columns): long ones get
@@ -1107,7 +874,267 @@ int32_t Solver::upload_plan() {
         HIPC(dev_upload(&d_need, need), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
         HIPC(hipMemset(d_sync, 0, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
+        return SUCCESSFUL_EXIT;
+    };
+    const bool sp_async = !(getenv("HIPMF_PLAN_THREAD") && atoi(getenv("HIPMF_PLAN_THREAD")) == 0); // (0: in line, for timing comparisons)
+    if (!sp_async) sp_code = solve_plans();
+    std::thread sp_thread([&]() {
+        if (!sp_async) return;
+        (void)hipSetDevice(device);
+        try {
+            sp_code = solve_plans();
+        } catch (const std::bad_alloc &) { // (an exception must not leave the thread)
+            last_error = "Not enough memory: a host allocation failed";
+            sp_code = ERROR_MALLOC;
+        }
+    });
+    struct SpJoiner { // (every early return below waits for the thread)
+        std::thread &t;
+        ~SpJoiner() {
+            if (t.joinable()) t.join();
+        }
+    } sp_joiner{sp_thread};
+
+    std::vector<int32_t> lists, tasks, allbig;
+    std::vector<ChainTask> chain;
+    chain_words = 0;
+    std::vector<FrontDesc> bigfd;
+    std::vector<EaTask> ea;
+    std::vector<EaRange> ear;
+    int32_t max_big = 0;
+    std::vector<SolveTask> stasks;
+    levels.assign((size_t)S.nlevels, LevelPlan());
+    for (int32_t l = 0; l < S.nlevels; l++) {
+        LevelPlan &L = levels[l];
+        std::vector<int32_t> small, big;
+        int32_t fmax_small = 1;
+        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            int32_t s = S.level_sn[k];
+            if (S.fsize(s) <= SMALL_F) {
+                small.push_back(s);
+                fmax_small = std::max(fmax_small, S.fsize(s));
+                L.small_pmax = std::max(L.small_pmax, S.npiv(s));
+            } else {
+                big.push_back(s);
+            }
+        }
+        std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
+        // symmetric mode: the tiled fronts of this level whose parent is a small front (it pulls a FULL contribution block)
+        std::vector<int32_t> mirror;
+        if (S.sym_mode)
+            for (int32_t a : big)
+                if (S.sn_parent[a] >= 0 && S.nrow(a) > 0 && S.fsize(S.sn_parent[a]) <= SMALL_F) mirror.push_back(a);
+        // the small fronts of a level go in two launches by size: the LDS a workgroup reserves is that of the largest front of
+        // its launch, and the assembly phases of k_small_factor are latency-bound, i.e. they live on the number of resident waves
+        std::stable_partition(small.begin(), small.end(), [&](int32_t a) { return S.fsize(a) <= small_split; });
+        L.small_cnt_a = 0;
+        int32_t fmax_a = 1;
+        for (int32_t a : small)
+            if (S.fsize(a) <= small_split) L.small_cnt_a++, fmax_a = std::max(fmax_a, S.fsize(a));
+        if (L.small_cnt_a < 2048 || (int32_t)small.size() - L.small_cnt_a < 2048) L.small_cnt_a = 0; // not worth a second launch
+        L.small_ld_a = fmax_a | 1;
+        L.small_off = (int32_t)lists.size();
+        L.small_cnt = (int32_t)small.size();
+        L.small_ld = fmax_small | 1;
+        lists.insert(lists.end(), small.begin(), small.end());
+        L.big_off = (int32_t)lists.size();
+        L.big_cnt = (int32_t)big.size();
+        lists.insert(lists.end(), big.begin(), big.end());
+        L.mirror_off = (int32_t)lists.size();
+        L.mirror_cnt = (int32_t)mirror.size();
+        lists.insert(lists.end(), mirror.begin(), mirror.end());
+        L.bigfd_off = (int32_t)bigfd.size();
+        for (int32_t a : big) bigfd.push_back(fd[(size_t)a]);
+        allbig.insert(allbig.end(), big.begin(), big.end());
+        max_big = std::max(max_big, L.big_cnt);
+        // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
+        int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
+        {
+            int32_t fmax_big = 0;
+            for (int32_t a : big) fmax_big = std::max(fmax_big, S.fsize(a));
+            const bool forced = getenv("HIPMF_UPD32_MAXF") != nullptr; // (an explicit setting also applies to the symmetric fronts)
+            L.upd_ts = (!big.empty() && fmax_big <= upd32_max_front && (!S.sym_mode || forced)) ? UPD_T_SMALL : UPD_T;
+        }
+        const int64_t UT = L.upd_ts;
+        for (int32_t k0 = 0; k0 < pmax; k0 += NB) {
+            StepPlan st;
+            while (st.nactive < L.big_cnt && S.npiv(big[st.nactive]) > k0) st.nactive++;
+            st.pfx_panel = (int64_t)tasks.size();
+            int64_t acc = 0;
+            for (int32_t a = 0; a < st.nactive; a++) {
+                tasks.push_back((int32_t)acc);
+                acc += 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
+            }
+            tasks.push_back((int32_t)acc);
+            st.n_panel = (int32_t)acc;
+            st.pfx_update = (int64_t)tasks.size();
+            acc = 0;
+            for (int32_t a = 0; a < st.nactive; a++) {
+                tasks.push_back((int32_t)acc);
+                // tiles per dimension of k_update at this step: [base, f) and [f, f + base) are tiled separately (base = k0 + nb)
+                const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
+                const int64_t ntF = (fa - basea + UT - 1) / UT, ntE = (basea + UT - 1) / UT;
+                int64_t nt = ntF + ntE;
+                const bool follow = S.npiv(big[a]) > k0 + NB;  // another step follows: look-ahead workgroup
+                const int32_t G = update_group(S.fsize(big[a]));
+                const bool narrow = follow && ((k0 / NB) % G) != G - 1; // not the last step of a group: block column + block row only
+                // (symmetric fronts enumerate only the tiles with live entries: lower triangle of F, rows of F x columns of E)
+                if (S.sym_mode) acc += (narrow ? nt : ntF * (ntF + 1) / 2 + ntF * ntE) + (follow ? 1 : 0);
+                else acc += (narrow ? 2 * nt : nt * nt) + (follow ? 1 : 0);
+            }
+            tasks.push_back((int32_t)acc);
+            if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
+            st.n_update = (int32_t)acc;
+            L.steps.push_back(st);
+        }
+        // the same steps as tasks of ONE launch (k_chain) for the levels near the root: panel tiles and update pieces in the order of the
+        // launches, each with the counters it waits for and the ones it bumps (kernels_factor_chain.hpp)
+        {
+            int64_t maxu = 0;
+            for (const StepPlan &st : L.steps) maxu = std::max<int64_t>(maxu, st.n_update);
+            if (use_chain && L.upd_ts == UPD_T && !L.steps.empty() && maxu <= chain_max_update && maxu >= chain_min_update && (int32_t)L.steps.size() <= chain_max_steps) {
+                const int32_t nsteps = (int32_t)L.steps.size();
+                const int64_t cbase = chain_words;
+                auto cidx = [&](int32_t a, int32_t si, int32_t j) { return (int32_t)(cbase + ((int64_t)a * nsteps + si) * 3 + j); };
+                chain_words += (int64_t)L.big_cnt * nsteps * 3;
+                std::vector<int32_t> prevC((size_t)L.big_cnt, 0), prevU((size_t)L.big_cnt, 0);
+                L.chain_off = (int64_t)chain.size();
+                for (int32_t si = 0; si < nsteps; si++) {
+                    const StepPlan &st = L.steps[(size_t)si];
+                    const int32_t k0 = si * NB;
+                    for (int32_t a = 0; a < st.nactive; a++) {
+                        const int32_t npan = 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
+                        for (int32_t t = 0; t < npan; t++) {
+                            ChainTask c{};
+                            c.slot = a, c.k0 = k0, c.t = t, c.kind = 0;
+                            c.w0 = si > 0 ? cidx(a, si - 1, chain_fine ? 1 : 2) : -1, c.n0 = si > 0 ? (chain_fine ? prevC[a] : prevU[a]) : 0;
+                            c.w1 = -1, c.n1 = 0, c.pub0 = cidx(a, si, 0), c.pub1 = -1;
+                            chain.push_back(c);
+                        }
+                    }
+                    for (int32_t a = 0; a < st.nactive; a++) {
+                        const int32_t npan = 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
+                        const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
+                        const int32_t ntF = (int32_t)((fa - basea + UPD_T - 1) / UPD_T), ntE = (int32_t)((basea + UPD_T - 1) / UPD_T), nt = ntF + ntE;
+                        const bool follow = S.npiv(big[a]) > k0 + NB;
+                        const int32_t G = update_group(S.fsize(big[a]));
+                        const bool narrow = follow && ((k0 / NB) % G) != G - 1;
+                        const int32_t ntri = ntF * (ntF + 1) / 2;
+                        const int32_t ntiles = S.sym_mode ? (narrow ? nt : ntri + ntF * ntE) : (narrow ? 2 * nt : nt * nt);
+                        // critical pieces: the look-ahead piece and the tiles that hold the next panel's block column (first tile column)
+                        // or block row (first tile row); a narrow step consists of them
+                        auto critical = [&](int32_t t) {
+                            if (t == ntiles || narrow) return true;
+                            if (!S.sym_mode) return t % nt == 0 || t / nt == 0;
+                            return t < ntF || (t >= ntri && (t - ntri) % ntF == 0);
+                        };
+                        int32_t nC = 0;
+                        auto emit = [&](int32_t t) {
+                            ChainTask c{};
+                            c.slot = a, c.k0 = k0, c.t = t, c.kind = 1;
+                            c.w0 = cidx(a, si, 0), c.n0 = npan;
+                            c.w1 = si > 0 ? cidx(a, si - 1, 2) : -1, c.n1 = si > 0 ? prevU[a] : 0;
+                            c.pub0 = cidx(a, si, 2), c.pub1 = critical(t) ? cidx(a, si, 1) : -1;
+                            if (c.pub1 >= 0) nC++;
+                            chain.push_back(c);
+                        };
+                        if (follow) emit(ntiles); // the look-ahead piece first: the longest serial piece of the step
+                        for (int32_t t = 0; t < ntiles; t++)
+                            if (critical(t)) emit(t);
+                        for (int32_t t = 0; t < ntiles; t++)
+                            if (!critical(t)) emit(t);
+                        prevC[a] = nC, prevU[a] = ntiles + (follow ? 1 : 0);
+                    }
+                }
+                L.chain_cnt = (int32_t)((int64_t)chain.size() - L.chain_off);
+            }
+        }
+        // extend-add tasks: 32-column x 256-row tiles of the parent
+        L.ea_off = (int32_t)ea.size();
+        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            int32_t s = S.level_sn[k];
+            bool any = false;
+            for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
+            if (!any) continue;
+            if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
+            int32_t f = S.fsize(s);
+            const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
+            // where every child's (ascending) relative indices cross the tile boundaries: computed once per child, not per tile (a front of
+            // 76 000 rows has 716 000 tiles; four binary searches per tile and child made `initialize` of such a matrix take minutes)
+            const int32_t nch_s = S.child_ptr[s + 1] - S.child_ptr[s];
+            const int32_t ncc = (f + cstep - 1) / cstep + 1, nrc = (f + rstep - 1) / rstep + 1;
+            std::vector<int32_t> ccut((size_t)nch_s * ncc), rcut((size_t)nch_s * nrc);
+            for (int32_t q = 0; q < nch_s; q++) {
+                const int32_t ch = S.child_idx[S.child_ptr[s] + q];
+                const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
+                for (int32_t k = 0; k < ncc; k++) ccut[(size_t)q * ncc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * cstep)) - rb);
+                for (int32_t k = 0; k < nrc; k++) rcut[(size_t)q * nrc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * rstep)) - rb);
+            }
+            for (int32_t c0 = 0; c0 < f; c0 += cstep)
+                for (int32_t r0 = 0; r0 < f; r0 += rstep) {
+                    EaTask tk;
+                    tk.f_off = S.front_off[s];
+                    tk.ld = S.front_ld[s];
+                    tk.piece_begin = (int32_t)ear.size();
+                    tk.sym = S.sym_mode ? 1 : 0; // L D L^T parent: lower triangle only
+                    const int32_t c1 = std::min(f, c0 + cstep), r1 = std::min(f, r0 + rstep);
+                    if (S.sym_mode && r1 <= c0) continue; // tile strictly above the diagonal
+                    for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
+                        int32_t ch = S.child_idx[c];
+                        const int32_t q = c - S.child_ptr[s];
+                        EaRange rg;
+                        rg.jlo = ccut[(size_t)q * ncc + c0 / cstep];
+                        rg.jhi = ccut[(size_t)q * ncc + c0 / cstep + 1];
+                        rg.ilo = rcut[(size_t)q * nrc + r0 / rstep];
+                        rg.ihi = rcut[(size_t)q * nrc + r0 / rstep + 1];
+                        if (rg.jlo >= rg.jhi || rg.ilo >= rg.ihi) continue;
+                        rg.ldc = S.front_ld[ch];
+                        rg.cb_off = S.front_off[ch] + S.npiv(ch) + (int64_t)S.npiv(ch) * rg.ldc;
+                        rg.rel_off = S.sn_rowptr[ch];
+                        rg.pad = 0;
+                        ear.push_back(rg);
+                    }
+                    tk.piece_end = (int32_t)ear.size();
+                    if (tk.piece_end > tk.piece_begin) ea.push_back(tk);
+                }
+        }
+        L.ea_cnt = (int32_t)ea.size() - L.ea_off;
+        // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
+        L.fwd_off = (int32_t)stasks.size();
+        int64_t nslab = 0;
+        for (int32_t s : big) {
+            L.big_pmax = std::max(L.big_pmax, S.npiv(s));
+            L.big_fmax = std::max(L.big_fmax, S.fsize(s));
+            nslab += (S.fsize(s) + SOLVE_SLAB - 1) / SOLVE_SLAB;
+        }
+        // few, large fronts (the levels near the root): narrow slabs and 32 column groups per workgroup
+        L.wide = !slab64 && nslab < 256 && L.big_pmax >= 128;
+        const int32_t slab = L.wide ? SOLVE_SLAB_WIDE : SOLVE_SLAB;
+        for (int32_t s : big) {
+            int32_t f = S.fsize(s);
+            for (int32_t r0 = 0; r0 < f; r0 += slab) stasks.push_back({s, r0, std::min(f, r0 + slab)});
+        }
+        L.fwd_cnt = (int32_t)stasks.size() - L.fwd_off;
+        L.bwd_off = (int32_t)stasks.size();
+        for (int32_t s : big) {
+            int32_t p = S.npiv(s);
+            for (int32_t r0 = 0; r0 < p; r0 += slab) stasks.push_back({s, r0, std::min(p, r0 + slab)});
+        }
+        L.bwd_cnt = (int32_t)stasks.size() - L.bwd_off;
+        if (L.big_pmax > MAX_LDS_DOUBLES || L.big_fmax > MAX_LDS_DOUBLES) {
+            // the level-set solve kernels stage a whole p- / f-vector in LDS; the dependency-driven ones work in chunks
+            // (without in-launch hand-offs such a factor is solved by the same kernels launched level by level: run_triangular)
+            level_path_ok = false;
+        }
     }
+    if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
+    pl_lap("factor launch plans");
+    allbig_off = (int32_t)lists.size();
+    allbig_cnt = (int32_t)allbig.size();
+    lists.insert(lists.end(), allbig.begin(), allbig.end());
+    // (the task lists of the dependency-driven solves were built beside the loop above: see solve_plans)
+    if (sp_thread.joinable()) sp_thread.join();
+    if (sp_code != SUCCESSFUL_EXIT) return sp_code;
     pl_lap("solve task lists + their uploads");
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_bigfd, bigfd), ERROR_HIP_MALLOC);
