@@ -34,11 +34,27 @@ struct InterfaceHIPMF {
     // the caller keeps handing over lower-triangle values, entry k of the handle's CSR is entry emap[k] of the caller's
     bool expanded = false;
     int64_t nnz_lower = 0;
+    // device words of solver_hipmf_broadcast_factor's plan check (8 x int64 header, 2 x int32 status), allocated at initialize: no rank
+    // can fail an allocation between two collectives
+    int64_t *d_hdr = nullptr;
 };
 
 // No C++ exception crosses the C boundary: a failed host allocation (the analysis of a large matrix takes gigabytes) comes back as
 // ERROR_MALLOC, the code of the reference's shims for the same event (c_code/constants.h:6), with a message the reference's harness
 // recognises as a memory error (stats_lin_sol.rs:334-340); anything else as ERROR_HIPMF_SYMBOLIC.
+// the handle's device for the duration of a scope (handles are Send), the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1, dev;
+    bool ok = true;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d) ok = hipSetDevice(d) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
 template <typename Fn> static int32_t guarded(struct InterfaceHIPMF *h, Fn fn) {
     try {
         return fn();
@@ -54,14 +70,22 @@ template <typename Fn> static int32_t guarded(struct InterfaceHIPMF *h, Fn fn) {
 extern "C" {
 
 struct InterfaceHIPMF *solver_hipmf_new(void) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return nullptr;
-    return new (std::nothrow) InterfaceHIPMF();
+    try { // (the handle's constructor allocates: NULL on any failure, like the reference's *_new, interface_cudss.cu:62-123)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return nullptr;
+        return new (std::nothrow) InterfaceHIPMF();
+    } catch (...) {
+        return nullptr;
+    }
 }
 
 void solver_hipmf_drop(struct InterfaceHIPMF *h) {
     if (!h) return;
-    h->solver.release();
+    try {
+        if (h->d_hdr) (void)hipFree(h->d_hdr);
+        h->solver.release();
+    } catch (...) {
+    }
     delete h;
 }
 
@@ -72,7 +96,9 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
     // tiled fronts are then factorised as L D L^T (positive definite: D > 0, the same arithmetic)
     if (!h || !row_pointers || !col_indices) return ERROR_NULL_POINTER;
     bool sym_lower = general_symmetric == 1 || positive_definite == 1;
-    if (sym_lower && general_symmetric != 1 && ndim >= 1 && row_pointers[0] == 0) {
+    if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
+    h->expanded = false, h->nnz_lower = 0; // (a handle whose earlier initialize failed half-way starts clean)
+    if (sym_lower && general_symmetric != 1 && ndim >= 1 && validate_csr(ndim, row_pointers, col_indices) == 0) {
         // positive_definite alone: LinSolParams::positive_definite is independent of the storage (lin_sol_params.rs:41-42), and the
         // reference's GPU plug-in accepts it with FULL storage (Sym::No) by taking the lower view (solver_cudss.rs:260-261).  A CSR
         // with entries above the diagonal is therefore factorised as the general matrix it is (LU), not refused.
@@ -159,6 +185,15 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
         else h->solver.release();
     } else {
         code = h->solver.initialize(ndim, row_pointers, col_indices, sym_lower, so, no, values);
+    }
+    if (code == SUCCESSFUL_EXIT && !h->d_hdr) {
+        DeviceGuard dg(h->solver.device);
+        if (hipMalloc((void **)&h->d_hdr, sizeof(int64_t) * 8 + sizeof(int32_t) * 2) != hipSuccess) {
+            h->d_hdr = nullptr;
+            h->solver.release();
+            h->expanded = false, h->nnz_lower = 0;
+            return ERROR_HIP_MALLOC;
+        }
     }
     if (verbose == 1 && code == SUCCESSFUL_EXIT) {
         const Symbolic &S = h->solver.S;
@@ -360,7 +395,7 @@ int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *h, double *d_x, const d
 
 int32_t solver_hipmf_mat_vec_mul(struct InterfaceHIPMF *h, double *v, double alpha, const double *u) {
     if (!h || !v || !u) return ERROR_NULL_POINTER;
-    return h->solver.spmv(v, u, alpha, false);
+    return guarded(h, [&]() { return h->solver.spmv(v, u, alpha, false); });
 }
 
 int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values,
@@ -433,7 +468,7 @@ int32_t solver_hipmf_adopt_factor(struct InterfaceHIPMF *h, const double *d_valu
     // the refinement SpMV.  A re-matching factorize on the sending side (HIPMF_COUNTER_REMATCH) invalidates those pointers.
     if (!h || !d_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
-    return h->solver.adopt_factor(d_values);
+    return guarded(h, [&]() { return h->solver.adopt_factor(d_values); });
 }
 
 int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *h) {
@@ -501,22 +536,18 @@ void hipmf_comm_destroy(void *comm) {
     if (comm && rccl_load()) (void)g_rccl.comm_destroy((ncclComm_t)comm);
 }
 
-int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *h, void *comm, int32_t root, int32_t rank, double *seconds, int64_t *bytes_sent) {
+static int32_t broadcast_factor_body(struct InterfaceHIPMF *h, void *comm, int32_t root, int32_t rank, double *seconds, int64_t *bytes_sent) {
+    // Errors of the CALL (every rank makes the same mistake) return at once; a condition that only ONE rank can be in -- the root without
+    // a factorisation, a plan that differs from the root's -- is carried into the collectives below, so that every rank takes part in
+    // every collective and all ranks return an error together instead of leaving their peers inside ncclBroadcast.
     if (!h || !comm) return ERROR_NULL_POINTER;
-    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
-    if (rank == root && !h->solver.factorized) return ERROR_NEED_FACTORIZATION;
+    if (!h->solver.initialized || !h->d_hdr) return ERROR_NEED_INITIALIZATION;
     if (!rccl_load()) return ERROR_NOT_AVAILABLE;
     Solver &s = h->solver;
-    // the handle's device for the duration of the call (handles are Send), the caller's device afterwards
-    int caller_device = -1;
-    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
-    if (hipSetDevice(s.device) != hipSuccess) return ERROR_HIPMF_NO_DEVICE;
-    struct Restore {
-        int dev, mine;
-        ~Restore() {
-            if (dev >= 0 && dev != mine) (void)hipSetDevice(dev);
-        }
-    } restore{caller_device, s.device};
+    DeviceGuard dg(s.device);
+    if (!dg.ok) return ERROR_HIPMF_NO_DEVICE;
+    const hipStream_t st = (hipStream_t)s.stream;
+    const bool root_unfactorized = rank == root && !s.factorized;
     // 1. every rank must hold the SAME plan as the root (same structure, same ordering, same matching): the root's plan signature
     //    travels first, every rank compares it with its own, and the ranks agree on the outcome (MIN over the ranks) before any
     //    factor data moves -- mismatched buffer sizes would otherwise hang the collective or, worse, be adopted into another plan.
@@ -525,23 +556,25 @@ int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *h, void *comm, int3
     const auto t0 = std::chrono::steady_clock::now();
     {
         int64_t mine[8] = {s.S.n, s.S.nnz_a, s.persist_bytes(), s.matched ? 1 : 0, (int64_t)s.plan_signature(), s.S.nsuper, s.S.sym_mode ? 1 : 0, 0};
-        int64_t *d_hdr = nullptr;
-        if (hipMalloc((void **)&d_hdr, sizeof(mine) + sizeof(int32_t) * 2) != hipSuccess) return ERROR_HIP_MALLOC;
+        int64_t *d_hdr = h->d_hdr;
         int32_t *d_ok = (int32_t *)(d_hdr + 8);
-        bool fail = hipMemcpyAsync(d_hdr, mine, sizeof(mine), hipMemcpyHostToDevice, (hipStream_t)s.stream) != hipSuccess;
-        fail = fail || g_rccl.broadcast(d_hdr, d_hdr, sizeof(mine), ncclChar, root, (ncclComm_t)comm, (hipStream_t)s.stream) != ncclSuccess;
-        int64_t got[8];
-        fail = fail || hipMemcpyAsync(got, d_hdr, sizeof(got), hipMemcpyDeviceToHost, (hipStream_t)s.stream) != hipSuccess;
-        fail = fail || hipStreamSynchronize((hipStream_t)s.stream) != hipSuccess;
-        int32_t ok = (!fail && memcmp(got, mine, sizeof(mine)) == 0) ? 1 : 0, all_ok = 0;
-        fail = fail || hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, (hipStream_t)s.stream) != hipSuccess;
-        fail = fail || g_rccl.all_reduce(d_ok, d_ok + 1, 1, ncclInt32, ncclMin, (ncclComm_t)comm, (hipStream_t)s.stream) != ncclSuccess;
-        fail = fail || hipMemcpyAsync(&all_ok, d_ok + 1, sizeof(all_ok), hipMemcpyDeviceToHost, (hipStream_t)s.stream) != hipSuccess;
-        fail = fail || hipStreamSynchronize((hipStream_t)s.stream) != hipSuccess;
-        (void)hipFree(d_hdr);
+        int64_t got[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // (a local copy that fails lowers this rank's status word; the collectives themselves are always entered)
+        bool local_fail = hipMemcpyAsync(d_hdr, mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess;
+        const bool c1 = g_rccl.broadcast(d_hdr, d_hdr, sizeof(mine), ncclChar, root, (ncclComm_t)comm, st) == ncclSuccess;
+        local_fail = local_fail || hipMemcpyAsync(got, d_hdr, sizeof(got), hipMemcpyDeviceToHost, st) != hipSuccess;
+        local_fail = local_fail || hipStreamSynchronize(st) != hipSuccess;
+        int32_t ok = (c1 && !local_fail && !root_unfactorized && memcmp(got, mine, sizeof(mine)) == 0) ? 1 : 0, all_ok = 0;
+        const bool up = hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, st) == hipSuccess;
+        if (!up) (void)hipMemsetAsync(d_ok, 0, sizeof(ok), st); // (status 0 = "not ok": the MIN carries it to everybody)
+        const bool c2 = g_rccl.all_reduce(d_ok, d_ok + 1, 1, ncclInt32, ncclMin, (ncclComm_t)comm, st) == ncclSuccess;
+        bool fail = !c1 || !c2 || local_fail || !up;
+        fail = hipMemcpyAsync(&all_ok, d_ok + 1, sizeof(all_ok), hipMemcpyDeviceToHost, st) != hipSuccess || fail;
+        fail = hipStreamSynchronize(st) != hipSuccess || fail;
+        if (root_unfactorized) return ERROR_NEED_FACTORIZATION;
         if (fail) return ERROR_HIPMF_COMM;
         if (all_ok != 1) {
-            s.last_error = ok == 1 ? "broadcast_factor: another rank holds a different plan than the root"
+            s.last_error = ok == 1 ? "broadcast_factor: another rank is not ready (the root has no factorisation, or a rank holds a different plan than the root)"
                                    : "broadcast_factor: this rank's plan differs from the root's (structure, ordering or matching); initialize it "
                                      "from the same structure and values as the root";
             return ERROR_HIPMF_INVALID_VALUE;
@@ -561,14 +594,18 @@ int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *h, void *comm, int3
         for (int64_t off = 0; off < nb[i]; off += chunk) {
             const int64_t len = std::min(chunk, nb[i] - off);
             char *p = (char *)ptrs[i] + off;
-            if (g_rccl.broadcast(p, p, (size_t)len, ncclChar, root, (ncclComm_t)comm, (hipStream_t)s.stream) != ncclSuccess) return ERROR_HIPMF_COMM;
+            if (g_rccl.broadcast(p, p, (size_t)len, ncclChar, root, (ncclComm_t)comm, st) != ncclSuccess) return ERROR_HIPMF_COMM;
             total += len;
         }
-    if (hipStreamSynchronize((hipStream_t)s.stream) != hipSuccess) return ERROR_HIP_SYNCHRONIZE;
+    if (hipStreamSynchronize(st) != hipSuccess) return ERROR_HIP_SYNCHRONIZE;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (bytes_sent) *bytes_sent = total;
     if (rank != root) s.mark_factor_adopted();
     return SUCCESSFUL_EXIT;
+}
+
+int32_t solver_hipmf_broadcast_factor(struct InterfaceHIPMF *h, void *comm, int32_t root, int32_t rank, double *seconds, int64_t *bytes_sent) {
+    return guarded(h, [&]() { return broadcast_factor_body(h, comm, root, rank, seconds, bytes_sent); });
 }
 #else
 int32_t hipmf_comm_unique_id(void *) { return ERROR_NOT_AVAILABLE; }

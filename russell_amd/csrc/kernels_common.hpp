@@ -73,6 +73,8 @@ struct FrontDesc {
 };
 constexpr int32_t FD_BIG = 1; // tiled path (f > SMALL_F)
 constexpr int32_t FD_SYM = 2; // big front factorised as L D L^T: only the lower triangle of F (and of its contribution block) is valid
+constexpr int32_t FD_DENSE_TOP = 4; // big front factorised by k_front (kernels_factor_front.hpp): E = [inv(F11); -F21 inv(F11)], E' = [I | -inv(F11) F12] --
+                                    // the pivot rows of E are a full p x p block (the tiled kernels leave inv(L11) P, block lower triangular)
 
 // Every field of a (workgroup-uniform) descriptor is requested in ONE scalar-memory round trip: without this the compiler fetches
 // the fields an early-exit test needs first and the rest after the branch -- one more dependent round trip (~1.5 us) at the head

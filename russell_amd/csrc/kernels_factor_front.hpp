@@ -1,0 +1,275 @@
+// kernels_factor_front.hpp -- the fronts in the MIDDLE of the tree (f > 64, p <= 64, m <= 4 CM, LU mode): ONE workgroup carries a
+// front through its whole partial factorisation in ONE launch per level and size class.
+//
+// The tiled path (kernels_factor.hpp) spends a launch pair per 32 pivots on these fronts -- k_panel + k_update, each a chain of
+// memory round trips -- and a 64 x 64 tile grid of which a quarter is live (a front with f = 100, p = 30 is nine tiles for 9 100
+// entries).  Here the p pivot ROWS of the front, [F11 F12] (p x f), stay on the CU -- F11 in LDS, F12 in the registers of four
+// wavefronts (lane = row, every wavefront holds every fourth column) -- and are reduced by Gauss-Jordan elimination with partial
+// pivoting over the pivot block:
+//
+//      [F11 F12]  ->  [G  V],   G = inv(F11),  V = inv(F11) F12          (in place: column k of F11 becomes a column of G)
+//
+// after which the rest of the front is ONE product with the column panel F21, streamed from the arena with lane = row:
+//
+//      [-W  S] = [0  F22] - F21 [G  V]           W = F21 inv(F11),  S = F22 - F21 inv(F11) F12  (the contribution block, in place)
+//
+// What the solves need of a tiled front is a pair (E, E') with  [y1; u] = E b1 + [0; b2]  and  x1 = E' [y1; x2]  (two GEMVs without
+// dependencies, kernels_common.hpp).  Any pair with  E'_left E_top = inv(F11),  E_bot = -F21 inv(F11),  E'_right = -inv(F11) F12
+// serves; the tiled kernels leave (inv(L11) P, inv(U11)), this kernel leaves
+//
+//      E  = [G; -W]      (f x p, stride ld)              E' = [I | -V]      (p x f, stride p)
+//
+// Its E_top is a full p x p block (the tiled one is block lower triangular in 32-column blocks, which the forward slabs exploit):
+// the descriptor carries FD_DENSE_TOP and the slabs read whole rows.  Pivots (diag) and interchanges (lperm) are those of an LU with
+// the same pivot sequence: the entries of a Gauss-Jordan pivot column in the rows not chosen yet are the LU's.
+//
+// Per pivot k: the wavefront that owns column k (k mod 4) holds that column in a register since it updated it, picks the pivot (one
+// 32-bit DPP max-reduction over the rows not chosen yet) and publishes the multipliers l_i = a_ik / d and the pivot row's lane
+// through LDS -- one workgroup barrier per pivot; every wavefront then subtracts l_i x (pivot row) from its columns: those of F11
+// by a read-modify-write of its own LDS columns (a column of F11 is only ever touched by its wavefront: no further barrier), those
+// of F12 in registers with v_readlane broadcasts of the pivot row.  Pivot rows are NOT scaled inside the loop (a chosen row keeps d
+// in its pivot column; every row is scaled by its own 1/d once at the end): the update is one FMA per entry for all lanes, the
+// pivot lane takes part with a zero multiplier.
+#pragma once
+#include <type_traits>
+
+#include "kernels_common.hpp"
+
+namespace hipmf {
+
+constexpr int MID_NW = 4;      // wavefronts per front
+constexpr int MID_PMAX = 64;   // pivots at most: one pivot row per lane
+constexpr int MID_CHUNK = 64;  // columns of [G V] staged in LDS per pass of the product with F21 (16 per wavefront)
+constexpr int MID_RBLD = 66;   // row stride of the staging buffer (even: 16-byte aligned rows for ds_read_b128 broadcasts;
+                               // 132 dwords = 4 mod 64: the sixteen lanes of a ds_write_b64 group hit sixteen bank pairs)
+
+struct MidLds {
+    double lm[2][64];     // multipliers of the current pivot, double-buffered: one barrier per pivot
+    double dv[2];         // the pivot
+    int32_t pv[2];        // lane of the pivot row
+    int32_t rk[MID_PMAX]; // lane of the pivot row of every step (= the front-local row that became pivot row k)
+};
+// dynamic LDS of a launch whose largest front has pmax pivots: F11 row-major with stride pmax | 1 (lane = row: an odd stride of
+// doubles spreads the 32 lanes of a ds_read_b64 group over 32 bank pairs), then the staging buffer of the product
+__host__ __device__ inline int mid_s11_ld(int pmax) { return pmax | 1; }
+__host__ __device__ inline size_t mid_lds_bytes(int pmax) { return sizeof(double) * ((size_t)((pmax * mid_s11_ld(pmax) + 1) & ~1) + (size_t)pmax * MID_RBLD); }
+
+template <int I, int N, class Fn> __device__ __forceinline__ void static_for(Fn &&fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(fn);
+    }
+}
+
+// CM: columns of F12 per wavefront and lane (fronts with m <= 4 CM off-diagonal rows)
+template <int CM>
+__global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restrict__ LFD, double *__restrict__ pool, int32_t *__restrict__ lperm,
+                                                       const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                       double *__restrict__ diag, int32_t pmax) {
+    HIPMF_DYN_SHARED(double, dyn);
+    __shared__ MidLds sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6); // (the wavefront's number in a scalar register)
+    HIPMF_STAMP(blockIdx.x, 0);
+    const FrontDesc fd = LFD[blockIdx.x];
+    fd_resident(fd);
+    const int p = fd.p, m = fd.m, f = p + m;
+    const int64_t ld = fd.ld;
+    double *__restrict__ F = pool + fd.off;
+    double *__restrict__ E = pool + fd.eoff;
+    double *__restrict__ Ep = pool + fd.epoff;
+    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    const int sld = mid_s11_ld(pmax);
+    double *S11 = dyn;                                   // (row, column) of F11 at S11[row * sld + column]
+    double *RB = dyn + ((pmax * sld + 1) & ~1);          // staging buffer of the product: [pivot step][MID_RBLD]
+    double *Srow = S11 + lane * sld;
+
+    // ---- the pivot rows: lane = row.  F12: this wavefront's columns p + wave, p + wave + 4, ... in registers; F11: its columns wave,
+    //      wave + 4, ... into LDS (every load of the thread is in flight before the first LDS store)
+    double a[CM];
+    double pcol = 0.0; // column k of F11 while this wavefront owns the next pivot
+    {
+        const double *Fr = F + (lane < p ? lane : 0);
+#pragma unroll
+        for (int q = 0; q < CM; q++) {
+            const int c = p + wave + MID_NW * q;
+            const double v = Fr[(int64_t)(c < f ? c : 0) * ld]; // (clamped address: unconditional load)
+            a[q] = (lane < p && c < f) ? v : 0.0;
+        }
+        for (int j0 = wave; j0 < p; j0 += 4 * MID_NW) {
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + MID_NW * u;
+                const double v = Fr[(int64_t)(j < p ? j : 0) * ld];
+                t[u] = (lane < p && j < p) ? v : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + MID_NW * u;
+                if (j < p) Srow[j] = t[u];
+                if (j == 0) pcol = t[u]; // (wave 0 owns pivot 0)
+            }
+        }
+    }
+    HIPMF_STAMP(blockIdx.x, 1);
+    // ---- Gauss-Jordan over the pivot block ----
+    int step = -1;     // the elimination step at which this lane's row was chosen
+    double dval = 1.0; // its pivot
+    int npert = 0, nzero = 0;
+    for (int k = 0; k < p; k++) {
+        const int ow = k & (MID_NW - 1), buf = k & 1;
+        if (wave == ow) { // (wave-uniform)
+            const double col = pcol;
+            const bool cand = lane < p && step < 0;
+            const unsigned mag = __float_as_uint((float)fabs(col));
+            const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - lane)) : 0u;
+            const double myinv = fast_rcp(col); // (off the dependent chain of the reduction)
+            const int pv = 63 - (int)(wave_max_u32(key) & 63u);
+            double d = wave_bcast(col, pv);
+            double inv = wave_bcast(myinv, pv);
+            if (fabs(d) < eps || d == 0.0) {
+                double dn = (d < 0.0) ? -eps : eps;
+                if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
+                npert++;
+                if (d == 0.0) nzero++;
+                d = dn;
+                inv = 1.0 / dn;
+            }
+            const double l = col * inv;
+            sh.lm[buf][lane] = (lane == pv) ? 0.0 : l;
+            Srow[k] = (lane == pv) ? 1.0 : -l; // column k of the identity block, stored in place of column k of F11
+            if (lane == 0) sh.pv[buf] = pv, sh.dv[buf] = d, sh.rk[k] = pv;
+        }
+        __syncthreads();
+        const double lm = sh.lm[buf][lane];
+        const int pv = wave_uniform(sh.pv[buf]);
+        if (lane == pv) {
+            step = k;
+            dval = sh.dv[buf];
+        }
+        // this wavefront's columns of F11 (LDS; column k itself holds its final content already), the next pivot column first
+        const double *Spv = S11 + pv * sld;
+        for (int j0 = wave; j0 < p; j0 += 4 * MID_NW) {
+            double x[4], u[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = j0 + MID_NW * t;
+                const int jc = j < p ? j : wave; // (clamped: the loads are unconditional)
+                x[t] = Srow[jc], u[t] = Spv[jc];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = j0 + MID_NW * t;
+                const double y = __builtin_fma(-lm, u[t], x[t]);
+                if (j < p && j != k) Srow[j] = y;
+                if (j == k + 1) pcol = y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CM; q++) a[q] = __builtin_fma(-lm, wave_bcast(a[q], pv), a[q]);
+    }
+    HIPMF_STAMP(blockIdx.x, 2);
+    if (lane == 0 && npert > 0) {
+        atomicAdd(&info->n_perturbed, npert);
+        if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
+    }
+    // every row by its own pivot: the lane that was chosen at step s holds row s of [G V]
+    const double inv_own = 1.0 / dval;
+#pragma unroll
+    for (int q = 0; q < CM; q++) a[q] *= inv_own;
+    __syncthreads(); // (sh.rk complete)
+    // ---- E' = [I | -V], pivots, interchanges ----
+    if (lane < p) {
+#pragma unroll
+        for (int q = 0; q < CM; q++) {
+            const int c = p + wave + MID_NW * q;
+            if (c < f) Ep[step + (int64_t)c * p] = -a[q];
+        }
+        for (int j = wave; j < p; j += MID_NW) Ep[step + (int64_t)j * p] = (j == step) ? 1.0 : 0.0;
+        if (wave == 0) {
+            diag[fd.first + step] = dval;
+            lperm[fd.first + step] = lane;
+        }
+    }
+    // ---- G in pivot order into the staging buffer (column position k of the in-place block is the column of front row rk[k]) and out:
+    //      E_top(s, rk[k]) = G(s, k) ----
+    if (lane < p) {
+        for (int j = wave; j < p; j += MID_NW) {
+            const double g = Srow[j] * inv_own;
+            RB[step * MID_RBLD + j] = g;
+            E[step + (int64_t)sh.rk[j] * ld] = g;
+        }
+    }
+    __syncthreads();
+    HIPMF_STAMP(blockIdx.x, 3);
+    if (m == 0) return;
+    // ---- [-W  S] = [0  F22] - F21 [G  V]: lane = row of F21, 16 columns of the staged block per wavefront ----
+    const int nrb = (m + 63) >> 6;
+    // one pass over the rows of F21 against the 16 staged columns [cs, cs + 16) of this wavefront; `ncol` of them exist; they are
+    // columns of G (gpart: result -> E_bot, scattered by rk) or the columns c0 .. of the front (result -> F22 in place)
+    auto product = [&](const int cs, const int ncol, const bool gpart, const int c0) {
+        const double *Rw = RB + cs;
+        for (int rb = 0; rb < nrb; rb++) {
+            const int i = rb * 64 + lane;
+            const bool rowok = i < m;
+            const double *Fi = F + p + (rowok ? i : 0); // row i of [F21 F22]
+            double acc[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const double v = Fi[(int64_t)((!gpart && c < ncol) ? c0 + c : 0) * ld];
+                acc[c] = (!gpart && c < ncol) ? v : 0.0;
+            }
+            for (int k0 = 0; k0 < p; k0 += 8) {
+                double ak[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = k0 + kk;
+                    const double v = Fi[(int64_t)(k < p ? k : 0) * ld];
+                    ak[kk] = k < p ? v : 0.0;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const double *Rk = Rw + (k0 + kk < p ? k0 + kk : 0) * MID_RBLD; // (rows beyond p: multiplied by ak = 0)
+#pragma unroll
+                    for (int c = 0; c < 16; c++) acc[c] = __builtin_fma(-ak[kk], Rk[c], acc[c]);
+                }
+            }
+            if (rowok) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    if (c < ncol) {
+                        if (gpart) E[(p + i) + (int64_t)wave_uniform(sh.rk[cs + c]) * ld] = acc[c];
+                        else F[(p + i) + (int64_t)(c0 + c) * ld] = acc[c];
+                    }
+                }
+            }
+        }
+    };
+    // the columns of G: 16 per wavefront
+    {
+        const int cs = 16 * wave;
+        if (cs < p) product(cs, (p - cs) < 16 ? (p - cs) : 16, true, 0);
+    }
+    HIPMF_STAMP(blockIdx.x, 4);
+    // the columns of V, 64 at a time: this wavefront stages its own (every fourth) and multiplies the 16 columns [16 wave, 16 wave + 16)
+    static_for<0, (CM + 15) / 16>([&](auto chc) {
+        constexpr int ch = decltype(chc)::value;
+        if (ch * MID_CHUNK < m) { // (workgroup-uniform)
+            __syncthreads();      // the block staged before has been consumed
+            if (lane < p) {
+#pragma unroll
+                for (int qq = 0; qq < 16; qq++) {
+                    constexpr int qbase = 16 * ch;
+                    if (qbase + qq < CM) RB[step * MID_RBLD + MID_NW * qq + wave] = a[(qbase + qq) < CM ? (qbase + qq) : 0];
+                }
+            }
+            __syncthreads();
+            const int cs = 16 * wave;
+            const int c0 = p + ch * MID_CHUNK + cs;
+            if (c0 < f) product(cs, (f - c0) < 16 ? (f - c0) : 16, false, c0);
+        }
+    });
+    HIPMF_STAMP(blockIdx.x, 5);
+}
+
+} // namespace hipmf

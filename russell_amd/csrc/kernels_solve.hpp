@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(SLAB *G) k_fwd_big(const SolveTask *__restrict
     const int r = r0 + rr;
     // rows of inv(L11) P are zero right of their own 32-column block
     int jmax = p;
-    if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
+    if (r1 <= p && !(fd.flags & FD_DENSE_TOP)) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p; // (k_front leaves a full block)
     double acc = 0.0;
     if (r < r1) acc = strided_dot(E + r, ld, w1, g, jmax, G);
     red[g][rr] = acc;

@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
     for (int i = tid; i < K * 128; i += 256) wsl[i] = 0.0;
     // rows of inv(L11) P are zero right of their own 32-column block
     int jmax = p;
-    if (r1 <= p) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p;
+    if (r1 <= p && !(fd.flags & FD_DENSE_TOP)) jmax = ((r1 - 1) / NB + 1) * NB < p ? ((r1 - 1) / NB + 1) * NB : p; // (k_front leaves a full block)
     // (K == 1) the first eight entries of this lane's row of E are on their way while the workgroup waits for the children
     constexpr int NPRE = 8;
     double e_pre[K == 1 ? NPRE : 1];

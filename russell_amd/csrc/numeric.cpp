@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "kernels.hpp"
 #include "matching.hpp"
@@ -22,6 +23,7 @@ namespace hipmf {
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
         if (e_ != hipSuccess) {                                                                \
+            std::lock_guard<std::mutex> lock_(err_mutex); /* (the planning thread of initialize reports through the same string) */ \
             last_error = std::string(#call) + ": " + hipGetErrorString(e_);                    \
             if (opt.verbose) fprintf(stderr, "hipmf: %s\n", last_error.c_str());               \
             return (code);                                                                     \
@@ -228,6 +230,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_CHAIN_MIN_WGS")) chain_min_update = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_CHAIN_MAX_STEPS")) chain_max_steps = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_UPD32_MAXF")) upd32_max_front = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_MID_FMAX")) mid_fmax = std::max(64, std::min(256, atoi(e)));
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -347,7 +351,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             for (int64_t o = o0; o < o0 + len; o += 16384) zt.push_back({o, (int32_t)std::min<int64_t>(16384, o0 + len - o), 0});
         };
         for (int32_t s = 0; s < ns; s++) {
-            if (S.fsize(s) <= SMALL_F) continue;
+            if (S.fsize(s) <= SMALL_F || is_mid(s)) continue; // (k_front writes every entry of its E / E')
             const int64_t f = S.fsize(s), p = S.npiv(s);
             zero_range(S.e_off[s], (int64_t)S.front_ld[s] * p);
             if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * p);
@@ -543,7 +547,7 @@ int32_t Solver::upload_plan() {
         d.ld = S.front_ld[s];
         d.ugroup = update_group(S.fsize(s));
         d.eoff = S.e_off[s], d.epoff = S.ep_off[s];
-        d.flags = S.fsize(s) > SMALL_F ? (FD_BIG | (S.sym_mode ? FD_SYM : 0)) : 0;
+        d.flags = S.fsize(s) > SMALL_F ? (FD_BIG | (S.sym_mode ? FD_SYM : 0) | (is_mid(s) ? FD_DENSE_TOP : 0)) : 0;
         d.pad = 0;
         work_doubles += d.p + d.m;
     }
@@ -842,8 +846,9 @@ int32_t Solver::upload_plan() {
                     rep_words = (int64_t)ntop * SF_REP * 16;
                     if (ntop > 0) {
                         HIPC(dev_upload(&d_rep_idx, ridx), ERROR_HIP_MALLOC);
-                        HIPC(hipMalloc((void **)&d_rep, sizeof(int32_t) * 2 * (size_t)rep_words), ERROR_HIP_MALLOC);
-                        HIPC(hipMemset(d_rep, 0, sizeof(int32_t) * 2 * (size_t)rep_words), ERROR_HIP_MALLOC);
+                        // (one set per solve lane: a lane clears and uses its own words whatever the other lanes are doing)
+                        HIPC(hipMalloc((void **)&d_rep, sizeof(int32_t) * 2 * (size_t)rep_words * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
+                        HIPC(hipMemset(d_rep, 0, sizeof(int32_t) * 2 * (size_t)rep_words * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
                     }
                 }
                 HIPC(dev_upload(&d_sf2, sf), ERROR_HIP_MALLOC);
@@ -884,6 +889,7 @@ int32_t Solver::upload_plan() {
         try {
             sp_code = solve_plans();
         } catch (const std::bad_alloc &) { // (an exception must not leave the thread)
+            std::lock_guard<std::mutex> lock(err_mutex);
             last_error = "Not enough memory: a host allocation failed";
             sp_code = ERROR_MALLOC;
         }
@@ -918,6 +924,16 @@ int32_t Solver::upload_plan() {
                 big.push_back(s);
             }
         }
+        // the fronts one workgroup factorises in one launch (k_front) leave the tiled list; by size class, then by pivots
+        std::vector<int32_t> mid;
+        {
+            std::vector<int32_t> tiled;
+            for (int32_t a : big) (is_mid(a) ? mid : tiled).push_back(a);
+            big.swap(tiled);
+            auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return m <= 80 ? 0 : (m <= 128 ? 1 : (m <= 192 ? 2 : 3)); }; // (the CM of k_front: 20 / 32 / 48 / 64)
+            std::stable_sort(mid.begin(), mid.end(), [&](int32_t a, int32_t b) { return cls(a) != cls(b) ? cls(a) < cls(b) : S.npiv(a) > S.npiv(b); });
+            for (int32_t a : mid) L.mid_cnt[cls(a)]++, L.mid_pmax[cls(a)] = std::max(L.mid_pmax[cls(a)], S.npiv(a));
+        }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
         // symmetric mode: the tiled fronts of this level whose parent is a small front (it pulls a FULL contribution block)
         std::vector<int32_t> mirror;
@@ -945,7 +961,9 @@ int32_t Solver::upload_plan() {
         lists.insert(lists.end(), mirror.begin(), mirror.end());
         L.bigfd_off = (int32_t)bigfd.size();
         for (int32_t a : big) bigfd.push_back(fd[(size_t)a]);
-        allbig.insert(allbig.end(), big.begin(), big.end());
+        L.mid_off = (int32_t)bigfd.size();
+        for (int32_t a : mid) bigfd.push_back(fd[(size_t)a]);
+        allbig.insert(allbig.end(), big.begin(), big.end()); // (k_set_identity: the tiled fronts only)
         max_big = std::max(max_big, L.big_cnt);
         // tiled steps over the augmented fronts: the active range of step k0 has f indices per dimension
         int32_t pmax = big.empty() ? 0 : S.npiv(big[0]);
@@ -1102,6 +1120,7 @@ int32_t Solver::upload_plan() {
         // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
         L.fwd_off = (int32_t)stasks.size();
         int64_t nslab = 0;
+        big.insert(big.end(), mid.begin(), mid.end()); // (the solves treat every front with f > 64 alike)
         for (int32_t s : big) {
             L.big_pmax = std::max(L.big_pmax, S.npiv(s));
             L.big_fmax = std::max(L.big_fmax, S.fsize(s));
@@ -1128,6 +1147,12 @@ int32_t Solver::upload_plan() {
         }
     }
     if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
+    if (use_mid && !S.sym_mode) { // (a front with 64 pivots stages 67 KB)
+        HIPMF_ALLOW_LDS(k_front<20>, mid_lds_bytes(MID_PMAX));
+        HIPMF_ALLOW_LDS(k_front<32>, mid_lds_bytes(MID_PMAX));
+        HIPMF_ALLOW_LDS(k_front<48>, mid_lds_bytes(MID_PMAX));
+        HIPMF_ALLOW_LDS(k_front<64>, mid_lds_bytes(MID_PMAX));
+    }
     pl_lap("factor launch plans");
     allbig_off = (int32_t)lists.size();
     allbig_cnt = (int32_t)allbig.size();
@@ -1219,7 +1244,17 @@ int32_t Solver::rematch_and_factorize() {
     fused_fallbacks = keep_fallbacks;
     // (hv holds the EXPANDED values of the handle's own CSR: they are factorised as they are, the expansion map comes back afterwards)
     code = factorize(hv.data(), false); // (rematching is still set: one re-analysis per call)
-    if (had_expansion && initialized) (void)set_expansion(keep_low, keep_emap);
+    if (had_expansion && initialized) {
+        // (without the map the next factorize would read the caller's lower-triangle buffer as expanded values)
+        const int32_t ecode = set_expansion(keep_low, keep_emap);
+        if (ecode != SUCCESSFUL_EXIT) {
+            rematching = false;
+            const std::string keep = last_error;
+            release();
+            last_error = "re-analysis after a change of the matching failed: " + keep;
+            return ecode;
+        }
+    }
     rematching = false;
     // a new matching that leaves the diagonal weak (structurally singular matrix, no perfect matching, the boundary case of the
     // criterion) cannot be improved by another one: later factorizes keep this order instead of redoing the analysis every time
@@ -1328,7 +1363,8 @@ int32_t Solver::run_factor() {
         }
         // a level's small fronts and its big fronts are independent of each other (both only need the level's extend-add):
         // when the level has both, the small ones are factorised on a second stream beside the tiled steps
-        const bool forked = overlap_small && ((L.small_cnt > 0 && !L.steps.empty()) || fill_next);
+        const bool has_mid = L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] + L.mid_cnt[3] > 0;
+        const bool forked = overlap_small && ((L.small_cnt > 0 && (!L.steps.empty() || has_mid)) || fill_next);
         if (L.small_cnt > 0) {
             size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
             hipStream_t sst = STREAM;
@@ -1410,6 +1446,26 @@ int32_t Solver::run_factor() {
             launches += 2;
             k0 += NB;
         }
+        // the fronts of the middle of the tree: one workgroup per front, one launch per size class (kernels_factor_front.hpp)
+        {
+            int32_t moff = L.mid_off;
+            for (int c = 3; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
+            for (int c = 3; c >= 0; c--) {
+                moff -= L.mid_cnt[c];
+                if (L.mid_cnt[c] == 0) continue;
+                const size_t dyn = mid_lds_bytes(L.mid_pmax[c]);
+                const FrontDesc *mfd = d_bigfd + moff;
+#define HIPMF_LAUNCH_FRONT(CF) \
+    hipLaunchKernelGGL(k_front<CF>, dim3(L.mid_cnt[c]), dim3(64 * MID_NW), dyn, STREAM, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, \
+                       L.mid_pmax[c])
+                if (c == 0) HIPMF_LAUNCH_FRONT(20);
+                else if (c == 1) HIPMF_LAUNCH_FRONT(32);
+                else if (c == 2) HIPMF_LAUNCH_FRONT(48);
+                else HIPMF_LAUNCH_FRONT(64);
+#undef HIPMF_LAUNCH_FRONT
+                launches++;
+            }
+        }
         if (L.mirror_cnt > 0) {
             hipLaunchKernelGGL(k_mirror_cb, dim3(L.mirror_cnt), dim3(256), 0, STREAM, d_lists + L.mirror_off, d_fd, d_pool);
             launches++;
@@ -1454,7 +1510,7 @@ int32_t Solver::run_factor() {
     return SUCCESSFUL_EXIT;
 }
 
-int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed) {
+int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed, int32_t lane_id) {
     int64_t launches = 0;
     if (use_fused) {
         const int32_t ns = S.nsuper;
@@ -1463,6 +1519,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
         if (tree_active && nk == 1) {
+            int32_t *const d_rep = this->d_rep ? this->d_rep + 2 * (size_t)rep_words * (size_t)lane_id : nullptr; // this lane's replicas
             if (d_rep) HIPC(hipMemsetAsync(d_rep, 0, sizeof(int32_t) * 2 * (size_t)rep_words, LST), ERROR_HIP_MEMCPY);
             // one wavefront per subtree of small fronts at the bottom (k_wt_fwd / k_wt_bwd), LDS-staged dependency-driven tasks above
             const int32_t wg = (wt_waves + WT_WAVES - 1) / WT_WAVES;
@@ -1704,6 +1761,7 @@ struct Solver::SolveLane {
     unsigned long long *norms = nullptr; // 2 words per column: |r|_inf bits, omega bits
     double *h_nrm = nullptr;             // pinned host copy of the norms (a pageable target would make the copy synchronous)
     bool timed = false;                  // records the forward / backward event pair (lane 0 only)
+    int32_t id = 0;                      // index of the lane (its set of completion replicas)
     // the block in flight
     bool busy = false;
     int32_t j0 = 0, nk = 0, it = 0;
@@ -1788,6 +1846,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     }
     for (int32_t l = 1; l < nlanes; l++) {
         SolveLane &L = lanes[l];
+        L.id = l;
         const LaneBuffers &r = extra_lanes[(size_t)l - 1];
         L.st = (hipStream_t)r.stream;
         L.XP = r.blk, L.DU = r.blk + (size_t)n * KB, L.RR = r.blk + 2 * (size_t)n * KB, L.BB = r.blk + 4 * (size_t)n * KB;
@@ -1856,7 +1915,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         L.cstr = on_device ? ldx : (int64_t)n;
         const uint32_t all = L.nk >= 32 ? 0xffffffffu : ((1u << L.nk) - 1u);
         if (L.nk > 1) hipLaunchKernelGGL(k_perm_in_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_rperm, d_rs, L.bj[0], L.cstr, L.XP, (int64_t)n, all);
-        int32_t code = run_triangular(L.XP, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed);
+        int32_t code = run_triangular(L.XP, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed, L.id);
         if (code != SUCCESSFUL_EXIT) return code;
         if (L.nk == 1) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.XP, L.xj[0], 0);
         else hipLaunchKernelGGL(k_perm_out_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_perm, d_cs, L.XP, (int64_t)n, L.xj[0], L.cstr, 0, all);
@@ -1899,7 +1958,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             if (L.active[c]) amask |= 1u << c;
         if (L.nk == 1) hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.RR, L.DU);
         else hipLaunchKernelGGL(k_perm_in_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_rperm, d_rs, L.RR, (int64_t)n, L.DU, (int64_t)n, amask); // finished columns ride along as zeros
-        int32_t code = run_triangular(L.DU, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed);
+        int32_t code = run_triangular(L.DU, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed, L.id);
         if (code != SUCCESSFUL_EXIT) return code;
         if (L.nk == 1) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU, L.xj[0], 1);
         else hipLaunchKernelGGL(k_perm_out_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_perm, d_cs, L.DU, (int64_t)n, L.xj[0], L.cstr, 1, amask);

@@ -1,6 +1,7 @@
 // numeric.hpp -- device-side state and drivers of the multifrontal LU backend (factorize / solve).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -79,6 +80,11 @@ struct LevelPlan {
     bool wide = false; // solve with 32-row slabs x 32 column groups (few large fronts)
     std::vector<StepPlan> steps;
     int32_t upd_ts = 64;    // edge of the trailing-update tiles on this level (32: k_update32, one wave per tile)
+    // fronts of the middle of the tree that ONE workgroup carries through their whole partial factorisation (k_front,
+    // kernels_factor_front.hpp): their descriptors follow the tiled ones in d_bigfd, grouped by size class
+    int32_t mid_off = 0;                 // first of them in d_bigfd
+    int32_t mid_cnt[4] = {0, 0, 0, 0};   // fronts per class (columns of F12 per wavefront 20 / 32 / 48 / 64)
+    int32_t mid_pmax[4] = {0, 0, 0, 0};  // largest pivot count per class (LDS of the launch)
     int64_t chain_off = 0;  // the level's tiled steps as ONE launch (k_chain): its tasks in d_chain, chain_cnt of them (0: one launch per step)
     int32_t chain_cnt = 0;
 };
@@ -133,6 +139,7 @@ class Solver {
     void *stream2 = nullptr;          // the small fronts of a level are factorised beside its tiled steps
     void *ev_fork = nullptr, *ev_join = nullptr;
     std::string last_error;
+    std::mutex err_mutex; // (the planning thread of initialize and the calling thread both report through last_error)
 
     // exported for the many-RHS / multi-GPU paths: the factor lives in [d_pool, d_pool + pool_doubles)
     double *d_pool = nullptr;
@@ -158,7 +165,7 @@ class Solver {
     int32_t run_factor();
     // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)
     struct SolveLane;
-    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed);
+    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed, int32_t lane_id);
     void harvest_tri();
     int32_t build_level_tasks();
     // optional task list of the blocked (many-RHS) instances with wider slabs (HIPMF_BLOCKED_SLABS=1).  Measured and NOT the default:
@@ -230,6 +237,11 @@ class Solver {
     int32_t upd32_max_front = 256;          // LU: levels whose largest tiled front has at most this many rows update with 32 x 32 tiles, one wave per tile
                                             // (HIPMF_UPD32_MAXF; 0: never).  Bit-identical to the 64 x 64 instance; 1000 x 1000: 7.30 -> 7.23 ms.  The L D L^T
                                             // fronts keep the 64 x 64 tiles (measured: 6.32 -> 6.35 ms with the small ones)
+    // LU mode: fronts with 64 < f <= mid_fmax and at most 64 pivots are factorised by one workgroup each, one launch per level and size
+    // class (HIPMF_MID_FRONT=0: off, HIPMF_MID_FMAX: rows at most, <= 256)
+    bool use_mid = false; // (off until it beats the tiled launches: profiles/r04_front_bench.txt)
+    int32_t mid_fmax = 256;
+    bool is_mid(int32_t s) const { return use_mid && !S.sym_mode && S.fsize(s) > 64 && S.fsize(s) <= mid_fmax && S.npiv(s) <= 64; }
     int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)
