@@ -84,7 +84,7 @@ _cache = {}
 
 
 def load(path=None):
-    path = path or DEFAULT_LIB
+    path = path or os.environ.get("HIPMF_DEV_LIB") or DEFAULT_LIB  # (HIPMF_DEV_LIB: a variant build under study, tools/gpu/*.sh)
     if path in _cache:
         return _cache[path]
     if not os.path.exists(path):

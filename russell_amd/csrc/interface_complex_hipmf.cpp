@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "numeric.hpp"
@@ -32,6 +33,20 @@ struct InterfaceComplexHIPMF {
     int32_t effective_ordering = 0;
     bool triplet_map = false; // the installed map reads the caller's COO triplets (complex_solver_hipmf_set_value_map)
 };
+
+// No C++ exception crosses the C boundary (the same rule as interface_hipmf.cpp): a failed host allocation comes back as ERROR_MALLOC
+// with a message the reference's harness recognises as a memory error (stats_lin_sol.rs:334-340), anything else as ERROR_HIPMF_SYMBOLIC.
+template <typename Fn> static int32_t guarded(struct InterfaceComplexHIPMF *h, Fn fn) {
+    try {
+        return fn();
+    } catch (const std::bad_alloc &) {
+        if (h) h->solver.last_error = "Not enough memory: a host allocation failed";
+        return ERROR_MALLOC;
+    } catch (const std::exception &e) {
+        if (h) h->solver.last_error = std::string("internal error: ") + e.what();
+        return ERROR_HIPMF_SYMBOLIC;
+    }
+}
 
 namespace {
 // builds the real-equivalent CSR pattern (rows 2i, 2i+1) of the complex CSR (mirroring the strict lower triangle when sym_lower) and,
@@ -105,18 +120,25 @@ int32_t install_map(InterfaceComplexHIPMF *h, int64_t nin_complex, const int32_t
 extern "C" {
 
 struct InterfaceComplexHIPMF *complex_solver_hipmf_new(void) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return nullptr;
-    return new (std::nothrow) InterfaceComplexHIPMF();
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return nullptr;
+        return new (std::nothrow) InterfaceComplexHIPMF();
+    } catch (...) {
+        return nullptr;
+    }
 }
 
 void complex_solver_hipmf_drop(struct InterfaceComplexHIPMF *h) {
     if (!h) return;
-    h->solver.release();
+    try {
+        h->solver.release();
+    } catch (...) {
+    }
     delete h;
 }
 
-int32_t complex_solver_hipmf_initialize(struct InterfaceComplexHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
+static int32_t c_initialize_body(struct InterfaceComplexHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
                                         int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, int32_t ndim,
                                         const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
     if (!h || !row_pointers || !col_indices) return ERROR_NULL_POINTER;
@@ -152,7 +174,13 @@ int32_t complex_solver_hipmf_initialize(struct InterfaceComplexHIPMF *h, int32_t
     return install_map(h, h->nnz, nullptr, nullptr);
 }
 
-int32_t complex_solver_hipmf_set_value_map(struct InterfaceComplexHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
+int32_t complex_solver_hipmf_initialize(struct InterfaceComplexHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
+                                        int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, int32_t ndim,
+                                        const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
+    return guarded(h, [&]() { return c_initialize_body(h, ordering, scaling, pivot_epsilon, refinement_nstep, verbose, general_symmetric, ndim, row_pointers, col_indices, values); });
+}
+
+static int32_t c_set_value_map_body(struct InterfaceComplexHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
     if (!h || !seg_ptr || !seg_idx) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     if (nnz_in < 1 || seg_ptr[0] != 0 || seg_ptr[h->nnz] != nnz_in) return ERROR_HIPMF_INVALID_VALUE;
@@ -162,6 +190,10 @@ int32_t complex_solver_hipmf_set_value_map(struct InterfaceComplexHIPMF *h, int3
         if (seg_idx[t] < 0 || seg_idx[t] >= nnz_in) return ERROR_HIPMF_INVALID_VALUE;
     h->triplet_map = true;
     return install_map(h, nnz_in, seg_ptr, seg_idx);
+}
+
+int32_t complex_solver_hipmf_set_value_map(struct InterfaceComplexHIPMF *h, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx) {
+    return guarded(h, [&]() { return c_set_value_map_body(h, nnz_in, seg_ptr, seg_idx); });
 }
 
 static int32_t finish(struct InterfaceComplexHIPMF *h, int32_t code, int32_t *effective_ordering, int32_t *effective_scaling, int32_t *num_perturbed,
@@ -176,7 +208,7 @@ static int32_t finish(struct InterfaceComplexHIPMF *h, int32_t code, int32_t *ef
     return code;
 }
 
-int32_t complex_solver_hipmf_factorize(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+static int32_t c_factorize_body(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
                                        int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL compute_determinant, C_BOOL verbose,
                                        const double *values) {
     if (!h || !values) return ERROR_NULL_POINTER;
@@ -191,7 +223,13 @@ int32_t complex_solver_hipmf_factorize(struct InterfaceComplexHIPMF *h, int32_t 
     return finish(h, h->solver.factorize_mapped(values, false), effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate);
 }
 
-int32_t complex_solver_hipmf_factorize_mapped(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+int32_t complex_solver_hipmf_factorize(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+                                       int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL compute_determinant, C_BOOL verbose,
+                                       const double *values) {
+    return guarded(h, [&]() { return c_factorize_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, compute_determinant, verbose, values); });
+}
+
+static int32_t c_factorize_mapped_body(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
                                               int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL verbose, const double *input_values) {
     if (!h || !input_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
@@ -199,16 +237,25 @@ int32_t complex_solver_hipmf_factorize_mapped(struct InterfaceComplexHIPMF *h, i
     return finish(h, h->solver.factorize_mapped(input_values, false), effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate);
 }
 
-int32_t complex_solver_hipmf_solve(struct InterfaceComplexHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
+int32_t complex_solver_hipmf_factorize_mapped(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
+                                              int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL verbose, const double *input_values) {
+    return guarded(h, [&]() { return c_factorize_mapped_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, verbose, input_values); });
+}
+
+static int32_t c_solve_body(struct InterfaceComplexHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
     if (!h || !x || !rhs) return ERROR_NULL_POINTER;
     if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
     h->solver.opt.verbose = verbose == 1;
     return h->solver.solve(x, rhs, 1, 2 * (int64_t)h->n, false); // interleaved complex vectors = vectors of the real-equivalent system
 }
 
+int32_t complex_solver_hipmf_solve(struct InterfaceComplexHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {
+    return guarded(h, [&]() { return c_solve_body(h, x, rhs, verbose); });
+}
+
 const char *complex_solver_hipmf_last_error(struct InterfaceComplexHIPMF *h) { return h ? h->solver.last_error.c_str() : "null solver"; }
 
-int32_t complex_solver_hipmf_get_stats(struct InterfaceComplexHIPMF *h, int64_t *is, double *ds) {
+static int32_t c_get_stats_body(struct InterfaceComplexHIPMF *h, int64_t *is, double *ds) {
     if (!h || !is || !ds) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     const Solver &s = h->solver;
@@ -220,6 +267,10 @@ int32_t complex_solver_hipmf_get_stats(struct InterfaceComplexHIPMF *h, int64_t 
     ds[0] = s.S.flops, ds[1] = s.S.flops_gemm, ds[2] = s.S.seconds_ordering, ds[3] = s.S.seconds_total, ds[4] = s.times.scale_assemble_ms;
     ds[5] = s.times.factor_ms, ds[6] = s.times.fwd_ms, ds[7] = s.times.bwd_ms, ds[8] = s.times.solve_total_ms, ds[9] = s.last_residual_inf;
     return SUCCESSFUL_EXIT;
+}
+
+int32_t complex_solver_hipmf_get_stats(struct InterfaceComplexHIPMF *h, int64_t *is, double *ds) {
+    return guarded(h, [&]() { return c_get_stats_body(h, is, ds); });
 }
 
 } // extern "C"

@@ -1042,8 +1042,18 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
 }
 
 
+#ifndef HIPMF_UPD_WAVES
+#define HIPMF_UPD_BOUNDS __launch_bounds__(256)
+#else
+#define HIPMF_UPD_BOUNDS __launch_bounds__(256, HIPMF_UPD_WAVES)
+#endif
+#ifndef HIPMF_UPD32_WAVES
+#define HIPMF_UPD32_BOUNDS __launch_bounds__(64)
+#else
+#define HIPMF_UPD32_BOUNDS __launch_bounds__(64, HIPMF_UPD32_WAVES)
+#endif
 template <bool SYM>
-__global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+__global__ void HIPMF_UPD_BOUNDS k_update(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
                                                 int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
@@ -1059,7 +1069,7 @@ __global__ void __launch_bounds__(256) k_update(const int32_t *__restrict__ pfx,
 
 // the same with 32 x 32 tiles, one wavefront per tile (levels whose largest tiled front has at most Solver::upd32_max_front rows)
 template <bool SYM>
-__global__ void __launch_bounds__(64) k_update32(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
+__global__ void HIPMF_UPD32_BOUNDS k_update32(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
                                                  int32_t k0, double *__restrict__ pool,
                                                  double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                  const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,

@@ -1,17 +1,22 @@
-// kernels_factor_front.hpp -- the fronts in the MIDDLE of the tree (f > 64, p <= 64, m <= 4 CM, LU mode): ONE workgroup carries a
+// kernels_factor_front.hpp -- the fronts in the MIDDLE of the tree (f > 64, p <= 64, m <= 8 CM, LU mode): ONE workgroup carries a
 // front through its whole partial factorisation in ONE launch per level and size class.
 //
 // The tiled path (kernels_factor.hpp) spends a launch pair per 32 pivots on these fronts -- k_panel + k_update, each a chain of
 // memory round trips -- and a 64 x 64 tile grid of which a quarter is live (a front with f = 100, p = 30 is nine tiles for 9 100
-// entries).  Here the p pivot ROWS of the front, [F11 F12] (p x f), stay on the CU -- F11 in LDS, F12 in the registers of four
-// wavefronts (lane = row, every wavefront holds every fourth column) -- and are reduced by Gauss-Jordan elimination with partial
+// entries).  Here the p pivot ROWS of the front, [F11 F12] (p x f), stay on the CU -- F11 in LDS, F12 in the registers of eight
+// wavefronts (lane = row, every wavefront holds every eighth column) -- and are reduced by Gauss-Jordan elimination with partial
 // pivoting over the pivot block:
 //
 //      [F11 F12]  ->  [G  V],   G = inv(F11),  V = inv(F11) F12          (in place: column k of F11 becomes a column of G)
 //
-// after which the rest of the front is ONE product with the column panel F21, streamed from the arena with lane = row:
+// after which the rest of the front is ONE product with the column panel F21 (fetched into LDS at the start of the kernel, beside the
+// pivot rows: the elimination hides its latency):
 //
 //      [-W  S] = [0  F22] - F21 [G  V]           W = F21 inv(F11),  S = F22 - F21 inv(F11) F12  (the contribution block, in place)
+//
+// Every global load the kernel needs before its last phase is issued in its first microsecond; a dependent round trip to memory costs
+// 1 - 2 us on this GPU and the first version of this kernel (round 4, profiles/r04_front_bench.txt) spent three quarters of its time
+// in a dozen of them.
 //
 // What the solves need of a tiled front is a pair (E, E') with  [y1; u] = E b1 + [0; b2]  and  x1 = E' [y1; x2]  (two GEMVs without
 // dependencies, kernels_common.hpp).  Any pair with  E'_left E_top = inv(F11),  E_bot = -F21 inv(F11),  E'_right = -inv(F11) F12
@@ -23,7 +28,7 @@
 // the descriptor carries FD_DENSE_TOP and the slabs read whole rows.  Pivots (diag) and interchanges (lperm) are those of an LU with
 // the same pivot sequence: the entries of a Gauss-Jordan pivot column in the rows not chosen yet are the LU's.
 //
-// Per pivot k: the wavefront that owns column k (k mod 4) holds that column in a register since it updated it, picks the pivot (one
+// Per pivot k: the wavefront that owns column k (k mod 8) holds that column in a register since it updated it, picks the pivot (one
 // 32-bit DPP max-reduction over the rows not chosen yet) and publishes the multipliers l_i = a_ik / d and the pivot row's lane
 // through LDS -- one workgroup barrier per pivot; every wavefront then subtracts l_i x (pivot row) from its columns: those of F11
 // by a read-modify-write of its own LDS columns (a column of F11 is only ever touched by its wavefront: no further barrier), those
@@ -37,11 +42,13 @@
 
 namespace hipmf {
 
-constexpr int MID_NW = 4;      // wavefronts per front
+constexpr int MID_NW = 8;      // wavefronts per front
 constexpr int MID_PMAX = 64;   // pivots at most: one pivot row per lane
-constexpr int MID_CHUNK = 64;  // columns of [G V] staged in LDS per pass of the product with F21 (16 per wavefront)
+constexpr int MID_MMAX = 192;  // off-diagonal rows at most (24 columns of F12 per wavefront and lane)
+constexpr int MID_CHUNK = 64;  // columns of [G V] staged in LDS per pass of the product with F21 (8 per wavefront)
 constexpr int MID_RBLD = 66;   // row stride of the staging buffer (even: 16-byte aligned rows for ds_read_b128 broadcasts;
                                // 132 dwords = 4 mod 64: the sixteen lanes of a ds_write_b64 group hit sixteen bank pairs)
+constexpr int MID_LDS_DOUBLES = 12288; // dynamic LDS of a front at most (96 KB): F11 + staging buffer + F21
 
 struct MidLds {
     double lm[2][64];     // multipliers of the current pivot, double-buffered: one barrier per pivot
@@ -49,10 +56,13 @@ struct MidLds {
     int32_t pv[2];        // lane of the pivot row
     int32_t rk[MID_PMAX]; // lane of the pivot row of every step (= the front-local row that became pivot row k)
 };
-// dynamic LDS of a launch whose largest front has pmax pivots: F11 row-major with stride pmax | 1 (lane = row: an odd stride of
-// doubles spreads the 32 lanes of a ds_read_b64 group over 32 bank pairs), then the staging buffer of the product
-__host__ __device__ inline int mid_s11_ld(int pmax) { return pmax | 1; }
-__host__ __device__ inline size_t mid_lds_bytes(int pmax) { return sizeof(double) * ((size_t)((pmax * mid_s11_ld(pmax) + 1) & ~1) + (size_t)pmax * MID_RBLD); }
+// dynamic LDS of a front with p pivots and m off-diagonal rows, in doubles: F11 row-major with stride p | 1 (lane = row: an odd
+// stride of doubles spreads the 32 lanes of a ds_read_b64 group over 32 bank pairs), the staging buffer of the product
+// (p x MID_RBLD), F21 column-major (m x p)
+__host__ __device__ inline int mid_s11_ld(int p) { return p | 1; }
+__host__ __device__ inline int mid_rb_off(int p) { return (p * mid_s11_ld(p) + 1) & ~1; }
+__host__ __device__ inline int mid_a21_off(int p) { return mid_rb_off(p) + p * MID_RBLD; }
+__host__ __device__ inline int mid_lds_doubles(int p, int m) { return mid_a21_off(p) + p * m; }
 
 template <int I, int N, class Fn> __device__ __forceinline__ void static_for(Fn &&fn) {
     if constexpr (I < N) {
@@ -61,11 +71,11 @@ template <int I, int N, class Fn> __device__ __forceinline__ void static_for(Fn 
     }
 }
 
-// CM: columns of F12 per wavefront and lane (fronts with m <= 4 CM off-diagonal rows)
+// CM: columns of F12 per wavefront and lane (fronts with m <= 8 CM off-diagonal rows)
 template <int CM>
 __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restrict__ LFD, double *__restrict__ pool, int32_t *__restrict__ lperm,
                                                        const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                       double *__restrict__ diag, int32_t pmax) {
+                                                       double *__restrict__ diag) {
     HIPMF_DYN_SHARED(double, dyn);
     __shared__ MidLds sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6); // (the wavefront's number in a scalar register)
@@ -77,14 +87,15 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
     double *__restrict__ F = pool + fd.off;
     double *__restrict__ E = pool + fd.eoff;
     double *__restrict__ Ep = pool + fd.epoff;
-    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
-    const int sld = mid_s11_ld(pmax);
-    double *S11 = dyn;                                   // (row, column) of F11 at S11[row * sld + column]
-    double *RB = dyn + ((pmax * sld + 1) & ~1);          // staging buffer of the product: [pivot step][MID_RBLD]
-    double *Srow = S11 + lane * sld;
+    const int sld = mid_s11_ld(p);
+    double *S11 = dyn;                  // (row, column) of F11 at S11[row * sld + column]
+    double *RB = dyn + mid_rb_off(p);   // staging buffer of the product: [pivot step][MID_RBLD]
+    double *A21 = dyn + mid_a21_off(p); // (row i, column k) of F21 at A21[i + k * m]
+    const bool rowl = lane < p;                  // this lane holds a pivot row
+    double *Srow = S11 + (rowl ? lane : 0) * sld; // (lanes beyond the pivot block read row 0 and never store)
 
-    // ---- the pivot rows: lane = row.  F12: this wavefront's columns p + wave, p + wave + 4, ... in registers; F11: its columns wave,
-    //      wave + 4, ... into LDS (every load of the thread is in flight before the first LDS store)
+    // ---- every load up front.  Pivot rows: lane = row; F12: this wavefront's columns p + wave, p + wave + 8, ... stay in registers;
+    //      F11: its columns wave, wave + 8, ... go to LDS; F21: column k of the panel by wavefront k mod 8, 64 rows per load
     double a[CM];
     double pcol = 0.0; // column k of F11 while this wavefront owns the next pivot
     {
@@ -95,22 +106,45 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
             const double v = Fr[(int64_t)(c < f ? c : 0) * ld]; // (clamped address: unconditional load)
             a[q] = (lane < p && c < f) ? v : 0.0;
         }
-        for (int j0 = wave; j0 < p; j0 += 4 * MID_NW) {
-            double t[4];
+        constexpr int NJ = MID_PMAX / MID_NW; // columns of F11 / of F21 per wavefront at most
+        double t[NJ];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + MID_NW * u;
-                const double v = Fr[(int64_t)(j < p ? j : 0) * ld];
-                t[u] = (lane < p && j < p) ? v : 0.0;
+        for (int u = 0; u < NJ; u++) {
+            const int j = wave + MID_NW * u;
+            t[u] = Fr[(int64_t)(j < p ? j : 0) * ld];
+        }
+        // F21: (MID_MMAX / 64) x NJ loads per thread at most, in two halves to bound the registers
+        const double *Fp = F + p;
+        constexpr int NRB = MID_MMAX / 64;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double w[NRB][NJ / 2];
+#pragma unroll
+            for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+                for (int u = 0; u < NJ / 2; u++) {
+                    const int k = wave + MID_NW * (u + h * (NJ / 2)), i = rb * 64 + lane;
+                    const bool in = k < p && i < m;
+                    w[rb][u] = Fp[(in ? i : 0) + (int64_t)(in ? k : 0) * ld];
+                }
+            if (h == 0) {
+#pragma unroll
+                for (int u = 0; u < NJ; u++) {
+                    const int j = wave + MID_NW * u;
+                    if (j < p && rowl) Srow[j] = t[u];
+                    if (j == 0) pcol = rowl ? t[u] : 0.0; // (wave 0 owns pivot 0)
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + MID_NW * u;
-                if (j < p) Srow[j] = t[u];
-                if (j == 0) pcol = t[u]; // (wave 0 owns pivot 0)
-            }
+            for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+                for (int u = 0; u < NJ / 2; u++) {
+                    const int k = wave + MID_NW * (u + h * (NJ / 2)), i = rb * 64 + lane;
+                    if (k < p && i < m) A21[i + k * m] = w[rb][u];
+                }
         }
     }
+    const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
     HIPMF_STAMP(blockIdx.x, 1);
     // ---- Gauss-Jordan over the pivot block ----
     int step = -1;     // the elimination step at which this lane's row was chosen
@@ -136,8 +170,8 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
                 inv = 1.0 / dn;
             }
             const double l = col * inv;
-            sh.lm[buf][lane] = (lane == pv) ? 0.0 : l;
-            Srow[k] = (lane == pv) ? 1.0 : -l; // column k of the identity block, stored in place of column k of F11
+            sh.lm[buf][lane] = (lane == pv || !rowl) ? 0.0 : l;
+            if (rowl) Srow[k] = (lane == pv) ? 1.0 : -l; // column k of the identity block, stored in place of column k of F11
             if (lane == 0) sh.pv[buf] = pv, sh.dv[buf] = d, sh.rk[k] = pv;
         }
         __syncthreads();
@@ -147,7 +181,7 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
             step = k;
             dval = sh.dv[buf];
         }
-        // this wavefront's columns of F11 (LDS; column k itself holds its final content already), the next pivot column first
+        // this wavefront's columns of F11 (LDS; column k itself holds its final content already), the next pivot column among them
         const double *Spv = S11 + pv * sld;
         for (int j0 = wave; j0 < p; j0 += 4 * MID_NW) {
             double x[4], u[4];
@@ -161,7 +195,7 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
             for (int t = 0; t < 4; t++) {
                 const int j = j0 + MID_NW * t;
                 const double y = __builtin_fma(-lm, u[t], x[t]);
-                if (j < p && j != k) Srow[j] = y;
+                if (j < p && j != k && rowl) Srow[j] = y;
                 if (j == k + 1) pcol = y;
             }
         }
@@ -203,70 +237,72 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
     __syncthreads();
     HIPMF_STAMP(blockIdx.x, 3);
     if (m == 0) return;
-    // ---- [-W  S] = [0  F22] - F21 [G  V]: lane = row of F21, 16 columns of the staged block per wavefront ----
+    // ---- [-W  S] = [0  F22] - F21 [G  V]: units of 64 rows of F21 x 8 staged columns, dealt to the wavefronts; lane = row ----
     const int nrb = (m + 63) >> 6;
-    // one pass over the rows of F21 against the 16 staged columns [cs, cs + 16) of this wavefront; `ncol` of them exist; they are
-    // columns of G (gpart: result -> E_bot, scattered by rk) or the columns c0 .. of the front (result -> F22 in place)
-    auto product = [&](const int cs, const int ncol, const bool gpart, const int c0) {
-        const double *Rw = RB + cs;
-        for (int rb = 0; rb < nrb; rb++) {
+    // the staged columns [0, nst) are columns of G (gpart: result -> E_bot, scattered by rk) or the columns c0 .. of the front
+    // (result -> F22 in place: the entries are requested before the products and needed after them)
+    auto product = [&](const int nst, const bool gpart, const int c0) {
+        const int ngr = (nst + 7) >> 3, nun = ngr * nrb;
+        for (int un = wave; un < nun; un += MID_NW) {
+            const int rb = un / ngr, cs = (un - rb * ngr) * 8;
+            const int ncol = (nst - cs) < 8 ? (nst - cs) : 8;
             const int i = rb * 64 + lane;
             const bool rowok = i < m;
-            const double *Fi = F + p + (rowok ? i : 0); // row i of [F21 F22]
-            double acc[16];
+            const int ic = rowok ? i : 0;
+            double cin[8];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const double v = Fi[(int64_t)((!gpart && c < ncol) ? c0 + c : 0) * ld];
-                acc[c] = (!gpart && c < ncol) ? v : 0.0;
+            for (int c = 0; c < 8; c++) {
+                const double v = gpart ? 0.0 : F[(p + ic) + (int64_t)(c < ncol ? c0 + cs + c : c0) * ld];
+                cin[c] = (!gpart && c < ncol) ? v : 0.0;
             }
-            for (int k0 = 0; k0 < p; k0 += 8) {
-                double ak[8];
+            double acc[8];
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
+            for (int c = 0; c < 8; c++) acc[c] = 0.0;
+            const double *Rw = RB + cs;
+            const double *Ai = A21 + ic;
+            for (int k0 = 0; k0 < p; k0 += 4) {
+                double ak[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
                     const int k = k0 + kk;
-                    const double v = Fi[(int64_t)(k < p ? k : 0) * ld];
+                    const double v = Ai[(k < p ? k : 0) * m];
                     ak[kk] = k < p ? v : 0.0;
                 }
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
+                for (int kk = 0; kk < 4; kk++) {
                     const double *Rk = Rw + (k0 + kk < p ? k0 + kk : 0) * MID_RBLD; // (rows beyond p: multiplied by ak = 0)
 #pragma unroll
-                    for (int c = 0; c < 16; c++) acc[c] = __builtin_fma(-ak[kk], Rk[c], acc[c]);
+                    for (int c = 0; c < 8; c++) acc[c] = __builtin_fma(ak[kk], Rk[c], acc[c]);
                 }
             }
             if (rowok) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
+                for (int c = 0; c < 8; c++) {
                     if (c < ncol) {
-                        if (gpart) E[(p + i) + (int64_t)wave_uniform(sh.rk[cs + c]) * ld] = acc[c];
-                        else F[(p + i) + (int64_t)(c0 + c) * ld] = acc[c];
+                        if (gpart) E[(p + i) + (int64_t)wave_uniform(sh.rk[cs + c]) * ld] = -acc[c];
+                        else F[(p + i) + (int64_t)(c0 + cs + c) * ld] = cin[c] - acc[c];
                     }
                 }
             }
         }
     };
-    // the columns of G: 16 per wavefront
-    {
-        const int cs = 16 * wave;
-        if (cs < p) product(cs, (p - cs) < 16 ? (p - cs) : 16, true, 0);
-    }
+    product(p, true, 0);
     HIPMF_STAMP(blockIdx.x, 4);
-    // the columns of V, 64 at a time: this wavefront stages its own (every fourth) and multiplies the 16 columns [16 wave, 16 wave + 16)
-    static_for<0, (CM + 15) / 16>([&](auto chc) {
+    // the columns of V, 64 at a time: every wavefront stages its own (every eighth) column
+    static_for<0, (CM + 7) / 8>([&](auto chc) {
         constexpr int ch = decltype(chc)::value;
         if (ch * MID_CHUNK < m) { // (workgroup-uniform)
             __syncthreads();      // the block staged before has been consumed
             if (lane < p) {
 #pragma unroll
-                for (int qq = 0; qq < 16; qq++) {
-                    constexpr int qbase = 16 * ch;
+                for (int qq = 0; qq < 8; qq++) {
+                    constexpr int qbase = 8 * ch;
                     if (qbase + qq < CM) RB[step * MID_RBLD + MID_NW * qq + wave] = a[(qbase + qq) < CM ? (qbase + qq) : 0];
                 }
             }
             __syncthreads();
-            const int cs = 16 * wave;
-            const int c0 = p + ch * MID_CHUNK + cs;
-            if (c0 < f) product(cs, (f - c0) < 16 ? (f - c0) : 16, false, c0);
+            const int c0 = p + ch * MID_CHUNK;
+            product((f - c0) < MID_CHUNK ? (f - c0) : MID_CHUNK, false, c0);
         }
     });
     HIPMF_STAMP(blockIdx.x, 5);

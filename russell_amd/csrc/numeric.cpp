@@ -57,6 +57,12 @@ static hipError_t dev_upload(T **dptr, const std::vector<T> &v) {
 }
 
 Solver::Solver() {}
+
+bool Solver::is_mid(int32_t s) const {
+    if (!use_mid || S.sym_mode) return false;
+    const int32_t p = S.npiv(s), m = S.nrow(s);
+    return p + m > SMALL_F && p <= MID_PMAX && m <= mid_mmax && mid_lds_doubles(p, m) <= MID_LDS_DOUBLES;
+}
 Solver::~Solver() { release(); }
 
 void Solver::release() {
@@ -121,7 +127,15 @@ void Solver::release() {
         (void)hipStreamDestroy((hipStream_t)stream2);
         stream2 = nullptr;
     }
-    for (void **e : {&ev_fork, &ev_join})
+#ifndef HIPMF_EMULATED
+    if (factor_graph) (void)hipGraphExecDestroy((hipGraphExec_t)factor_graph);
+#endif
+    factor_graph = nullptr, graph_launches = 0;
+    if (stream3) {
+        (void)hipStreamDestroy((hipStream_t)stream3);
+        stream3 = nullptr;
+    }
+    for (void **e : {&ev_fork, &ev_join, &ev_fork3, &ev_join3})
         if (*e) {
             (void)hipEventDestroy((hipEvent_t)*e);
             *e = nullptr;
@@ -173,10 +187,14 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         stream = st;
         HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
         stream2 = st;
-        hipEvent_t e1, e2;
+        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+        stream3 = st;
+        hipEvent_t e1, e2, e3, e4;
         HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
         HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-        ev_fork = e1, ev_join = e2;
+        HIPC(hipEventCreateWithFlags(&e3, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+        HIPC(hipEventCreateWithFlags(&e4, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+        ev_fork = e1, ev_join = e2, ev_fork3 = e3, ev_join3 = e4;
     }
     if (!rematching) {
         h_rp_keep.assign(rp, rp + n + 1);
@@ -230,8 +248,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_CHAIN_MIN_WGS")) chain_min_update = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_CHAIN_MAX_STEPS")) chain_max_steps = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_UPD32_MAXF")) upd32_max_front = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_FACTOR_GRAPH")) use_graph = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
-    if (const char *e = getenv("HIPMF_MID_FMAX")) mid_fmax = std::max(64, std::min(256, atoi(e)));
+    if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(1, std::min(MID_MMAX, atoi(e)));
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -930,9 +949,9 @@ int32_t Solver::upload_plan() {
             std::vector<int32_t> tiled;
             for (int32_t a : big) (is_mid(a) ? mid : tiled).push_back(a);
             big.swap(tiled);
-            auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return m <= 80 ? 0 : (m <= 128 ? 1 : (m <= 192 ? 2 : 3)); }; // (the CM of k_front: 20 / 32 / 48 / 64)
+            auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return m <= 80 ? 0 : (m <= 128 ? 1 : 2); }; // (the CM of k_front: 10 / 16 / 24)
             std::stable_sort(mid.begin(), mid.end(), [&](int32_t a, int32_t b) { return cls(a) != cls(b) ? cls(a) < cls(b) : S.npiv(a) > S.npiv(b); });
-            for (int32_t a : mid) L.mid_cnt[cls(a)]++, L.mid_pmax[cls(a)] = std::max(L.mid_pmax[cls(a)], S.npiv(a));
+            for (int32_t a : mid) L.mid_cnt[cls(a)]++, L.mid_lds[cls(a)] = std::max(L.mid_lds[cls(a)], mid_lds_doubles(S.npiv(a), S.nrow(a)));
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
         // symmetric mode: the tiled fronts of this level whose parent is a small front (it pulls a FULL contribution block)
@@ -1148,10 +1167,9 @@ int32_t Solver::upload_plan() {
     }
     if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
     if (use_mid && !S.sym_mode) { // (a front with 64 pivots stages 67 KB)
-        HIPMF_ALLOW_LDS(k_front<20>, mid_lds_bytes(MID_PMAX));
-        HIPMF_ALLOW_LDS(k_front<32>, mid_lds_bytes(MID_PMAX));
-        HIPMF_ALLOW_LDS(k_front<48>, mid_lds_bytes(MID_PMAX));
-        HIPMF_ALLOW_LDS(k_front<64>, mid_lds_bytes(MID_PMAX));
+        HIPMF_ALLOW_LDS(k_front<10>, sizeof(double) * MID_LDS_DOUBLES);
+        HIPMF_ALLOW_LDS(k_front<16>, sizeof(double) * MID_LDS_DOUBLES);
+        HIPMF_ALLOW_LDS(k_front<24>, sizeof(double) * MID_LDS_DOUBLES);
     }
     pl_lap("factor launch plans");
     allbig_off = (int32_t)lists.size();
@@ -1351,6 +1369,11 @@ int32_t Solver::run_factor() {
             launches++;
         }
     };
+    // Everything from here to the last level is a FIXED sequence of launches (grids, arguments and cross-stream edges are set by the
+    // plan): it is captured once into a hipGraph and replayed by later factorisations -- the host-side event calls between the
+    // streams cost 5 - 11 us of idle device at every level boundary when issued eagerly (profiles/r03_factor_sequence.txt: 214 us
+    // of gaps in one factorisation of the 1M-DOF matrix).
+    auto enqueue_levels = [&]() -> int32_t {
     if (!levels.empty()) fill_level(levels[0], STREAM);
     for (size_t li = 0; li < levels.size(); li++) {
         const LevelPlan &L = levels[li];
@@ -1363,7 +1386,7 @@ int32_t Solver::run_factor() {
         }
         // a level's small fronts and its big fronts are independent of each other (both only need the level's extend-add):
         // when the level has both, the small ones are factorised on a second stream beside the tiled steps
-        const bool has_mid = L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] + L.mid_cnt[3] > 0;
+        const bool has_mid = L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] > 0;
         const bool forked = overlap_small && ((L.small_cnt > 0 && (!L.steps.empty() || has_mid)) || fill_next);
         if (L.small_cnt > 0) {
             size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
@@ -1395,6 +1418,33 @@ int32_t Solver::run_factor() {
         }
         if (fill_next) fill_level(*Lnext, forked ? (hipStream_t)stream2 : STREAM);
         if (forked) HIPC(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)stream2), ERROR_HIP_SYNCHRONIZE);
+        // the fronts of the middle of the tree: one workgroup per front, one launch per size class (kernels_factor_front.hpp)
+        // beside the level's tiled steps (and its small fronts): all three only depend on the level's extend-add
+        const bool mid_forked = overlap_small && has_mid && (!L.steps.empty() || forked);
+        if (has_mid) {
+            hipStream_t mst = STREAM;
+            if (mid_forked) {
+                HIPC(hipEventRecord((hipEvent_t)ev_fork3, STREAM), ERROR_HIP_SYNCHRONIZE);
+                HIPC(hipStreamWaitEvent((hipStream_t)stream3, (hipEvent_t)ev_fork3, 0), ERROR_HIP_SYNCHRONIZE);
+                mst = (hipStream_t)stream3;
+            }
+            int32_t moff = L.mid_off;
+            for (int c = 2; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
+            for (int c = 2; c >= 0; c--) {
+                moff -= L.mid_cnt[c];
+                if (L.mid_cnt[c] == 0) continue;
+                const size_t dyn = sizeof(double) * (size_t)L.mid_lds[c];
+                const FrontDesc *mfd = d_bigfd + moff;
+#define HIPMF_LAUNCH_FRONT(CM) \
+    hipLaunchKernelGGL(k_front<CM>, dim3(L.mid_cnt[c]), dim3(64 * MID_NW), dyn, mst, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag)
+                if (c == 0) HIPMF_LAUNCH_FRONT(10);
+                else if (c == 1) HIPMF_LAUNCH_FRONT(16);
+                else HIPMF_LAUNCH_FRONT(24);
+#undef HIPMF_LAUNCH_FRONT
+                launches++;
+            }
+            if (mid_forked) HIPC(hipEventRecord((hipEvent_t)ev_join3, (hipStream_t)stream3), ERROR_HIP_SYNCHRONIZE);
+        }
         int32_t k0 = 0;
         if (chained && L.chain_cnt > 0) {
             // all tiled steps of the level in one launch (kernels_factor_chain.hpp)
@@ -1446,31 +1496,46 @@ int32_t Solver::run_factor() {
             launches += 2;
             k0 += NB;
         }
-        // the fronts of the middle of the tree: one workgroup per front, one launch per size class (kernels_factor_front.hpp)
-        {
-            int32_t moff = L.mid_off;
-            for (int c = 3; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
-            for (int c = 3; c >= 0; c--) {
-                moff -= L.mid_cnt[c];
-                if (L.mid_cnt[c] == 0) continue;
-                const size_t dyn = mid_lds_bytes(L.mid_pmax[c]);
-                const FrontDesc *mfd = d_bigfd + moff;
-#define HIPMF_LAUNCH_FRONT(CF) \
-    hipLaunchKernelGGL(k_front<CF>, dim3(L.mid_cnt[c]), dim3(64 * MID_NW), dyn, STREAM, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, \
-                       L.mid_pmax[c])
-                if (c == 0) HIPMF_LAUNCH_FRONT(20);
-                else if (c == 1) HIPMF_LAUNCH_FRONT(32);
-                else if (c == 2) HIPMF_LAUNCH_FRONT(48);
-                else HIPMF_LAUNCH_FRONT(64);
-#undef HIPMF_LAUNCH_FRONT
-                launches++;
-            }
-        }
         if (L.mirror_cnt > 0) {
             hipLaunchKernelGGL(k_mirror_cb, dim3(L.mirror_cnt), dim3(256), 0, STREAM, d_lists + L.mirror_off, d_fd, d_pool);
             launches++;
         }
         if (forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
+        if (mid_forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join3, 0), ERROR_HIP_SYNCHRONIZE);
+    }
+    return SUCCESSFUL_EXIT;
+    };
+#ifndef HIPMF_EMULATED
+    bool replayed = false;
+    if (use_graph && !chained) {
+        if (!factor_graph) {
+            // capture (nothing runs), instantiate; any failure falls back to eager launches for good
+            const int64_t before = launches;
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            bool ok = hipStreamBeginCapture(STREAM, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int32_t ccode = enqueue_levels();
+                const bool ended = hipStreamEndCapture(STREAM, &g) == hipSuccess && g != nullptr;
+                ok = ccode == SUCCESSFUL_EXIT && ended && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess && ge != nullptr;
+                if (g) (void)hipGraphDestroy(g);
+            }
+            (void)hipGetLastError();
+            if (ok) factor_graph = (void *)ge, graph_launches = launches - before;
+            else use_graph = false;
+            launches = before;
+        }
+        if (factor_graph) {
+            HIPC(hipGraphLaunch((hipGraphExec_t)factor_graph, STREAM), ERROR_HIP_LAUNCH);
+            launches += graph_launches;
+            replayed = true;
+        }
+    }
+    if (!replayed)
+#endif
+    {
+        const int32_t lcode = enqueue_levels();
+        if (lcode != SUCCESSFUL_EXIT) return lcode;
     }
     HIPC(hipEventRecord((hipEvent_t)ev[2], STREAM), ERROR_HIP_SYNCHRONIZE);
     FactorInfo hinfo;

@@ -83,8 +83,8 @@ struct LevelPlan {
     // fronts of the middle of the tree that ONE workgroup carries through their whole partial factorisation (k_front,
     // kernels_factor_front.hpp): their descriptors follow the tiled ones in d_bigfd, grouped by size class
     int32_t mid_off = 0;                 // first of them in d_bigfd
-    int32_t mid_cnt[4] = {0, 0, 0, 0};   // fronts per class (columns of F12 per wavefront 20 / 32 / 48 / 64)
-    int32_t mid_pmax[4] = {0, 0, 0, 0};  // largest pivot count per class (LDS of the launch)
+    int32_t mid_cnt[3] = {0, 0, 0};      // fronts per class (columns of F12 per wavefront 10 / 16 / 24)
+    int32_t mid_lds[3] = {0, 0, 0};      // dynamic LDS of the class's launch, in doubles (its largest front)
     int64_t chain_off = 0;  // the level's tiled steps as ONE launch (k_chain): its tasks in d_chain, chain_cnt of them (0: one launch per step)
     int32_t chain_cnt = 0;
 };
@@ -138,6 +138,12 @@ class Solver {
     void *stream = nullptr;
     void *stream2 = nullptr;          // the small fronts of a level are factorised beside its tiled steps
     void *ev_fork = nullptr, *ev_join = nullptr;
+    // the launches of a factorisation's levels, captured once and replayed (HIPMF_FACTOR_GRAPH=0: eager launches)
+    bool use_graph = false; // (measured: no gain at 1000 x 1000 -- the gaps at the level boundaries are the cross-stream edges themselves, not host latency)
+    void *factor_graph = nullptr;
+    int64_t graph_launches = 0;
+    void *stream3 = nullptr;          // ... and so are the fronts one workgroup factorises (k_front)
+    void *ev_fork3 = nullptr, *ev_join3 = nullptr;
     std::string last_error;
     std::mutex err_mutex; // (the planning thread of initialize and the calling thread both report through last_error)
 
@@ -237,11 +243,12 @@ class Solver {
     int32_t upd32_max_front = 256;          // LU: levels whose largest tiled front has at most this many rows update with 32 x 32 tiles, one wave per tile
                                             // (HIPMF_UPD32_MAXF; 0: never).  Bit-identical to the 64 x 64 instance; 1000 x 1000: 7.30 -> 7.23 ms.  The L D L^T
                                             // fronts keep the 64 x 64 tiles (measured: 6.32 -> 6.35 ms with the small ones)
-    // LU mode: fronts with 64 < f <= mid_fmax and at most 64 pivots are factorised by one workgroup each, one launch per level and size
-    // class (HIPMF_MID_FRONT=0: off, HIPMF_MID_FMAX: rows at most, <= 256)
-    bool use_mid = false; // (off until it beats the tiled launches: profiles/r04_front_bench.txt)
-    int32_t mid_fmax = 256;
-    bool is_mid(int32_t s) const { return use_mid && !S.sym_mode && S.fsize(s) > 64 && S.fsize(s) <= mid_fmax && S.npiv(s) <= 64; }
+    // LU mode: fronts with f > 64, at most 64 pivots and at most mid_mmax off-diagonal rows whose pivot rows + column panel fit the
+    // LDS budget of k_front are factorised by one workgroup each, one launch per level and size class (HIPMF_MID_FRONT=0: off,
+    // HIPMF_MID_MMAX: rows at most, <= 192)
+    bool use_mid = true;
+    int32_t mid_mmax = 80; // (above 80 rows the tiled launches are as fast or faster: profiles/r04_front_bench.txt)
+    bool is_mid(int32_t s) const;
     int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging
     bool use_fused = true;                  // false: level-set launches (HIPMF_FUSED_SOLVE=0, or after a hand-off timeout)

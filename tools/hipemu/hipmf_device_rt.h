@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#define HIPMF_EMULATED 1 // (no graph capture, no RCCL: the emulator runs launches synchronously)
+
 typedef double f64x4 __attribute__((vector_size(32)));
 
 struct f64x2 {

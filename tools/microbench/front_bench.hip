@@ -21,9 +21,9 @@ using namespace hipmf;
         }                                                                      \
     } while (0)
 
-template <int CM> static void launch(int n, size_t dyn, const FrontDesc *fd, double *pool, int32_t *lperm, unsigned long long *an, FactorInfo *info, double *diag, int pmax) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<CM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds_bytes(MID_PMAX)));
-    hipLaunchKernelGGL(k_front<CM>, dim3(n), dim3(64 * MID_NW), dyn, 0, fd, pool, lperm, an, 1e-13, info, diag, pmax);
+template <int CM> static void launch(int n, size_t dyn, const FrontDesc *fd, double *pool, int32_t *lperm, unsigned long long *an, FactorInfo *info, double *diag) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<CM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * MID_LDS_DOUBLES)));
+    hipLaunchKernelGGL(k_front<CM>, dim3(n), dim3(64 * MID_NW), dyn, 0, fd, pool, lperm, an, 1e-13, info, diag);
 }
 
 static void run(int p, int m, int nf, bool check) {
@@ -57,8 +57,12 @@ static void run(int p, int m, int nf, bool check) {
     double one = 1.0;
     CK(hipMemcpy(an, &one, 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dfd, fd.data(), sizeof(FrontDesc) * (size_t)nf, hipMemcpyHostToDevice));
-    const size_t dyn = mid_lds_bytes(p);
-    const int cls = m <= 80 ? 0 : (m <= 128 ? 1 : (m <= 192 ? 2 : 3));
+    const size_t dyn = sizeof(double) * (size_t)mid_lds_doubles(p, m);
+    if (mid_lds_doubles(p, m) > MID_LDS_DOUBLES || m > MID_MMAX) {
+        printf("p=%3d m=%3d: not eligible (%d doubles of LDS)\n", p, m, mid_lds_doubles(p, m));
+        return;
+    }
+    const int cls = m <= 80 ? 0 : (m <= 128 ? 1 : 2);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -66,10 +70,9 @@ static void run(int p, int m, int nf, bool check) {
     for (int rep = 0; rep < 4; rep++) {
         CK(hipMemcpy(pool, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, 0));
-        if (cls == 0) launch<20>(nf, dyn, dfd, pool, lperm, an, info, diag, p);
-        else if (cls == 1) launch<32>(nf, dyn, dfd, pool, lperm, an, info, diag, p);
-        else if (cls == 2) launch<48>(nf, dyn, dfd, pool, lperm, an, info, diag, p);
-        else launch<64>(nf, dyn, dfd, pool, lperm, an, info, diag, p);
+        if (cls == 0) launch<10>(nf, dyn, dfd, pool, lperm, an, info, diag);
+        else if (cls == 1) launch<16>(nf, dyn, dfd, pool, lperm, an, info, diag);
+        else launch<24>(nf, dyn, dfd, pool, lperm, an, info, diag);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -146,8 +149,8 @@ static void run(int p, int m, int nf, bool check) {
 
 int main(int argc, char **argv) {
     const bool check = argc > 1 && atoi(argv[1]) != 0;
-    const int cfg[][3] = {{16, 50, 1},  {16, 50, 256},  {16, 50, 1024}, {30, 70, 1},  {30, 70, 256}, {30, 70, 768}, {30, 70, 1536}, {40, 100, 1},
-                          {40, 100, 512}, {48, 120, 1}, {48, 120, 512}, {60, 190, 1}, {60, 190, 256}, {64, 192, 300}};
+    const int cfg[][3] = {{2, 70, 64}, {5, 75, 256}, {16, 50, 1},  {16, 50, 256},  {16, 50, 1024}, {30, 70, 1},  {30, 70, 256}, {30, 70, 768}, {30, 70, 1536}, {40, 100, 1},
+                          {40, 100, 512}, {48, 120, 1}, {48, 120, 512}, {56, 130, 1}, {56, 130, 256}, {32, 192, 256}};
     for (auto &c : cfg) run(c[0], c[1], c[2], check);
     return 0;
 }
