@@ -1145,7 +1145,7 @@ void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.initialize_ns.push_back(time_initialize_ns);
     stats.factorize_ns.push_back(time_factorize_ns);
     stats.solve_ns.push_back(time_solve_ns);
-    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Metis"; // nested dissection
+    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Nd"; // the backend's own nested dissection, whatever of Amd / Colamd / Metis / ... was asked for (none of those libraries is used)
     stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
     stats.rcond_estimate = rcond_estimate;
     stats.det_mantissa = 0.0, stats.det_base = 0.0, stats.det_exponent = 0.0; // (not available: see include/russell_hipmf.h)
@@ -1169,7 +1169,7 @@ void SolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.initialize_ns.push_back(time_initialize_ns);
     stats.factorize_ns.push_back(time_factorize_ns);
     stats.solve_ns.push_back(time_solve_ns);
-    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Metis"; // nested dissection
+    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Nd"; // the backend's own nested dissection, whatever of Amd / Colamd / Metis / ... was asked for (none of those libraries is used)
     stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
     stats.rcond_estimate = rcond_estimate;
     stats.det_mantissa = determinant_coefficient;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 #include "kernels.hpp"
@@ -181,21 +182,84 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         return ERROR_HIPMF_NO_DEVICE;
     }
     HIPC(hipGetDevice(&device), ERROR_HIPMF_NO_DEVICE);
-    if (!stream) {
-        hipStream_t st;
-        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
-        stream = st;
-        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
-        stream2 = st;
-        HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
-        stream3 = st;
-        hipEvent_t e1, e2, e3, e4;
-        HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-        HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-        HIPC(hipEventCreateWithFlags(&e3, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-        HIPC(hipEventCreateWithFlags(&e4, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-        ev_fork = e1, ev_join = e2, ev_fork3 = e3, ev_join3 = e4;
-    }
+    // Everything the device needs that does NOT depend on the analysis runs on a host thread of its own beside it: streams and events,
+    // the first touch of the device (a cold process pays 30 - 45 ms for it), the free-memory figure the analysis refuses too large a
+    // matrix by, and the upload of the matrix structure (refinement SpMV).  Joined right after the analysis.
+    std::atomic<double> live_pool_limit{0.0};
+    int32_t prep_code = SUCCESSFUL_EXIT;
+    auto prep = [&]() -> int32_t {
+        (void)hipSetDevice(device);
+        if (!stream) {
+            hipStream_t st;
+            HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+            stream = st;
+            HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+            stream2 = st;
+            HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+            stream3 = st;
+            hipEvent_t e1, e2, e3, e4;
+            HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e3, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e4, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            ev_fork = e1, ev_join = e2, ev_fork3 = e3, ev_join3 = e4;
+        }
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) live_pool_limit.store(0.95 * (double)free_b);
+            if (const char *e = getenv("HIPMF_POOL_LIMIT_GB")) live_pool_limit.store(0.95e9 * atof(e)); // (tests: force the refusal)
+        }
+        // matrix structure (kept for the refinement SpMV) and per-entry row/col indices
+        const int64_t nnz = rp[n];
+        std::vector<int32_t> h_arow((size_t)nnz);
+        for (int32_t i = 0; i < n; i++)
+            for (int32_t p = rp[i]; p < rp[i + 1]; p++) h_arow[p] = i;
+        {
+            // row blocks of the stream SpMV: consecutive rows with at most SPMV_CAP stored entries (a longer row stands alone)
+            std::vector<int32_t> rb(1, 0);
+            int32_t start = 0;
+            for (int32_t i = 0; i < n; i++)
+                if (rp[i + 1] - rp[start] > SPMV_CAP && i > start) rb.push_back(i), start = i;
+            // (the row that opens a block may itself exceed the cap: it is closed by the next row)
+            rb.push_back(n);
+            spmv_blocks = (int32_t)rb.size() - 1;
+            HIPC(dev_upload(&d_row_blk, rb), ERROR_HIP_MALLOC);
+        }
+        HIPC(hipMalloc((void **)&d_rp, sizeof(int32_t) * ((size_t)n + 1)), ERROR_HIP_MALLOC);
+        HIPC(hipMemcpy(d_rp, rp, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_ci, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+        if (nnz > 0) HIPC(hipMemcpy(d_ci, ci, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice), ERROR_HIP_MALLOC);
+        HIPC(dev_upload(&d_arow, h_arow), ERROR_HIP_MALLOC);
+        if (sym_lower) {
+            // transpose lists: for every row i, the stored entries (r, i), r > i, mirrored into row i
+            std::vector<int32_t> tptr((size_t)n + 1, 0), tidx;
+            for (int64_t k = 0; k < nnz; k++)
+                if (ci[k] != h_arow[k]) tptr[ci[k] + 1]++;
+            for (int32_t i = 0; i < n; i++) tptr[i + 1] += tptr[i];
+            tidx.resize((size_t)tptr[n]);
+            std::vector<int32_t> w(tptr.begin(), tptr.end() - 1);
+            for (int64_t k = 0; k < nnz; k++)
+                if (ci[k] != h_arow[k]) tidx[w[ci[k]]++] = (int32_t)k;
+            HIPC(dev_upload(&d_tptr, tptr), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_tidx, tidx), ERROR_HIP_MALLOC);
+        }
+        return SUCCESSFUL_EXIT;
+    };
+    std::thread prep_thread([&]() {
+        try {
+            prep_code = prep();
+        } catch (const std::bad_alloc &) { // (an exception must not leave the thread)
+            std::lock_guard<std::mutex> lock(err_mutex);
+            last_error = "Not enough memory: a host allocation failed";
+            prep_code = ERROR_MALLOC;
+        }
+    });
+    struct PrepJoiner { // (every early return below waits for the thread)
+        std::thread &t;
+        ~PrepJoiner() {
+            if (t.joinable()) t.join();
+        }
+    } prep_joiner{prep_thread};
     if (!rematching) {
         h_rp_keep.assign(rp, rp + n + 1);
         h_ci_keep.assign(ci, ci + rp[n]);
@@ -237,6 +301,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_UP_STAGE_BWD")) up_stage_bwd = std::max(8, std::min(64, atoi(e) / 8 * 8));
     if (const char *e = getenv("HIPMF_UP_TOP_FRONTS")) up_top_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_UP_REPLICAS")) use_rep = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_UP_PAIR_XCD")) up_pair_xcd = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_UP_MAX_GROUPS")) up_max_groups = std::max(2, std::min(32, atoi(e)));
     if (const char *e = getenv("HIPMF_BLOCKED_SLABS")) blocked_slabs = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_UP_STAGE_MID")) up_stage_mid = std::max(0, std::min(32, atoi(e) / 8 * 8));
     if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
@@ -274,14 +340,15 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             fprintf(stderr, "hipmf: initialize: the matrix has no perfect matching (structurally singular); continuing without\n");
         }
     }
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) so.pool_limit_bytes = 0.95 * (double)free_b;
-        if (const char *e = getenv("HIPMF_POOL_LIMIT_GB")) so.pool_limit_bytes = 0.95e9 * atof(e); // (tests: force the refusal)
-    }
+    so.pool_limit_live = &live_pool_limit; // (the free-memory figure arrives from the set-up thread while the ordering runs)
     lap("matching test");
     int rc = matched ? analyse(n, rpB.data(), ciB.data(), false, so, S) : analyse(n, rp, ci, sym_lower, so, S);
     lap("analyse");
+    prep_thread.join();
+    so.pool_limit_bytes = live_pool_limit.load();
+    if (prep_code != SUCCESSFUL_EXIT) return prep_code;
+    if (rc == 0 && so.pool_limit_bytes > 0.0 && S.pool_estimate_bytes > so.pool_limit_bytes) rc = -40; // (the figure came too late for the analysis' own test)
+    lap("wait for the device set-up");
     if (rc == -40) {
         char msg[256];
         snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free)", S.pool_estimate_bytes / 1e9,
@@ -391,145 +458,120 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
       }
     });
     Joiner asm_joiner{asm_thread};
+    // What follows the descriptor uploads of upload_plan -- permutation, plan signature, the assembly lists, the value and vector
+    // buffers -- does not depend on the task lists of the solves, which a host thread builds meanwhile (a third of upload_plan's time):
+    // it runs as upload_plan's tail, before that thread is joined.
+    auto tail = [&]() -> int32_t {
+        lap("plan + descriptor uploads");
+        const int64_t nnz = S.nnz_a;
+        HIPC(dev_upload(&d_perm, S.perm), ERROR_HIP_MALLOC);
+        d_rperm = d_perm;
+        {
+            uint64_t hsh = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) {
+                for (int b = 0; b < 8; b++) hsh = (hsh ^ ((v >> (8 * b)) & 0xff)) * 1099511628211ull;
+            };
+            for (int32_t k = 0; k < n; k++) mix((uint64_t)(uint32_t)S.perm[k] | ((uint64_t)(matched ? (uint32_t)mrow[S.perm[k]] : 0u) << 32));
+            mix((uint64_t)S.persist_doubles), mix((uint64_t)S.temp_doubles), mix((uint64_t)S.nsuper);
+            plan_sig = hsh & 0x7fffffffffffffffull;
+        }
+        if (matched) {
+            std::vector<int32_t> rperm((size_t)n);
+            for (int32_t k = 0; k < n; k++) rperm[k] = mrow[S.perm[k]];
+            HIPC(dev_upload(&d_rperm, rperm), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_cs, dc), ERROR_HIP_MALLOC);
+            std::vector<int32_t> dcol((size_t)n);
+            for (int32_t j = 0; j < n; j++) dcol[(size_t)mrow[j]] = j; // row mrow[j] of A is pivot row j: its diagonal entry sits in column j
+            HIPC(dev_upload(&d_dcol, dcol), ERROR_HIP_MALLOC);
+            // parity of the row permutation (determinant)
+            std::vector<char> seen((size_t)n, 0);
+            match_parity = 0;
+            for (int32_t i = 0; i < n; i++) {
+                if (seen[i]) continue;
+                int len = 0;
+                for (int32_t j = i; !seen[j]; j = mrow[j]) seen[j] = 1, len++;
+                if ((len & 1) == 0) match_parity ^= 1;
+            }
+        }
+        lap("perm + signature");
+        {
+            // (joined below: the lists were computed beside upload_plan)
+            if (asm_thread.joinable()) asm_thread.join();
+            if (AL.status == 1) {
+                last_error = "too many entries in the tiled fronts";
+                return ERROR_HIPMF_SYMBOLIC;
+            }
+            if (AL.status == 2) {
+                last_error = "too many zero-fill tasks";
+                return ERROR_HIPMF_SYMBOLIC;
+            }
+            if (AL.status == 3) {
+                last_error = "Not enough memory: a host allocation failed";
+                return ERROR_MALLOC;
+            }
+            const int32_t ns = S.nsuper;
+            for (int32_t l = 0; l < S.nlevels; l++) {
+                levels[(size_t)l].sc_off = (int32_t)AL.sc_cnt[(size_t)l], levels[(size_t)l].sc_cnt = (int32_t)(AL.sc_cnt[(size_t)l + 1] - AL.sc_cnt[(size_t)l]);
+                levels[(size_t)l].zero_off = AL.zero_off[(size_t)l], levels[(size_t)l].zero_cnt = AL.zero_n[(size_t)l];
+            }
+            zero_cnt = AL.zero_cnt;
+            HIPC(dev_upload(&d_sa_ptr, AL.sa_ptr), ERROR_HIP_MALLOC);
+            {
+                // descriptors in launch order (the plan is on the device already: read it back rather than keep host copies around)
+                std::vector<FrontDesc> h_fd((size_t)ns);
+                std::vector<int32_t> h_lists((size_t)n_lists);
+                HIPC(hipMemcpy(h_fd.data(), d_fd, sizeof(FrontDesc) * (size_t)ns, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
+                if (n_lists > 0) HIPC(hipMemcpy(h_lists.data(), d_lists, sizeof(int32_t) * (size_t)n_lists, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
+                std::vector<SmallDesc> sd(h_lists.size());
+                for (size_t q = 0; q < h_lists.size(); q++) {
+                    const int32_t s = h_lists[q];
+                    sd[q].fd = h_fd[(size_t)s];
+                    sd[q].e0 = AL.sa_ptr[(size_t)s], sd[q].e1 = AL.sa_ptr[(size_t)s + 1]; // (empty ranges for the big fronts, which never read them)
+                }
+                HIPC(dev_upload(&d_sd, sd), ERROR_HIP_MALLOC);
+            }
+            HIPC(dev_upload(&d_sa_k, AL.sa_k), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_sa_pos, AL.sa_pos), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_sc_k, AL.sc_k), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_sc_at, AL.sc_at), ERROR_HIP_MALLOC);
+            HIPC(dev_upload(&d_zero, AL.zt), ERROR_HIP_MALLOC);
+        }
+        lap("assembly lists + zero tasks");
+        std::vector<int64_t>().swap(S.amap);
+        std::vector<int64_t>().swap(S.amap2);
+        std::vector<int32_t>().swap(S.amap_sn);
+        HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_vs, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+        if (sym_lower) HIPC(hipMalloc((void **)&d_vs2, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
+        // (+ WT_X: a wave-subtree fetches its part of the vector / of the interchanges as WT_X entries from its first pivot column on)
+        for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
+        if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
+        HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
+        HIPC(hipMemsetAsync(d_lperm, 0, sizeof(int32_t) * ((size_t)n + WT_X), STREAM), ERROR_HIP_MEMCPY);
+        for (double *p : {d_xp, d_du}) HIPC(hipMemsetAsync(p + n, 0, sizeof(double) * WT_X, STREAM), ERROR_HIP_MEMCPY);
+        HIPC(hipMalloc((void **)&d_diag, sizeof(double) * n), ERROR_HIP_MALLOC);
+        if (S.sym_mode) d_cs = d_rs; // symmetric scaling S A S keeps the big fronts symmetric: column scale = row scale
+        HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+        for (auto &e : ev) {
+            hipEvent_t he;
+            HIPC(hipEventCreate(&he), ERROR_HIP_MALLOC);
+            e = he;
+        }
+        HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+        lap("value / vector buffers");
+        return SUCCESSFUL_EXIT;
+    };
     const auto t_plan = std::chrono::steady_clock::now();
-    int32_t code = upload_plan();
+    int32_t code = upload_plan(tail);
     if (code != SUCCESSFUL_EXIT) return code;
-    lap("plan + upload");
+    lap("wait for the solve task lists");
     if (opt.verbose)
         fprintf(stderr,
                 "hipmf: initialize: graph %.3f s, ordering %.3f s, etree %.3f s, supernodes %.3f s, row structures %.3f s, layout %.3f s, "
-                "assembly map %.3f s; plan + device allocation + upload %.3f s\n",
+                "assembly map %.3f s; plan + device allocation + upload + tail %.3f s\n",
                 S.seconds_phase[0], S.seconds_phase[1], S.seconds_phase[2], S.seconds_phase[3], S.seconds_phase[4], S.seconds_phase[5],
                 S.seconds_phase[6], std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan).count());
-    // matrix structure (kept for the refinement SpMV) and per-entry row/col indices
-    const int64_t nnz = S.nnz_a;
-    std::vector<int32_t> h_rp(rp, rp + n + 1), h_ci(ci, ci + nnz), h_arow((size_t)nnz);
-    for (int32_t i = 0; i < n; i++)
-        for (int32_t p = rp[i]; p < rp[i + 1]; p++) h_arow[p] = i;
-    {
-        // row blocks of the stream SpMV: consecutive rows with at most SPMV_CAP stored entries (a longer row stands alone)
-        std::vector<int32_t> rb(1, 0);
-        int32_t start = 0;
-        for (int32_t i = 0; i < n; i++)
-            if (rp[i + 1] - rp[start] > SPMV_CAP && i > start) rb.push_back(i), start = i;
-        // (the row that opens a block may itself exceed the cap: it is closed by the next row)
-        rb.push_back(n);
-        spmv_blocks = (int32_t)rb.size() - 1;
-        HIPC(dev_upload(&d_row_blk, rb), ERROR_HIP_MALLOC);
-    }
-    HIPC(dev_upload(&d_rp, h_rp), ERROR_HIP_MALLOC);
-    HIPC(dev_upload(&d_ci, h_ci), ERROR_HIP_MALLOC);
-    HIPC(dev_upload(&d_arow, h_arow), ERROR_HIP_MALLOC);
-    if (sym_lower) {
-        // transpose lists: for every row i, the stored entries (r, i), r > i, mirrored into row i
-        std::vector<int32_t> tptr((size_t)n + 1, 0), tidx;
-        for (int64_t k = 0; k < nnz; k++)
-            if (h_ci[k] != h_arow[k]) tptr[h_ci[k] + 1]++;
-        for (int32_t i = 0; i < n; i++) tptr[i + 1] += tptr[i];
-        tidx.resize((size_t)tptr[n]);
-        std::vector<int32_t> w(tptr.begin(), tptr.end() - 1);
-        for (int64_t k = 0; k < nnz; k++)
-            if (h_ci[k] != h_arow[k]) tidx[w[h_ci[k]]++] = (int32_t)k;
-        HIPC(dev_upload(&d_tptr, tptr), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_tidx, tidx), ERROR_HIP_MALLOC);
-    }
-    lap("matrix structure + transpose index");
-    HIPC(dev_upload(&d_perm, S.perm), ERROR_HIP_MALLOC);
-    d_rperm = d_perm;
-    {
-        uint64_t hsh = 1469598103934665603ull;
-        auto mix = [&](uint64_t v) {
-            for (int b = 0; b < 8; b++) hsh = (hsh ^ ((v >> (8 * b)) & 0xff)) * 1099511628211ull;
-        };
-        for (int32_t k = 0; k < n; k++) mix((uint64_t)(uint32_t)S.perm[k] | ((uint64_t)(matched ? (uint32_t)mrow[S.perm[k]] : 0u) << 32));
-        mix((uint64_t)S.persist_doubles), mix((uint64_t)S.temp_doubles), mix((uint64_t)S.nsuper);
-        plan_sig = hsh & 0x7fffffffffffffffull;
-    }
-    if (matched) {
-        std::vector<int32_t> rperm((size_t)n);
-        for (int32_t k = 0; k < n; k++) rperm[k] = mrow[S.perm[k]];
-        HIPC(dev_upload(&d_rperm, rperm), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_cs, dc), ERROR_HIP_MALLOC);
-        std::vector<int32_t> dcol((size_t)n);
-        for (int32_t j = 0; j < n; j++) dcol[(size_t)mrow[j]] = j; // row mrow[j] of A is pivot row j: its diagonal entry sits in column j
-        HIPC(dev_upload(&d_dcol, dcol), ERROR_HIP_MALLOC);
-        // parity of the row permutation (determinant)
-        std::vector<char> seen((size_t)n, 0);
-        match_parity = 0;
-        for (int32_t i = 0; i < n; i++) {
-            if (seen[i]) continue;
-            int len = 0;
-            for (int32_t j = i; !seen[j]; j = mrow[j]) seen[j] = 1, len++;
-            if ((len & 1) == 0) match_parity ^= 1;
-        }
-    }
-    lap("perm + signature");
-    {
-        // (joined below: the lists were computed beside upload_plan)
-        if (asm_thread.joinable()) asm_thread.join();
-        if (AL.status == 1) {
-            last_error = "too many entries in the tiled fronts";
-            return ERROR_HIPMF_SYMBOLIC;
-        }
-        if (AL.status == 2) {
-            last_error = "too many zero-fill tasks";
-            return ERROR_HIPMF_SYMBOLIC;
-        }
-        if (AL.status == 3) {
-            last_error = "Not enough memory: a host allocation failed";
-            return ERROR_MALLOC;
-        }
-        const int32_t ns = S.nsuper;
-        for (int32_t l = 0; l < S.nlevels; l++) {
-            levels[(size_t)l].sc_off = (int32_t)AL.sc_cnt[(size_t)l], levels[(size_t)l].sc_cnt = (int32_t)(AL.sc_cnt[(size_t)l + 1] - AL.sc_cnt[(size_t)l]);
-            levels[(size_t)l].zero_off = AL.zero_off[(size_t)l], levels[(size_t)l].zero_cnt = AL.zero_n[(size_t)l];
-        }
-        zero_cnt = AL.zero_cnt;
-        HIPC(dev_upload(&d_sa_ptr, AL.sa_ptr), ERROR_HIP_MALLOC);
-        {
-            // descriptors in launch order (the plan is on the device already: read it back rather than keep host copies around)
-            std::vector<FrontDesc> h_fd((size_t)ns);
-            std::vector<int32_t> h_lists((size_t)n_lists);
-            HIPC(hipMemcpy(h_fd.data(), d_fd, sizeof(FrontDesc) * (size_t)ns, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
-            if (n_lists > 0) HIPC(hipMemcpy(h_lists.data(), d_lists, sizeof(int32_t) * (size_t)n_lists, hipMemcpyDeviceToHost), ERROR_HIP_MEMCPY);
-            std::vector<SmallDesc> sd(h_lists.size());
-            for (size_t q = 0; q < h_lists.size(); q++) {
-                const int32_t s = h_lists[q];
-                sd[q].fd = h_fd[(size_t)s];
-                sd[q].e0 = AL.sa_ptr[(size_t)s], sd[q].e1 = AL.sa_ptr[(size_t)s + 1]; // (empty ranges for the big fronts, which never read them)
-            }
-            HIPC(dev_upload(&d_sd, sd), ERROR_HIP_MALLOC);
-        }
-        HIPC(dev_upload(&d_sa_k, AL.sa_k), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_sa_pos, AL.sa_pos), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_sc_k, AL.sc_k), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_sc_at, AL.sc_at), ERROR_HIP_MALLOC);
-        HIPC(dev_upload(&d_zero, AL.zt), ERROR_HIP_MALLOC);
-    }
-    lap("assembly lists + zero tasks");
-    std::vector<int64_t>().swap(S.amap);
-    std::vector<int64_t>().swap(S.amap2);
-    std::vector<int32_t>().swap(S.amap_sn);
-    HIPC(hipMalloc((void **)&d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_vs, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
-    if (sym_lower) HIPC(hipMalloc((void **)&d_vs2, sizeof(double) * std::max<int64_t>(nnz, 1)), ERROR_HIP_MALLOC);
-    // (+ WT_X: a wave-subtree fetches its part of the vector / of the interchanges as WT_X entries from its first pivot column on)
-    for (double **p : {&d_xp, &d_r, &d_den, &d_b, &d_x, &d_du, &d_rs}) HIPC(hipMalloc((void **)p, sizeof(double) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
-    if (matched) HIPC(hipMemcpy(d_rs, dr.data(), sizeof(double) * n, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
-    HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
-    HIPC(hipMemsetAsync(d_lperm, 0, sizeof(int32_t) * ((size_t)n + WT_X), STREAM), ERROR_HIP_MEMCPY);
-    for (double *p : {d_xp, d_du}) HIPC(hipMemsetAsync(p + n, 0, sizeof(double) * WT_X, STREAM), ERROR_HIP_MEMCPY);
-    HIPC(hipMalloc((void **)&d_diag, sizeof(double) * n), ERROR_HIP_MALLOC);
-    if (S.sym_mode) d_cs = d_rs; // symmetric scaling S A S keeps the big fronts symmetric: column scale = row scale
-    HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
-    HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
-    for (auto &e : ev) {
-        hipEvent_t he;
-        HIPC(hipEventCreate(&he), ERROR_HIP_MALLOC);
-        e = he;
-    }
-    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
-    lap("value / vector buffers");
     if (opt.verbose) {
         fprintf(stderr, "hipmf: initialize: host pieces:");
         for (const auto &l : laps) fprintf(stderr, " %s %.3f s;", l.first, l.second);
@@ -539,7 +581,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     return SUCCESSFUL_EXIT;
 }
 
-int32_t Solver::upload_plan() {
+int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     const int32_t ns = S.nsuper;
     auto pl_t = std::chrono::steady_clock::now();
     std::string pl_log;
@@ -606,7 +648,7 @@ int32_t Solver::upload_plan() {
             // per thread where 8-row slabs (G = 32) allow it
             if (tree && !slab64 && S.sn_level[s] >= top_level) {
                 int32_t G = 2;
-                while (G < 32 && len > 32 * G) G *= 2;
+                while (G < up_max_groups && len > 32 * G) G *= 2;
                 return G == 32 ? 3 : (G == 16 ? 4 : (G == 8 ? 5 : (G == 4 ? 6 : 7)));
             }
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
@@ -628,7 +670,18 @@ int32_t Solver::upload_plan() {
                     for (int32_t q0 = 0; q0 < ext; q0 += SF_ASM_ROWS) sf.push_back({1, s, q0, std::min(ext, q0 + SF_ASM_ROWS), 0, 0}), nasm++;
                 }
                 need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows + nasm;
+                const size_t first_slab = sf.size();
                 for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), nasm, 0});
+                // 8-row slabs read 64-byte segments of E / E': two neighbouring slabs share every 128-byte line, and a line is fetched once per
+                // XCD that asks for it (tools/microbench/fetch_calib.hip: 64-byte segments move twice their bytes).  Workgroup b runs on XCD
+                // b mod 8 (observed, MI355X_MICROARCH.md), so the slabs 2j and 2j + 1 are placed eight tasks apart: the second one finds
+                // the line in its XCD's L2.  Speed only: any placement is correct.
+                if (kind == 3 && up_pair_xcd) {
+                    const size_t cnt = sf.size() - first_slab;
+                    std::vector<SfTask> tmp(sf.begin() + (std::ptrdiff_t)first_slab, sf.end());
+                    for (size_t g0 = 0; g0 + 16 <= cnt; g0 += 16)
+                        for (size_t j = 0; j < 8; j++) sf[first_slab + g0 + j] = tmp[g0 + 2 * j], sf[first_slab + g0 + 8 + j] = tmp[g0 + 2 * j + 1];
+                }
             }
             for (size_t k = 0; k < small.size(); k += 4) {
                 SfTask t = {0, small[k], -1, -1, -1, 0};
@@ -929,6 +982,7 @@ int32_t Solver::upload_plan() {
     int32_t max_big = 0;
     std::vector<SolveTask> stasks;
     levels.assign((size_t)S.nlevels, LevelPlan());
+    mid_front_count = 0;
     for (int32_t l = 0; l < S.nlevels; l++) {
         LevelPlan &L = levels[l];
         std::vector<int32_t> small, big;
@@ -951,6 +1005,7 @@ int32_t Solver::upload_plan() {
             big.swap(tiled);
             auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return m <= 80 ? 0 : (m <= 128 ? 1 : 2); }; // (the CM of k_front: 10 / 16 / 24)
             std::stable_sort(mid.begin(), mid.end(), [&](int32_t a, int32_t b) { return cls(a) != cls(b) ? cls(a) < cls(b) : S.npiv(a) > S.npiv(b); });
+            mid_front_count += (int64_t)mid.size();
             for (int32_t a : mid) L.mid_cnt[cls(a)]++, L.mid_lds[cls(a)] = std::max(L.mid_lds[cls(a)], mid_lds_doubles(S.npiv(a), S.nrow(a)));
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
@@ -1175,10 +1230,6 @@ int32_t Solver::upload_plan() {
     allbig_off = (int32_t)lists.size();
     allbig_cnt = (int32_t)allbig.size();
     lists.insert(lists.end(), allbig.begin(), allbig.end());
-    // (the task lists of the dependency-driven solves were built beside the loop above: see solve_plans)
-    if (sp_thread.joinable()) sp_thread.join();
-    if (sp_code != SUCCESSFUL_EXIT) return sp_code;
-    pl_lap("solve task lists + their uploads");
     HIPC(dev_upload(&d_fd, fd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_bigfd, bigfd), ERROR_HIP_MALLOC);
     HIPC(dev_upload(&d_ea, ea), ERROR_HIP_MALLOC);
@@ -1211,6 +1262,15 @@ int32_t Solver::upload_plan() {
     HIPC(hipMalloc((void **)&d_pool, sizeof(double) * (std::max<int64_t>(pool_doubles, 1) + WT_CHUNK)), ERROR_HIP_MALLOC);
     HIPC(hipMalloc((void **)&d_work, sizeof(double) * (std::max<int64_t>(work_doubles, 1) + 64)), ERROR_HIP_MALLOC);
     pl_lap("pool + workspace allocation");
+    if (tail) {
+        const int32_t tcode = tail();
+        if (tcode != SUCCESSFUL_EXIT) return tcode;
+        pl_lap("tail (permutation, assembly lists, buffers)");
+    }
+    // (the task lists of the dependency-driven solves were built beside everything above: see solve_plans)
+    if (sp_thread.joinable()) sp_thread.join();
+    if (sp_code != SUCCESSFUL_EXIT) return sp_code;
+    pl_lap("wait for the solve task lists + their uploads");
     if (opt.verbose) fprintf(stderr, "hipmf: initialize: plan pieces:%s\n", pl_log.c_str());
     return SUCCESSFUL_EXIT;
 }

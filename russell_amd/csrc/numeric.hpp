@@ -1,6 +1,7 @@
 // numeric.hpp -- device-side state and drivers of the multifrontal LU backend (factorize / solve).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -131,6 +132,7 @@ class Solver {
     int64_t rematch_count = 0; // factorisations that recomputed the maximum-product matching (and the analysis) for new values
     int32_t refinement_steps_done = 0;
     int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
+    int64_t mid_front_count = 0; // fronts of this plan that one workgroup factorises in one launch (k_front)
     int64_t chain_fallbacks = 0; // factorisations repeated with one launch per tiled step after a hand-off timeout of a chained launch (never expected)
     int64_t persist_bytes() const { return S.persist_doubles * 8; }
     double last_residual_inf = 0.0, last_omega = 0.0;
@@ -160,7 +162,7 @@ class Solver {
   private:
     int32_t initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
                             const NumericOptions &nopt, const double *values);
-    int32_t upload_plan();
+    int32_t upload_plan(const std::function<int32_t()> &tail); // tail: what initialize runs after the descriptor uploads, beside the solve task lists
     int32_t rematch_and_factorize(); // the values in d_vals invalidate the pivot order: new matching + analysis, then factorize
     // what a re-analysis needs: the caller's structure and options, the value map
     std::vector<int32_t> h_rp_keep, h_ci_keep, h_seg_ptr, h_seg_idx;
@@ -221,6 +223,8 @@ class Solver {
     int32_t *d_rep_idx = nullptr;           // per front: index of its "complete" replicas (tiled fronts of the top levels), else -1
     int32_t *d_rep = nullptr;               // the replicas: forward part, then backward part (zeroed before every pass)
     int64_t rep_words = 0;
+    bool up_pair_xcd = true;                // HIPMF_UP_PAIR_XCD=0: the 8-row slabs of a top-level front in row order (1: neighbours eight tasks apart = same XCD)
+    int32_t up_max_groups = 32;             // HIPMF_UP_MAX_GROUPS: column groups of a top-level slab at most (32: 8-row slabs; 16: 16-row slabs = whole 128-byte lines)
     bool use_rep = true;                    // HIPMF_UP_REPLICAS=0: every waiter polls the front's counter
     int32_t *d_need2 = nullptr;             // completed-task counts of that list (the slabs are cut differently)
     bool tree_active = false;               // the plan above exists for this matrix

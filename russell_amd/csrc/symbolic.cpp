@@ -731,7 +731,8 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             pool_total += f > (double)opt.augment_above ? f * p * (opt.symmetric_ldlt ? 1.0 : 2.0) : f * f + p * f;
         }
         S.pool_estimate_bytes = 8.0 * pool_total;
-        if (rows_total > 1.0e9 || (opt.pool_limit_bytes > 0.0 && 8.0 * pool_total > opt.pool_limit_bytes)) return -40;
+        const double limit = opt.pool_limit_live ? opt.pool_limit_live->load() : opt.pool_limit_bytes;
+        if (rows_total > 1.0e9 || (limit > 0.0 && 8.0 * pool_total > limit)) return -40;
     }
     S.sn_of.resize((size_t)n);
     for (int32_t s = 0; s < S.nsuper; s++)
@@ -993,7 +994,10 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         S.temp_doubles = top;
     }
     S.pool_estimate_bytes = 8.0 * (double)(S.persist_doubles + S.temp_doubles);
-    if (opt.pool_limit_bytes > 0.0 && S.pool_estimate_bytes > opt.pool_limit_bytes) return -40;
+    {
+        const double limit = opt.pool_limit_live ? opt.pool_limit_live->load() : opt.pool_limit_bytes;
+        if (limit > 0.0 && S.pool_estimate_bytes > limit) return -40;
+    }
 
     S.seconds_phase[5] = since(t_phase), t_phase = clk::now();
     // ---- assembly map: where every input entry lands ------------------------------------------

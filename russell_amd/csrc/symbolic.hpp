@@ -7,6 +7,7 @@
 // Everything here is integer graph work on the host; it is deterministic (no hashing, no
 // threads, ties broken by vertex number) so the permutation is reproducible bit for bit.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct SymbolicOptions {
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
     int32_t split_pivots = 4096;  // supernodes with more pivots are split into a chain of supernodes (0: never); see symbolic.cpp
     double pool_limit_bytes = 0.0; // analyse gives up (-40) when the fronts would need more than this (0: no limit)
+    const std::atomic<double> *pool_limit_live = nullptr; // the same figure when it is produced by another thread while analyse runs (read at the tests; 0: not known yet)
     int32_t augment_above = 64;   // fronts with f > this take the tiled, augmented path (must equal kernels_common.hpp SMALL_F)
     bool symmetric_ldlt = false;  // the big fronts are factorised as L D L^T (symmetric-lower input): no E' panels
     int32_t relax_ncol[3] = {4, 16, 48};

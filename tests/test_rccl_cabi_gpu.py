@@ -103,3 +103,32 @@ def test_rccl_broadcast_and_sharded_solve_two_gpus(tmp_path):
     if _capi.load().hipmf_device_count() < 2:
         pytest.skip("needs two GPUs (the driver's multi-GPU node); one-rank variant and the gloo CPU twin cover the logic")
     _run(2, tmp_path)
+
+
+@pytest.mark.gpu
+def test_bench_distributed_branch_with_one_rank():
+    """bench.py's many-RHS section under BENCH_FORCE_DIST=1: a torch `nccl` (= RCCL) process group of ONE rank drives the same code as
+    `--gpus N` -- unique id through the group, hipmf_comm_init_rank, solver_hipmf_broadcast_factor (plan check, MIN all-reduce,
+    ncclBroadcast of the factor parts), the sharded solve -- with nranks as data.  What a node with N GPUs adds is ranks, not code."""
+    import json
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--grid", "300",
+                        "--nrhs", "32", "--grid3d", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    many = out["many_rhs"]
+    assert "error" not in many, many
+    assert many["nrhs_total"] == 32 and many["rhs_per_gpu"] == 32
+    bc = many["broadcast"]
+    assert "error" not in bc, bc
+    assert bc["broadcast_bytes"] > 0 and bc["broadcast_ms"] > 0.0
+    assert bc["max_abs_error_all_columns"] < 1e-9 and many["max_abs_error_all_columns"] < 1e-9
+    assert many["roofline"]["fused_solve_fallbacks"] == 0
+    assert out["relative_error"] < 1e-10

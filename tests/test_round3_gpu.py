@@ -123,7 +123,8 @@ def test_config3_bbmat_like_convection_dominated_needs_the_matching():
     s.close()
     xo = spla.splu(A.tocsc(), permc_spec="COLAMD").solve(b)
     err, err_slu = np.max(np.abs(x - xs)), np.max(np.abs(xo - xs))
-    assert err <= max(100.0 * err_slu, 1e-9 * np.max(np.abs(xs))), (err, err_slu, st["n_perturbed"])
+    print("config-3 stand-in: forward error %.3e (SuperLU/COLAMD %.3e), perturbed pivots %d" % (err, err_slu, st["n_perturbed"]))
+    assert err <= max(10.0 * err_slu, 1e-10 * np.max(np.abs(xs))), (err, err_slu, st["n_perturbed"])
     r = A @ x - b
     assert np.max(np.abs(r)) / (np.max(np.abs(v2)) + 1.0) <= 1e-10
 
@@ -154,10 +155,10 @@ def test_config4_matrix_200_cubed_with_a_block_of_32_right_hand_sides_on_one_gpu
     s.dev_free(d_b), s.dev_free(d_x)
     s.close()
     worst_fwd, worst_res = 0.0, 0.0
-    for j in (0, 7, 15, 16, 31):  # (the host-side residual of all 32 columns would take longer than the solves)
-        xj = X[j]
-        worst_fwd = max(worst_fwd, float(np.max(np.abs(xj - xs * (1.0 + 0.125 * j))) / (1.0 + 0.125 * j)))
-        r = P.csr_matvec(n, rp, ci, v, xj) - B[j]
+    for j in range(nrhs):  # the forward error of EVERY column (its solution is known) ...
+        worst_fwd = max(worst_fwd, float(np.max(np.abs(X[j] - xs * (1.0 + 0.125 * j))) / (1.0 + 0.125 * j)))
+    for j in (0, 7, 15, 16, 31):  # ... and the reference's residual metric on five of them (a host matvec of 8 M rows each)
+        r = P.csr_matvec(n, rp, ci, v, X[j]) - B[j]
         worst_res = max(worst_res, float(np.max(np.abs(r)) / (np.max(np.abs(v)) + 1.0)))
     assert worst_res <= 1e-10
     assert worst_fwd < 1e-9

@@ -1,0 +1,77 @@
+"""Round 4 on the device: the fronts one workgroup factorises in one launch (k_front, kernels_factor_front.hpp) against the tiled
+launches and against SuperLU -- the hand-built fronts of tests/test_mid_fronts_cpu.py (very few pivots, interchanges, 64 pivots), trees
+with hundreds of such fronts, the 1M-DOF matrix of config 2 -- and the graph replay of the factorisation's launches."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from russell_amd import problems as P
+from russell_amd.backend import Hipmf
+from test_mid_fronts_cpu import _run, _two_leaves_and_a_root
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("p,m,weak", [(2, 70, False), (5, 75, False), (6, 62, True), (20, 60, True), (33, 80, False), (64, 40, True)])
+def test_one_workgroup_fronts_by_hand_on_the_device(p, m, weak):
+    n, rp, ci, v, M = _two_leaves_and_a_root(p, m, seed=100 * p + m, weak=weak)
+    got = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "1"}, ordering=2)
+    ref = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "0"}, ordering=2)
+    assert got[4] >= 1 and ref[4] == 0
+    xo = spla.splu(M.tocsc()).solve(got[1][0])
+    tol = 1e-11 * max(np.max(np.abs(xo)), 1.0)
+    assert np.max(np.abs(got[0][0] - xo)) <= tol and np.max(np.abs(ref[0][0] - xo)) <= tol
+    assert got[3] == ref[3] and abs(got[2] - ref[2]) <= 1e-10 * abs(ref[2])
+
+
+@pytest.mark.parametrize("case", ["poisson2d 300", "convection-diffusion 220", "fe blocks 40x40x3", "poisson3d 24"])
+def test_trees_with_one_workgroup_fronts_against_the_tiled_launches(case):
+    if case.startswith("poisson2d"):
+        n, rp, ci, v = P.poisson2d(300)
+    elif case.startswith("convection"):
+        n, rp, ci, v = P.convection_diffusion2d(220, peclet=30.0, scale_decades=3.0)
+    elif case.startswith("fe"):
+        n, rp, ci, v = P.fe_block2d(40, 40, 3, symmetric=False, scale_decades=2.0)
+    else:
+        n, rp, ci, v = P.poisson3d(24)
+    got = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "1"}, nrhs=17)
+    ref = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "0"}, nrhs=17)
+    assert got[4] > 0 and ref[4] == 0
+    lu = spla.splu(sp.csr_matrix((v, ci, rp), shape=(n, n)).tocsc())
+    for j in range(17):
+        xo = lu.solve(got[1][j])
+        tol = 1e-9 * max(1.0, np.max(np.abs(xo)))
+        assert np.max(np.abs(got[0][j] - xo)) <= tol and np.max(np.abs(ref[0][j] - xo)) <= tol, (case, j)
+    assert got[3] == ref[3] and abs(got[2] - ref[2]) <= 1e-8 * abs(ref[2])
+    assert got[5] == ref[5]
+
+
+def test_config2_with_and_without_one_workgroup_fronts_and_graph_replay(monkeypatch):
+    # the 1M-DOF matrix: the default build (k_front on the fronts with at most 80 off-diagonal rows), the tiled launches alone, and the
+    # levels' launches replayed from a hipGraph -- the reference's residual metric at 1e-10 each, and the three solutions against each other
+    n, rp, ci, v = P.poisson2d(1000)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    xs_by = {}
+    for name, env in (("default", {}), ("tiled", {"HIPMF_MID_FRONT": "0"}), ("graph", {"HIPMF_FACTOR_GRAPH": "1"})):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci) == 0
+        for _ in range(3):  # (the second factorisation of the graph variant is the first replay)
+            assert s.factorize(v) == 0
+        x = s.solve(b)
+        mid = s.counter("mid_fronts")
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (mid > 2000) == (name != "tiled"), (name, mid)
+        r = P.csr_matvec(n, rp, ci, v, x) - b
+        assert np.max(np.abs(r)) / (np.max(np.abs(v)) + 1.0) <= 1e-10
+        assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-9
+        xs_by[name] = x
+    assert np.max(np.abs(xs_by["default"] - xs_by["tiled"])) < 1e-9
+    assert np.array_equal(xs_by["default"], xs_by["graph"])  # (the same launches, replayed)
