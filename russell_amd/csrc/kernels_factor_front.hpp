@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "kernels_common.hpp"
+#include "kernels_factor.hpp" // tile_lu32
 
 namespace hipmf {
 
@@ -305,6 +306,255 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
             product((f - c0) < MID_CHUNK ? (f - c0) : MID_CHUNK, false, c0);
         }
     });
+    HIPMF_STAMP(blockIdx.x, 5);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// k_front_lu -- the same fronts with at most 32 pivots (most of levels 3 - 6 of a 2D mesh), second formulation (round 4).
+// k_front above spends ~800 wavefront-instructions per pivot on 8 wavefronts (pivot search, hand-off through LDS, three instructions
+// per entry of the rank-1 updates) for p f / 64 useful multiply-adds: it is bound by instruction issue, and so are the levels it runs
+// on (thousands of fronts).  Here the only sequential piece is the inversion of the p x p pivot block by ONE wavefront in registers:
+// in-place Gauss-Jordan with partial pivoting, one row per lane, the 32 columns in 32 register pairs (the pattern of tile_lu32, the tiled
+// path's diagonal-tile factorisation; identity padding up to 32, ~0.35 us per pivot, no LDS, no barrier).  Everything else is a
+// product with G = inv(F11) whose loops run over k with static accumulators -- compact code, ~1.5 instructions per multiply-add
+// (the operands of G come as LDS broadcasts):
+//
+//      G = inv(F11)                     wavefront 0, rows in registers           (a first version factorised P F11 = L U and substituted:
+//      W = F21 G                        lane = row of F21, 32 accumulators        64 unrolled substitution steps are 50 KB of straight-
+//      V = G F12                        lane = column of F12, 32 accumulators     line code that runs once per wavefront -- instruction
+//      S = F22 - W F12                  lane = row, 8 columns per unit            fetch made it slower than k_front, profiles/r04_front_bench.txt)
+//
+// The pair (E, E') it leaves is k_front's (FD_DENSE_TOP): E = [G; -W], E' = [I | -V]; pivots and interchanges are those of an LU with
+// the same pivot sequence.  Column position k of the in-place block belongs to front row rk[k] (the row chosen at step k), as in k_front.
+// LDS (doubles): Gs[p][ldd] = G by pivot step and column position, GsT its transpose; B12[p][ldb] the rows of F12; A21 / Wp [m x p]
+// column-major: F21 first, then (in place, row by row: a row is read and written by the same lane) W by column position.
+constexpr int MIDL_P = 32;      // pivots at most
+constexpr int MIDL_NW = 4;      // wavefronts per front: the inversion is one wavefront's work; four wavefronts leave room for three fronts per CU
+constexpr int MIDL_LDS_DOUBLES = 16384; // 128 KB
+__host__ __device__ inline int midl_ldd(int) { return MIDL_P + 2; } // (rows of Gs / GsT are 32 wide whatever p: positions beyond p hold zeros, the product loops carry no tests)
+__host__ __device__ inline int midl_ldb(int m) { return (m + 3) & ~1; }
+__host__ __device__ inline int midl_off_dt(int p) { return MIDL_P * midl_ldd(p); }     // (Gs and GsT are 32 x 34 whatever p)
+__host__ __device__ inline int midl_off_b(int p) { return 2 * MIDL_P * midl_ldd(p); }
+__host__ __device__ inline int midl_off_y(int p, int m) { return midl_off_b(p) + p * midl_ldb(m); }
+__host__ __device__ inline int midl_lds_doubles(int p, int m) { return midl_off_y(p, m) + p * m; }
+
+struct MidlLds {
+    int32_t rk[MIDL_P]; // front-local row that became pivot row k (= the front row column position k of the in-place block belongs to)
+};
+
+// In-place inversion of a 32 x 32 block held one ROW PER LANE in registers (lanes 0..31), Gauss-Jordan with partial pivoting; a smaller
+// block is padded by the caller with identity rows / columns (pivots 1, chosen last).  Implicit pivoting: rows never move between lanes;
+// `step` = the elimination step at which this lane's row was chosen, `dval` its pivot.  Pivot rows are not scaled inside the loop (the
+// update is one FMA per entry for every lane, the pivot lane takes part with a zero multiplier); on exit row `step` of the inverse sits in
+// this lane, column position k belonging to the row chosen at step k (rk, written by the caller's lane).  np: steps to run (<= 32).
+__device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np, double eps, int &step, double &dval, int32_t *rk, int &npert, int &nzero) {
+    step = -1;
+    dval = 1.0;
+    npert = 0;
+    nzero = 0;
+#pragma clang loop unroll(full)
+    for (int c = 0; c < MIDL_P; c++) {
+        if (c < np) { // (wave-uniform)
+            const bool cand = lane < MIDL_P && step < 0;
+            const unsigned mag = __float_as_uint((float)fabs(a[c]));
+            const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
+            const double myinv = fast_rcp(a[c]);
+            const int pv = 31 - (int)(wave_max_u32<2>(key) & 31u);
+            double d = wave_bcast(a[c], pv);
+            double inv = wave_bcast(myinv, pv);
+            if (fabs(d) < eps || d == 0.0) {
+                double dn = (d < 0.0) ? -eps : eps;
+                if (dn == 0.0) dn = 1.0;
+                npert++;
+                if (d == 0.0) nzero++;
+                d = dn;
+                inv = 1.0 / dn;
+            }
+            if (lane == pv) step = c, dval = d, rk[c] = lane;
+            const double lm = (lane == pv) ? 0.0 : a[c] * inv;
+#pragma clang loop unroll(full)
+            for (int cc = 0; cc < MIDL_P; cc++)
+                if (cc != c) a[cc] -= lm * wave_bcast(a[cc], pv);
+            a[c] = (lane == pv) ? 1.0 : -lm; // column c of the identity block, in place of column c of the block
+        }
+    }
+    const double inv_own = 1.0 / dval;
+#pragma unroll
+    for (int cc = 0; cc < MIDL_P; cc++) a[cc] *= inv_own;
+}
+
+__global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__restrict__ LFD, double *__restrict__ pool, int32_t *__restrict__ lperm,
+                                                           const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
+                                                           double *__restrict__ diag) {
+    HIPMF_DYN_SHARED(double, dyn);
+    __shared__ MidlLds sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    HIPMF_STAMP(blockIdx.x, 0);
+    const FrontDesc fd = LFD[blockIdx.x];
+    fd_resident(fd);
+    const int p = fd.p, m = fd.m;
+    const int64_t ld = fd.ld;
+    double *__restrict__ F = pool + fd.off;
+    double *__restrict__ E = pool + fd.eoff;
+    double *__restrict__ Ep = pool + fd.epoff;
+    const int ldd = midl_ldd(p), ldb = midl_ldb(m);
+    double *Gs = dyn, *GsT = dyn + midl_off_dt(p), *B12 = dyn + midl_off_b(p), *Wp = dyn + midl_off_y(p, m);
+    const int nrb = (m + 63) >> 6;
+    // ---- every load up front.  Wavefront 0: its row of F11 (registers).  Wavefronts 1 .. 3: F12 -> LDS row-major (a column of F12 is p
+    //      contiguous doubles in memory: lanes = rows) and F21 -> LDS column-major (lanes = rows of F21), eight loads in flight per lane ----
+    double a[MIDL_P];
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < MIDL_P; c++) {
+            const bool in = lane < p && c < p;
+            const double v = F[(in ? lane : 0) + (int64_t)(in ? c : 0) * ld];
+            a[c] = in ? v : (lane == c ? 1.0 : 0.0); // identity padding: those pivots are 1 and are chosen last
+        }
+    } else {
+        const double *Fr = F + (lane < p ? lane : 0);
+        for (int j0 = wave - 1; j0 < m; j0 += 8 * (MIDL_NW - 1)) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + (MIDL_NW - 1) * u;
+                t[u] = Fr[(int64_t)(p + (j < m ? j : 0)) * ld];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + (MIDL_NW - 1) * u;
+                if (j < m && lane < p) B12[lane * ldb + j] = t[u];
+            }
+        }
+        for (int rb = 0; rb < nrb; rb++) {
+            const int i = rb * 64 + lane;
+            const double *Fi = F + p + (i < m ? i : 0);
+            for (int k0 = wave - 1; k0 < p; k0 += 8 * (MIDL_NW - 1)) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + (MIDL_NW - 1) * u;
+                    t[u] = Fi[(int64_t)(k < p ? k : 0) * ld];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + (MIDL_NW - 1) * u;
+                    if (k < p && i < m) Wp[i + k * m] = t[u];
+                }
+            }
+        }
+    }
+    HIPMF_STAMP(blockIdx.x, 1);
+    // ---- G = inv(F11) in the registers of wavefront 0; out: Gs / GsT (LDS), E_top, the identity part of E', pivots, interchanges ----
+    if (wave == 0) {
+        const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        int step, npert, nzero;
+        double dval;
+        tile_inv32(a, lane, p, eps, step, dval, sh.rk, npert, nzero);
+        wave_sync(); // (sh.rk of every step visible to the lanes of this wavefront)
+        if (lane < p) { // (the rows of the block are the lanes 0 .. p-1: each was chosen at some step < p)
+#pragma unroll
+            for (int k = 0; k < MIDL_P; k++) {
+                Gs[step * ldd + k] = a[k], GsT[k * ldd + step] = a[k]; // (k >= p: zeros -- the padded columns of a real row stay zero)
+                if (k < p) {
+                    E[step + (int64_t)sh.rk[k] * ld] = a[k];
+                    Ep[step + (int64_t)k * p] = (k == step) ? 1.0 : 0.0;
+                }
+            }
+            diag[fd.first + step] = dval;
+            lperm[fd.first + step] = lane;
+        }
+        if (lane == 0 && npert > 0) {
+            atomicAdd(&info->n_perturbed, npert);
+            if (nzero > 0) atomicAdd(&info->n_zero_pivot, nzero);
+        }
+    }
+    __syncthreads();
+    HIPMF_STAMP(blockIdx.x, 2);
+    // ---- W = F21 G (units: 64 rows of F21, lane = row; in place in LDS) and V = G (rk-rows of F12) (units: 64 columns, lane = column):
+    //      the units are dealt to the wavefronts; 32 static accumulators, the loop runs over k ----
+    {
+        const int ncu = (m + 63) >> 6;
+        for (int un = wave; un < nrb + ncu; un += MIDL_NW) {
+            double acc[MIDL_P];
+#pragma unroll
+            for (int c = 0; c < MIDL_P; c++) acc[c] = 0.0;
+            if (un < nrb) {
+                const int i = un * 64 + lane;
+                const double *Ai = Wp + (i < m ? i : 0);
+                for (int k = 0; k < p; k++) {
+                    const double av = Ai[k * m];
+                    const double *Gk = Gs + k * ldd; // row k of G by column position
+#pragma unroll
+                    for (int c = 0; c < MIDL_P; c++) acc[c] = __builtin_fma(av, Gk[c], acc[c]);
+                }
+                if (i < m) {
+#pragma unroll
+                    for (int c = 0; c < MIDL_P; c++)
+                        if (c < p) {
+                            Wp[i + c * m] = acc[c]; // (this lane's row: read above, written here)
+                            E[(p + i) + (int64_t)wave_uniform(sh.rk[c]) * ld] = -acc[c];
+                        }
+                }
+            } else {
+                const int j = (un - nrb) * 64 + lane;
+                const double *Bj = B12 + (j < m ? j : 0);
+                for (int k = 0; k < p; k++) {
+                    const double bv = Bj[wave_uniform(sh.rk[k]) * ldb];
+                    const double *Gk = GsT + k * ldd; // column position k of G, by pivot step
+#pragma unroll
+                    for (int c = 0; c < MIDL_P; c++) acc[c] = __builtin_fma(bv, Gk[c], acc[c]);
+                }
+                if (j < m) {
+#pragma unroll
+                    for (int c = 0; c < MIDL_P; c++)
+                        if (c < p) Ep[c + (int64_t)(p + j) * p] = -acc[c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    HIPMF_STAMP(blockIdx.x, 3);
+    if (m == 0) return;
+    // ---- S = F22 - W (rk-rows of F12): units of 64 rows x 8 columns dealt to the wavefronts; lane = row ----
+    {
+        const int ngr = (m + 7) >> 3, nun = ngr * nrb;
+        for (int un = wave; un < nun; un += MIDL_NW) {
+            const int rb = un / ngr, cs = (un - rb * ngr) * 8;
+            const int ncol = (m - cs) < 8 ? (m - cs) : 8;
+            const int i = rb * 64 + lane;
+            const bool rowok = i < m;
+            const int ic = rowok ? i : 0;
+            double cin[8], acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                cin[c] = F[(p + ic) + (int64_t)(p + cs + (c < ncol ? c : 0)) * ld];
+                acc[c] = 0.0;
+            }
+            const double *Wi = Wp + ic;
+            for (int k0 = 0; k0 < p; k0 += 4) {
+                double wk[4];
+                int pk[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int k = k0 + kk < p ? k0 + kk : 0;
+                    const double v = Wi[k * m];
+                    wk[kk] = k0 + kk < p ? v : 0.0;
+                    pk[kk] = wave_uniform(sh.rk[k]);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const double *Bk = B12 + pk[kk] * ldb + cs;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) acc[c] = __builtin_fma(wk[kk], Bk[c], acc[c]);
+                }
+            }
+            if (rowok) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (c < ncol) F[(p + i) + (int64_t)(p + cs + c) * ld] = cin[c] - acc[c];
+            }
+        }
+    }
     HIPMF_STAMP(blockIdx.x, 5);
 }
 

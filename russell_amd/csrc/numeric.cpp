@@ -59,8 +59,14 @@ static hipError_t dev_upload(T **dptr, const std::vector<T> &v) {
 
 Solver::Solver() {}
 
+bool Solver::is_mid_lu(int32_t s) const {
+    if (!use_mid || !use_mid_lu || S.sym_mode) return false;
+    const int32_t p = S.npiv(s), m = S.nrow(s);
+    return p + m > SMALL_F && p <= MIDL_P && m <= mid_lu_mmax && midl_lds_doubles(p, m) <= MIDL_LDS_DOUBLES;
+}
 bool Solver::is_mid(int32_t s) const {
     if (!use_mid || S.sym_mode) return false;
+    if (is_mid_lu(s)) return true;
     const int32_t p = S.npiv(s), m = S.nrow(s);
     return p + m > SMALL_F && p <= MID_PMAX && m <= mid_mmax && mid_lds_doubles(p, m) <= MID_LDS_DOUBLES;
 }
@@ -316,7 +322,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_UPD32_MAXF")) upd32_max_front = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_FACTOR_GRAPH")) use_graph = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
-    if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(1, std::min(MID_MMAX, atoi(e)));
+    if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(0, std::min(MID_MMAX, atoi(e)));
+    if (const char *e = getenv("HIPMF_MID_LU")) use_mid_lu = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_MID_LU_MMAX")) mid_lu_mmax = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
@@ -1003,10 +1011,18 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             std::vector<int32_t> tiled;
             for (int32_t a : big) (is_mid(a) ? mid : tiled).push_back(a);
             big.swap(tiled);
-            auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return m <= 80 ? 0 : (m <= 128 ? 1 : 2); }; // (the CM of k_front: 10 / 16 / 24)
-            std::stable_sort(mid.begin(), mid.end(), [&](int32_t a, int32_t b) { return cls(a) != cls(b) ? cls(a) < cls(b) : S.npiv(a) > S.npiv(b); });
+            // class 3: k_front_lu (at most 32 pivots); 0 .. 2: k_front by the columns of F12 per wavefront (10 / 16 / 24)
+            auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return is_mid_lu(a) ? 3 : (m <= 80 ? 0 : (m <= 128 ? 1 : 2)); };
+            // (within a class: by the work of the front, largest first -- the workgroups that run longest start first)
+            std::stable_sort(mid.begin(), mid.end(), [&](int32_t a, int32_t b) {
+                return cls(a) != cls(b) ? cls(a) < cls(b) : (int64_t)S.npiv(a) * S.fsize(a) * S.fsize(a) > (int64_t)S.npiv(b) * S.fsize(b) * S.fsize(b);
+            });
             mid_front_count += (int64_t)mid.size();
-            for (int32_t a : mid) L.mid_cnt[cls(a)]++, L.mid_lds[cls(a)] = std::max(L.mid_lds[cls(a)], mid_lds_doubles(S.npiv(a), S.nrow(a)));
+            for (int32_t a : mid) {
+                const int c = cls(a);
+                L.mid_cnt[c]++;
+                L.mid_lds[c] = std::max(L.mid_lds[c], c == 3 ? midl_lds_doubles(S.npiv(a), S.nrow(a)) : mid_lds_doubles(S.npiv(a), S.nrow(a)));
+            }
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
         // symmetric mode: the tiled fronts of this level whose parent is a small front (it pulls a FULL contribution block)
@@ -1225,6 +1241,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         HIPMF_ALLOW_LDS(k_front<10>, sizeof(double) * MID_LDS_DOUBLES);
         HIPMF_ALLOW_LDS(k_front<16>, sizeof(double) * MID_LDS_DOUBLES);
         HIPMF_ALLOW_LDS(k_front<24>, sizeof(double) * MID_LDS_DOUBLES);
+        HIPMF_ALLOW_LDS(k_front_lu, sizeof(double) * MIDL_LDS_DOUBLES);
     }
     pl_lap("factor launch plans");
     allbig_off = (int32_t)lists.size();
@@ -1446,7 +1463,7 @@ int32_t Solver::run_factor() {
         }
         // a level's small fronts and its big fronts are independent of each other (both only need the level's extend-add):
         // when the level has both, the small ones are factorised on a second stream beside the tiled steps
-        const bool has_mid = L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] > 0;
+        const bool has_mid = L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] + L.mid_cnt[3] > 0;
         const bool forked = overlap_small && ((L.small_cnt > 0 && (!L.steps.empty() || has_mid)) || fill_next);
         if (L.small_cnt > 0) {
             size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
@@ -1489,12 +1506,17 @@ int32_t Solver::run_factor() {
                 mst = (hipStream_t)stream3;
             }
             int32_t moff = L.mid_off;
-            for (int c = 2; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
-            for (int c = 2; c >= 0; c--) {
+            for (int c = 3; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
+            for (int c = 3; c >= 0; c--) {
                 moff -= L.mid_cnt[c];
                 if (L.mid_cnt[c] == 0) continue;
                 const size_t dyn = sizeof(double) * (size_t)L.mid_lds[c];
                 const FrontDesc *mfd = d_bigfd + moff;
+                if (c == 3) {
+                    hipLaunchKernelGGL(k_front_lu, dim3(L.mid_cnt[c]), dim3(64 * MIDL_NW), dyn, mst, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                    launches++;
+                    continue;
+                }
 #define HIPMF_LAUNCH_FRONT(CM) \
     hipLaunchKernelGGL(k_front<CM>, dim3(L.mid_cnt[c]), dim3(64 * MID_NW), dyn, mst, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag)
                 if (c == 0) HIPMF_LAUNCH_FRONT(10);

@@ -84,8 +84,8 @@ struct LevelPlan {
     // fronts of the middle of the tree that ONE workgroup carries through their whole partial factorisation (k_front,
     // kernels_factor_front.hpp): their descriptors follow the tiled ones in d_bigfd, grouped by size class
     int32_t mid_off = 0;                 // first of them in d_bigfd
-    int32_t mid_cnt[3] = {0, 0, 0};      // fronts per class (columns of F12 per wavefront 10 / 16 / 24)
-    int32_t mid_lds[3] = {0, 0, 0};      // dynamic LDS of the class's launch, in doubles (its largest front)
+    int32_t mid_cnt[4] = {0, 0, 0, 0};   // fronts per class: k_front with 10 / 16 / 24 columns of F12 per wavefront, k_front_lu (at most 32 pivots)
+    int32_t mid_lds[4] = {0, 0, 0, 0};   // dynamic LDS of the class's launch, in doubles (its largest front)
     int64_t chain_off = 0;  // the level's tiled steps as ONE launch (k_chain): its tasks in d_chain, chain_cnt of them (0: one launch per step)
     int32_t chain_cnt = 0;
 };
@@ -251,7 +251,11 @@ class Solver {
     // LDS budget of k_front are factorised by one workgroup each, one launch per level and size class (HIPMF_MID_FRONT=0: off,
     // HIPMF_MID_MMAX: rows at most, <= 192)
     bool use_mid = true;
-    int32_t mid_mmax = 80; // (above 80 rows the tiled launches are as fast or faster: profiles/r04_front_bench.txt)
+    int32_t mid_mmax = 0;  // HIPMF_MID_MMAX: k_front (eight wavefronts, up to 64 pivots) takes the fronts with at most this many off-diagonal rows that
+                           // k_front_lu does not take; off by default -- measured 7.13 ms with it (80 rows) against 7.10 without, 7.28 on tiled launches alone
+    bool use_mid_lu = true; // HIPMF_MID_LU=0: fronts with at most 32 pivots take k_front / the tiled path like the others
+    int32_t mid_lu_mmax = 192; // HIPMF_MID_LU_MMAX: off-diagonal rows of a k_front_lu front at most
+    bool is_mid_lu(int32_t s) const;
     bool is_mid(int32_t s) const;
     int32_t diag0_min_panels = 512;         // step 0 of a level: from this many panel workgroups the first diagonal tiles get their own launch (k_diag0)
     bool level_path_ok = true;              // false: some front is too large for the level-set solves' LDS staging

@@ -1,6 +1,7 @@
-"""k_front (kernels_factor_front.hpp): ONE workgroup carries a front with f > 64, at most 64 pivots and at most 80 off-diagonal rows
-through its whole partial factorisation -- Gauss-Jordan with partial pivoting over the pivot rows (kept on the CU), one product with the
-column panel.  It leaves another (E, E') pair than the tiled launches (E_top = inv(F11), E'_left = I) and the same pivots.  On the CPU
+"""kernels_factor_front.hpp: ONE workgroup carries a front with f > 64 through its whole partial factorisation in one launch.  Two
+kernels: k_front_lu (the default, at most 32 pivots: the pivot block is inverted in the registers of one wavefront, the rest are
+products with the inverse) and k_front (opt-in, HIPMF_MID_MMAX: up to 64 pivots, Gauss-Jordan over the pivot rows on eight
+wavefronts).  Both leave another (E, E') pair than the tiled launches (E_top = inv(F11), E'_left = I) and the same pivots.  On the CPU
 emulator: against the tiled launches (HIPMF_MID_FRONT=0), against SuperLU, determinants included; fronts with very few pivots (the
 lanes beyond the pivot block must not store: the bug the device found in round 4), row interchanges inside the pivot block, and the
 many-right-hand-side solves through the dense-top flag.  tests/test_round4_gpu.py repeats it on the device."""
@@ -55,11 +56,17 @@ def _two_leaves_and_a_root(p, m, seed, weak=False):
     return n, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64), M
 
 
-@pytest.mark.parametrize("p,m,weak", [(2, 70, False), (5, 75, False), (6, 62, True), (20, 60, True), (33, 80, False), (64, 40, True)])
-def test_one_workgroup_fronts_by_hand(emu_lib, p, m, weak):
+LU32 = {"HIPMF_MID_FRONT": "1"}                                                   # the default: k_front_lu where p <= 32
+GJ8 = {"HIPMF_MID_FRONT": "1", "HIPMF_MID_LU": "0", "HIPMF_MID_MMAX": "80"}      # k_front (eight wavefronts) for everything it takes
+HAND = [(2, 70, False, LU32), (5, 75, False, LU32), (6, 62, True, LU32), (20, 60, True, LU32), (32, 120, True, LU32), (2, 70, False, GJ8), (6, 62, True, GJ8),
+        (20, 60, True, GJ8), (33, 80, False, GJ8), (64, 40, True, GJ8)]
+
+
+@pytest.mark.parametrize("p,m,weak,env", HAND, ids=lambda v: ("gj8" if v is GJ8 else "lu32") if isinstance(v, dict) else str(v))
+def test_one_workgroup_fronts_by_hand(emu_lib, p, m, weak, env):
     n, rp, ci, v, M = _two_leaves_and_a_root(p, m, seed=100 * p + m, weak=weak)
     kw = {"ordering": 2}  # HIPMF_ORDERING_NONE: the supernodes are the ones built above
-    got = _run(emu_lib, n, rp, ci, v, {"HIPMF_MID_FRONT": "1"}, **kw)
+    got = _run(emu_lib, n, rp, ci, v, env, **kw)
     ref = _run(emu_lib, n, rp, ci, v, {"HIPMF_MID_FRONT": "0"}, **kw)
     assert got[4] >= 1 and ref[4] == 0  # the leaves take the new kernel (the relaxed amalgamation may merge a leaf of a few columns into the root)
     xo = spla.splu(M.tocsc()).solve(got[1][0])
@@ -72,15 +79,16 @@ def test_one_workgroup_fronts_by_hand(emu_lib, p, m, weak):
     assert np.sign(got[2]) == sign and abs(np.log10(abs(got[2])) + got[3] - logdet / np.log(10.0)) < 1e-9
 
 
+@pytest.mark.parametrize("env", [LU32, GJ8], ids=["lu32", "gj8"])
 @pytest.mark.parametrize("case", ["poisson2d 60x52", "convection-diffusion 50", "fe blocks 12x12x3"])
-def test_tree_with_one_workgroup_fronts_against_the_tiled_launches(emu_lib, case):
+def test_tree_with_one_workgroup_fronts_against_the_tiled_launches(emu_lib, case, env):
     if case.startswith("poisson"):
         n, rp, ci, v = P.poisson2d(60, 52)
     elif case.startswith("convection"):
         n, rp, ci, v = P.convection_diffusion2d(50, peclet=30.0, scale_decades=2.0)
     else:
         n, rp, ci, v = P.fe_block2d(12, 12, 3, symmetric=False, scale_decades=1.0)
-    got = _run(emu_lib, n, rp, ci, v, {"HIPMF_MID_FRONT": "1"}, nrhs=9)   # (9 columns: the blocked forward slabs read the dense E_top too)
+    got = _run(emu_lib, n, rp, ci, v, env, nrhs=9)   # (9 columns: the blocked forward slabs read the dense E_top too)
     ref = _run(emu_lib, n, rp, ci, v, {"HIPMF_MID_FRONT": "0"}, nrhs=9)
     assert got[4] > 0 and ref[4] == 0
     A = sp.csr_matrix((v, ci, rp), shape=(n, n)).tocsc()

@@ -10,15 +10,16 @@ import scipy.sparse.linalg as spla
 
 from russell_amd import problems as P
 from russell_amd.backend import Hipmf
-from test_mid_fronts_cpu import _run, _two_leaves_and_a_root
+from test_mid_fronts_cpu import GJ8, HAND, LU32, _run, _two_leaves_and_a_root
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("p,m,weak", [(2, 70, False), (5, 75, False), (6, 62, True), (20, 60, True), (33, 80, False), (64, 40, True)])
-def test_one_workgroup_fronts_by_hand_on_the_device(p, m, weak):
+@pytest.mark.parametrize("p,m,weak,env", HAND + [(32, 192, True, LU32), (17, 191, False, LU32)],
+                         ids=lambda v: ("gj8" if v is GJ8 else "lu32") if isinstance(v, dict) else str(v))
+def test_one_workgroup_fronts_by_hand_on_the_device(p, m, weak, env):
     n, rp, ci, v, M = _two_leaves_and_a_root(p, m, seed=100 * p + m, weak=weak)
-    got = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "1"}, ordering=2)
+    got = _run(None, n, rp, ci, v, env, ordering=2)
     ref = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "0"}, ordering=2)
     assert got[4] >= 1 and ref[4] == 0
     xo = spla.splu(M.tocsc()).solve(got[1][0])
@@ -27,8 +28,9 @@ def test_one_workgroup_fronts_by_hand_on_the_device(p, m, weak):
     assert got[3] == ref[3] and abs(got[2] - ref[2]) <= 1e-10 * abs(ref[2])
 
 
+@pytest.mark.parametrize("env", [LU32, GJ8], ids=["lu32", "gj8"])
 @pytest.mark.parametrize("case", ["poisson2d 300", "convection-diffusion 220", "fe blocks 40x40x3", "poisson3d 24"])
-def test_trees_with_one_workgroup_fronts_against_the_tiled_launches(case):
+def test_trees_with_one_workgroup_fronts_against_the_tiled_launches(case, env):
     if case.startswith("poisson2d"):
         n, rp, ci, v = P.poisson2d(300)
     elif case.startswith("convection"):
@@ -37,7 +39,7 @@ def test_trees_with_one_workgroup_fronts_against_the_tiled_launches(case):
         n, rp, ci, v = P.fe_block2d(40, 40, 3, symmetric=False, scale_decades=2.0)
     else:
         n, rp, ci, v = P.poisson3d(24)
-    got = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "1"}, nrhs=17)
+    got = _run(None, n, rp, ci, v, env, nrhs=17)
     ref = _run(None, n, rp, ci, v, {"HIPMF_MID_FRONT": "0"}, nrhs=17)
     assert got[4] > 0 and ref[4] == 0
     lu = spla.splu(sp.csr_matrix((v, ci, rp), shape=(n, n)).tocsc())
@@ -50,7 +52,7 @@ def test_trees_with_one_workgroup_fronts_against_the_tiled_launches(case):
 
 
 def test_config2_with_and_without_one_workgroup_fronts_and_graph_replay(monkeypatch):
-    # the 1M-DOF matrix: the default build (k_front on the fronts with at most 80 off-diagonal rows), the tiled launches alone, and the
+    # the 1M-DOF matrix: the default build (k_front_lu on the fronts with at most 32 pivots), the tiled launches alone, and the
     # levels' launches replayed from a hipGraph -- the reference's residual metric at 1e-10 each, and the three solutions against each other
     n, rp, ci, v = P.poisson2d(1000)
     xs = P.manufactured_solution(n)

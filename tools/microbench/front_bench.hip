@@ -26,6 +26,7 @@ template <int CM> static void launch(int n, size_t dyn, const FrontDesc *fd, dou
     hipLaunchKernelGGL(k_front<CM>, dim3(n), dim3(64 * MID_NW), dyn, 0, fd, pool, lperm, an, 1e-13, info, diag);
 }
 
+static bool g_lu = false; // argv[2] = 1: k_front_lu for the fronts with at most 32 pivots
 static void run(int p, int m, int nf, bool check) {
     const int f = p + m, ld = f;
     const int64_t per = (int64_t)f * f + (int64_t)f * p + (int64_t)p * f; // F | E | E'
@@ -57,8 +58,9 @@ static void run(int p, int m, int nf, bool check) {
     double one = 1.0;
     CK(hipMemcpy(an, &one, 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dfd, fd.data(), sizeof(FrontDesc) * (size_t)nf, hipMemcpyHostToDevice));
-    const size_t dyn = sizeof(double) * (size_t)mid_lds_doubles(p, m);
-    if (mid_lds_doubles(p, m) > MID_LDS_DOUBLES || m > MID_MMAX) {
+    const bool lu = g_lu && p <= MIDL_P && midl_lds_doubles(p, m) <= MIDL_LDS_DOUBLES;
+    const size_t dyn = sizeof(double) * (size_t)(lu ? midl_lds_doubles(p, m) : mid_lds_doubles(p, m));
+    if (!lu && (mid_lds_doubles(p, m) > MID_LDS_DOUBLES || m > MID_MMAX)) {
         printf("p=%3d m=%3d: not eligible (%d doubles of LDS)\n", p, m, mid_lds_doubles(p, m));
         return;
     }
@@ -70,7 +72,10 @@ static void run(int p, int m, int nf, bool check) {
     for (int rep = 0; rep < 4; rep++) {
         CK(hipMemcpy(pool, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, 0));
-        if (cls == 0) launch<10>(nf, dyn, dfd, pool, lperm, an, info, diag);
+        if (lu) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_lu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * MIDL_LDS_DOUBLES)));
+            hipLaunchKernelGGL(k_front_lu, dim3(nf), dim3(64 * MIDL_NW), dyn, 0, dfd, pool, lperm, an, 1e-13, info, diag);
+        } else if (cls == 0) launch<10>(nf, dyn, dfd, pool, lperm, an, info, diag);
         else if (cls == 1) launch<16>(nf, dyn, dfd, pool, lperm, an, info, diag);
         else launch<24>(nf, dyn, dfd, pool, lperm, an, info, diag);
         CK(hipEventRecord(e1, 0));
@@ -80,7 +85,7 @@ static void run(int p, int m, int nf, bool check) {
         if (rep > 0 && ms < best) best = ms;
     }
     CK(hipGetLastError());
-    printf("p=%3d m=%3d f=%3d fronts=%5d class=%d  launch %8.1f us  (%.2f us per front and CU-slot, %.2f GFLOP/s)", p, m, f, nf, cls, best * 1e3,
+    printf("%s p=%3d m=%3d f=%3d fronts=%5d class=%d  launch %8.1f us  (%.2f us per front and CU-slot, %.2f GFLOP/s)", lu ? "k_front_lu" : "k_front   ", p, m, f, nf, cls, best * 1e3,
            best * 1e3 / std::max(1.0, nf / 256.0), 2.0 * p * f * (double)f * nf / (best * 1e-3) * 1e-9);
 #ifdef HIPMF_STAMPS
     {
@@ -149,8 +154,9 @@ static void run(int p, int m, int nf, bool check) {
 
 int main(int argc, char **argv) {
     const bool check = argc > 1 && atoi(argv[1]) != 0;
+    g_lu = argc > 2 && atoi(argv[2]) != 0;
     const int cfg[][3] = {{2, 70, 64}, {5, 75, 256}, {16, 50, 1},  {16, 50, 256},  {16, 50, 1024}, {30, 70, 1},  {30, 70, 256}, {30, 70, 768}, {30, 70, 1536}, {40, 100, 1},
-                          {40, 100, 512}, {48, 120, 1}, {48, 120, 512}, {56, 130, 1}, {56, 130, 256}, {32, 192, 256}};
+                          {40, 100, 512}, {32, 120, 1}, {32, 120, 512}, {48, 120, 512}, {32, 192, 1}, {32, 192, 256}};
     for (auto &c : cfg) run(c[0], c[1], c[2], check);
     return 0;
 }
