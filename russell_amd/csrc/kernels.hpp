@@ -5,6 +5,7 @@
 #include "kernels_common.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_factor_front.hpp"
+#include "kernels_factor_binv.hpp"
 #include "kernels_solve.hpp"
 #include "kernels_solve_fused.hpp"
 #include "kernels_factor_chain.hpp"

@@ -124,6 +124,7 @@ struct EaTask {
     int32_t ld;                       // its leading dimension
     int32_t piece_begin, piece_end;   // the EaRange pieces (children in ascending order) that hit this tile of the parent
     int32_t sym;                      // parent factorised as L D L^T: only entries on or below its diagonal are added
+    int32_t c0, r0, nc, nr;           // the tile: columns [c0, c0 + nc), rows [r0, r0 + nr) of the parent (k_extend_add_lds writes all of it)
 };
 
 // One child's contribution block restricted to one tile of the parent: everything the kernel needs in one load.

@@ -760,11 +760,14 @@ template <int TS> struct UpdateLdsT {
 typedef UpdateLdsT<UPD_T> UpdateLds;
 
 // One tile (t < ntiles) or the look-ahead piece (t == ntiles) of the trailing update of step k0 of the front in `slot`.
+// part (LU instances, full steps only): 0 = every tile; 1 = the tiles of the first block column and block row (what the next two panels
+// and the look-ahead touch: the "critical strips") + the look-ahead piece; 2 = all other tiles.  A full step split this way runs its
+// part 2 on a side stream beside the next group's panel steps (numeric.cpp); the tiles' arithmetic is the same: identical bits.
 template <bool SYM, bool COH, int TS = UPD_T>
-__device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, const int t, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
+__device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, const int t_in, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
                                             double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                             const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                            double *__restrict__ diag) {
+                                            double *__restrict__ diag, const int part = 0) {
     typedef TileMem<COH> M;
     constexpr bool CLA = COH || HIPMF_CLAMP_LA;
     static_assert(TS == 64 || TS == 32, "tile edge");
@@ -794,10 +797,22 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
     // the block row.  The host counts the same way.
     const int ntE = nt - ntF;
     const int ntri = ntF * (ntF + 1) / 2;
-    const int ntiles = SYM ? (narrow ? nt : ntri + ntF * ntE) : (narrow ? 2 * nt : nt * nt);
+    const bool split = !SYM && part != 0 && !narrow; // this front's step is a full one and the launch carries one part of it
+    const int ntiles_all = SYM ? (narrow ? nt : ntri + ntF * ntE) : (narrow ? 2 * nt : nt * nt);
+    // tiles of this front in THIS launch (the host counts the same way): a narrow step belongs to part 1 as a whole
+    const int ntiles = !split ? (part == 2 ? 0 : ntiles_all) : (part == 1 ? 2 * nt - 1 : (nt - 1) * (nt - 1));
+    // index of the tile in the full enumeration
+    int t = t_in;
+    if (split && t_in < ntiles) {
+        if (part == 1) t = t_in < nt ? t_in : (t_in - nt + 1) * nt;                                   // (ti, 0), then (0, tj), tj >= 1
+        else t = (1 + t_in % (nt - 1)) + (1 + t_in / (nt - 1)) * nt;                                   // (ti, tj), both >= 1
+    } else if (t_in == ntiles && part != 2)
+        t = ntiles_all; // the look-ahead piece
+    else if (t_in >= ntiles)
+        return;
     const AugView A = aug_view(fd, pool);
     double *F = A.F;
-    if (t == ntiles) {
+    if (t == ntiles_all) {
         // ---- look-ahead workgroup: only wave 0 works (its LDS phases are ordered by wave_sync: no workgroup barrier in here) ----
         if (tid >= 64) return;
         const int r = tid & 31, half = tid >> 5; // row, column half (16 columns each)
@@ -1057,14 +1072,14 @@ __global__ void HIPMF_UPD_BOUNDS k_update(const int32_t *__restrict__ pfx, int32
                                                 int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                double *__restrict__ diag) {
+                                                double *__restrict__ diag, int32_t part) {
     __shared__ UpdateLds sh;
     int pfx_slot;
     const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
     const int t = blockIdx.x - pfx_slot;
     FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
     fd_resident(fd);
-    update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
+    update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag, SYM ? 0 : part);
 }
 
 // the same with 32 x 32 tiles, one wavefront per tile (levels whose largest tiled front has at most Solver::upd32_max_front rows)

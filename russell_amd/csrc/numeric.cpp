@@ -78,7 +78,7 @@ void Solver::release() {
     if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     (void)hipSetDevice(device);
     void *ptrs[] = {d_vs, d_vs2, d_sa_ptr, d_sa_k, d_sa_pos, d_zero, d_seg_ptr, d_seg_idx, d_vin, d_blk, d_work_blk, d_cs == d_rs ? nullptr : d_cs, matched ? d_rperm : nullptr, d_trace, d_sf, d_need, d_sync, d_dws,   d_ear,   d_fd,    d_ea,    d_st,    d_info, d_scalar, d_work, d_vals, d_xp,   d_r,    d_den,  d_b,    d_x,     d_du,   d_rows,
-                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_diag, d_bigfd, d_row_blk, d_dcol, d_pool, d_lperm,
+                    d_rel,   d_child, d_lists, d_tasks, d_rp,    d_ci,   d_arow, d_tptr, d_tidx, d_perm, d_sc_k, d_sc_at, d_ea_sc, d_sc_pos, d_diag, d_bigfd, d_row_blk, d_dcol, d_pool, d_lperm,
                     d_rs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -120,7 +120,7 @@ void Solver::release() {
     d_fd = nullptr, d_ea = nullptr, d_st = nullptr, d_info = nullptr, d_scalar = nullptr;
     d_work = d_vals = d_xp = d_r = d_den = d_b = d_x = d_du = d_pool = d_rs = nullptr;
     d_rows = d_rel = d_child = d_lists = d_tasks = d_rp = d_ci = d_arow = d_tptr = d_tidx = d_perm = d_lperm = nullptr;
-    d_sc_k = nullptr, d_sc_at = nullptr, d_diag = nullptr, d_bigfd = nullptr, d_row_blk = nullptr, d_dcol = nullptr;
+    d_sc_k = nullptr, d_sc_at = nullptr, d_ea_sc = nullptr, d_sc_pos = nullptr, d_diag = nullptr, d_bigfd = nullptr, d_row_blk = nullptr, d_dcol = nullptr;
     for (auto &e : ev)
         if (e) {
             (void)hipEventDestroy((hipEvent_t)e);
@@ -142,7 +142,11 @@ void Solver::release() {
         (void)hipStreamDestroy((hipStream_t)stream3);
         stream3 = nullptr;
     }
-    for (void **e : {&ev_fork, &ev_join, &ev_fork3, &ev_join3})
+    if (stream4) {
+        (void)hipStreamDestroy((hipStream_t)stream4);
+        stream4 = nullptr;
+    }
+    for (void **e : {&ev_fork, &ev_join, &ev_fork3, &ev_join3, &ev_pb, &ev_rest})
         if (*e) {
             (void)hipEventDestroy((hipEvent_t)*e);
             *e = nullptr;
@@ -203,7 +207,12 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             stream2 = st;
             HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
             stream3 = st;
-            hipEvent_t e1, e2, e3, e4;
+            HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
+            stream4 = st;
+            hipEvent_t e1, e2, e3, e4, e5, e6;
+            HIPC(hipEventCreateWithFlags(&e5, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e6, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            ev_pb = e5, ev_rest = e6;
             HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
             HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
             HIPC(hipEventCreateWithFlags(&e3, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
@@ -321,6 +330,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_CHAIN_MAX_STEPS")) chain_max_steps = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_UPD32_MAXF")) upd32_max_front = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_FACTOR_GRAPH")) use_graph = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_UPD_SPLIT")) upd_split_min = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_BLOCK_INV")) use_binv = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_EA_LDS")) use_ea_lds = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(0, std::min(MID_MMAX, atoi(e)));
     if (const char *e = getenv("HIPMF_MID_LU")) use_mid_lu = atoi(e) != 0;
@@ -384,6 +396,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         std::vector<int32_t> sa_ptr, sa_k, sc_k, zero_off, zero_n;
         std::vector<uint16_t> sa_pos;
         std::vector<int64_t> sc_cnt, sc_at;
+        std::vector<int32_t> ea_sc;   // (k_extend_add_lds) entries of A per extend-add task: sc_k is then in task order, sc_pos the position in the tile
+        std::vector<uint16_t> sc_pos;
         std::vector<ZeroTask> zt;
         int32_t zero_cnt = 0, status = 0;
     } AL;
@@ -437,6 +451,47 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
                     AL.sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
                     AL.sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
                 }
+        }
+        if (ea_lds_active()) {
+            // k_extend_add_lds: the same entries by task.  Task numbering of upload_plan: levels ascending, the big fronts of a level in level
+            // order, every tile of a front, tile columns outer, tile rows inner.
+            std::vector<int32_t> ea_base((size_t)ns, -1);
+            int64_t ntask = 0;
+            for (int32_t l = 0; l < S.nlevels; l++)
+                for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+                    const int32_t s = S.level_sn[k];
+                    const int64_t f = S.fsize(s);
+                    if (f <= SMALL_F) continue;
+                    ea_base[(size_t)s] = (int32_t)ntask;
+                    ntask += ((f + EA_TILE_C - 1) / EA_TILE_C) * ((f + EA_TILE_R - 1) / EA_TILE_R);
+                }
+            if (ntask > 0x7ffffff0LL) {
+                AL.status = 1;
+                return;
+            }
+            const size_t ne = AL.sc_k.size();
+            std::vector<int32_t> task_of(ne);
+            AL.ea_sc.assign((size_t)ntask + 1, 0);
+            AL.sc_pos.resize(ne);
+            std::vector<uint16_t> pos_of(ne);
+            for (size_t e = 0; e < ne; e++) {
+                const int32_t k = AL.sc_k[e] < 0 ? ~AL.sc_k[e] : AL.sc_k[e];
+                const int32_t s = S.amap_sn[(size_t)k];
+                const int64_t off = AL.sc_at[e] - S.front_off[s], ld = S.front_ld[s], f = S.fsize(s);
+                const int64_t r = off % ld, c = off / ld;
+                const int64_t nrt = (f + EA_TILE_R - 1) / EA_TILE_R;
+                task_of[e] = ea_base[(size_t)s] + (int32_t)((c / EA_TILE_C) * nrt + r / EA_TILE_R);
+                pos_of[e] = (uint16_t)((r % EA_TILE_R) + (c % EA_TILE_C) * EA_TILE_R);
+                AL.ea_sc[(size_t)task_of[e] + 1]++;
+            }
+            for (int64_t t = 0; t < ntask; t++) AL.ea_sc[(size_t)t + 1] += AL.ea_sc[(size_t)t];
+            std::vector<int32_t> wt(AL.ea_sc.begin(), AL.ea_sc.end() - 1), k2(ne);
+            for (size_t e = 0; e < ne; e++) { // (stable: the entries of a task keep the order of the level's list)
+                const size_t q = (size_t)wt[(size_t)task_of[e]]++;
+                k2[q] = AL.sc_k[e], AL.sc_pos[q] = pos_of[e];
+            }
+            AL.sc_k.swap(k2);
+            std::vector<int64_t>().swap(AL.sc_at); // (positions are per tile now)
         }
         // zero-fill tasks, 16 Ki doubles per workgroup: first the persistent E / E' panels of all big fronts (one launch per
         // factorisation), then the working blocks level by level
@@ -542,6 +597,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             HIPC(dev_upload(&d_sa_pos, AL.sa_pos), ERROR_HIP_MALLOC);
             HIPC(dev_upload(&d_sc_k, AL.sc_k), ERROR_HIP_MALLOC);
             HIPC(dev_upload(&d_sc_at, AL.sc_at), ERROR_HIP_MALLOC);
+            if (ea_lds_active()) {
+                HIPC(dev_upload(&d_ea_sc, AL.ea_sc), ERROR_HIP_MALLOC);
+                HIPC(dev_upload(&d_sc_pos, AL.sc_pos), ERROR_HIP_MALLOC);
+            }
             HIPC(dev_upload(&d_zero, AL.zt), ERROR_HIP_MALLOC);
         }
         lap("assembly lists + zero tasks");
@@ -1093,7 +1152,48 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             tasks.push_back((int32_t)acc);
             if (acc > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
             st.n_update = (int32_t)acc;
+            // Split this step's update?  LU, 64 x 64 tiles, no active front in a narrow step (the group's last step: every front applies the
+            // whole rank-64 update), some front goes on afterwards (there is a panel chain to run beside the bulk), enough workgroups
+            // for the bulk to be worth a stream of its own.
+            bool any_narrow = false, any_follow = false, any_full = false;
+            for (int32_t a = 0; a < st.nactive; a++) {
+                const bool follow = S.npiv(big[a]) > k0 + NB;
+                const int32_t G = update_group(S.fsize(big[a]));
+                const bool nar = follow && ((k0 / NB) % G) != G - 1;
+                any_narrow |= nar, any_follow |= follow, any_full |= !nar;
+            }
+            st.all_narrow = !any_full;
+            if (!S.sym_mode && UT == UPD_T && upd_split_min > 0 && st.n_update >= upd_split_min && !use_chain) {
+                if (!any_narrow && any_follow) {
+                    st.split = true;
+                    for (int part = 1; part <= 2; part++) {
+                        (part == 1 ? st.pfx_crit : st.pfx_rest) = (int64_t)tasks.size();
+                        int64_t acc2 = 0;
+                        for (int32_t a = 0; a < st.nactive; a++) {
+                            tasks.push_back((int32_t)acc2);
+                            const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
+                            const int64_t nt = (fa - basea + UT - 1) / UT + (basea + UT - 1) / UT;
+                            const bool follow = S.npiv(big[a]) > k0 + NB;
+                            acc2 += part == 1 ? (2 * nt - 1) + (follow ? 1 : 0) : (nt - 1) * (nt - 1);
+                        }
+                        tasks.push_back((int32_t)acc2);
+                        (part == 1 ? st.n_crit : st.n_rest) = (int32_t)acc2;
+                    }
+                }
+            }
             L.steps.push_back(st);
+        }
+        // k_eflush (one-launch steps, LU): per tiled front (block columns) x (tiles of 64 rows of its p rows of E')
+        L.pfx_flush = (int64_t)tasks.size();
+        {
+            int64_t accf = 0;
+            for (int32_t a : big) {
+                tasks.push_back((int32_t)accf);
+                const int64_t pa = S.npiv(a);
+                if (pa > NB) accf += ((pa + NB - 1) / NB) * ((pa + 63) / 64);
+            }
+            tasks.push_back((int32_t)accf);
+            L.n_flush = S.sym_mode ? 0 : (int32_t)accf;
         }
         // the same steps as tasks of ONE launch (k_chain) for the levels near the root: panel tiles and update pieces in the order of the
         // launches, each with the counters it waits for and the ones it bumps (kernels_factor_chain.hpp)
@@ -1163,7 +1263,8 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             int32_t s = S.level_sn[k];
             bool any = false;
             for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
-            if (!any) continue;
+            const bool all_tiles = ea_lds_active(); // k_extend_add_lds writes the working block: every tile of every big front has a task
+            if (!any && !all_tiles) continue;
             if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
             int32_t f = S.fsize(s);
             const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
@@ -1203,7 +1304,8 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                         ear.push_back(rg);
                     }
                     tk.piece_end = (int32_t)ear.size();
-                    if (tk.piece_end > tk.piece_begin) ea.push_back(tk);
+                    tk.c0 = c0, tk.r0 = r0, tk.nc = c1 - c0, tk.nr = r1 - r0;
+                    if (tk.piece_end > tk.piece_begin || all_tiles) ea.push_back(tk);
                 }
         }
         L.ea_cnt = (int32_t)ea.size() - L.ea_off;
@@ -1237,6 +1339,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         }
     }
     if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
+    if (ea_lds_active()) HIPMF_ALLOW_LDS(k_extend_add_lds, sizeof(double) * EA_TILE_C * EA_TILE_R);
     if (use_mid && !S.sym_mode) { // (a front with 64 pivots stages 67 KB)
         HIPMF_ALLOW_LDS(k_front<10>, sizeof(double) * MID_LDS_DOUBLES);
         HIPMF_ALLOW_LDS(k_front<16>, sizeof(double) * MID_LDS_DOUBLES);
@@ -1451,13 +1554,17 @@ int32_t Solver::run_factor() {
     // streams cost 5 - 11 us of idle device at every level boundary when issued eagerly (profiles/r03_factor_sequence.txt: 214 us
     // of gaps in one factorisation of the 1M-DOF matrix).
     auto enqueue_levels = [&]() -> int32_t {
-    if (!levels.empty()) fill_level(levels[0], STREAM);
+    const bool ea_lds = ea_lds_active(); // the working blocks are written whole by the extend-add: no zero-fill / scatter launches
+    if (!levels.empty() && !ea_lds) fill_level(levels[0], STREAM);
     for (size_t li = 0; li < levels.size(); li++) {
         const LevelPlan &L = levels[li];
         const LevelPlan *Lnext = li + 1 < levels.size() ? &levels[li + 1] : nullptr;
-        const bool fill_next = Lnext && (Lnext->zero_cnt > 0 || Lnext->sc_cnt > 0);
+        const bool fill_next = !ea_lds && Lnext && (Lnext->zero_cnt > 0 || Lnext->sc_cnt > 0);
         if (L.ea_cnt > 0) {
-            if (S.sym_mode) hipLaunchKernelGGL(k_extend_add<true>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
+            if (ea_lds)
+                hipLaunchKernelGGL(k_extend_add_lds, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
+                                   d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2);
+            else if (S.sym_mode) hipLaunchKernelGGL(k_extend_add<true>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             else hipLaunchKernelGGL(k_extend_add<false>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             launches++;
         }
@@ -1546,11 +1653,12 @@ int32_t Solver::run_factor() {
                 hipLaunchKernelGGL(k_chain<false>, dim3(L.chain_cnt), dim3(256), 0, STREAM, ct, lfd, d_pool, d_lperm, d_dws, dws_stride, d_scalar,
                                    opt.pivot_epsilon, d_info, d_diag, pre_lu, d_chain_cnt, d_chain_cnt + (chain_words - 1));
             launches++;
-        } else
+        } else {
+        bool rest_pending = false; // the bulk of a split update is in flight on stream4
         for (const StepPlan &st : L.steps) {
             const FrontDesc *lfd = d_bigfd + L.bigfd_off; // descriptors of the level's tiled fronts, in slot order
             // step 0 of a level with many tiled fronts: the first diagonal tiles are factorised once, by a launch of their own (k_diag0)
-            const int32_t pre_lu = (k0 == 0 && st.n_panel >= diag0_min_panels) ? 1 : 0;
+            const int32_t pre_lu = (k0 == 0 && st.n_panel >= diag0_min_panels && (S.sym_mode || !use_binv)) ? 1 : 0;
             if (pre_lu) {
                 if (S.sym_mode) hipLaunchKernelGGL(k_diag0<true>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                 else hipLaunchKernelGGL(k_diag0<false>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
@@ -1561,22 +1669,59 @@ int32_t Solver::run_factor() {
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
                 if (st.n_update > 0 && L.upd_ts == UPD_T)
                     hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 0);
                 else if (st.n_update > 0)
                     hipLaunchKernelGGL(k_update32<true>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                        d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+            } else if (use_binv) {
+                // one launch per step: every tile forms its own rows of W = A inv(D) (kernels_factor_binv.hpp)
+                if (k0 == 0) {
+                    hipLaunchKernelGGL(k_dinv0, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                    launches++;
+                }
+                if (L.upd_ts == UPD_T)
+                    hipLaunchKernelGGL(k_bstep, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0, d_pool, d_lperm,
+                                       d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else
+                    hipLaunchKernelGGL(k_bstep32, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0, d_pool, d_lperm,
+                                       d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                launches--;
             } else {
                 hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
-                if (L.upd_ts == UPD_T)
+                if (L.upd_ts == UPD_T && st.split && st.n_rest > 0) {
+                    // the bulk of the previous split step must be through before anything touches its tiles again
+                    if (rest_pending) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_rest, 0), ERROR_HIP_SYNCHRONIZE);
+                    HIPC(hipEventRecord((hipEvent_t)ev_pb, STREAM), ERROR_HIP_SYNCHRONIZE);
+                    HIPC(hipStreamWaitEvent((hipStream_t)stream4, (hipEvent_t)ev_pb, 0), ERROR_HIP_SYNCHRONIZE);
+                    hipLaunchKernelGGL(k_update<false>, dim3(st.n_crit), dim3(256), 0, STREAM, d_tasks + st.pfx_crit, st.nactive, lfd, k0, d_pool, d_dws,
+                                       dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 1);
+                    hipLaunchKernelGGL(k_update<false>, dim3(st.n_rest), dim3(256), 0, (hipStream_t)stream4, d_tasks + st.pfx_rest, st.nactive, lfd, k0,
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 2);
+                    HIPC(hipEventRecord((hipEvent_t)ev_rest, (hipStream_t)stream4), ERROR_HIP_SYNCHRONIZE);
+                    rest_pending = true;
+                    launches++;
+                } else if (L.upd_ts == UPD_T) {
+                    // (an unsplit update may touch any tile: the bulk of a split step before it has to be through)
+                    if (rest_pending && !st.all_narrow) {
+                        HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_rest, 0), ERROR_HIP_SYNCHRONIZE);
+                        rest_pending = false;
+                    }
                     hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
-                else
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 0);
+                } else
                     hipLaunchKernelGGL(k_update32<false>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                        d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             }
             launches += 2;
             k0 += NB;
+        }
+        if (rest_pending) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_rest, 0), ERROR_HIP_SYNCHRONIZE);
+        if (use_binv && !S.sym_mode && L.n_flush > 0) {
+            // E' above its diagonal blocks: A(:, k) -> A(:, k) inv(D_k) (kernels_factor_binv.hpp)
+            hipLaunchKernelGGL(k_eflush, dim3(L.n_flush), dim3(64), 0, STREAM, d_tasks + L.pfx_flush, L.big_cnt, d_bigfd + L.bigfd_off, d_pool);
+            launches++;
+        }
         }
         if (L.mirror_cnt > 0) {
             hipLaunchKernelGGL(k_mirror_cb, dim3(L.mirror_cnt), dim3(256), 0, STREAM, d_lists + L.mirror_off, d_fd, d_pool);

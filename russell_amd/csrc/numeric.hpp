@@ -66,6 +66,12 @@ struct StepPlan {
     int32_t nactive = 0;
     int64_t pfx_panel = 0, pfx_update = 0; // offsets into d_tasks
     int32_t n_panel = 0, n_update = 0;
+    // a full step whose trailing update runs in two launches: the critical strips (first block column / row + look-ahead) on the main
+    // stream, the other tiles on a side stream beside the next group's panel steps
+    bool split = false;
+    bool all_narrow = false; // every active front is inside a group of panels: the update only touches the next panel's strips
+    int64_t pfx_crit = 0, pfx_rest = 0;
+    int32_t n_crit = 0, n_rest = 0;
 };
 struct LevelPlan {
     int32_t small_off = 0, small_cnt = 0, small_ld = 0, small_pmax = 1; // fronts with f <= SMALL_F
@@ -80,6 +86,8 @@ struct LevelPlan {
     int32_t big_pmax = 0, big_fmax = 0;
     bool wide = false; // solve with 32-row slabs x 32 column groups (few large fronts)
     std::vector<StepPlan> steps;
+    int64_t pfx_flush = 0;  // k_eflush: prefix of tasks per tiled front (into d_tasks), their total
+    int32_t n_flush = 0;
     int32_t upd_ts = 64;    // edge of the trailing-update tiles on this level (32: k_update32, one wave per tile)
     // fronts of the middle of the tree that ONE workgroup carries through their whole partial factorisation (k_front,
     // kernels_factor_front.hpp): their descriptors follow the tiled ones in d_bigfd, grouped by size class
@@ -144,6 +152,10 @@ class Solver {
     bool use_graph = false; // (measured: no gain at 1000 x 1000 -- the gaps at the level boundaries are the cross-stream edges themselves, not host latency)
     void *factor_graph = nullptr;
     int64_t graph_launches = 0;
+    bool use_binv = false;            // HIPMF_BLOCK_INV=1: LU fronts of the tiled path take ONE launch per step (kernels_factor_binv.hpp) instead of k_panel + k_update; measured slower (profiles/r04_rejected_experiments.txt)
+    void *stream4 = nullptr;          // ... and the bulk of a split trailing update (HIPMF_UPD_SPLIT)
+    void *ev_pb = nullptr, *ev_rest = nullptr;
+    int32_t upd_split_min = 0;        // HIPMF_UPD_SPLIT=n: full steps (two-launch form) with at least n update workgroups are split (0: never; measured: no gain)
     void *stream3 = nullptr;          // ... and so are the fronts one workgroup factorises (k_front)
     void *ev_fork3 = nullptr, *ev_join3 = nullptr;
     std::string last_error;
@@ -308,6 +320,10 @@ class Solver {
            *d_du = nullptr;
     int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
     int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
+    bool use_ea_lds = true;       // HIPMF_EA_LDS=0: LU working blocks go back to k_zero + k_scatter + k_extend_add (read-modify-write per child) instead of k_extend_add_lds
+    bool ea_lds_active() const { return use_ea_lds && !S.sym_mode; }
+    int32_t *d_ea_sc = nullptr;   // k_extend_add_lds: per task, the range of its entries of A in d_sc_k / d_sc_pos (cumulative, all levels)
+    uint16_t *d_sc_pos = nullptr; // ... position inside the task's tile
     int32_t *d_sc_k = nullptr;   // scatter lists of the tiled fronts, by level: input entry k (or ~k: mirrored copy) ...
     int64_t *d_sc_at = nullptr;  // ... and the pool offset it goes to
     double *d_diag = nullptr;    // pivots in pivot order (determinant, rcond, D of the symmetric fronts)

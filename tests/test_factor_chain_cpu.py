@@ -64,3 +64,23 @@ def test_small_update_tiles_give_the_same_factor_bit_for_bit(emu_lib, case):
         assert np.array_equal(ref[0], got[0]), mf
         assert ref[1:3] == got[1:3], mf
         assert np.array_equal(ref[3], got[3])
+
+
+def _split_cases():  # separators of more than 64 vertices: a group of panels with a follower
+    yield "poisson2d 70x72", P.poisson2d(70, 72), {}
+    yield "convection-diffusion 72 (interchanges)", P.convection_diffusion2d(72, peclet=30.0, scale_decades=0.0), {}
+
+
+@pytest.mark.parametrize("case", list(_split_cases()), ids=lambda c: c[0])
+def test_split_full_updates_give_the_same_factor_bit_for_bit(emu_lib, case):
+    # HIPMF_UPD_SPLIT: the last update of a group of panels goes out as two launches -- first block column / row (what the next group's
+    # panels touch) and the other tiles (on a side stream on the device).  Same tiles, same arithmetic: the same bits.  64 x 64 tiles
+    # only (HIPMF_UPD32_MAXF=0), every full step with a follower (threshold 1), no one-workgroup fronts so that the tiled path has work.
+    _, (n, rp, ci, v), kw = case
+    base = {"HIPMF_UPD32_MAXF": "0", "HIPMF_MID_LU": "0", "HIPMF_MID_FRONT": "0"}
+    ref = _run(emu_lib, n, rp, ci, v, dict(base, HIPMF_UPD_SPLIT="0"), **kw)
+    got = _run(emu_lib, n, rp, ci, v, dict(base, HIPMF_UPD_SPLIT="1"), **kw)
+    assert np.array_equal(ref[0], got[0])
+    assert ref[1:3] == got[1:3]
+    assert np.array_equal(ref[3], got[3])
+    assert got[4] > ref[4]  # (some step was split: one launch more for each)
