@@ -4,6 +4,7 @@
 #include "kernels_assembly.hpp"
 #include "kernels_common.hpp"
 #include "kernels_factor.hpp"
+#include "kernels_extend_add.hpp"
 #include "kernels_factor_front.hpp"
 #include "kernels_factor_binv.hpp"
 #include "kernels_solve.hpp"

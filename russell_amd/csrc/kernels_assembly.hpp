@@ -198,64 +198,4 @@ __global__ void k_extend_add(const EaTask *__restrict__ tasks, const EaRange *__
     }
 }
 
-// extend-add with FIRST TOUCH (LU fronts, round 4): the task owns a 32-column x 256-row tile of the parent's working block and builds it
-// in LDS -- zero, the entries of A that land in the tile (per-task lists: what k_scatter did for the level), the children's contribution
-// blocks in child order -- and writes the WHOLE tile once.  The order of the additions is k_zero + k_scatter + k_extend_add's: the same
-// bits.  What it saves: the block was zero-filled (8 bytes per entry), then read and written once per child that hits an entry (16 bytes
-// beside the 8 of the child's entry); now an entry costs 8 bytes per child + 8.  The zero-fill / scatter launches of the level and the
-// side stream they ran on are gone with their cross-stream edge (5 - 7 us at each of the upper levels' boundaries).  Every tile of every
-// big front of the level has a task (a tile no child touches is still zero + A).  Dynamic LDS: EA_TILE_C x EA_TILE_R doubles.
-constexpr int EA_TILE_C = 32, EA_TILE_R = 256;
-__global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const int32_t *__restrict__ rel,
-                                                        double *__restrict__ pool, const int32_t *__restrict__ ea_sc, const int32_t *__restrict__ sc_k,
-                                                        const uint16_t *__restrict__ sc_pos, const double *__restrict__ vs, const double *__restrict__ vs2) {
-    HIPMF_DYN_SHARED(double, T); // T[(c - c0) * EA_TILE_R + (r - r0)]
-    const EaTask t = tasks[blockIdx.x];
-    const int tid = threadIdx.x;
-    const int s0 = ea_sc[blockIdx.x], s1 = ea_sc[blockIdx.x + 1];
-    EaRange rg = {};
-    if (t.piece_begin < t.piece_end) rg = ranges[t.piece_begin];
-    for (int c = 0; c < t.nc; c++) T[c * EA_TILE_R + tid] = 0.0;
-    __syncthreads();
-    for (int e = s0 + tid; e < s1; e += 256) {
-        const int32_t k = sc_k[e];
-        T[sc_pos[e]] = k < 0 ? vs2[~k] : vs[k];
-    }
-    __syncthreads();
-    const int c0 = t.c0, r0 = t.r0;
-    for (int pc = t.piece_begin; pc < t.piece_end; pc++) {
-        const EaRange nxt = ranges[pc + 1 < t.piece_end ? pc + 1 : pc];
-        const int64_t ldc = rg.ldc;
-        const double *CB = pool + rg.cb_off;
-        const int32_t *relc = rel + rg.rel_off;
-        const int jlo = rg.jlo, jhi = rg.jhi, ilo = rg.ilo, ihi = rg.ihi;
-        const int ni = ihi - ilo;
-        const int sh = ni <= 16 ? 4 : (ni <= 32 ? 5 : 6);
-        const int tx = tid & ((1 << sh) - 1), ty = tid >> sh, ng = 256 >> sh;
-        for (int i = ilo + tx; i < ihi; i += (1 << sh)) {
-            const int ri = relc[i] - r0;
-            for (int j0 = jlo + ty; j0 < jhi; j0 += 8 * ng) {
-                double cb[8];
-                int at[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int j = j0 + q * ng;
-                    at[q] = j < jhi ? ri + (relc[j] - c0) * EA_TILE_R : -1;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (at[q] >= 0) cb[q] = CB[i + (int64_t)(j0 + q * ng) * ldc];
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (at[q] >= 0) T[at[q]] += cb[q]; // (within one child the targets are distinct: rel is strictly increasing)
-            }
-        }
-        __syncthreads(); // the next child may hit the same entries from other threads
-        rg = nxt;
-    }
-    double *F = pool + t.f_off + r0 + (int64_t)c0 * t.ld;
-    if (tid < t.nr)
-        for (int c = 0; c < t.nc; c++) F[tid + (int64_t)c * t.ld] = T[c * EA_TILE_R + tid];
-}
-
 } // namespace hipmf

@@ -125,6 +125,8 @@ struct EaTask {
     int32_t piece_begin, piece_end;   // the EaRange pieces (children in ascending order) that hit this tile of the parent
     int32_t sym;                      // parent factorised as L D L^T: only entries on or below its diagonal are added
     int32_t c0, r0, nc, nr;           // the tile: columns [c0, c0 + nc), rows [r0, r0 + nr) of the parent (k_extend_add_lds writes all of it)
+    int32_t lu_slot, lu_first, lu_nb; // k_extend_add_lds, first tile of a tiled LU front: its slot in the level (< 0: none), first pivot, size of the first diagonal tile
+    int32_t pad;
 };
 
 // One child's contribution block restricted to one tile of the parent: everything the kernel needs in one load.

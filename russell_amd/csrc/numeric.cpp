@@ -333,6 +333,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_UPD_SPLIT")) upd_split_min = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_BLOCK_INV")) use_binv = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_EA_LDS")) use_ea_lds = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_EA_LU")) use_ea_lu = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(0, std::min(MID_MMAX, atoi(e)));
     if (const char *e = getenv("HIPMF_MID_LU")) use_mid_lu = atoi(e) != 0;
@@ -455,16 +456,24 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         if (ea_lds_active()) {
             // k_extend_add_lds: the same entries by task.  Task numbering of upload_plan: levels ascending, the big fronts of a level in level
             // order, every tile of a front, tile columns outer, tile rows inner.
-            std::vector<int32_t> ea_base((size_t)ns, -1);
+            // ... the first tiles of the level's fronts lead the level's tasks: first tile of the q-th big front = level base + q, its other
+            // tiles follow the first tiles of all fronts in the order above.
+            std::vector<int32_t> ea_first((size_t)ns, -1), ea_base((size_t)ns, -1); // task of tile (0, 0); task of tile (ct, rt) != (0, 0) is ea_base + ct nrt + rt
             int64_t ntask = 0;
-            for (int32_t l = 0; l < S.nlevels; l++)
+            for (int32_t l = 0; l < S.nlevels; l++) {
+                int64_t nbig = 0;
+                for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) nbig += S.fsize(S.level_sn[k]) > SMALL_F ? 1 : 0;
+                int64_t q = 0, others = ntask + nbig;
                 for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                     const int32_t s = S.level_sn[k];
                     const int64_t f = S.fsize(s);
                     if (f <= SMALL_F) continue;
-                    ea_base[(size_t)s] = (int32_t)ntask;
-                    ntask += ((f + EA_TILE_C - 1) / EA_TILE_C) * ((f + EA_TILE_R - 1) / EA_TILE_R);
+                    ea_first[(size_t)s] = (int32_t)(ntask + q++);
+                    ea_base[(size_t)s] = (int32_t)(others - 1); // (linear tile index 1 is the first of the others)
+                    others += ((f + EA_TILE_C - 1) / EA_TILE_C) * ((f + EA_TILE_R - 1) / EA_TILE_R) - 1;
                 }
+                ntask = others;
+            }
             if (ntask > 0x7ffffff0LL) {
                 AL.status = 1;
                 return;
@@ -480,7 +489,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
                 const int64_t off = AL.sc_at[e] - S.front_off[s], ld = S.front_ld[s], f = S.fsize(s);
                 const int64_t r = off % ld, c = off / ld;
                 const int64_t nrt = (f + EA_TILE_R - 1) / EA_TILE_R;
-                task_of[e] = ea_base[(size_t)s] + (int32_t)((c / EA_TILE_C) * nrt + r / EA_TILE_R);
+                const int64_t lin = (c / EA_TILE_C) * nrt + r / EA_TILE_R;
+                task_of[e] = lin == 0 ? ea_first[(size_t)s] : ea_base[(size_t)s] + (int32_t)lin;
                 pos_of[e] = (uint16_t)((r % EA_TILE_R) + (c % EA_TILE_C) * EA_TILE_R);
                 AL.ea_sc[(size_t)task_of[e] + 1]++;
             }
@@ -1257,8 +1267,14 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                 L.chain_cnt = (int32_t)((int64_t)chain.size() - L.chain_off);
             }
         }
-        // extend-add tasks: 32-column x 256-row tiles of the parent
+        // extend-add tasks: 32-column x 256-row tiles of the parent (k_extend_add_lds: EA_TILE_C x EA_TILE_R, every tile, and the first tile
+        // of a tiled LU front also factorises the front's first diagonal tile -- those tasks lead the level's list: they are the long ones)
         L.ea_off = (int32_t)ea.size();
+        std::vector<int32_t> tiled_slot; // (s -> slot among the level's tiled fronts)
+        if (ea_lds_active()) {
+            tiled_slot.assign((size_t)S.nsuper, -1);
+            for (size_t q = 0; q < big.size(); q++) tiled_slot[(size_t)big[q]] = (int32_t)q;
+        }
         for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
             int32_t s = S.level_sn[k];
             bool any = false;
@@ -1267,7 +1283,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             if (!any && !all_tiles) continue;
             if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
             int32_t f = S.fsize(s);
-            const int32_t cstep = f <= 64 ? f : 32, rstep = f <= 64 ? f : 256;
+            const int32_t cstep = f <= 64 ? f : (all_tiles ? EA_TILE_C : 32), rstep = f <= 64 ? f : (all_tiles ? EA_TILE_R : 256);
             // where every child's (ascending) relative indices cross the tile boundaries: computed once per child, not per tile (a front of
             // 76 000 rows has 716 000 tiles; four binary searches per tile and child made `initialize` of such a matrix take minutes)
             const int32_t nch_s = S.child_ptr[s + 1] - S.child_ptr[s];
@@ -1305,10 +1321,16 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                     }
                     tk.piece_end = (int32_t)ear.size();
                     tk.c0 = c0, tk.r0 = r0, tk.nc = c1 - c0, tk.nr = r1 - r0;
+                    tk.lu_slot = -1, tk.lu_first = 0, tk.lu_nb = 0, tk.pad = 0;
+                    if (all_tiles && c0 == 0 && r0 == 0) {
+                        tk.pad = 1; // (first tile of its front: sorted to the head of the level below)
+                        if (tiled_slot[(size_t)s] >= 0 && ea_lu_active()) tk.lu_slot = tiled_slot[(size_t)s], tk.lu_first = S.sn_first[s], tk.lu_nb = std::min<int32_t>(NB, S.npiv(s));
+                    }
                     if (tk.piece_end > tk.piece_begin || all_tiles) ea.push_back(tk);
                 }
         }
         L.ea_cnt = (int32_t)ea.size() - L.ea_off;
+        if (ea_lds_active()) std::stable_partition(ea.begin() + L.ea_off, ea.end(), [](const EaTask &t) { return t.pad == 1; });
         // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
         L.fwd_off = (int32_t)stasks.size();
         int64_t nslab = 0;
@@ -1563,7 +1585,7 @@ int32_t Solver::run_factor() {
         if (L.ea_cnt > 0) {
             if (ea_lds)
                 hipLaunchKernelGGL(k_extend_add_lds, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
-                                   d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2);
+                                   d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             else if (S.sym_mode) hipLaunchKernelGGL(k_extend_add<true>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             else hipLaunchKernelGGL(k_extend_add<false>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             launches++;
@@ -1658,8 +1680,9 @@ int32_t Solver::run_factor() {
         for (const StepPlan &st : L.steps) {
             const FrontDesc *lfd = d_bigfd + L.bigfd_off; // descriptors of the level's tiled fronts, in slot order
             // step 0 of a level with many tiled fronts: the first diagonal tiles are factorised once, by a launch of their own (k_diag0)
-            const int32_t pre_lu = (k0 == 0 && st.n_panel >= diag0_min_panels && (S.sym_mode || !use_binv)) ? 1 : 0;
-            if (pre_lu) {
+            const bool ea_lu = ea_lu_active(); // the first diagonal tiles were factorised by the extend-add (k_extend_add_lds)
+            const int32_t pre_lu = (k0 == 0 && (ea_lu || (st.n_panel >= diag0_min_panels && (S.sym_mode || !use_binv)))) ? 1 : 0;
+            if (pre_lu && !ea_lu) {
                 if (S.sym_mode) hipLaunchKernelGGL(k_diag0<true>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                 else hipLaunchKernelGGL(k_diag0<false>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                 launches++;

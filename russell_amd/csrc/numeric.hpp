@@ -322,6 +322,8 @@ class Solver {
     int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
     bool use_ea_lds = true;       // HIPMF_EA_LDS=0: LU working blocks go back to k_zero + k_scatter + k_extend_add (read-modify-write per child) instead of k_extend_add_lds
     bool ea_lds_active() const { return use_ea_lds && !S.sym_mode; }
+    bool use_ea_lu = true;        // HIPMF_EA_LU=0: the first diagonal tiles go back to k_diag0 / the first panel launch
+    bool ea_lu_active() const { return ea_lds_active() && use_ea_lu && !use_binv; }
     int32_t *d_ea_sc = nullptr;   // k_extend_add_lds: per task, the range of its entries of A in d_sc_k / d_sc_pos (cumulative, all levels)
     uint16_t *d_sc_pos = nullptr; // ... position inside the task's tile
     int32_t *d_sc_k = nullptr;   // scatter lists of the tiled fronts, by level: input entry k (or ~k: mirrored copy) ...
