@@ -29,8 +29,43 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
     const EaTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
     const int s0 = ea_sc[blockIdx.x], s1 = ea_sc[blockIdx.x + 1];
-    EaRange rg = {};
-    if (t.piece_begin < t.piece_end) rg = ranges[t.piece_begin];
+    const int c0 = t.c0, r0 = t.r0;
+    // A child's part of the tile: at most EA_TILE_R rows x EA_TILE_C columns of its contribution block.  Thread = (row tx, column group ty),
+    // EA_PQ columns each.  The children are taken two at a time and the loads of a pair -- descriptors, then the relative indices of both,
+    // then the entries of both -- are issued together, the first pair BEFORE the tile is zeroed and A's entries are placed: a workgroup is
+    // a chain of dependent round trips to memory (2 us each) and used to make two per child, one child after the other.
+    constexpr int EA_NG = 256 / EA_TILE_R, EA_PQ = (EA_TILE_C + EA_NG - 1) / EA_NG;
+    static_assert(EA_TILE_R <= 256 && EA_PQ <= 16, "extend-add thread map");
+    const int tx = tid % EA_TILE_R, ty = tid / EA_TILE_R;
+    double cbA[EA_PQ], cbB[EA_PQ];
+    int atA[EA_PQ], atB[EA_PQ];
+    auto load_pair = [&](int pc) {
+        const bool hasA = pc < t.piece_end, hasB = pc + 1 < t.piece_end;
+        EaRange ra = {}, rb = {};
+        if (hasA) ra = ranges[pc];
+        if (hasB) rb = ranges[pc + 1];
+        const int32_t *relA = rel + ra.rel_off, *relB = rel + rb.rel_off;
+        const int iA = ra.ilo + tx, iB = rb.ilo + tx;
+        const bool okA = hasA && iA < ra.ihi, okB = hasB && iB < rb.ihi;
+        int riA = 0, riB = 0, rjA[EA_PQ], rjB[EA_PQ];
+        if (okA) riA = relA[iA];
+        if (okB) riB = relB[iB];
+#pragma unroll
+        for (int q = 0; q < EA_PQ; q++) {
+            const int jA = ra.jlo + ty + q * EA_NG, jB = rb.jlo + ty + q * EA_NG;
+            rjA[q] = (okA && jA < ra.jhi) ? relA[jA] : -1;
+            rjB[q] = (okB && jB < rb.jhi) ? relB[jB] : -1;
+        }
+        const double *CA = pool + ra.cb_off + iA, *CBb = pool + rb.cb_off + iB;
+#pragma unroll
+        for (int q = 0; q < EA_PQ; q++) {
+            atA[q] = rjA[q] >= 0 ? (riA - r0) + (rjA[q] - c0) * EA_TILE_R : -1;
+            atB[q] = rjB[q] >= 0 ? (riB - r0) + (rjB[q] - c0) * EA_TILE_R : -1;
+            cbA[q] = atA[q] >= 0 ? CA[(int64_t)(ra.jlo + ty + q * EA_NG) * ra.ldc] : 0.0;
+            cbB[q] = atB[q] >= 0 ? CBb[(int64_t)(rb.jlo + ty + q * EA_NG) * rb.ldc] : 0.0;
+        }
+    };
+    load_pair(t.piece_begin);
     for (int e = tid; e < t.nc * EA_TILE_R; e += 256) T[e] = 0.0;
     __syncthreads();
     for (int e = s0 + tid; e < s1; e += 256) {
@@ -38,36 +73,18 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
         T[sc_pos[e]] = k < 0 ? vs2[~k] : vs[k];
     }
     __syncthreads();
-    const int c0 = t.c0, r0 = t.r0;
-    for (int pc = t.piece_begin; pc < t.piece_end; pc++) {
-        const EaRange nxt = ranges[pc + 1 < t.piece_end ? pc + 1 : pc];
-        const int64_t ldc = rg.ldc;
-        const double *CB = pool + rg.cb_off;
-        const int32_t *relc = rel + rg.rel_off;
-        const int jlo = rg.jlo, jhi = rg.jhi, ilo = rg.ilo, ihi = rg.ihi;
-        const int ni = ihi - ilo;
-        const int sh = ni <= 16 ? 4 : (ni <= 32 ? 5 : 6);
-        const int tx = tid & ((1 << sh) - 1), ty = tid >> sh, ng = 256 >> sh;
-        for (int i = ilo + tx; i < ihi; i += (1 << sh)) {
-            const int ri = relc[i] - r0;
-            for (int j0 = jlo + ty; j0 < jhi; j0 += 8 * ng) {
-                double cb[8];
-                int at[8];
+    for (int pc = t.piece_begin; pc < t.piece_end; pc += 2) {
+        if (pc > t.piece_begin) load_pair(pc);
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int j = j0 + q * ng;
-                    at[q] = j < jhi ? ri + (relc[j] - c0) * EA_TILE_R : -1;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (at[q] >= 0) cb[q] = CB[i + (int64_t)(j0 + q * ng) * ldc];
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (at[q] >= 0) T[at[q]] += cb[q]; // (within one child the targets are distinct: rel is strictly increasing)
-            }
-        }
+        for (int q = 0; q < EA_PQ; q++)
+            if (atA[q] >= 0) T[atA[q]] += cbA[q]; // (within one child the targets are distinct: rel is strictly increasing)
         __syncthreads(); // the next child may hit the same entries from other threads
-        rg = nxt;
+        if (pc + 1 < t.piece_end) {
+#pragma unroll
+            for (int q = 0; q < EA_PQ; q++)
+                if (atB[q] >= 0) T[atB[q]] += cbB[q];
+            __syncthreads();
+        }
     }
     // The first tile of a tiled front now holds the front's first 32 x 32 diagonal tile: wavefront 0 factorises it here (what k_diag0 or
     // the first panel launch did, 18 - 22 us in front of every level's first panel step) while the other wavefronts write the tile out and
