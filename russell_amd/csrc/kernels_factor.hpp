@@ -767,8 +767,9 @@ template <bool SYM, bool COH, int TS = UPD_T>
 __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, const int t_in, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
                                             double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                             const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                            double *__restrict__ diag, const int part = 0) {
+                                            double *__restrict__ diag, const int part_in = 0, const int gshift = 0) {
     typedef TileMem<COH> M;
+    const int part = part_in & 3;
     constexpr bool CLA = COH || HIPMF_CLAMP_LA;
     static_assert(TS == 64 || TS == 32, "tile edge");
     constexpr int NT = TS == 64 ? 256 : 64; // threads of the workgroup
@@ -810,6 +811,30 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
         t = ntiles_all; // the look-ahead piece
     else if (t_in >= ntiles)
         return;
+#ifndef HIPMF_XCD_MIN_NT
+#define HIPMF_XCD_MIN_NT 8
+#endif
+    else if (!SYM && !narrow && (part_in & 4) && nt >= HIPMF_XCD_MIN_NT) {
+        // XCD-aware order of a full step's tiles.  Workgroups go to the eight XCDs round-robin by their index in the launch (gshift = index
+        // of this front's first workgroup mod 8), every XCD has its own L2, and a tile reads the block row of U of its tile column and the
+        // block column of L of its tile row: with the plain order every XCD ends up fetching every panel.  Here the tiles are sorted by
+        // (tile column mod 8, tile column, tile row) and XCD x takes the x-th eighth of that list: whole tile columns, so a block of U is
+        // fetched into one L2 (its neighbours' boundary columns aside).  A permutation of the tiles: the arithmetic of a tile is untouched.
+        const int x = (t_in + gshift) & 7;
+        const int first_x = (x - gshift) & 7;
+        int q = (t_in - first_x) >> 3; // how many of this XCD's workgroups came before
+        for (int y = 0; y < x; y++) {
+            const int first_y = (y - gshift) & 7;
+            q += first_y < ntiles ? (ntiles - first_y + 7) >> 3 : 0;
+        }
+        int c = 0; // class of tile columns (column mod 8) the q-th tile of the sorted list belongs to
+        for (; c < 7; c++) {
+            const int size_c = ((nt - c + 7) >> 3) * nt;
+            if (q < size_c) break;
+            q -= size_c;
+        }
+        t = (q % nt) + (c + 8 * (q / nt)) * nt;
+    }
     const AugView A = aug_view(fd, pool);
     double *F = A.F;
     if (t == ntiles_all) {
@@ -1079,7 +1104,7 @@ __global__ void HIPMF_UPD_BOUNDS k_update(const int32_t *__restrict__ pfx, int32
     const int t = blockIdx.x - pfx_slot;
     FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
     fd_resident(fd);
-    update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag, SYM ? 0 : part);
+    update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag, SYM ? 0 : part, pfx_slot & 7);
 }
 
 // the same with 32 x 32 tiles, one wavefront per tile (levels whose largest tiled front has at most Solver::upd32_max_front rows)

@@ -146,7 +146,7 @@ void Solver::release() {
         (void)hipStreamDestroy((hipStream_t)stream4);
         stream4 = nullptr;
     }
-    for (void **e : {&ev_fork, &ev_join, &ev_fork3, &ev_join3, &ev_pb, &ev_rest})
+    for (void **e : {&ev_fork, &ev_join, &ev_fork3, &ev_join3, &ev_pb, &ev_rest, &ev_pre0, &ev_pre1})
         if (*e) {
             (void)hipEventDestroy((hipEvent_t)*e);
             *e = nullptr;
@@ -213,6 +213,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             HIPC(hipEventCreateWithFlags(&e5, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
             HIPC(hipEventCreateWithFlags(&e6, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
             ev_pb = e5, ev_rest = e6;
+            hipEvent_t e7, e8;
+            HIPC(hipEventCreateWithFlags(&e7, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e8, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            ev_pre0 = e7, ev_pre1 = e8;
             HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
             HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
             HIPC(hipEventCreateWithFlags(&e3, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
@@ -334,6 +338,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_BLOCK_INV")) use_binv = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_EA_LDS")) use_ea_lds = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_EA_LU")) use_ea_lu = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_UPD_XCD")) upd_xcd = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(0, std::min(MID_MMAX, atoi(e)));
     if (const char *e = getenv("HIPMF_MID_LU")) use_mid_lu = atoi(e) != 0;
@@ -1547,15 +1552,28 @@ int32_t Solver::run_factor() {
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
     hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar, d_info);
     launches += 2;
+    // What only the big fronts (or nobody before the end) need runs beside the first levels, which hold small fronts only: the diagonal
+    // check and the zero-fill / identity blocks of E, E' -- 65 of the 128 us this phase took in front of the 1M-DOF factorisation.
+    bool pre_forked = false;
+#ifndef HIPMF_EMULATED
+    pre_forked = overlap_small && !use_graph && !levels.empty() && levels[0].ea_cnt == 0 && levels[0].steps.empty();
+#endif
+    hipStream_t pst = STREAM;
+    if (pre_forked) {
+        HIPC(hipEventRecord((hipEvent_t)ev_pre0, STREAM), ERROR_HIP_SYNCHRONIZE);
+        HIPC(hipStreamWaitEvent((hipStream_t)stream4, (hipEvent_t)ev_pre0, 0), ERROR_HIP_SYNCHRONIZE);
+        pst = (hipStream_t)stream4;
+    }
     if (!S.sym_lower && opt.matching > 0) { // (general storage: would a maximum-product matching be called for with these values?)
-        hipLaunchKernelGGL(k_diag_check, dim3((n + 255) / 256), dim3(256), 0, STREAM, n, d_rp, d_ci, d_vs, d_dcol, 0.01, d_info);
+        hipLaunchKernelGGL(k_diag_check, dim3((n + 255) / 256), dim3(256), 0, pst, n, d_rp, d_ci, d_vs, d_dcol, 0.01, d_info);
         launches++;
     }
     if (zero_cnt > 0) { // the E / E' panels start as [I; 0] / [I, 0]
-        hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, STREAM, d_zero, d_pool);
-        hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, STREAM, d_lists + allbig_off, d_fd, d_pool);
+        hipLaunchKernelGGL(k_zero, dim3(zero_cnt), dim3(256), 0, pst, d_zero, d_pool);
+        hipLaunchKernelGGL(k_set_identity, dim3(allbig_cnt), dim3(256), 0, pst, d_lists + allbig_off, d_fd, d_pool);
         launches += 2;
     }
+    if (pre_forked) HIPC(hipEventRecord((hipEvent_t)ev_pre1, (hipStream_t)stream4), ERROR_HIP_SYNCHRONIZE);
     HIPC(hipEventRecord((hipEvent_t)ev[1], STREAM), ERROR_HIP_SYNCHRONIZE);
     // The working blocks of a level take over storage other fronts have left: they are zero-filled and receive A's entries when the
     // level BEFORE has pulled its children's contribution blocks (the storage plan frees a block after its parent's level's
@@ -1577,11 +1595,16 @@ int32_t Solver::run_factor() {
     // of gaps in one factorisation of the 1M-DOF matrix).
     auto enqueue_levels = [&]() -> int32_t {
     const bool ea_lds = ea_lds_active(); // the working blocks are written whole by the extend-add: no zero-fill / scatter launches
+    bool pre_pending = pre_forked;
     if (!levels.empty() && !ea_lds) fill_level(levels[0], STREAM);
     for (size_t li = 0; li < levels.size(); li++) {
         const LevelPlan &L = levels[li];
         const LevelPlan *Lnext = li + 1 < levels.size() ? &levels[li + 1] : nullptr;
         const bool fill_next = !ea_lds && Lnext && (Lnext->zero_cnt > 0 || Lnext->sc_cnt > 0);
+        if (pre_pending && (L.ea_cnt > 0 || !L.steps.empty() || L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] + L.mid_cnt[3] > 0 || fill_next)) {
+            HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_pre1, 0), ERROR_HIP_SYNCHRONIZE);
+            pre_pending = false;
+        }
         if (L.ea_cnt > 0) {
             if (ea_lds)
                 hipLaunchKernelGGL(k_extend_add_lds, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
@@ -1731,7 +1754,7 @@ int32_t Solver::run_factor() {
                         rest_pending = false;
                     }
                     hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 0);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, upd_xcd ? 4 : 0);
                 } else
                     hipLaunchKernelGGL(k_update32<false>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                        d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
@@ -1753,6 +1776,7 @@ int32_t Solver::run_factor() {
         if (forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
         if (mid_forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join3, 0), ERROR_HIP_SYNCHRONIZE);
     }
+    if (pre_pending) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_pre1, 0), ERROR_HIP_SYNCHRONIZE);
     return SUCCESSFUL_EXIT;
     };
 #ifndef HIPMF_EMULATED

@@ -155,6 +155,7 @@ class Solver {
     bool use_binv = false;            // HIPMF_BLOCK_INV=1: LU fronts of the tiled path take ONE launch per step (kernels_factor_binv.hpp) instead of k_panel + k_update; measured slower (profiles/r04_rejected_experiments.txt)
     void *stream4 = nullptr;          // ... and the bulk of a split trailing update (HIPMF_UPD_SPLIT)
     void *ev_pb = nullptr, *ev_rest = nullptr;
+    void *ev_pre0 = nullptr, *ev_pre1 = nullptr; // the work before the first level that only the big fronts need (zero-fill of E / E', identity blocks, diagonal check) runs on stream4 beside the levels of small fronts
     int32_t upd_split_min = 0;        // HIPMF_UPD_SPLIT=n: full steps (two-launch form) with at least n update workgroups are split (0: never; measured: no gain)
     void *stream3 = nullptr;          // ... and so are the fronts one workgroup factorises (k_front)
     void *ev_fork3 = nullptr, *ev_join3 = nullptr;
@@ -320,6 +321,7 @@ class Solver {
            *d_du = nullptr;
     int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
     int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
+    bool upd_xcd = true;          // HIPMF_UPD_XCD=0: the tiles of a full trailing update in plain order (1: whole tile columns per XCD)
     bool use_ea_lds = true;       // HIPMF_EA_LDS=0: LU working blocks go back to k_zero + k_scatter + k_extend_add (read-modify-write per child) instead of k_extend_add_lds
     bool ea_lds_active() const { return use_ea_lds && !S.sym_mode; }
     bool use_ea_lu = true;        // HIPMF_EA_LU=0: the first diagonal tiles go back to k_diag0 / the first panel launch
