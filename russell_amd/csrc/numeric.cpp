@@ -339,6 +339,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_EA_LDS")) use_ea_lds = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_EA_LU")) use_ea_lu = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_UPD_XCD")) upd_xcd = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_MID_LU_SPLIT")) mid_lu_split = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_FRONT")) use_mid = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MID_MMAX")) mid_mmax = std::max(0, std::min(MID_MMAX, atoi(e)));
     if (const char *e = getenv("HIPMF_MID_LU")) use_mid_lu = atoi(e) != 0;
@@ -1086,7 +1087,14 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             for (int32_t a : big) (is_mid(a) ? mid : tiled).push_back(a);
             big.swap(tiled);
             // class 3: k_front_lu (at most 32 pivots); 0 .. 2: k_front by the columns of F12 per wavefront (10 / 16 / 24)
-            auto cls = [&](int32_t a) { const int32_t m = S.nrow(a); return is_mid_lu(a) ? 3 : (m <= 80 ? 0 : (m <= 128 ? 1 : 2)); };
+            // (k_front_lu: a launch reserves the LDS of its largest front for every workgroup -- one front of 32 x 192 (117 KB) in the launch and
+            //  every front has a CU to itself; by LDS class the many smaller ones run two or four to a CU)
+            auto cls = [&](int32_t a) {
+                const int32_t m = S.nrow(a);
+                if (!is_mid_lu(a)) return m <= 80 ? 0 : (m <= 128 ? 1 : 2);
+                const int32_t w = midl_lds_doubles(S.npiv(a), m);
+                return (mid_lu_split && w <= 5000) ? 3 : ((mid_lu_split && w <= 10000) ? 4 : 5);
+            };
             // (within a class: by the work of the front, largest first -- the workgroups that run longest start first)
             std::stable_sort(mid.begin(), mid.end(), [&](int32_t a, int32_t b) {
                 return cls(a) != cls(b) ? cls(a) < cls(b) : (int64_t)S.npiv(a) * S.fsize(a) * S.fsize(a) > (int64_t)S.npiv(b) * S.fsize(b) * S.fsize(b);
@@ -1095,7 +1103,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             for (int32_t a : mid) {
                 const int c = cls(a);
                 L.mid_cnt[c]++;
-                L.mid_lds[c] = std::max(L.mid_lds[c], c == 3 ? midl_lds_doubles(S.npiv(a), S.nrow(a)) : mid_lds_doubles(S.npiv(a), S.nrow(a)));
+                L.mid_lds[c] = std::max(L.mid_lds[c], c >= 3 ? midl_lds_doubles(S.npiv(a), S.nrow(a)) : mid_lds_doubles(S.npiv(a), S.nrow(a)));
             }
         }
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return S.npiv(a) > S.npiv(b); });
@@ -1601,7 +1609,7 @@ int32_t Solver::run_factor() {
         const LevelPlan &L = levels[li];
         const LevelPlan *Lnext = li + 1 < levels.size() ? &levels[li + 1] : nullptr;
         const bool fill_next = !ea_lds && Lnext && (Lnext->zero_cnt > 0 || Lnext->sc_cnt > 0);
-        if (pre_pending && (L.ea_cnt > 0 || !L.steps.empty() || L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] + L.mid_cnt[3] > 0 || fill_next)) {
+        if (pre_pending && (L.ea_cnt > 0 || !L.steps.empty() || L.mid_total() > 0 || fill_next)) {
             HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_pre1, 0), ERROR_HIP_SYNCHRONIZE);
             pre_pending = false;
         }
@@ -1615,7 +1623,7 @@ int32_t Solver::run_factor() {
         }
         // a level's small fronts and its big fronts are independent of each other (both only need the level's extend-add):
         // when the level has both, the small ones are factorised on a second stream beside the tiled steps
-        const bool has_mid = L.mid_cnt[0] + L.mid_cnt[1] + L.mid_cnt[2] + L.mid_cnt[3] > 0;
+        const bool has_mid = L.mid_total() > 0;
         const bool forked = overlap_small && ((L.small_cnt > 0 && (!L.steps.empty() || has_mid)) || fill_next);
         if (L.small_cnt > 0) {
             size_t shmem = sizeof(double) * (size_t)L.small_ld * (size_t)L.small_ld;
@@ -1658,13 +1666,13 @@ int32_t Solver::run_factor() {
                 mst = (hipStream_t)stream3;
             }
             int32_t moff = L.mid_off;
-            for (int c = 3; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
-            for (int c = 3; c >= 0; c--) {
+            for (int c = LevelPlan::MID_CLASSES - 1; c >= 0; c--) moff += L.mid_cnt[c]; // (the largest class goes first: its workgroups run longest)
+            for (int c = LevelPlan::MID_CLASSES - 1; c >= 0; c--) {
                 moff -= L.mid_cnt[c];
                 if (L.mid_cnt[c] == 0) continue;
                 const size_t dyn = sizeof(double) * (size_t)L.mid_lds[c];
                 const FrontDesc *mfd = d_bigfd + moff;
-                if (c == 3) {
+                if (c >= 3) {
                     hipLaunchKernelGGL(k_front_lu, dim3(L.mid_cnt[c]), dim3(64 * MIDL_NW), dyn, mst, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                     launches++;
                     continue;

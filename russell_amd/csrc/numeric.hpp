@@ -92,8 +92,14 @@ struct LevelPlan {
     // fronts of the middle of the tree that ONE workgroup carries through their whole partial factorisation (k_front,
     // kernels_factor_front.hpp): their descriptors follow the tiled ones in d_bigfd, grouped by size class
     int32_t mid_off = 0;                 // first of them in d_bigfd
-    int32_t mid_cnt[4] = {0, 0, 0, 0};   // fronts per class: k_front with 10 / 16 / 24 columns of F12 per wavefront, k_front_lu (at most 32 pivots)
-    int32_t mid_lds[4] = {0, 0, 0, 0};   // dynamic LDS of the class's launch, in doubles (its largest front)
+    static constexpr int MID_CLASSES = 6;
+    int32_t mid_cnt[MID_CLASSES] = {0, 0, 0, 0, 0, 0}; // fronts per class: 0 .. 2 k_front with 10 / 16 / 24 columns of F12 per wavefront; 3 .. 5 k_front_lu (at most 32 pivots) by the LDS a front needs: up to 40 KB (four workgroups per CU), 80 KB (two), more (one)
+    int32_t mid_lds[MID_CLASSES] = {0, 0, 0, 0, 0, 0}; // dynamic LDS of the class's launch, in doubles (its largest front)
+    int32_t mid_total() const {
+        int32_t t = 0;
+        for (int c = 0; c < MID_CLASSES; c++) t += mid_cnt[c];
+        return t;
+    }
     int64_t chain_off = 0;  // the level's tiled steps as ONE launch (k_chain): its tasks in d_chain, chain_cnt of them (0: one launch per step)
     int32_t chain_cnt = 0;
 };
@@ -321,6 +327,7 @@ class Solver {
            *d_du = nullptr;
     int32_t *d_rows = nullptr, *d_rel = nullptr, *d_child = nullptr, *d_lists = nullptr, *d_tasks = nullptr;
     int32_t *d_rp = nullptr, *d_ci = nullptr, *d_arow = nullptr, *d_tptr = nullptr, *d_tidx = nullptr, *d_perm = nullptr;
+    bool mid_lu_split = false;    // HIPMF_MID_LU_SPLIT=1: the k_front_lu fronts of a level in three launches by LDS class (two or four fronts per CU for the smaller ones); measured slower: 6.58 -> 6.95 ms
     bool upd_xcd = true;          // HIPMF_UPD_XCD=0: the tiles of a full trailing update in plain order (1: whole tile columns per XCD)
     bool use_ea_lds = true;       // HIPMF_EA_LDS=0: LU working blocks go back to k_zero + k_scatter + k_extend_add (read-modify-write per child) instead of k_extend_add_lds
     bool ea_lds_active() const { return use_ea_lds && !S.sym_mode; }

@@ -67,8 +67,8 @@ def test_small_update_tiles_give_the_same_factor_bit_for_bit(emu_lib, case):
 
 
 def _split_cases():  # separators of more than 64 vertices: a group of panels with a follower
-    yield "poisson2d 70x72", P.poisson2d(70, 72), {}
-    yield "convection-diffusion 72 (interchanges)", P.convection_diffusion2d(72, peclet=30.0, scale_decades=0.0), {}
+    yield "poisson2d 66x68", P.poisson2d(66, 68), {}
+    yield "convection-diffusion 66 (interchanges)", P.convection_diffusion2d(66, peclet=30.0, scale_decades=0.0), {}
 
 
 @pytest.mark.parametrize("case", list(_split_cases()), ids=lambda c: c[0])

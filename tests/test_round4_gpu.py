@@ -77,3 +77,40 @@ def test_config2_with_and_without_one_workgroup_fronts_and_graph_replay(monkeypa
         xs_by[name] = x
     assert np.max(np.abs(xs_by["default"] - xs_by["tiled"])) < 1e-9
     assert np.array_equal(xs_by["default"], xs_by["graph"])  # (the same launches, replayed)
+
+
+@pytest.mark.parametrize("case", ["poisson2d 600", "convection-diffusion 220", "poisson3d 24"])
+def test_first_touch_extend_add_and_xcd_tile_order_are_bitwise_neutral_on_the_device(case):
+    # k_extend_add_lds (tile built in LDS, written once, first diagonal tiles factorised by the task that holds them) against the
+    # zero-fill + scatter + read-modify-write launches, and the XCD-aware order of a full trailing update's tiles against the plain one:
+    # the same additions in the same order, the same tiles -- the same bits (600 x 600: fronts with more than eight tile columns)
+    if case.startswith("poisson2d"):
+        n, rp, ci, v = P.poisson2d(600)
+    elif case.startswith("convection"):
+        n, rp, ci, v = P.convection_diffusion2d(220, peclet=30.0, scale_decades=3.0)
+    else:
+        n, rp, ci, v = P.poisson3d(24)
+    ref = _run(None, n, rp, ci, v, {"HIPMF_EA_LDS": "0", "HIPMF_UPD_XCD": "0"}, nrhs=3)
+    for env in ({"HIPMF_EA_LDS": "1", "HIPMF_EA_LU": "0", "HIPMF_UPD_XCD": "0"}, {"HIPMF_EA_LDS": "1", "HIPMF_EA_LU": "1", "HIPMF_UPD_XCD": "0"},
+                {"HIPMF_EA_LDS": "0", "HIPMF_UPD_XCD": "1"}, {}):
+        got = _run(None, n, rp, ci, v, env, nrhs=3)
+        assert np.array_equal(ref[0], got[0]), (case, env)
+        assert ref[2:4] == got[2:4] and ref[5] == got[5], (case, env)
+
+
+@pytest.mark.parametrize("case", ["poisson2d 300", "convection-diffusion 220"])
+def test_one_launch_tiled_steps_are_an_accurate_opt_in(case):
+    # HIPMF_BLOCK_INV=1 (kernels_factor_binv.hpp): block elimination with the inverse of the diagonal tile, one launch per step; slower than
+    # the default on MI355X (profiles/r04_rejected_experiments.txt) and kept as an opt-in: same pivots, same determinant, solutions to rounding
+    if case.startswith("poisson2d"):
+        n, rp, ci, v = P.poisson2d(300)
+    else:
+        n, rp, ci, v = P.convection_diffusion2d(220, peclet=30.0, scale_decades=3.0)
+    ref = _run(None, n, rp, ci, v, {"HIPMF_BLOCK_INV": "0"}, nrhs=3)
+    got = _run(None, n, rp, ci, v, {"HIPMF_BLOCK_INV": "1"}, nrhs=3)
+    lu = spla.splu(sp.csr_matrix((v, ci, rp), shape=(n, n)).tocsc())
+    for j in range(3):
+        xo = lu.solve(got[1][j])
+        tol = 1e-9 * max(1.0, np.max(np.abs(xo)))
+        assert np.max(np.abs(got[0][j] - xo)) <= tol and np.max(np.abs(ref[0][j] - xo)) <= tol, (case, j)
+    assert got[3] == ref[3] and abs(got[2] - ref[2]) <= 1e-8 * abs(ref[2]) and got[5] == ref[5]

@@ -8,7 +8,7 @@ run() { timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-b
 import sys,json
 d=json.loads(sys.stdin.read())
 print('$1 value', d['value'], 'factor', d['phases_ms']['factor'], 'sptrsv', d['phases_ms']['sptrsv_pair'], 'solve', d['phases_ms']['solve_total_last'], 'copy GB/s', d['roofline']['measured_copy_gbs'])"; }
-( HIPMF_FACTOR_GRAPH=0 run eager; HIPMF_FACTOR_GRAPH=1 run graph; HIPMF_MID_FRONT=0 run tiled_only ) > $OUT/variants.txt 2>&1
+( run default; HIPMF_EA_LDS=0 run extend_add_read_modify_write; HIPMF_EA_LU=0 run first_tiles_by_the_panel_step; HIPMF_UPD_XCD=0 run plain_tile_order; HIPMF_MID_FRONT=0 run tiled_only; HIPMF_FACTOR_GRAPH=1 run graph; HIPMF_BLOCK_INV=1 run one_launch_steps; HIPMF_UPD_SPLIT=1000 HIPMF_EA_LDS=0 run split_updates_1000; HIPMF_MID_LU_SPLIT=1 run front_lu_by_lds_class; run default ) > $OUT/variants.txt 2>&1
 cat $OUT/variants.txt
 # 1. the driver's bench command
 timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
@@ -46,6 +46,7 @@ tail -5 $OUT/config4_one_gpu.txt
 python tools/init_phases.py 1000 2>&1 | grep -v "^solver_hipmf" | tail -3 > $OUT/init_phases.txt
 python tools/init_phases.py 100 3d sym 2>&1 | grep -v "^solver_hipmf" | tail -3 >> $OUT/init_phases.txt
 ./tools/microbench/front_bench 1 > $OUT/front_bench.txt 2>&1
+./tools/microbench/tile_bench > $OUT/tile_bench.txt 2>&1
 # 8. config 5 (Radau5 + Brusselator, npoint 513) end to end
 ( time timeout 600 ./russell_amd/lib/brusselator_pde --npoint 513 -g hipmf ) > $OUT/config5_radau5_brusselator_513.txt 2>&1
 tail -12 $OUT/config5_radau5_brusselator_513.txt
