@@ -175,7 +175,7 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 #define HIPMF_COUNTER_SYM_EXPANDED 6       /* 1: symmetric-lower input with a weak diagonal (indefinite / saddle-point): mirrored to general
                                             * storage at initialize, factorised by LU with the maximum-product matching; the caller keeps
                                             * handing over lower-triangle values */
-#define HIPMF_COUNTER_MID_FRONTS 8        /* fronts one workgroup factorises in one launch (k_front: f > 64, at most 64 pivots and 80 off-diagonal rows, LU mode) */
+#define HIPMF_COUNTER_MID_FRONTS 8        /* fronts one workgroup factorises in one launch per level (k_front_lu: f > 64, at most 32 pivots and 192 off-diagonal rows, LU mode; k_front where switched on) */
 #define HIPMF_COUNTER_CHAIN_FALLBACKS 7    /* factorisations repeated with one launch per tiled step after a hand-off of a chained launch timed out */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
