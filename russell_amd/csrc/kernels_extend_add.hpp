@@ -47,22 +47,24 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
         const int32_t *relA = rel + ra.rel_off, *relB = rel + rb.rel_off;
         const int iA = ra.ilo + tx, iB = rb.ilo + tx;
         const bool okA = hasA && iA < ra.ihi, okB = hasB && iB < rb.ihi;
+        // (which entries exist is known from the ranges alone: the entries are requested together with the relative indices, not after them)
         int riA = 0, riB = 0, rjA[EA_PQ], rjB[EA_PQ];
         if (okA) riA = relA[iA];
         if (okB) riB = relB[iB];
+        const double *CA = pool + ra.cb_off + iA, *CBb = pool + rb.cb_off + iB;
 #pragma unroll
         for (int q = 0; q < EA_PQ; q++) {
             const int jA = ra.jlo + ty + q * EA_NG, jB = rb.jlo + ty + q * EA_NG;
-            rjA[q] = (okA && jA < ra.jhi) ? relA[jA] : -1;
-            rjB[q] = (okB && jB < rb.jhi) ? relB[jB] : -1;
+            const bool inA = okA && jA < ra.jhi, inB = okB && jB < rb.jhi;
+            rjA[q] = inA ? relA[jA] : -1;
+            rjB[q] = inB ? relB[jB] : -1;
+            cbA[q] = inA ? CA[(int64_t)jA * ra.ldc] : 0.0;
+            cbB[q] = inB ? CBb[(int64_t)jB * rb.ldc] : 0.0;
         }
-        const double *CA = pool + ra.cb_off + iA, *CBb = pool + rb.cb_off + iB;
 #pragma unroll
         for (int q = 0; q < EA_PQ; q++) {
             atA[q] = rjA[q] >= 0 ? (riA - r0) + (rjA[q] - c0) * EA_TILE_R : -1;
             atB[q] = rjB[q] >= 0 ? (riB - r0) + (rjB[q] - c0) * EA_TILE_R : -1;
-            cbA[q] = atA[q] >= 0 ? CA[(int64_t)(ra.jlo + ty + q * EA_NG) * ra.ldc] : 0.0;
-            cbB[q] = atB[q] >= 0 ? CBb[(int64_t)(rb.jlo + ty + q * EA_NG) * rb.ldc] : 0.0;
         }
     };
     load_pair(t.piece_begin);

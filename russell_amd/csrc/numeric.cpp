@@ -209,18 +209,25 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             stream3 = st;
             HIPC(hipStreamCreate(&st), ERROR_HIPMF_NO_DEVICE);
             stream4 = st;
+            // events that order this handle's streams among themselves: no timing, and no system-scope fence at the record (the cache
+            // write-back + invalidate of the default costs 5 - 7 us on the stream that records; kernels of the same device see each
+            // other's results through the agent-scope release at a kernel's end).  HIPMF_EVENT_FENCE=1: the default flags.
+            unsigned xflags = hipEventDisableTiming;
+#ifndef HIPMF_EMULATED
+            if (!(getenv("HIPMF_EVENT_FENCE") && atoi(getenv("HIPMF_EVENT_FENCE")) != 0)) xflags |= hipEventDisableSystemFence;
+#endif
             hipEvent_t e1, e2, e3, e4, e5, e6;
-            HIPC(hipEventCreateWithFlags(&e5, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-            HIPC(hipEventCreateWithFlags(&e6, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e5, xflags), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e6, xflags), ERROR_HIPMF_NO_DEVICE);
             ev_pb = e5, ev_rest = e6;
             hipEvent_t e7, e8;
-            HIPC(hipEventCreateWithFlags(&e7, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-            HIPC(hipEventCreateWithFlags(&e8, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e7, xflags), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e8, xflags), ERROR_HIPMF_NO_DEVICE);
             ev_pre0 = e7, ev_pre1 = e8;
-            HIPC(hipEventCreateWithFlags(&e1, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-            HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-            HIPC(hipEventCreateWithFlags(&e3, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
-            HIPC(hipEventCreateWithFlags(&e4, hipEventDisableTiming), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e1, xflags), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e2, xflags), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e3, xflags), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e4, xflags), ERROR_HIPMF_NO_DEVICE);
             ev_fork = e1, ev_join = e2, ev_fork3 = e3, ev_join3 = e4;
         }
         {
@@ -1661,8 +1668,12 @@ int32_t Solver::run_factor() {
         if (has_mid) {
             hipStream_t mst = STREAM;
             if (mid_forked) {
-                HIPC(hipEventRecord((hipEvent_t)ev_fork3, STREAM), ERROR_HIP_SYNCHRONIZE);
-                HIPC(hipStreamWaitEvent((hipStream_t)stream3, (hipEvent_t)ev_fork3, 0), ERROR_HIP_SYNCHRONIZE);
+                // (one record serves both side streams: nothing went out on the main stream since the fork of the small fronts)
+                if (forked) HIPC(hipStreamWaitEvent((hipStream_t)stream3, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);
+                else {
+                    HIPC(hipEventRecord((hipEvent_t)ev_fork3, STREAM), ERROR_HIP_SYNCHRONIZE);
+                    HIPC(hipStreamWaitEvent((hipStream_t)stream3, (hipEvent_t)ev_fork3, 0), ERROR_HIP_SYNCHRONIZE);
+                }
                 mst = (hipStream_t)stream3;
             }
             int32_t moff = L.mid_off;
@@ -1685,7 +1696,11 @@ int32_t Solver::run_factor() {
 #undef HIPMF_LAUNCH_FRONT
                 launches++;
             }
-            if (mid_forked) HIPC(hipEventRecord((hipEvent_t)ev_join3, (hipStream_t)stream3), ERROR_HIP_SYNCHRONIZE);
+            if (mid_forked) {
+                // (... and one wait joins both: stream3 takes stream2's end along)
+                if (forked) HIPC(hipStreamWaitEvent((hipStream_t)stream3, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
+                HIPC(hipEventRecord((hipEvent_t)ev_join3, (hipStream_t)stream3), ERROR_HIP_SYNCHRONIZE);
+            }
         }
         int32_t k0 = 0;
         if (chained && L.chain_cnt > 0) {
@@ -1781,8 +1796,8 @@ int32_t Solver::run_factor() {
             hipLaunchKernelGGL(k_mirror_cb, dim3(L.mirror_cnt), dim3(256), 0, STREAM, d_lists + L.mirror_off, d_fd, d_pool);
             launches++;
         }
-        if (forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
         if (mid_forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join3, 0), ERROR_HIP_SYNCHRONIZE);
+        else if (forked) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join, 0), ERROR_HIP_SYNCHRONIZE);
     }
     if (pre_pending) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_pre1, 0), ERROR_HIP_SYNCHRONIZE);
     return SUCCESSFUL_EXIT;
