@@ -199,6 +199,26 @@ __device__ __forceinline__ int find_slot_pfx(const int32_t *pfx, int n, int g, i
     return lo;
 }
 
+// Slot + descriptor of the workgroup's front in the tiled kernels.  Launches with at most four fronts (the levels near the root, whose
+// kernels are links of a latency chain) get the prefix words of slots 1 .. 3 as kernel ARGUMENTS (q.x, q.y, q.z; INT_MAX where there is no
+// such slot): the slot comes out of scalar compares and the descriptor is requested at once -- prefix -> slot -> descriptor were two
+// dependent round trips (~1.5 us each) at the head of every such kernel (root alone: 6.59 -> 6.51 ms).  (Requesting the prefix words and
+// all four descriptors at once and picking afterwards was measured too: the picked descriptor no longer lives in scalar registers,
+// 6.56 -> 7.45 ms.)
+struct Pfx4 {
+    int32_t x, y, z;
+};
+__device__ __forceinline__ FrontDesc load_front_pfx(const int32_t *__restrict__ pfx, const int n, const FrontDesc *__restrict__ LFD, const int g, const Pfx4 q,
+                                                    int &slot, int &pfx_slot) {
+    if (n <= 4 && q.x >= 0) { // (q.x < 0: no prefix arguments for this launch; fronts without tasks have the prefix of their successor: the LAST slot whose prefix is <= g, as find_slot_pfx)
+        slot = g >= q.z ? 3 : (g >= q.y ? 2 : (g >= q.x ? 1 : 0));
+        pfx_slot = slot == 3 ? q.z : (slot == 2 ? q.y : (slot == 1 ? q.x : 0));
+        return LFD[slot];
+    }
+    slot = find_slot_pfx(pfx, n, g, pfx_slot);
+    return LFD[slot];
+}
+
 // wave-wide arg-max of (value, index); ties resolved towards the smaller index (deterministic)
 __device__ __forceinline__ void wave_argmax(double &v, int &i) {
     for (int off = 32; off > 0; off >>= 1) {

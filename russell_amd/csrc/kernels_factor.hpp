@@ -707,12 +707,11 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
                                                    int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
                                                    const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                   double *__restrict__ diag, int32_t pre_lu) {
+                                                   double *__restrict__ diag, int32_t pre_lu, Pfx4 q4) {
     __shared__ PanelLds sh;
-    int pfx_slot;
-    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    int pfx_slot, slot;
+    FrontDesc fd = load_front_pfx(pfx, nactive, LFD, blockIdx.x, q4, slot, pfx_slot); // (LFD: the descriptors of the level's tiled fronts in slot order)
     const int t = blockIdx.x - pfx_slot;
-    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
     fd_resident(fd);
     panel_body<SYM, false, PANEL_T>(sh, slot, t, fd, k0, pool, lperm, dws, dws_stride, anorm_bits, pivot_eps, info, diag, pre_lu);
 }
@@ -1097,12 +1096,11 @@ __global__ void HIPMF_UPD_BOUNDS k_update(const int32_t *__restrict__ pfx, int32
                                                 int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                 const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                double *__restrict__ diag, int32_t part) {
+                                                double *__restrict__ diag, int32_t part, Pfx4 q4) {
     __shared__ UpdateLds sh;
-    int pfx_slot;
-    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    int pfx_slot, slot;
+    FrontDesc fd = load_front_pfx(pfx, nactive, LFD, blockIdx.x, q4, slot, pfx_slot); // (LFD: the descriptors of the level's tiled fronts in slot order)
     const int t = blockIdx.x - pfx_slot;
-    FrontDesc fd = LFD[slot]; // (LFD: the descriptors of the level's tiled fronts in slot order)
     fd_resident(fd);
     update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag, SYM ? 0 : part, pfx_slot & 7);
 }
@@ -1113,12 +1111,11 @@ __global__ void HIPMF_UPD32_BOUNDS k_update32(const int32_t *__restrict__ pfx, i
                                                  int32_t k0, double *__restrict__ pool,
                                                  double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                                  const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
-                                                 double *__restrict__ diag) {
+                                                 double *__restrict__ diag, Pfx4 q4) {
     __shared__ UpdateLdsT<UPD_T_SMALL> sh;
-    int pfx_slot;
-    const int slot = find_slot_pfx(pfx, nactive, blockIdx.x, pfx_slot);
+    int pfx_slot, slot;
+    FrontDesc fd = load_front_pfx(pfx, nactive, LFD, blockIdx.x, q4, slot, pfx_slot);
     const int t = blockIdx.x - pfx_slot;
-    FrontDesc fd = LFD[slot];
     fd_resident(fd);
     update_body<SYM, false, UPD_T_SMALL>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
 }

@@ -1160,6 +1160,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             int64_t acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
+                if (a >= 1 && a <= 3) st.ppfx[a - 1] = (int32_t)acc;
                 acc += 2 * ((S.fsize(big[a]) + PANEL_T - 1) / PANEL_T);
             }
             tasks.push_back((int32_t)acc);
@@ -1168,6 +1169,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             acc = 0;
             for (int32_t a = 0; a < st.nactive; a++) {
                 tasks.push_back((int32_t)acc);
+                if (a >= 1 && a <= 3) st.upfx[a - 1] = (int32_t)acc;
                 // tiles per dimension of k_update at this step: [base, f) and [f, f + base) are tiled separately (base = k0 + nb)
                 const int64_t fa = S.fsize(big[a]), nba = std::min<int64_t>(NB, S.npiv(big[a]) - k0), basea = k0 + nba;
                 const int64_t ntF = (fa - basea + UT - 1) / UT, ntE = (basea + UT - 1) / UT;
@@ -1735,13 +1737,13 @@ int32_t Solver::run_factor() {
             }
             if (S.sym_mode) {
                 hipLaunchKernelGGL(k_panel<true>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
-                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
+                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu, Pfx4{st.ppfx[0], st.ppfx[1], st.ppfx[2]});
                 if (st.n_update > 0 && L.upd_ts == UPD_T)
                     hipLaunchKernelGGL(k_update<true>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 0);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 0, Pfx4{st.upfx[0], st.upfx[1], st.upfx[2]});
                 else if (st.n_update > 0)
                     hipLaunchKernelGGL(k_update32<true>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, Pfx4{st.upfx[0], st.upfx[1], st.upfx[2]});
             } else if (use_binv) {
                 // one launch per step: every tile forms its own rows of W = A inv(D) (kernels_factor_binv.hpp)
                 if (k0 == 0) {
@@ -1757,16 +1759,16 @@ int32_t Solver::run_factor() {
                 launches--;
             } else {
                 hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
-                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu);
+                                   d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu, Pfx4{st.ppfx[0], st.ppfx[1], st.ppfx[2]});
                 if (L.upd_ts == UPD_T && st.split && st.n_rest > 0) {
                     // the bulk of the previous split step must be through before anything touches its tiles again
                     if (rest_pending) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_rest, 0), ERROR_HIP_SYNCHRONIZE);
                     HIPC(hipEventRecord((hipEvent_t)ev_pb, STREAM), ERROR_HIP_SYNCHRONIZE);
                     HIPC(hipStreamWaitEvent((hipStream_t)stream4, (hipEvent_t)ev_pb, 0), ERROR_HIP_SYNCHRONIZE);
                     hipLaunchKernelGGL(k_update<false>, dim3(st.n_crit), dim3(256), 0, STREAM, d_tasks + st.pfx_crit, st.nactive, lfd, k0, d_pool, d_dws,
-                                       dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 1);
+                                       dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 1, Pfx4{-1, -1, -1});
                     hipLaunchKernelGGL(k_update<false>, dim3(st.n_rest), dim3(256), 0, (hipStream_t)stream4, d_tasks + st.pfx_rest, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 2);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 2, Pfx4{-1, -1, -1});
                     HIPC(hipEventRecord((hipEvent_t)ev_rest, (hipStream_t)stream4), ERROR_HIP_SYNCHRONIZE);
                     rest_pending = true;
                     launches++;
@@ -1777,10 +1779,10 @@ int32_t Solver::run_factor() {
                         rest_pending = false;
                     }
                     hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, upd_xcd ? 4 : 0);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, upd_xcd ? 4 : 0, Pfx4{st.upfx[0], st.upfx[1], st.upfx[2]});
                 } else
                     hipLaunchKernelGGL(k_update32<false>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
-                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                                       d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, Pfx4{st.upfx[0], st.upfx[1], st.upfx[2]});
             }
             launches += 2;
             k0 += NB;

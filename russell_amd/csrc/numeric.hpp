@@ -66,6 +66,7 @@ struct StepPlan {
     int32_t nactive = 0;
     int64_t pfx_panel = 0, pfx_update = 0; // offsets into d_tasks
     int32_t n_panel = 0, n_update = 0;
+    int32_t ppfx[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, upfx[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}; // prefix words of slots 1 .. 3 (kernel arguments of launches with at most four fronts)
     // a full step whose trailing update runs in two launches: the critical strips (first block column / row + look-ahead) on the main
     // stream, the other tiles on a side stream beside the next group's panel steps
     bool split = false;
