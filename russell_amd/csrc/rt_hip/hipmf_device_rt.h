@@ -83,15 +83,14 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long ke
 // four row maxima through v_readlane.
 template <int ROWS = 4> __device__ __forceinline__ unsigned wave_max_u32(unsigned key) { // ROWS: 16-lane rows that can hold a candidate
     int k = (int)key;
-#define HIPMF_DPP_MAX32(ctrl)                                                  \
-    {                                                                          \
-        unsigned o = (unsigned)__builtin_amdgcn_update_dpp(k, k, ctrl, 0xf, 0xf, false); \
-        k = (int)(o > (unsigned)k ? o : (unsigned)k);                          \
-    }
-    HIPMF_DPP_MAX32(0xB1)  // quad_perm [1,0,3,2]
-    HIPMF_DPP_MAX32(0x4E)  // quad_perm [2,3,0,1]
-    HIPMF_DPP_MAX32(0x141) // row_half_mirror
-    HIPMF_DPP_MAX32(0x140) // row_mirror
+    // one VOP2-with-DPP instruction per stage: k = max(k from the partner lane, k).  (Through __builtin_amdgcn_update_dpp the compiler emits
+    // v_mov, s_nop, v_mov_dpp, v_max per stage; this reduction sits in the pivot search of every step of the register tile LU, the longest
+    // sequential piece of a tiled step.  s_nop 1: a VALU result needs two wait states before a DPP read of it.)
+#define HIPMF_DPP_MAX32(ctrl) asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(k));
+    HIPMF_DPP_MAX32("quad_perm:[1,0,3,2]")
+    HIPMF_DPP_MAX32("quad_perm:[2,3,0,1]")
+    HIPMF_DPP_MAX32("row_half_mirror")
+    HIPMF_DPP_MAX32("row_mirror")
 #undef HIPMF_DPP_MAX32
     unsigned best = 0;
 #pragma unroll
