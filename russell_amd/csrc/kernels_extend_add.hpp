@@ -5,7 +5,8 @@
 
 namespace hipmf {
 
-// extend-add with FIRST TOUCH (LU fronts, round 4): the task owns an EA_TILE_C-column x EA_TILE_R-row tile (32 x 64: sixteen KB of LDS; measured 6.93 ms of numeric LU with 32 x 256, 6.78 with 16 x 256, 6.73 with 32 x 128, 6.67 with 16 x 128, 6.65 with 32 x 64, 6.80 with 8 x 128, 6.95 with 8 x 64) of the parent's working block and builds it
+// extend-add with FIRST TOUCH (round 4; SYM: L D L^T fronts -- only entries on or below the parent's diagonal are added, the tiles strictly
+// above it have no task and are never read): the task owns an EA_TILE_C-column x EA_TILE_R-row tile (32 x 64: sixteen KB of LDS; measured 6.93 ms of numeric LU with 32 x 256, 6.78 with 16 x 256, 6.73 with 32 x 128, 6.67 with 16 x 128, 6.65 with 32 x 64, 6.80 with 8 x 128, 6.95 with 8 x 64) of the parent's working block and builds it
 // in LDS -- zero, the entries of A that land in the tile (per-task lists: what k_scatter did for the level), the children's contribution
 // blocks in child order -- and writes the WHOLE tile once.  The order of the additions is k_zero + k_scatter + k_extend_add's: the same
 // bits.  What it saves: the block was zero-filled (8 bytes per entry), then read and written once per child that hits an entry (16 bytes
@@ -20,6 +21,7 @@ namespace hipmf {
 #endif
 constexpr int EA_TILE_C = HIPMF_EA_TILE_C, EA_TILE_R = HIPMF_EA_TILE_R; // (EA_TILE_R: a power of two, 32 .. 256; EA_TILE_C >= 32: the first tile of a front holds its first diagonal tile)
 static_assert(EA_TILE_C >= NB && EA_TILE_R >= NB && EA_TILE_R <= 256 && (EA_TILE_R & (EA_TILE_R - 1)) == 0 && EA_TILE_C * EA_TILE_R <= 65536, "extend-add tile");
+template <bool SYM>
 __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const int32_t *__restrict__ rel,
                                                         double *__restrict__ pool, const int32_t *__restrict__ ea_sc, const int32_t *__restrict__ sc_k,
                                                         const uint16_t *__restrict__ sc_pos, const double *__restrict__ vs, const double *__restrict__ vs2,
@@ -55,7 +57,8 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
 #pragma unroll
         for (int q = 0; q < EA_PQ; q++) {
             const int jA = ra.jlo + ty + q * EA_NG, jB = rb.jlo + ty + q * EA_NG;
-            const bool inA = okA && jA < ra.jhi, inB = okB && jB < rb.jhi;
+            // (SYM: a child's block is valid on and below its diagonal; rel is increasing, so those entries land on or below the parent's)
+            const bool inA = okA && jA < ra.jhi && (!SYM || jA <= iA), inB = okB && jB < rb.jhi && (!SYM || jB <= iB);
             rjA[q] = inA ? relA[jA] : -1;
             rjB[q] = inB ? relB[jB] : -1;
             cbA[q] = inA ? CA[(int64_t)jA * ra.ldc] : 0.0;
@@ -95,10 +98,13 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
         const int nb = t.lu_nb;
         double a[NB];
 #pragma unroll
-        for (int c = 0; c < NB; c++) a[c] = (tid < nb && c < nb) ? T[c * EA_TILE_R + tid] : (tid == c ? 1.0 : 0.0);
+        for (int c = 0; c < NB; c++) {
+            const int rr = (SYM && tid < c) ? c : tid, cc = (SYM && tid < c) ? tid : c; // (SYM: only the lower triangle is assembled)
+            a[c] = (tid < nb && c < nb) ? T[cc * EA_TILE_R + rr] : (tid == c ? 1.0 : 0.0);
+        }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32<true>(a, tid, eps, step, npert, nzero);
+        tile_lu32<!SYM>(a, tid, eps, step, npert, nzero);
         if (tid < nb) {
             double *dw = dws + (int64_t)t.lu_slot * NB * NB;
             double dg = 1.0;

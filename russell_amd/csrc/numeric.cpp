@@ -467,6 +467,15 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
                 }
         }
         if (ea_lds_active()) {
+            // linear index of tile (ct, rt) of a front with f rows among the tiles that have a task, tile columns outer, tile rows inner
+            // (L D L^T fronts: the tiles strictly above the diagonal have none: rows (rt + 1) R <= ct C)
+            auto ea_tile_index = [&](int64_t f, int64_t ct, int64_t rt) {
+                const int64_t nrt = (f + EA_TILE_R - 1) / EA_TILE_R;
+                if (!S.sym_mode) return ct * nrt + rt;
+                int64_t idx = 0;
+                for (int64_t c = 0; c < ct; c++) idx += nrt - std::min<int64_t>(nrt, (c * EA_TILE_C) / EA_TILE_R);
+                return idx + rt - (ct * EA_TILE_C) / EA_TILE_R;
+            };
             // k_extend_add_lds: the same entries by task.  Task numbering of upload_plan: levels ascending, the big fronts of a level in level
             // order, every tile of a front, tile columns outer, tile rows inner.
             // ... the first tiles of the level's fronts lead the level's tasks: first tile of the q-th big front = level base + q, its other
@@ -483,7 +492,11 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
                     if (f <= SMALL_F) continue;
                     ea_first[(size_t)s] = (int32_t)(ntask + q++);
                     ea_base[(size_t)s] = (int32_t)(others - 1); // (linear tile index 1 is the first of the others)
-                    others += ((f + EA_TILE_C - 1) / EA_TILE_C) * ((f + EA_TILE_R - 1) / EA_TILE_R) - 1;
+                    {
+                        // (the index one past the front's last tile = the number of its tiles)
+                        const int64_t nct = (f + EA_TILE_C - 1) / EA_TILE_C;
+                        others += ea_tile_index(f, nct, S.sym_mode ? (nct * EA_TILE_C) / EA_TILE_R : 0) - 1;
+                    }
                 }
                 ntask = others;
             }
@@ -501,8 +514,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
                 const int32_t s = S.amap_sn[(size_t)k];
                 const int64_t off = AL.sc_at[e] - S.front_off[s], ld = S.front_ld[s], f = S.fsize(s);
                 const int64_t r = off % ld, c = off / ld;
-                const int64_t nrt = (f + EA_TILE_R - 1) / EA_TILE_R;
-                const int64_t lin = (c / EA_TILE_C) * nrt + r / EA_TILE_R;
+                const int64_t lin = ea_tile_index(f, c / EA_TILE_C, r / EA_TILE_R);
                 task_of[e] = lin == 0 ? ea_first[(size_t)s] : ea_base[(size_t)s] + (int32_t)lin;
                 pos_of[e] = (uint16_t)((r % EA_TILE_R) + (c % EA_TILE_C) * EA_TILE_R);
                 AL.ea_sc[(size_t)task_of[e] + 1]++;
@@ -1383,7 +1395,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         }
     }
     if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
-    if (ea_lds_active()) HIPMF_ALLOW_LDS(k_extend_add_lds, sizeof(double) * EA_TILE_C * EA_TILE_R);
+    if (ea_lds_active()) {
+        HIPMF_ALLOW_LDS(k_extend_add_lds<false>, sizeof(double) * EA_TILE_C * EA_TILE_R);
+        HIPMF_ALLOW_LDS(k_extend_add_lds<true>, sizeof(double) * EA_TILE_C * EA_TILE_R);
+    }
     if (use_mid && !S.sym_mode) { // (a front with 64 pivots stages 67 KB)
         HIPMF_ALLOW_LDS(k_front<10>, sizeof(double) * MID_LDS_DOUBLES);
         HIPMF_ALLOW_LDS(k_front<16>, sizeof(double) * MID_LDS_DOUBLES);
@@ -1623,8 +1638,11 @@ int32_t Solver::run_factor() {
             pre_pending = false;
         }
         if (L.ea_cnt > 0) {
-            if (ea_lds)
-                hipLaunchKernelGGL(k_extend_add_lds, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
+            if (ea_lds && S.sym_mode)
+                hipLaunchKernelGGL(k_extend_add_lds<true>, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
+                                   d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+            else if (ea_lds)
+                hipLaunchKernelGGL(k_extend_add_lds<false>, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
                                    d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             else if (S.sym_mode) hipLaunchKernelGGL(k_extend_add<true>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             else hipLaunchKernelGGL(k_extend_add<false>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);

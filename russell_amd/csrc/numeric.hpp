@@ -331,7 +331,7 @@ class Solver {
     bool mid_lu_split = false;    // HIPMF_MID_LU_SPLIT=1: the k_front_lu fronts of a level in three launches by LDS class (two or four fronts per CU for the smaller ones); measured slower: 6.58 -> 6.95 ms
     bool upd_xcd = true;          // HIPMF_UPD_XCD=0: the tiles of a full trailing update in plain order (1: whole tile columns per XCD)
     bool use_ea_lds = true;       // HIPMF_EA_LDS=0: LU working blocks go back to k_zero + k_scatter + k_extend_add (read-modify-write per child) instead of k_extend_add_lds
-    bool ea_lds_active() const { return use_ea_lds && !S.sym_mode; }
+    bool ea_lds_active() const { return use_ea_lds; }
     bool use_ea_lu = true;        // HIPMF_EA_LU=0: the first diagonal tiles go back to k_diag0 / the first panel launch
     bool ea_lu_active() const { return ea_lds_active() && use_ea_lu && !use_binv; }
     int32_t *d_ea_sc = nullptr;   // k_extend_add_lds: per task, the range of its entries of A in d_sc_k / d_sc_pos (cumulative, all levels)

@@ -1,5 +1,6 @@
 """Round 4, second half, on the CPU emulator: the extend-add with first touch (k_extend_add_lds, kernels_extend_add.hpp: the task builds its
-tile of the parent in LDS and writes it once; the task that holds a tiled front's first diagonal tile also factorises it) against the
+tile of the parent in LDS and writes it once; the task that holds a tiled front's first diagonal tile also factorises it; LU and L D L^T
+fronts) against the
 zero-fill + scatter + read-modify-write launches it replaces -- the order of the additions is the same, so factors, pivots and
 determinants agree bit for bit; and the one-launch tiled step with the inverse of the diagonal tile (kernels_factor_binv.hpp, an
 opt-in) against the two-launch step: another elimination order, so solutions and determinants agree to rounding."""
@@ -29,13 +30,19 @@ def test_extend_add_with_first_touch_gives_the_same_factor_bit_for_bit(emu_lib, 
         assert ref[2:4] == got[2:4] and ref[5] == got[5], env
 
 
-def test_symmetric_mode_keeps_the_read_modify_write_extend_add(emu_lib):
-    # L D L^T fronts: only the lower triangle is assembled; the first-touch instance is LU-only and must not be taken
+def test_first_touch_extend_add_of_symmetric_fronts_gives_the_same_factor_bit_for_bit(emu_lib):
+    # L D L^T fronts: only entries on or below the parent's diagonal are added, tiles strictly above it have no task (k_extend_add_lds<true>)
     n, rp, ci, v = P.poisson3d(8)
     low = (n,) + tuple(P.lower_triangle(n, rp, ci, v))
     a = _run(emu_lib, *low, {"HIPMF_EA_LDS": "0"}, general_symmetric=True)
-    b = _run(emu_lib, *low, {"HIPMF_EA_LDS": "1"}, general_symmetric=True)
-    assert np.array_equal(a[0], b[0]) and a[2:4] == b[2:4]
+    for env in ({"HIPMF_EA_LDS": "1", "HIPMF_EA_LU": "0"}, {"HIPMF_EA_LDS": "1", "HIPMF_EA_LU": "1"}):
+        b = _run(emu_lib, *low, env, general_symmetric=True)
+        assert np.array_equal(a[0], b[0]) and a[2:4] == b[2:4], env
+    n2, rp2, ci2, v2 = P.poisson2d(52, 48)  # (a front with more than one tile row: tiles above the diagonal are skipped)
+    low2 = (n2,) + tuple(P.lower_triangle(n2, rp2, ci2, v2))
+    a2 = _run(emu_lib, *low2, {"HIPMF_EA_LDS": "0"}, general_symmetric=True)
+    b2 = _run(emu_lib, *low2, {"HIPMF_EA_LDS": "1"}, general_symmetric=True)
+    assert np.array_equal(a2[0], b2[0]) and a2[2:4] == b2[2:4]
     xo = np.linalg.solve(sp.csr_matrix((v, ci, rp), shape=(n, n)).toarray(), a[1][0])
     assert np.max(np.abs(a[0][0] - xo)) <= 1e-11 * np.max(np.abs(xo))
 

@@ -98,6 +98,23 @@ def test_first_touch_extend_add_and_xcd_tile_order_are_bitwise_neutral_on_the_de
         assert ref[2:4] == got[2:4] and ref[5] == got[5], (case, env)
 
 
+@pytest.mark.parametrize("case", ["poisson2d 600", "poisson3d 24", "fe blocks 40x40x3 symmetric"])
+def test_first_touch_extend_add_of_symmetric_fronts_is_bitwise_neutral_on_the_device(case):
+    # the same for L D L^T fronts (lower triangle handed over, general_symmetric): k_extend_add_lds<true>
+    if case.startswith("poisson2d"):
+        n, rp, ci, v = P.poisson2d(600)
+    elif case.startswith("poisson3d"):
+        n, rp, ci, v = P.poisson3d(24)
+    else:
+        n, rp, ci, v = P.fe_block2d(40, 40, 3, symmetric=True, scale_decades=0.0)
+    rp, ci, v = P.lower_triangle(n, rp, ci, v)
+    ref = _run(None, n, rp, ci, v, {"HIPMF_EA_LDS": "0"}, nrhs=3, general_symmetric=True)
+    for env in ({"HIPMF_EA_LDS": "1", "HIPMF_EA_LU": "0"}, {}):
+        got = _run(None, n, rp, ci, v, env, nrhs=3, general_symmetric=True)
+        assert np.array_equal(ref[0], got[0]), (case, env)
+        assert ref[2:4] == got[2:4] and ref[5] == got[5], (case, env)
+
+
 @pytest.mark.parametrize("case", ["poisson2d 300", "convection-diffusion 220"])
 def test_one_launch_tiled_steps_are_an_accurate_opt_in(case):
     # HIPMF_BLOCK_INV=1 (kernels_factor_binv.hpp): block elimination with the inverse of the diagonal tile, one launch per step; slower than
