@@ -298,6 +298,13 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr
     memset(d, v, n);
     return hipSuccess;
 }
+constexpr unsigned hipStreamDefault = 0;
+inline hipError_t hipStreamCreate(hipStream_t *s);
+inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) {
+    *least = 0, *greatest = 0;
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
 inline hipError_t hipStreamCreate(hipStream_t *s) {
     *s = nullptr;
     return hipSuccess;
