@@ -636,7 +636,7 @@ def main():
                          "measured_copy_gbs": round(copy_gbs.value, 1),
                          "frac_of_measured_copy": round(achieved / copy_gbs.value, 4) if copy_gbs.value > 0 else None,
                          "fused_solve_fallbacks": st.get("fused_fallbacks", 0)},
-            "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_panel, k_update MFMA f64, k_extend_add)",
+            "roofline_factor": {"kernel": "numeric multifrontal LU (k_small_factor, k_front_lu, k_panel, k_update / k_update32 MFMA f64, k_extend_add_lds)",
                                 "bound": "mfma", "achieved": round(st["flops"] / (fact_ms * 1e-3) / 1e12, 3) if fact_ms > 0 else 0.0,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(st["flops"] / (fact_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if fact_ms > 0 else 0.0,
