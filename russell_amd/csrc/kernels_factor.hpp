@@ -215,7 +215,8 @@ struct SmallAsm {
 //         wavefronts: a third of the latency per pivot, for the launches with few, large fronts between the leaves and the tiled
 //         levels, where one front's LU (up to 64 pivots x ~1.3 us) is the whole launch.
 template <int NW>
-__global__ void __launch_bounds__(64 * NW) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
+// (one wavefront per front: six waves per SIMD -- 78 registers instead of 96 -- measured 6.560 -> 6.545 ms; eight spill: 6.72)
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
                                                           double *__restrict__ pool, int32_t *__restrict__ lperm,
                                                           const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
                                                           FactorInfo *info, int32_t ld, SmallAsm A, double *__restrict__ diag) {
