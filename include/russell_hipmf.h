@@ -234,8 +234,10 @@ const char *solver_hipmf_last_error(struct InterfaceHIPMF *solver);
  * holds one of these next to the real solver (russell_ode/src/radau5.rs:48-51,264-301).  `values`, `x`, `rhs` are interleaved
  * (re, im) pairs: COMPLEX64 of c_code/constants.h:18 = double[2].  0-based CSR of the n x n complex matrix; general_symmetric: the
  * LOWER triangle of a complex SYMMETRIC (not Hermitian) matrix.  The system is solved in its real-equivalent form of order 2 n on
- * the same device path as real matrices; the expansion of the values happens on the device.  The determinant is not available
- * (compute_determinant = 1 returns ERROR_NOT_AVAILABLE).  set_value_map / factorize_mapped: as for the real solver, with the
+ * the same device path as real matrices; the expansion of the values happens on the device.  Round 4: the pivot searches take the two rows of a
+ * complex row together (a complex LU with partial pivoting in real arithmetic), so the determinant IS available: determinant_coefficient_real /
+ * _imag / _exponent as umfpack_zi_get_determinant returns them to interface_complex_umfpack.c:143-155,187-200 (det = (re + i im) x 10^exponent;
+ * zeros when compute_determinant = 0).  set_value_map / factorize_mapped: as for the real solver, with the
  * caller's complex COO triplets as input (Radau5's K_comp = (alpha + i beta) M - J keeps its structure over the whole run). */
 struct InterfaceComplexHIPMF;
 struct InterfaceComplexHIPMF *complex_solver_hipmf_new(void);
@@ -244,8 +246,11 @@ int32_t complex_solver_hipmf_initialize(struct InterfaceComplexHIPMF *solver, in
                                         int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, int32_t ndim,
                                         const int32_t *row_pointers, const int32_t *col_indices, const double *values);
 int32_t complex_solver_hipmf_factorize(struct InterfaceComplexHIPMF *solver, int32_t *effective_ordering, int32_t *effective_scaling,
-                                       int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL compute_determinant, C_BOOL verbose,
+                                       int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient_real,
+                                       double *determinant_coefficient_imag, double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose,
                                        const double *values);
+int32_t complex_solver_hipmf_get_determinant(struct InterfaceComplexHIPMF *solver, double *determinant_coefficient_real,
+                                             double *determinant_coefficient_imag, double *determinant_exponent);
 int32_t complex_solver_hipmf_solve(struct InterfaceComplexHIPMF *solver, double *x, const double *rhs, C_BOOL verbose);
 int32_t complex_solver_hipmf_set_value_map(struct InterfaceComplexHIPMF *solver, int32_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx);
 int32_t complex_solver_hipmf_factorize_mapped(struct InterfaceComplexHIPMF *solver, int32_t *effective_ordering, int32_t *effective_scaling,

@@ -94,6 +94,8 @@ void *rh_clinsolver_new(const char **err);
 void rh_clinsolver_free(void *solver);
 const char *rh_clinsolver_factorize(void *solver, void *ccoo, const struct RhParams *params_or_null);
 const char *rh_clinsolver_solve(void *solver, double *x, int64_t nx, const double *rhs, int64_t nr, int32_t verbose);
+/* determinant = (det_re + i det_im) x 10^det_exp (LinSolParams.compute_determinant; complex_solver_umfpack.rs:411-414) */
+void rh_clinsolver_outputs(void *solver, double *det_re, double *det_im, double *det_exp, double *rcond, int32_t *npert);
 
 void *rh_linsolver_new(int32_t genie, const char **err);
 void rh_linsolver_free(void *solver);

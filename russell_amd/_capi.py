@@ -44,7 +44,9 @@ SYMBOLS = {
     "complex_solver_hipmf_initialize": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                      i32p, i32p, C.c_void_p]),
     "complex_solver_hipmf_factorize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                                    C.POINTER(C.c_double), C.c_int32, C.c_int32, f64p]),
+                                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                    C.c_int32, C.c_int32, f64p]),
+    "complex_solver_hipmf_get_determinant": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "complex_solver_hipmf_solve": (C.c_int32, [C.c_void_p, f64p, f64p, C.c_int32]),
     "complex_solver_hipmf_set_value_map": (C.c_int32, [C.c_void_p, C.c_int32, i32p, i32p]),
     "complex_solver_hipmf_factorize_mapped": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -742,6 +742,7 @@ struct Backend {
     decltype(&complex_solver_hipmf_solve) zsolve = nullptr;
     decltype(&complex_solver_hipmf_set_value_map) zset_value_map = nullptr;
     decltype(&complex_solver_hipmf_factorize_mapped) zfactorize_mapped = nullptr;
+    decltype(&complex_solver_hipmf_get_determinant) zget_determinant = nullptr;
     decltype(&complex_solver_hipmf_get_stats) zget_stats = nullptr;
     bool tried = false;
 };
@@ -790,6 +791,7 @@ bool load_backend() {
     BIND(zsolve, "complex_solver_hipmf_solve")
     BIND(zset_value_map, "complex_solver_hipmf_set_value_map")
     BIND(zfactorize_mapped, "complex_solver_hipmf_factorize_mapped")
+    BIND(zget_determinant, "complex_solver_hipmf_get_determinant")
     BIND(zget_stats, "complex_solver_hipmf_get_stats")
 #undef BIND
     g_backend.dl = dl;
@@ -1072,7 +1074,7 @@ StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSol
         if (mat.nrow != mat.ncol) return "the matrix must be square";
         if (mat.nnz < 1) return "the COO matrix must have at least one non-zero value";
         if (mat.symmetric == Sym::YesFull || mat.symmetric == Sym::YesUpper) return "HIPMF requires Sym::YesLower for symmetric matrices";
-        if (par.compute_determinant) return "the complex twin of HIPMF does not compute the determinant";
+        compute_determinant = par.compute_determinant;
         StrError e = to_csr(mat, true);
         if (e) return e;
         uint64_t t0 = now_ns();
@@ -1109,6 +1111,9 @@ StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSol
     if (value_map_set) {
         status = g_backend.zfactorize_mapped((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
                                              verbose, mat.values.data());
+        determinant_coefficient_real = 0.0, determinant_coefficient_imag = 0.0, determinant_exponent = 0.0;
+        if (status == SUCCESSFUL_EXIT && compute_determinant)
+            status = g_backend.zget_determinant((InterfaceComplexHIPMF *)solver, &determinant_coefficient_real, &determinant_coefficient_imag, &determinant_exponent);
     } else {
         // no value map (the backend refused it): the values go through a fresh conversion, and the pattern is checked on every call,
         // as the real SolverHIPMF does -- summing through the segments of the first call's triplet order would be silently wrong
@@ -1117,7 +1122,8 @@ StrError ComplexSolverHIPMF::factorize(const ComplexCooMatrix &mat, const LinSol
         StrError e = to_csr(mat, true);
         if (e) return e;
         if (zrp != rp0 || zci != ci0) return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
-        status = g_backend.zfactorize((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate, 0,
+        status = g_backend.zfactorize((InterfaceComplexHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
+                                      &determinant_coefficient_real, &determinant_coefficient_imag, &determinant_exponent, compute_determinant ? 1 : 0,
                                       verbose, zvals.data());
     }
     if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
@@ -1148,7 +1154,9 @@ void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Nd"; // the backend's own nested dissection, whatever of Amd / Colamd / Metis / ... was asked for (none of those libraries is used)
     stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
     stats.rcond_estimate = rcond_estimate;
-    stats.det_mantissa = 0.0, stats.det_base = 0.0, stats.det_exponent = 0.0; // (not available: see include/russell_hipmf.h)
+    // (complex_solver_umfpack.rs:411-414)
+    stats.det_mantissa = determinant_coefficient_real, stats.det_mantissa_imag = determinant_coefficient_imag;
+    stats.det_base = 10.0, stats.det_exponent = determinant_exponent;
     stats.perturbed_pivots = perturbed_pivots;
     stats.effective_matching = effective_matching ? "MaxProdScaled" : "None";
 }
@@ -1631,6 +1639,12 @@ const char *rh_clinsolver_solve(void *h, double *x, int64_t nx, const double *rh
     StrError e = s->s->solve(xx, rr, verbose != 0);
     if (!e) std::copy(xx.begin(), xx.end(), x);
     return e;
+}
+
+void rh_clinsolver_outputs(void *h, double *det_re, double *det_im, double *det_exp, double *rcond, int32_t *npert) {
+    RhComplexSolver *s = (RhComplexSolver *)h;
+    s->s->get_determinant(*det_re, *det_im, *det_exp);
+    *rcond = s->s->get_rcond(), *npert = s->s->get_perturbed_pivots();
 }
 
 void *rh_linsolver_new(int32_t genie, const char **err) {

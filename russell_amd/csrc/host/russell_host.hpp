@@ -246,6 +246,10 @@ class ComplexSolverHIPMF {
     uint64_t get_ns_init() const { return time_initialize_ns; }
     uint64_t get_ns_fact() const { return time_factorize_ns; }
     uint64_t get_ns_solve() const { return time_solve_ns; }
+    // determinant = (re + i im) x 10^exponent when LinSolParams.compute_determinant was set (complex_solver_umfpack.rs:154-167, 411-414)
+    void get_determinant(double &re, double &im, double &exponent) const { re = determinant_coefficient_real, im = determinant_coefficient_imag, exponent = determinant_exponent; }
+    double get_rcond() const { return rcond_estimate; }
+    int32_t get_perturbed_pivots() const { return perturbed_pivots; }
 
   private:
     ComplexSolverHIPMF() {}
@@ -257,7 +261,8 @@ class ComplexSolverHIPMF {
     std::vector<int32_t> zrp, zci, seg_ptr, seg_idx;
     std::vector<double> zvals;          // summed CSR values (first call / fallback when the triplet order changes)
     int32_t effective_ordering = -1, effective_scaling = -1, perturbed_pivots = 0;
-    double rcond_estimate = 0.0;
+    double rcond_estimate = 0.0, determinant_coefficient_real = 0.0, determinant_coefficient_imag = 0.0, determinant_exponent = 0.0;
+    bool compute_determinant = false;
     bool effective_matching = false;
     uint64_t time_initialize_ns = 0, time_factorize_ns = 0, time_solve_ns = 0;
     StrError to_csr(const ComplexCooMatrix &mat, bool pattern_too);

@@ -189,7 +189,6 @@ int main(int argc, char **argv) {
             if (genie != Genie::Hipmf) return fail("only the HIPMF backend is available");
             if (StrError e = ComplexSolverHIPMF::create(solver)) return fail(e);
             LinSolParams zparams = params;
-            zparams.compute_determinant = false; // not available through the real-equivalent system
             if (StrError e = solver->factorize(coo, &zparams)) return fail(e);
             if (StrError e = solver->solve(x, rhs, opt.verbose)) return fail(e);
             solver->update_stats(stats);

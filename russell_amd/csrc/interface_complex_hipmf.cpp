@@ -8,7 +8,12 @@
 // so the interleaved complex vectors ARE the real vectors (no copy), and the caller's complex values are expanded ON THE DEVICE
 // (signed value map + k_gather_values): a factorisation moves nnz x 16 bytes over PCIe, nothing is expanded on the host.
 // A complex SYMMETRIC matrix handed over as its lower triangle has an unsymmetric real-equivalent form: the mirrored entries are
-// written out in the pattern (general LU on the device).  The determinant is not available (det of the real form is |det A|^2).
+// written out in the pattern (general LU on the device).
+// Round 4: the real path runs in its PAIRED mode (NumericOptions.complex_pairs): the ordering and the matching work on the graph / the
+// moduli of the complex matrix and keep rows 2 k, 2 k + 1 together, and every pivot search takes a pair of rows at a time (the row with
+// the largest real or imaginary part in the column, then its partner) -- a complex LU with partial pivoting carried out in real
+// arithmetic, whose complex pivots give the determinant (the real pivots alone only give |det A|^2).  HIPMF_COMPLEX_PAIRS=0: the plain
+// real-equivalent factorisation of rounds 2 - 3 (no determinant).
 #include <hipmf_device_rt.h>
 
 #include <algorithm>
@@ -158,6 +163,8 @@ static int32_t c_initialize_body(struct InterfaceComplexHIPMF *h, int32_t orderi
     if (pivot_epsilon >= 0.0) no.pivot_epsilon = pivot_epsilon;
     if (refinement_nstep >= 0) no.refinement_nstep = refinement_nstep;
     no.verbose = verbose == 1;
+    no.complex_pairs = true;
+    if (const char *e = getenv("HIPMF_COMPLEX_PAIRS")) no.complex_pairs = atoi(e) != 0;
     h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
     // the values (when given) let the analysis apply the maximum-product matching to a weak diagonal, as for real matrices
     std::vector<double> v2;
@@ -208,25 +215,40 @@ static int32_t finish(struct InterfaceComplexHIPMF *h, int32_t code, int32_t *ef
     return code;
 }
 
+// determinant_coefficient_real / _imag / _exponent: det A = (real + i imag) x 10^exponent, the triple umfpack_zi_get_determinant hands
+// to interface_complex_umfpack.c:187-195 (zeros when compute_determinant = 0, as there: :196-200)
+static int32_t determinant_out(struct InterfaceComplexHIPMF *h, int32_t code, C_BOOL compute_determinant, double *det_re, double *det_im, double *det_exp) {
+    if (det_re) *det_re = 0.0;
+    if (det_im) *det_im = 0.0;
+    if (det_exp) *det_exp = 0.0;
+    if (code != SUCCESSFUL_EXIT || compute_determinant != 1) return code;
+    return h->solver.determinant_complex(det_re, det_im, det_exp, nullptr);
+}
+
 static int32_t c_factorize_body(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
-                                       int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL compute_determinant, C_BOOL verbose,
-                                       const double *values) {
+                                       int32_t *num_perturbed_pivots, double *rcond_estimate, double *det_re, double *det_im, double *det_exp,
+                                       C_BOOL compute_determinant, C_BOOL verbose, const double *values) {
     if (!h || !values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
-    if (compute_determinant == 1) return ERROR_NOT_AVAILABLE; // det of the real-equivalent form is |det A|^2: the phase is lost
+    if (compute_determinant == 1 && !h->solver.opt.complex_pairs) return ERROR_NOT_AVAILABLE; // det of the plain real-equivalent form is |det A|^2: the phase is lost
     if (h->triplet_map) { // a triplet map is installed: plain CSR values need the identity map back
         int32_t c = install_map(h, h->nnz, nullptr, nullptr);
         if (c != SUCCESSFUL_EXIT) return c;
         h->triplet_map = false;
     }
     h->solver.opt.verbose = verbose == 1;
-    return finish(h, h->solver.factorize_mapped(values, false), effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate);
+    const int32_t code = finish(h, h->solver.factorize_mapped(values, false), effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate);
+    return determinant_out(h, code, compute_determinant, det_re, det_im, det_exp);
 }
 
 int32_t complex_solver_hipmf_factorize(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
-                                       int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL compute_determinant, C_BOOL verbose,
+                                       int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient_real,
+                                       double *determinant_coefficient_imag, double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose,
                                        const double *values) {
-    return guarded(h, [&]() { return c_factorize_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, compute_determinant, verbose, values); });
+    return guarded(h, [&]() {
+        return c_factorize_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, determinant_coefficient_real,
+                                determinant_coefficient_imag, determinant_exponent, compute_determinant, verbose, values);
+    });
 }
 
 static int32_t c_factorize_mapped_body(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
@@ -240,6 +262,13 @@ static int32_t c_factorize_mapped_body(struct InterfaceComplexHIPMF *h, int32_t 
 int32_t complex_solver_hipmf_factorize_mapped(struct InterfaceComplexHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
                                               int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL verbose, const double *input_values) {
     return guarded(h, [&]() { return c_factorize_mapped_body(h, effective_ordering, effective_scaling, num_perturbed_pivots, rcond_estimate, verbose, input_values); });
+}
+
+// the determinant of the last factorisation (complex_solver_hipmf_factorize_mapped has no determinant arguments: Radau5 never asks)
+int32_t complex_solver_hipmf_get_determinant(struct InterfaceComplexHIPMF *h, double *determinant_coefficient_real, double *determinant_coefficient_imag,
+                                             double *determinant_exponent) {
+    if (!h) return ERROR_NULL_POINTER;
+    return guarded(h, [&]() { return h->solver.determinant_complex(determinant_coefficient_real, determinant_coefficient_imag, determinant_exponent, nullptr); });
 }
 
 static int32_t c_solve_body(struct InterfaceComplexHIPMF *h, double *x, const double *rhs, C_BOOL verbose) {

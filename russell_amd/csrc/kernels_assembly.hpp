@@ -82,7 +82,7 @@ __global__ void k_absmax(int64_t nnz, const double *__restrict__ vals, const int
 // `threshold` times the row's largest scaled entry counts as weak -- the criterion initialize uses to decide on the maximum-product
 // matching (matching.cpp, diagonal_is_weak).  One thread per row; dcol == nullptr: identity.
 __global__ void k_diag_check(int32_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ vs,
-                             const int32_t *__restrict__ dcol, double threshold, FactorInfo *info) {
+                             const int32_t *__restrict__ dcol, double threshold, FactorInfo *info, int32_t pairs) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int dc = dcol ? dcol[r] : r;
@@ -90,7 +90,8 @@ __global__ void k_diag_check(int32_t n, const int32_t *__restrict__ rp, const in
     for (int p = rp[r]; p < rp[r + 1]; p++) {
         const double a = fabs(vs[p]);
         mx = a > mx ? a : mx;
-        if (ci[p] == dc) dg = a;
+        // (pairs -- the real-equivalent form of a complex matrix: the larger part of the complex diagonal entry)
+        if (ci[p] == dc || (pairs && ci[p] == (dc ^ 1))) dg = a > dg ? a : dg;
     }
     if (!(dg > threshold * mx) || dg == 0.0) atomicAdd(&info->n_weak_diag, 1);
 }

@@ -149,6 +149,22 @@ struct FactorInfo {
     int32_t n_nonfinite;  // NaN / Inf among the scaled input values (the factorisation is refused)
     int32_t n_weak_diag;  // rows whose (matched, scaled) diagonal is below 1 % of the row's largest entry (k_diag_check)
 };
+// What the device allocation behind a FactorInfo pointer really holds.  zdiag (PAIRED instances of the factorisation kernels only: the
+// real-equivalent form of a complex matrix, interface_complex_hipmf.cpp): the COMPLEX pivots, zdiag[2 k], zdiag[2 k + 1] = Re, Im of the
+// pivot of the complex elimination step k (permuted numbering: k = first / 2 + step / 2 of the front) -- what the determinant of the
+// complex matrix is the product of (the real pivots multiply to |det|^2: the phase is not in them).
+struct FactorInfoExt {
+    FactorInfo i;
+    double *zdiag;
+};
+template <bool PAIRED> __device__ __forceinline__ void store_zpivot(FactorInfo *info, int at, int step, double zr, double zi) {
+    if constexpr (PAIRED) {
+        if ((step & 1) == 0) { // the lane whose row was the pivot row of an even step holds the pair's complex pivot
+            double *zd = reinterpret_cast<const FactorInfoExt *>(info)->zdiag;
+            zd[at + step] = zr, zd[at + step + 1] = zi;
+        }
+    }
+}
 
 __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int v) {
     int lo = 0, hi = n;

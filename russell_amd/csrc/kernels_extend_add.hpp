@@ -21,7 +21,7 @@ namespace hipmf {
 #endif
 constexpr int EA_TILE_C = HIPMF_EA_TILE_C, EA_TILE_R = HIPMF_EA_TILE_R; // (EA_TILE_R: a power of two, 32 .. 256; EA_TILE_C >= 32: the first tile of a front holds its first diagonal tile)
 static_assert(EA_TILE_C >= NB && EA_TILE_R >= NB && EA_TILE_R <= 256 && (EA_TILE_R & (EA_TILE_R - 1)) == 0 && EA_TILE_C * EA_TILE_R <= 65536, "extend-add tile");
-template <bool SYM>
+template <bool SYM, bool PAIRED = false>
 __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict__ tasks, const EaRange *__restrict__ ranges, const int32_t *__restrict__ rel,
                                                         double *__restrict__ pool, const int32_t *__restrict__ ea_sc, const int32_t *__restrict__ sc_k,
                                                         const uint16_t *__restrict__ sc_pos, const double *__restrict__ vs, const double *__restrict__ vs2,
@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32<!SYM>(a, tid, eps, step, npert, nzero);
+        double zr = 0.0, zi = 0.0;
+        tile_lu32_z<!SYM, PAIRED>(a, tid, eps, step, npert, nzero, zr, zi);
         if (tid < nb) {
             double *dw = dws + (int64_t)t.lu_slot * NB * NB;
             double dg = 1.0;
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
             }
             lperm[t.lu_first + step] = tid;
             diag[t.lu_first + step] = dg;
+            store_zpivot<PAIRED>(info, t.lu_first, step, zr, zi);
         }
         if (tid == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);

@@ -29,9 +29,13 @@ namespace hipmf {
 // lp[position] = front-local row that ended up there (identity on entry).  Static pivoting as everywhere: |pivot| < eps -> +-eps.
 // (PIVOT = false: the pivot of step c is row c.)
 constexpr int LU_KB = 8;
-template <int NW, bool PIVOT>
+// PAIRED (see tile_lu32_z; the front's pivots and rows come in (real, imaginary) pairs, p and f even): the odd step of a pair takes
+// the partner of the even step's pivot row -- physical positions 2 k, 2 k + 1 hold the two rows of ONE pair at all times (a pair moves
+// to the pivot positions as a whole, the pair it displaces moves to where it came from), possibly in swapped order: which of the two
+// is the real row is the parity of its original position, lp.  zd: where the complex pivots of this front go (2 doubles per pair).
+template <int NW, bool PIVOT, bool PAIRED = false>
 __device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int ld, const int f, const int p, int32_t *lp, int32_t *pivpos,
-                                               const double eps, FactorInfo *info) {
+                                               const double eps, FactorInfo *info, double *zd = nullptr) {
     constexpr int KB = LU_KB, T = 64 * NW;
     const int lin = threadIdx.x, lane = lin & 63, wave = lin >> 6;
     for (int c0 = 0; c0 < p; c0 += KB) {
@@ -47,13 +51,16 @@ __device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int
             bool chosen = false;
             int npert = 0, nzero = 0;
             const int lp_old = (PIVOT && r >= c0 && r < p) ? lp[r] : 0;
+            int pv_prev = 0;
 #pragma unroll
             for (int st = 0; st < KB; st++) {
                 if (st < kb) { // (wave-uniform)
                     int pv;
                     // (every lane forms the reciprocal of its own entry while the arg-max runs: the divide is off the dependent chain)
                     const double myinv = fast_rcp(a[st]);
-                    if (PIVOT) {
+                    if (PAIRED && (st & 1)) {
+                        pv = pv_prev ^ 1;
+                    } else if (PIVOT) {
                         const bool cand = active && !chosen && r < p;
                         const unsigned mag = __float_as_uint((float)fabs(a[st]));
                         const unsigned key = cand ? ((mag & ~127u) | 64u | (unsigned)(63 - r)) : 0u;
@@ -61,6 +68,7 @@ __device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int
                     } else {
                         pv = c0 + st;
                     }
+                    pv_prev = pv;
                     double d = wave_bcast(a[st], pv);
                     double inv = wave_bcast(myinv, pv);
                     if (fabs(d) < eps || d == 0.0) {
@@ -71,6 +79,14 @@ __device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int
                         if (d == 0.0) nzero++;
                         d = dn;
                         inv = 1.0 / dn;
+                    }
+                    if constexpr (PAIRED) {
+                        if ((st & 1) == 0) {
+                            // column c0 + st is a real-part column: the pair's real row holds Re there, its imaginary row Im
+                            const double q = wave_bcast(a[st], pv ^ 1);
+                            const int imag_row = wave_bcast_i32(lp_old, pv) & 1;
+                            if (lane == 0) zd[c0 + st] = imag_row ? q : d, zd[c0 + st + 1] = imag_row ? d : q;
+                        }
                     }
                     if (PIVOT) {
                         const int P = wave_bcast_i32(pos, pv);
@@ -214,7 +230,7 @@ struct SmallAsm {
 // NW = 4: the columns of the rank-1 updates (and the zero-fill, the gather of A's entries, the final store) are spread over four
 //         wavefronts: a third of the latency per pivot, for the launches with few, large fronts between the leaves and the tiled
 //         levels, where one front's LU (up to 64 pivots x ~1.3 us) is the whole launch.
-template <int NW>
+template <int NW, bool PAIRED = false>
 // (one wavefront per front: six waves per SIMD -- 78 registers instead of 96 -- measured 6.560 -> 6.545 ms; eight spill: 6.72)
 __global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD,
                                                           double *__restrict__ pool, int32_t *__restrict__ lperm,
@@ -310,7 +326,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const
         if (tid < p) lp[tid] = tid;
     }
     __syncthreads();
-    lds_lu_blocked<NW, true>(sm, ld, f, p, lp, pivpos, eps, info);
+    if constexpr (PAIRED) lds_lu_blocked<NW, true, true>(sm, ld, f, p, lp, pivpos, eps, info, reinterpret_cast<const FactorInfoExt *>(info)->zdiag + fd.first);
+    else lds_lu_blocked<NW, true>(sm, ld, f, p, lp, pivpos, eps, info);
     // A front with a packed copy of its rows of U keeps L alone in its pivot block (zeros on and above the diagonal) and U alone in the
     // copy (zeros below the diagonal of U11): the wave-subtree solves (kernels_solve_tree.hpp) then need no per-lane tests in their
     // substitution steps; every other reader masks those entries anyway.
@@ -343,11 +360,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const
 // lane's row was chosen as the pivot row (ties go to the lowest row: deterministic).  On exit the row
 // holds its multipliers in columns < step and its row of U in columns >= step; npert / nzero count the
 // perturbed / exactly-zero pivots (wave-uniform).
-template <bool PIVOT = true>
-__device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero) {
+// PAIRED (the real-equivalent form of a complex matrix: rows / columns 2 k, 2 k + 1 are the real and imaginary parts of complex row /
+// column k, the tile starts at an even row): the pivot search runs at the EVEN steps only, the odd step takes the chosen row's partner
+// (lane ^ 1) -- the two steps together are one step of a complex LU with partial pivoting (the pivot's real or imaginary part is the
+// largest of the column: its modulus is within sqrt 2 of the largest), and the 2 x 2 blocks [a -b; b a] keep their shape in the
+// Schur complement (to rounding).  zr + i zi: the complex pivot, valid in the lane that was chosen at an even step.
+template <bool PIVOT = true, bool PAIRED = false>
+__device__ __forceinline__ void tile_lu32_z(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero, double &zr, double &zi) {
     step = -1;
     npert = 0;
     nzero = 0;
+    int pv_prev = 0;
 #pragma clang loop unroll(full)
     for (int c = 0; c < NB; c++) {
         // arg-max as ONE 32-bit max-reduction (4 DPP max steps): key = float(|a|) bits with the low 6 bits
@@ -359,7 +382,10 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
         const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
         const double myinv = fast_rcp(a[c]);
         // (PIVOT = false, the symmetric fronts: the pivot of step c is row c -- L D L^T in the guise of an LU without interchanges)
-        const int pv = PIVOT ? 31 - (int)(wave_max_u32<2>(key) & 31u) : c; // (candidates live in lanes 0..31: two rows)
+        int pv;
+        if constexpr (PAIRED) pv = (c & 1) ? (pv_prev ^ 1) : 31 - (int)(wave_max_u32<2>(key) & 31u);
+        else pv = PIVOT ? 31 - (int)(wave_max_u32<2>(key) & 31u) : c; // (candidates live in lanes 0..31: two rows)
+        pv_prev = pv;
         if (lane == pv) step = c;
         double d = wave_bcast(a[c], pv);
         double inv = wave_bcast(myinv, pv);
@@ -370,6 +396,14 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
             npert++;
             if (d == 0.0) nzero++;
             inv = 1.0 / dn;
+            d = dn;
+        }
+        if constexpr (PAIRED) {
+            if ((c & 1) == 0) {
+                // column c is a real-part column: the real row of the pair holds Re there, the imaginary row Im
+                const double q = wave_bcast(a[c], pv ^ 1);
+                if (lane == pv) zr = (pv & 1) ? q : d, zi = (pv & 1) ? d : q;
+            }
         }
         const bool below = lane < NB && step < 0; // rows not yet chosen as pivot
         if (below) a[c] *= inv;
@@ -380,12 +414,16 @@ __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps,
         for (int cc = c + 1; cc < NB; cc++) a[cc] -= lmul * wave_bcast(a[cc], pv);
     }
 }
+template <bool PIVOT = true> __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero) {
+    double zr, zi;
+    tile_lu32_z<PIVOT, false>(a, lane, eps, step, npert, nzero, zr, zi);
+}
 
 // Tiled path, step 0 of the levels with MANY tiled fronts: one wavefront per front factorises the first diagonal tile and parks it
 // (with its interchanges and pivots) where k_panel finds the tiles of the later steps.  k_panel's own "every workgroup factorises
 // the tile itself" saves a dependent launch for the few large fronts near the root; with a thousand fronts in the level it is three
 // redundant 5 us factorisations per front in workgroups whose other wavefront waits.
-template <bool SYM>
+template <bool SYM, bool PAIRED = false>
 __global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD, double *__restrict__ pool, int32_t *__restrict__ lperm,
                                               double *__restrict__ dws, const unsigned long long *__restrict__ anorm_bits, double pivot_eps,
                                               FactorInfo *info, double *__restrict__ diag) {
@@ -402,7 +440,8 @@ __global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD,
     }
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
     int step, npert, nzero;
-    tile_lu32<!SYM>(a, tid, eps, step, npert, nzero);
+    double zr = 0.0, zi = 0.0;
+    tile_lu32_z<!SYM, PAIRED>(a, tid, eps, step, npert, nzero, zr, zi);
     if (tid < nb) {
         double *dw = dws + (int64_t)slot * NB * NB; // step 0 uses buffer 0
         double dg = 1.0;
@@ -413,6 +452,7 @@ __global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD,
         }
         lperm[fd.first + step] = tid;
         diag[fd.first + step] = dg;
+        store_zpivot<PAIRED>(info, fd.first, step, zr, zi);
     }
     if (tid == 0 && npert > 0) {
         atomicAdd(&info->n_perturbed, npert);
@@ -467,7 +507,7 @@ struct PanelLds {
 // the tile is factorised without interchanges from its lower triangle.
 // One panel tile (tile t of the front in `slot`) of step k0.  NT = threads of the workgroup: PANEL_T of them work (k_chain's
 // workgroups have 256: the others only take part in the barriers).
-template <bool SYM, bool COH, int NT>
+template <bool SYM, bool COH, int NT, bool PAIRED = false>
 __device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const int t, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
                                            int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
                                            const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
@@ -599,7 +639,8 @@ __device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const i
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32<!SYM>(a, tid, eps, step, npert, nzero);
+        double zr = 0.0, zi = 0.0;
+        tile_lu32_z<!SYM, PAIRED>(a, tid, eps, step, npert, nzero, zr, zi);
         if (tid < NB) {
             // rows go to LDS in pivot order: row `step` of the interchanged tile is this lane's row
             double dg = 1.0;
@@ -611,7 +652,10 @@ __device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const i
             }
             dinv[step] = 1.0 / dg;
             lp[step] = tid;
-            if (t == 0 && tid < nb) diag[fd.first + k0 + step] = dg;
+            if (t == 0 && tid < nb) {
+                diag[fd.first + k0 + step] = dg;
+                store_zpivot<PAIRED>(info, fd.first + k0, step, zr, zi);
+            }
         }
         if (t == 0 && tid == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);
@@ -703,7 +747,7 @@ __device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const i
     }
 }
 
-template <bool SYM>
+template <bool SYM, bool PAIRED = false>
 __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
                                                    int32_t k0, double *__restrict__ pool,
                                                    int32_t *__restrict__ lperm, double *__restrict__ dws, int32_t dws_stride,
@@ -714,7 +758,7 @@ __global__ void __launch_bounds__(PANEL_T) k_panel(const int32_t *__restrict__ p
     FrontDesc fd = load_front_pfx(pfx, nactive, LFD, blockIdx.x, q4, slot, pfx_slot); // (LFD: the descriptors of the level's tiled fronts in slot order)
     const int t = blockIdx.x - pfx_slot;
     fd_resident(fd);
-    panel_body<SYM, false, PANEL_T>(sh, slot, t, fd, k0, pool, lperm, dws, dws_stride, anorm_bits, pivot_eps, info, diag, pre_lu);
+    panel_body<SYM, false, PANEL_T, PAIRED>(sh, slot, t, fd, k0, pool, lperm, dws, dws_stride, anorm_bits, pivot_eps, info, diag, pre_lu);
 }
 
 // Tiled path, step k0: trailing update  A22 -= L21 * U12  on v_mfma_f64_16x16x4_f64 over the active
@@ -763,7 +807,7 @@ typedef UpdateLdsT<UPD_T> UpdateLds;
 // part (LU instances, full steps only): 0 = every tile; 1 = the tiles of the first block column and block row (what the next two panels
 // and the look-ahead touch: the "critical strips") + the look-ahead piece; 2 = all other tiles.  A full step split this way runs its
 // part 2 on a side stream beside the next group's panel steps (numeric.cpp); the tiles' arithmetic is the same: identical bits.
-template <bool SYM, bool COH, int TS = UPD_T>
+template <bool SYM, bool COH, int TS = UPD_T, bool PAIRED = false>
 __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, const int t_in, const FrontDesc &fd, int32_t k0, double *__restrict__ pool,
                                             double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
                                             const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
@@ -905,7 +949,8 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        tile_lu32<!SYM>(a2, tid, eps, step, npert, nzero); // lanes >= 32 are not candidates and take no part
+        double zr = 0.0, zi = 0.0;
+        tile_lu32_z<!SYM, PAIRED>(a2, tid, eps, step, npert, nzero, zr, zi); // lanes >= 32 are not candidates and take no part
         if (tid < nb2) {
             double *dwo = dws + ((int64_t)(((k0 / NB) + 1) & 1) * dws_stride + slot) * NB * NB;
             double dgv = 1.0;
@@ -916,6 +961,7 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
             }
             M::sti(lperm + fd.first + base + step, base + tid);
             diag[fd.first + base + step] = dgv;
+            store_zpivot<PAIRED>(info, fd.first + base, step, zr, zi);
         }
         if (tid == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);
@@ -1092,7 +1138,7 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
 #else
 #define HIPMF_UPD32_BOUNDS __launch_bounds__(64, HIPMF_UPD32_WAVES)
 #endif
-template <bool SYM>
+template <bool SYM, bool PAIRED = false>
 __global__ void HIPMF_UPD_BOUNDS k_update(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
                                                 int32_t k0, double *__restrict__ pool,
                                                 double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
@@ -1103,11 +1149,11 @@ __global__ void HIPMF_UPD_BOUNDS k_update(const int32_t *__restrict__ pfx, int32
     FrontDesc fd = load_front_pfx(pfx, nactive, LFD, blockIdx.x, q4, slot, pfx_slot); // (LFD: the descriptors of the level's tiled fronts in slot order)
     const int t = blockIdx.x - pfx_slot;
     fd_resident(fd);
-    update_body<SYM, false>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag, SYM ? 0 : part, pfx_slot & 7);
+    update_body<SYM, false, UPD_T, PAIRED>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag, SYM ? 0 : part, pfx_slot & 7);
 }
 
 // the same with 32 x 32 tiles, one wavefront per tile (levels whose largest tiled front has at most Solver::upd32_max_front rows)
-template <bool SYM>
+template <bool SYM, bool PAIRED = false>
 __global__ void HIPMF_UPD32_BOUNDS k_update32(const int32_t *__restrict__ pfx, int32_t nactive, const FrontDesc *__restrict__ LFD,
                                                  int32_t k0, double *__restrict__ pool,
                                                  double *__restrict__ dws, int32_t dws_stride, int32_t *__restrict__ lperm,
@@ -1118,7 +1164,7 @@ __global__ void HIPMF_UPD32_BOUNDS k_update32(const int32_t *__restrict__ pfx, i
     FrontDesc fd = load_front_pfx(pfx, nactive, LFD, blockIdx.x, q4, slot, pfx_slot);
     const int t = blockIdx.x - pfx_slot;
     fd_resident(fd);
-    update_body<SYM, false, UPD_T_SMALL>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
+    update_body<SYM, false, UPD_T_SMALL, PAIRED>(sh, slot, t, fd, k0, pool, dws, dws_stride, lperm, anorm_bits, pivot_eps, info, diag);
 }
 
 } // namespace hipmf

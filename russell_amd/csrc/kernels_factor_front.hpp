@@ -347,11 +347,15 @@ struct MidlLds {
 // `step` = the elimination step at which this lane's row was chosen, `dval` its pivot.  Pivot rows are not scaled inside the loop (the
 // update is one FMA per entry for every lane, the pivot lane takes part with a zero multiplier); on exit row `step` of the inverse sits in
 // this lane, column position k belonging to the row chosen at step k (rk, written by the caller's lane).  np: steps to run (<= 32).
-__device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np, double eps, int &step, double &dval, int32_t *rk, int &npert, int &nzero) {
+// PAIRED: as tile_lu32_z (np even) -- the odd step takes the partner row of the even step's pivot; zr + i zi: the pair's complex pivot.
+template <bool PAIRED = false>
+__device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np, double eps, int &step, double &dval, int32_t *rk, int &npert, int &nzero,
+                                           double &zr, double &zi) {
     step = -1;
     dval = 1.0;
     npert = 0;
     nzero = 0;
+    int pv_prev = 0;
 #pragma clang loop unroll(full)
     for (int c = 0; c < MIDL_P; c++) {
         if (c < np) { // (wave-uniform)
@@ -359,7 +363,10 @@ __device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np
             const unsigned mag = __float_as_uint((float)fabs(a[c]));
             const unsigned key = cand ? ((mag & ~63u) | 32u | (unsigned)(31 - lane)) : 0u;
             const double myinv = fast_rcp(a[c]);
-            const int pv = 31 - (int)(wave_max_u32<2>(key) & 31u);
+            int pv;
+            if constexpr (PAIRED) pv = (c & 1) ? (pv_prev ^ 1) : 31 - (int)(wave_max_u32<2>(key) & 31u);
+            else pv = 31 - (int)(wave_max_u32<2>(key) & 31u);
+            pv_prev = pv;
             double d = wave_bcast(a[c], pv);
             double inv = wave_bcast(myinv, pv);
             if (fabs(d) < eps || d == 0.0) {
@@ -369,6 +376,12 @@ __device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np
                 if (d == 0.0) nzero++;
                 d = dn;
                 inv = 1.0 / dn;
+            }
+            if constexpr (PAIRED) {
+                if ((c & 1) == 0) {
+                    const double q = wave_bcast(a[c], pv ^ 1);
+                    if (lane == pv) zr = (pv & 1) ? q : d, zi = (pv & 1) ? d : q;
+                }
             }
             if (lane == pv) step = c, dval = d, rk[c] = lane;
             const double lm = (lane == pv) ? 0.0 : a[c] * inv;
@@ -383,6 +396,7 @@ __device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np
     for (int cc = 0; cc < MIDL_P; cc++) a[cc] *= inv_own;
 }
 
+template <bool PAIRED = false>
 __global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__restrict__ LFD, double *__restrict__ pool, int32_t *__restrict__ lperm,
                                                            const unsigned long long *__restrict__ anorm_bits, double pivot_eps, FactorInfo *info,
                                                            double *__restrict__ diag) {
@@ -448,8 +462,8 @@ __global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__re
     if (wave == 0) {
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
         int step, npert, nzero;
-        double dval;
-        tile_inv32(a, lane, p, eps, step, dval, sh.rk, npert, nzero);
+        double dval, zr = 0.0, zi = 0.0;
+        tile_inv32<PAIRED>(a, lane, p, eps, step, dval, sh.rk, npert, nzero, zr, zi);
         wave_sync(); // (sh.rk of every step visible to the lanes of this wavefront)
         if (lane < p) { // (the rows of the block are the lanes 0 .. p-1: each was chosen at some step < p)
 #pragma unroll
@@ -462,6 +476,7 @@ __global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__re
             }
             diag[fd.first + step] = dval;
             lperm[fd.first + step] = lane;
+            store_zpivot<PAIRED>(info, fd.first, step, zr, zi);
         }
         if (lane == 0 && npert > 0) {
             atomicAdd(&info->n_perturbed, npert);

@@ -25,12 +25,13 @@
 
 namespace hipmf {
 
-bool diagonal_is_weak(int32_t n, const int32_t *rp, const int32_t *ci, const double *v, double threshold) {
+bool diagonal_is_weak(int32_t n, const int32_t *rp, const int32_t *ci, const double *v, double threshold, bool pairs) {
     for (int32_t i = 0; i < n; i++) {
         double d = 0.0, mx = 0.0;
         for (int32_t p = rp[i]; p < rp[i + 1]; p++) {
             const double a = std::fabs(v[p]);
-            if (ci[p] == i) d += a; // duplicates were summed by the caller's COO -> CSR; a split diagonal is still counted
+            // (pairs: the real or the imaginary part of the complex diagonal entry -- the paired pivot search takes the larger)
+            if (ci[p] == i || (pairs && ci[p] == (i ^ 1))) d += a; // duplicates were summed by the caller's COO -> CSR; a split diagonal is still counted
             mx = a > mx ? a : mx;
         }
         if (!(d >= threshold * mx) || d == 0.0) return true;
@@ -164,6 +165,35 @@ int32_t max_product_matching(int32_t n, const int32_t *rp, const int32_t *ci, co
     dc.resize((size_t)n);
     for (int32_t i = 0; i < n; i++) dr[i] = std::exp(u[i]);
     for (int32_t j = 0; j < n; j++) dc[j] = std::exp(w[j]) / cmax[j];
+    return 0;
+}
+
+int32_t paired_matching(int32_t n, const int32_t *rp, const int32_t *ci, const double *v, std::vector<int32_t> &mrow, std::vector<double> &dr,
+                        std::vector<double> &dc) {
+    if (n % 2 != 0) return -1;
+    const int32_t nc = n / 2;
+    std::vector<int32_t> rpc((size_t)nc + 1, 0), cic;
+    std::vector<double> vc;
+    cic.reserve((size_t)rp[n] / 4 + 1), vc.reserve((size_t)rp[n] / 4 + 1);
+    for (int32_t i = 0; i < nc; i++) {
+        // row 2 i of the real-equivalent form holds (Re, -Im) of complex entry (i, j) in columns 2 j, 2 j + 1 (ascending)
+        for (int32_t p = rp[2 * i]; p < rp[2 * i + 1]; p++) {
+            const int32_t j = ci[p] / 2;
+            if (!cic.empty() && (int32_t)cic.size() > rpc[i] && cic.back() == j) vc.back() = std::hypot(vc.back(), v[p]);
+            else cic.push_back(j), vc.push_back(std::fabs(v[p]));
+        }
+        rpc[(size_t)i + 1] = (int32_t)cic.size();
+    }
+    std::vector<int32_t> mc;
+    std::vector<double> drc, dcc;
+    const int32_t rc = max_product_matching(nc, rpc.data(), cic.data(), vc.data(), mc, drc, dcc);
+    if (rc != 0) return rc;
+    mrow.resize((size_t)n), dr.resize((size_t)n), dc.resize((size_t)n);
+    for (int32_t k = 0; k < nc; k++) {
+        mrow[2 * k] = 2 * mc[k], mrow[2 * k + 1] = 2 * mc[k] + 1;
+        dr[2 * k] = dr[2 * k + 1] = drc[k];
+        dc[2 * k] = dc[2 * k + 1] = dcc[k];
+    }
     return 0;
 }
 

@@ -305,6 +305,11 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     // as L D L^T on their lower triangle -- half the flops, half the factor (HIPMF_SYM_LDLT=0: LU of the mirrored matrix)
     so.symmetric_ldlt = sym_lower;
     if (const char *e = getenv("HIPMF_SYM_LDLT")) so.symmetric_ldlt = sym_lower && atoi(e) != 0;
+    if (opt.complex_pairs && (sym_lower || n % 2 != 0)) {
+        last_error = "complex pairs need general storage and an even order";
+        return ERROR_HIPMF_INVALID_MATRIX;
+    }
+    so.pair_blocks = opt.complex_pairs;
     // fewer, fatter fronts: nested-dissection leaves of <= 16 vertices become single dense supernodes
     // (1000^2 Poisson: 503 796 -> 113 068 fronts, 29 -> 20 levels, nnz(L) +18 %); see DESIGN.md section 4
     so.nd_leaf = 16;
@@ -360,14 +365,18 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_DIAG0_MIN")) diag0_min_panels = atoi(e); // tuning knob: panel workgroups of a level's step 0 from which k_diag0 runs
     if (const char *e = getenv("HIPMF_SOLVE_SLAB64")) slab64 = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_MATCHING")) opt.matching = atoi(e);
+    if (opt.complex_pairs) {
+        // the pivot searches of k_front (opt-in), of the chained launch and of the block-inverse step do not pair
+        use_chain = false, use_binv = false, mid_mmax = 0;
+    }
     // Maximum-product matching + scaling (matching.cpp) when the numbers are known and the diagonal is weak: the
     // analysis then runs on B = A(mrow, :), whose diagonal holds the matched entries (all 1 after scaling).
     std::vector<int32_t> mrow, rpB, ciB;
     std::vector<int64_t> kB; // position in B's CSR of every entry of A
     std::vector<double> dr, dc;
     matched = false;
-    if (values && !sym_lower && n > 1 && opt.matching > 0 && rp[0] == 0 && (opt.matching >= 2 || diagonal_is_weak(n, rp, ci, values, 0.01))) {
-        if (max_product_matching(n, rp, ci, values, mrow, dr, dc) == 0) {
+    if (values && !sym_lower && n > 1 && opt.matching > 0 && rp[0] == 0 && (opt.matching >= 2 || diagonal_is_weak(n, rp, ci, values, 0.01, opt.complex_pairs))) {
+        if ((opt.complex_pairs ? paired_matching(n, rp, ci, values, mrow, dr, dc) : max_product_matching(n, rp, ci, values, mrow, dr, dc)) == 0) {
             matched = true;
             rpB.assign((size_t)n + 1, 0);
             for (int32_t j = 0; j < n; j++) rpB[j + 1] = rpB[j] + (rp[mrow[j] + 1] - rp[mrow[j]]);
@@ -596,6 +605,16 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
                 for (int32_t j = i; !seen[j]; j = mrow[j]) seen[j] = 1, len++;
                 if ((len & 1) == 0) match_parity ^= 1;
             }
+            if (opt.complex_pairs) { // the permutation of the complex rows (pairs move as a whole: paired_matching)
+                match_parity = 0;
+                std::fill(seen.begin(), seen.end(), 0);
+                for (int32_t i = 0; i < n / 2; i++) {
+                    if (seen[i]) continue;
+                    int len = 0;
+                    for (int32_t j = i; !seen[j]; j = mrow[2 * j] / 2) seen[j] = 1, len++;
+                    if ((len & 1) == 0) match_parity ^= 1;
+                }
+            }
         }
         lap("perm + signature");
         {
@@ -657,9 +676,15 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         HIPC(hipMalloc((void **)&d_lperm, sizeof(int32_t) * ((size_t)n + WT_X)), ERROR_HIP_MALLOC);
         HIPC(hipMemsetAsync(d_lperm, 0, sizeof(int32_t) * ((size_t)n + WT_X), STREAM), ERROR_HIP_MEMCPY);
         for (double *p : {d_xp, d_du}) HIPC(hipMemsetAsync(p + n, 0, sizeof(double) * WT_X, STREAM), ERROR_HIP_MEMCPY);
-        HIPC(hipMalloc((void **)&d_diag, sizeof(double) * n), ERROR_HIP_MALLOC);
+        // (complex pairs: the n / 2 complex pivots follow the n real ones)
+        HIPC(hipMalloc((void **)&d_diag, sizeof(double) * n * (opt.complex_pairs ? 2 : 1)), ERROR_HIP_MALLOC);
         if (S.sym_mode) d_cs = d_rs; // symmetric scaling S A S keeps the big fronts symmetric: column scale = row scale
-        HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfo)), ERROR_HIP_MALLOC);
+        {
+            HIPC(hipMalloc((void **)&d_info, sizeof(FactorInfoExt)), ERROR_HIP_MALLOC);
+            FactorInfoExt ext = {};
+            ext.zdiag = opt.complex_pairs ? d_diag + n : nullptr;
+            HIPC(hipMemcpy(d_info, &ext, sizeof ext, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
+        }
         HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
         for (auto &e : ev) {
             hipEvent_t he;
@@ -1409,7 +1434,8 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         HIPMF_ALLOW_LDS(k_front<10>, sizeof(double) * MID_LDS_DOUBLES);
         HIPMF_ALLOW_LDS(k_front<16>, sizeof(double) * MID_LDS_DOUBLES);
         HIPMF_ALLOW_LDS(k_front<24>, sizeof(double) * MID_LDS_DOUBLES);
-        HIPMF_ALLOW_LDS(k_front_lu, sizeof(double) * MIDL_LDS_DOUBLES);
+        HIPMF_ALLOW_LDS(k_front_lu<false>, sizeof(double) * MIDL_LDS_DOUBLES);
+        HIPMF_ALLOW_LDS(k_front_lu<true>, sizeof(double) * MIDL_LDS_DOUBLES);
     }
     pl_lap("factor launch plans");
     allbig_off = (int32_t)lists.size();
@@ -1586,6 +1612,7 @@ int32_t Solver::run_factor() {
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     const bool chained = use_chain && d_chain_cnt != nullptr;
+    const bool PZ = opt.complex_pairs; // the pivot searches keep the (real, imaginary) rows of a complex row together (tile_lu32_z)
     if (chained) HIPC(hipMemsetAsync(d_chain_cnt, 0, sizeof(int32_t) * (size_t)chain_words, STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
     hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, STREAM, nnz, d_vals, d_arow, d_ci, d_rs, d_cs, d_vs, d_vs2, d_scalar, d_info);
@@ -1603,7 +1630,7 @@ int32_t Solver::run_factor() {
         pst = (hipStream_t)stream4;
     }
     if (!S.sym_lower && opt.matching > 0) { // (general storage: would a maximum-product matching be called for with these values?)
-        hipLaunchKernelGGL(k_diag_check, dim3((n + 255) / 256), dim3(256), 0, pst, n, d_rp, d_ci, d_vs, d_dcol, 0.01, d_info);
+        hipLaunchKernelGGL(k_diag_check, dim3((n + 255) / 256), dim3(256), 0, pst, n, d_rp, d_ci, d_vs, d_dcol, 0.01, d_info, opt.complex_pairs ? 1 : 0);
         launches++;
     }
     if (zero_cnt > 0) { // the E / E' panels start as [I; 0] / [I, 0]
@@ -1648,7 +1675,7 @@ int32_t Solver::run_factor() {
                 hipLaunchKernelGGL(k_extend_add_lds<true>, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
                                    d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             else if (ea_lds)
-                hipLaunchKernelGGL(k_extend_add_lds<false>, dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
+                hipLaunchKernelGGL((PZ ? k_extend_add_lds<false, true> : k_extend_add_lds<false, false>), dim3(L.ea_cnt), dim3(256), sizeof(double) * EA_TILE_C * EA_TILE_R, STREAM, d_ea + L.ea_off, d_ear, d_rel,
                                    d_pool, d_ea_sc + L.ea_off, d_sc_k, d_sc_pos, d_vs, d_vs2, d_dws, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
             else if (S.sym_mode) hipLaunchKernelGGL(k_extend_add<true>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
             else hipLaunchKernelGGL(k_extend_add<false>, dim3(L.ea_cnt), dim3(256), 0, STREAM, d_ea + L.ea_off, d_ear, d_rel, d_pool);
@@ -1669,17 +1696,17 @@ int32_t Solver::run_factor() {
             const SmallAsm sasm = {d_sd, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel, d_lists};
             if (L.small_cnt_a > 0) {
                 const size_t shmem_a = sizeof(double) * (size_t)L.small_ld_a * (size_t)L.small_ld_a;
-                hipLaunchKernelGGL(k_small_factor<1>, dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
+                hipLaunchKernelGGL((PZ ? k_small_factor<1, true> : k_small_factor<1, false>), dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld_a, sasm, d_diag);
                 launches++;
             }
             // few fronts in the launch: four wavefronts per front (the launch lasts as long as one front's LU)
             const int32_t cnt_b = L.small_cnt - L.small_cnt_a;
             if (cnt_b <= small_wide_max && L.small_ld > 33)
-                hipLaunchKernelGGL(k_small_factor<4>, dim3(cnt_b), dim3(256), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
+                hipLaunchKernelGGL((PZ ? k_small_factor<4, true> : k_small_factor<4, false>), dim3(cnt_b), dim3(256), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm, d_diag);
             else
-                hipLaunchKernelGGL(k_small_factor<1>, dim3(cnt_b), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
+                hipLaunchKernelGGL((PZ ? k_small_factor<1, true> : k_small_factor<1, false>), dim3(cnt_b), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm, d_diag);
             launches++;
         } else if (forked) {
@@ -1710,7 +1737,7 @@ int32_t Solver::run_factor() {
                 const size_t dyn = sizeof(double) * (size_t)L.mid_lds[c];
                 const FrontDesc *mfd = d_bigfd + moff;
                 if (c >= 3) {
-                    hipLaunchKernelGGL(k_front_lu, dim3(L.mid_cnt[c]), dim3(64 * MIDL_NW), dyn, mst, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                    hipLaunchKernelGGL((PZ ? k_front_lu<true> : k_front_lu<false>), dim3(L.mid_cnt[c]), dim3(64 * MIDL_NW), dyn, mst, mfd, d_pool, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                     launches++;
                     continue;
                 }
@@ -1736,7 +1763,7 @@ int32_t Solver::run_factor() {
             const int32_t pre_lu = 1; // (the first diagonal tiles always get their launch here: a panel task that factorises the tile itself is 10 us longer)
             if (pre_lu) {
                 if (S.sym_mode) hipLaunchKernelGGL(k_diag0<true>, dim3(st0.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
-                else hipLaunchKernelGGL(k_diag0<false>, dim3(st0.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else hipLaunchKernelGGL((PZ ? k_diag0<false, true> : k_diag0<false, false>), dim3(st0.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                 launches++;
             }
             const ChainTask *ct = (const ChainTask *)d_chain + L.chain_off;
@@ -1756,7 +1783,7 @@ int32_t Solver::run_factor() {
             const int32_t pre_lu = (k0 == 0 && (ea_lu || (st.n_panel >= diag0_min_panels && (S.sym_mode || !use_binv)))) ? 1 : 0;
             if (pre_lu && !ea_lu) {
                 if (S.sym_mode) hipLaunchKernelGGL(k_diag0<true>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
-                else hipLaunchKernelGGL(k_diag0<false>, dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
+                else hipLaunchKernelGGL((PZ ? k_diag0<false, true> : k_diag0<false, false>), dim3(st.nactive), dim3(64), 0, STREAM, lfd, d_pool, d_lperm, d_dws, d_scalar, opt.pivot_epsilon, d_info, d_diag);
                 launches++;
             }
             if (S.sym_mode) {
@@ -1782,16 +1809,16 @@ int32_t Solver::run_factor() {
                                        d_scalar, opt.pivot_epsilon, d_info, d_diag);
                 launches--;
             } else {
-                hipLaunchKernelGGL(k_panel<false>, dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
+                hipLaunchKernelGGL((PZ ? k_panel<false, true> : k_panel<false, false>), dim3(st.n_panel), dim3(PANEL_T), 0, STREAM, d_tasks + st.pfx_panel, st.nactive, lfd, k0,
                                    d_pool, d_lperm, d_dws, dws_stride, d_scalar, opt.pivot_epsilon, d_info, d_diag, pre_lu, Pfx4{st.ppfx[0], st.ppfx[1], st.ppfx[2]});
                 if (L.upd_ts == UPD_T && st.split && st.n_rest > 0) {
                     // the bulk of the previous split step must be through before anything touches its tiles again
                     if (rest_pending) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_rest, 0), ERROR_HIP_SYNCHRONIZE);
                     HIPC(hipEventRecord((hipEvent_t)ev_pb, STREAM), ERROR_HIP_SYNCHRONIZE);
                     HIPC(hipStreamWaitEvent((hipStream_t)stream4, (hipEvent_t)ev_pb, 0), ERROR_HIP_SYNCHRONIZE);
-                    hipLaunchKernelGGL(k_update<false>, dim3(st.n_crit), dim3(256), 0, STREAM, d_tasks + st.pfx_crit, st.nactive, lfd, k0, d_pool, d_dws,
+                    hipLaunchKernelGGL((PZ ? k_update<false, true> : k_update<false, false>), dim3(st.n_crit), dim3(256), 0, STREAM, d_tasks + st.pfx_crit, st.nactive, lfd, k0, d_pool, d_dws,
                                        dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 1, Pfx4{-1, -1, -1});
-                    hipLaunchKernelGGL(k_update<false>, dim3(st.n_rest), dim3(256), 0, (hipStream_t)stream4, d_tasks + st.pfx_rest, st.nactive, lfd, k0,
+                    hipLaunchKernelGGL((PZ ? k_update<false, true> : k_update<false, false>), dim3(st.n_rest), dim3(256), 0, (hipStream_t)stream4, d_tasks + st.pfx_rest, st.nactive, lfd, k0,
                                        d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, 2, Pfx4{-1, -1, -1});
                     HIPC(hipEventRecord((hipEvent_t)ev_rest, (hipStream_t)stream4), ERROR_HIP_SYNCHRONIZE);
                     rest_pending = true;
@@ -1802,10 +1829,10 @@ int32_t Solver::run_factor() {
                         HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_rest, 0), ERROR_HIP_SYNCHRONIZE);
                         rest_pending = false;
                     }
-                    hipLaunchKernelGGL(k_update<false>, dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                    hipLaunchKernelGGL((PZ ? k_update<false, true> : k_update<false, false>), dim3(st.n_update), dim3(256), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                        d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, upd_xcd ? 4 : 0, Pfx4{st.upfx[0], st.upfx[1], st.upfx[2]});
                 } else
-                    hipLaunchKernelGGL(k_update32<false>, dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
+                    hipLaunchKernelGGL((PZ ? k_update32<false, true> : k_update32<false, false>), dim3(st.n_update), dim3(64), 0, STREAM, d_tasks + st.pfx_update, st.nactive, lfd, k0,
                                        d_pool, d_dws, dws_stride, d_lperm, d_scalar, opt.pivot_epsilon, d_info, d_diag, Pfx4{st.upfx[0], st.upfx[1], st.upfx[2]});
             }
             launches += 2;
@@ -2561,6 +2588,75 @@ int32_t Solver::determinant(double *mantissa, double *exponent, double *rcond) {
     if (mantissa) *mantissa = m;
     if (exponent) *exponent = e;
     if (rcond) *rcond = (umax > 0.0 && std::isfinite(umin)) ? umin / umax : 0.0;
+    return SUCCESSFUL_EXIT;
+}
+
+// Determinant of the COMPLEX matrix whose real-equivalent form was factorised with opt.complex_pairs (the coefficient / exponent pair
+// umfpack_zi_get_determinant returns, /root/reference/russell_sparse/c_code/interface_complex_umfpack.c:187-195): the product of the
+// complex pivots the paired pivot searches left (kernels_common.hpp, FactorInfoExt), over the scalings of the pairs, times the sign of
+// the permutation of the complex rows (interchanges inside the pivot blocks, matching).
+int32_t Solver::determinant_complex(double *mantissa_re, double *mantissa_im, double *exponent, double *rcond) {
+    if (!factorized) return ERROR_NEED_FACTORIZATION;
+    if (!opt.complex_pairs) return ERROR_NOT_AVAILABLE;
+    DeviceScope dev_scope(device);
+    const int32_t n = S.n, nc = n / 2;
+    std::vector<double> zd((size_t)n), rs((size_t)n), cs;
+    std::vector<int32_t> lp((size_t)n);
+    const bool col_scaled = d_cs != nullptr;
+    if (col_scaled) {
+        cs.resize((size_t)n);
+        HIPC(hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    }
+    HIPC(hipMemcpyAsync(zd.data(), d_diag + n, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpyAsync(rs.data(), d_rs, sizeof(double) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipMemcpyAsync(lp.data(), d_lperm, sizeof(int32_t) * n, hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+    HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+    double mr = 1.0, mi = 0.0, e = 0.0, zmin = INFINITY, zmax = 0.0;
+    bool zero = false;
+    for (int32_t k = 0; k < nc; k++) {
+        // (the two rows of a pair carry the same scale up to rounding; any pairing of pivots and scales: only the products matter)
+        double sc = std::sqrt(rs[2 * k] * rs[2 * k + 1]);
+        if (col_scaled) sc *= std::sqrt(cs[2 * k] * cs[2 * k + 1]);
+        const double a = zd[2 * k], b = zd[2 * k + 1], mod = std::hypot(a, b);
+        zmin = std::min(zmin, mod), zmax = std::max(zmax, mod);
+        const double zr = a / sc, zi = b / sc;
+        if ((zr == 0.0 && zi == 0.0) || !std::isfinite(zr) || !std::isfinite(zi)) {
+            zero = true;
+            continue;
+        }
+        const double tr = mr * zr - mi * zi, ti = mr * zi + mi * zr;
+        mr = tr, mi = ti;
+        double mm = std::hypot(mr, mi);
+        while (mm >= 10.0) mr /= 10.0, mi /= 10.0, mm /= 10.0, e += 1.0;
+        while (mm < 1.0 && mm > 0.0) mr *= 10.0, mi *= 10.0, mm *= 10.0, e -= 1.0;
+    }
+    int parity = 0;
+    std::vector<char> seen;
+    for (int32_t s = 0; s < S.nsuper; s++) {
+        const int32_t first = S.sn_first[s], pc = S.npiv(s) / 2;
+        if ((first & 1) || (S.npiv(s) & 1)) return ERROR_HIPMF_SYMBOLIC; // (analyse with pair_blocks keeps the pairs inside one supernode)
+        seen.assign((size_t)pc, 0);
+        for (int32_t i = 0; i < pc; i++) {
+            if (seen[i]) continue;
+            int len = 0;
+            for (int32_t j = i; !seen[j]; j = lp[first + 2 * j] >> 1) {
+                if ((lp[first + 2 * j] >> 1) != (lp[first + 2 * j + 1] >> 1) || (lp[first + 2 * j] >> 1) >= pc) {
+                    last_error = "internal error: a pivot pair was split";
+                    return ERROR_HIPMF_SYMBOLIC;
+                }
+                seen[j] = 1;
+                len++;
+            }
+            if ((len & 1) == 0) parity ^= 1;
+        }
+    }
+    if (matched) parity ^= match_parity;
+    if (parity) mr = -mr, mi = -mi;
+    if (zero || n_zero_pivot > 0) mr = 0.0, mi = 0.0, e = 0.0;
+    if (mantissa_re) *mantissa_re = mr;
+    if (mantissa_im) *mantissa_im = mi;
+    if (exponent) *exponent = e;
+    if (rcond) *rcond = (zmax > 0.0 && std::isfinite(zmin)) ? zmin / zmax : 0.0;
     return SUCCESSFUL_EXIT;
 }
 

@@ -51,6 +51,9 @@ struct NumericOptions {
     int32_t refinement_nstep = 2;   // UMFPACK's default UMFPACK_IRSTEP is 2
     int32_t matching = 1;           // maximum-product matching + scaling at initialize: 0 never, 1 when the diagonal is weak, 2 always
                                     // (needs the values at initialize; general storage only)
+    bool complex_pairs = false;     // the system is the real-equivalent form of a complex matrix (rows / columns 2 k, 2 k + 1 = Re, Im of complex
+                                    // row / column k; interface_complex_hipmf.cpp): ordering, matching and pivot searches keep the pairs together,
+                                    // and the factorisation leaves the complex pivots for determinant_complex()
     bool verbose = false;
 };
 
@@ -121,6 +124,7 @@ class Solver {
     int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
     int32_t determinant(double *mantissa, double *exponent, double *rcond);
     int32_t rcond_estimate(double *rcond); // min |u_ii| / max |u_ii| by a device reduction
+    int32_t determinant_complex(double *mantissa_re, double *mantissa_im, double *exponent, double *rcond); // opt.complex_pairs: det of the COMPLEX matrix = (re + i im) x 10^exponent
     int32_t adopt_factor(const double *d_values); // factor buffers were filled by a peer (many-RHS multi-GPU path)
     // The caller's value arrays hold nnz_lower entries (the lower triangle it handed to the C-ABI) while the handle was analysed with
     // the mirrored general matrix: entry k of the handle's CSR is entry emap[k] of the caller's.  Every entry point that takes CSR

@@ -588,7 +588,42 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
 
     Graph g;
     const int threads = host_threads(opt);
-    int rc = build_graph(n, rp, ci, g, threads);
+    int rc;
+    const bool pairs = opt.pair_blocks;
+    if (pairs) {
+        // the structure of the pair (2 k, 2 k + 1) is made explicit: both rows hold both columns of every pair either of them touches, the
+        // pair's own 2 x 2 block included (whatever the caller stored; entries that are not in A are structural zeros of the fronts).  Then
+        // 2 k + 1 is the parent of 2 k in the elimination tree and its only child, the two columns have the same structure below them, and
+        // the postorder keeps them next to each other: one fundamental supernode holds both.
+        if (n % 2 != 0 || sym_lower) return -1;
+        std::vector<int32_t> rp2((size_t)n + 1, 0), ci2, mark((size_t)n / 2, -1);
+        ci2.reserve((size_t)rp[n] * 2 + (size_t)n * 2);
+        for (int32_t k = 0; k < n / 2; k++) {
+            const size_t b = ci2.size();
+            mark[k] = k, ci2.push_back(k);
+            for (int32_t i = 2 * k; i < 2 * k + 2; i++) {
+                if (rp[i + 1] < rp[i]) return -1;
+                for (int32_t q = rp[i]; q < rp[i + 1]; q++) {
+                    const int32_t j = ci[q];
+                    if (j < 0 || j >= n) return -2;
+                    if (mark[j / 2] != k) mark[j / 2] = k, ci2.push_back(j / 2);
+                }
+            }
+            std::sort(ci2.begin() + b, ci2.end());
+            const size_t cnt = ci2.size() - b;
+            // (pair columns -> both columns, twice: rows 2 k and 2 k + 1)
+            ci2.resize(b + 4 * cnt);
+            for (size_t e = cnt; e-- > 0;) {
+                const int32_t c = ci2[b + e];
+                ci2[b + 2 * e] = 2 * c, ci2[b + 2 * e + 1] = 2 * c + 1;
+            }
+            std::copy(ci2.begin() + b, ci2.begin() + b + 2 * cnt, ci2.begin() + b + 2 * cnt);
+            rp2[2 * k + 1] = (int32_t)(b + 2 * cnt), rp2[2 * k + 2] = (int32_t)(b + 4 * cnt);
+            if (ci2.size() > 0x7fffffffULL) return -1;
+        }
+        rc = build_graph(n, rp2.data(), ci2.data(), g, threads);
+    } else
+        rc = build_graph(n, rp, ci, g, threads);
     if (rc != 0) return rc;
 
     S.seconds_phase[0] = since(t_phase), t_phase = clk::now();
@@ -598,6 +633,26 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     bool single_front = n <= opt.dense_n;
     if (single_front || opt.ordering == ORDERING_NATURAL) {
         std::iota(perm0.begin(), perm0.end(), 0);
+    } else if (pairs) {
+        // the graph of the pairs is ordered, every pair takes two consecutive places
+        Graph gc;
+        gc.n = n / 2;
+        gc.ptr.assign((size_t)n / 2 + 1, 0);
+        for (int32_t k = 0; k < n / 2; k++) gc.ptr[(size_t)k + 1] = gc.ptr[k] + (g.ptr[2 * k + 1] - g.ptr[2 * k] - 1) / 2;
+        gc.adj.resize((size_t)gc.ptr[n / 2]);
+        for (int32_t k = 0; k < n / 2; k++) {
+            int64_t w = gc.ptr[k];
+            for (int64_t q = g.ptr[2 * k]; q < g.ptr[2 * k + 1]; q++)
+                if ((g.adj[q] & 1) == 0 && g.adj[q] != 2 * k) gc.adj[(size_t)w++] = g.adj[q] / 2; // (ascending, one per pair: 2 k's list holds 2 k + 1 and both columns of every other pair)
+            if (w != gc.ptr[(size_t)k + 1]) return -11;
+        }
+        std::vector<int32_t> permc, leafc;
+        nested_dissection(gc, opt, permc, leafc);
+        for (int32_t k = 0; k < n / 2; k++) perm0[2 * k] = 2 * permc[k], perm0[2 * k + 1] = 2 * permc[k] + 1;
+        if (!leafc.empty()) {
+            leaf_of.resize((size_t)n);
+            for (int32_t k = 0; k < n / 2; k++) leaf_of[2 * k] = leaf_of[2 * k + 1] = leafc[k];
+        }
     } else {
         nested_dissection(g, opt, perm0, leaf_of);
     }

@@ -31,6 +31,9 @@ struct SymbolicOptions {
     const std::atomic<double> *pool_limit_live = nullptr; // the same figure when it is produced by another thread while analyse runs (read at the tests; 0: not known yet)
     int32_t augment_above = 64;   // fronts with f > this take the tiled, augmented path (must equal kernels_common.hpp SMALL_F)
     bool symmetric_ldlt = false;  // the big fronts are factorised as L D L^T (symmetric-lower input): no E' panels
+    bool pair_blocks = false;     // n even, rows / columns 2 k and 2 k + 1 belong together (real and imaginary part of complex unknown k,
+                                  // interface_complex_hipmf.cpp): the ordering runs on the graph of the pairs, a pair stays adjacent (2 k' , 2 k' + 1
+                                  // in the permuted numbering) and inside one supernode, every front has an even number of pivots and of rows
     int32_t relax_ncol[3] = {4, 16, 48};
     double relax_zeros[3] = {0.8, 0.1, 0.05};
 };

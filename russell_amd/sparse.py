@@ -180,6 +180,7 @@ def _L():
         "rh_clinsolver_free": (None, [vp]),
         "rh_clinsolver_factorize": (cp, [vp, vp, pp(_RhParams)]),
         "rh_clinsolver_solve": (cp, [vp, vp, i64, vp, i64, i32]),
+        "rh_clinsolver_outputs": (None, [vp, pp(f64), pp(f64), pp(f64), pp(f64), pp(i32)]),
         "rh_error_string": (cp, [i32]),
         "rh_format_nanoseconds": (None, [C.c_uint64, C.c_char_p, i32]),
         "rh_is_memory_error": (i32, [cp]),
@@ -600,6 +601,12 @@ class _ComplexActual:
         if x is not None:
             x[:] = z
         return z
+
+    def outputs(self):
+        """determinant = determinant_coefficient x 10^determinant_exponent (complex_solver_umfpack.rs:411-414), rcond, perturbed pivots"""
+        dr, di, de, rc, npv = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        _L().rh_clinsolver_outputs(self._h, C.byref(dr), C.byref(di), C.byref(de), C.byref(rc), C.byref(npv))
+        return dict(determinant_coefficient=complex(dr.value, di.value), determinant_exponent=de.value, rcond_estimate=rc.value, perturbed_pivots=npv.value)
 
 
 class ComplexLinSolver:

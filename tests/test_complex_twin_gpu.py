@@ -101,3 +101,84 @@ def test_radau5_like_complex_shifted_system():
     solver.actual.factorize(coo, None)
     z = solver.actual.solve(rhs)
     assert np.max(np.abs(z - zs)) / np.max(np.abs(zs)) < 1e-12
+
+
+def _check_complex_det(A_dense, m, e):
+    sign, logabs = np.linalg.slogdet(A_dense)
+    assert 1.0 <= abs(m) < 10.0
+    assert abs(np.log10(abs(m)) + e - logabs / np.log(10.0)) < 1e-9
+    assert abs(m / abs(m) - sign) < 1e-9, (m / abs(m), sign)
+
+
+def test_determinant_works():
+    # complex_solver_umfpack.rs:523-545: compute_determinant = true on the reference's 5 x 5 sample, det = mantissa x 10^exponent
+    # (round 4: the paired pivot searches of the real-equivalent factorisation leave the complex pivots; oracle: numpy's dense complex LU)
+    A = np.zeros((5, 5), dtype=complex)
+    A[0, 0], A[0, 1] = 2 + 1j, 3 + 1j
+    A[1, 0], A[1, 2], A[1, 4] = 3 - 1j, 4 + 2j, 6 + 3j
+    A[2, 1], A[2, 2], A[2, 3] = -1 + 1j, -3 - 1j, 2 + 2j
+    A[3, 2] = 1
+    A[4, 1], A[4, 2], A[4, 4] = 4, 2, 1 + 1j
+    coo = ComplexCooMatrix(5, 5, 13, Sym.No)
+    for i, j in zip(*np.nonzero(A)):
+        coo.put(int(i), int(j), A[i, j])
+    par = LinSolParams()
+    par.compute_determinant = True
+    solver = ComplexLinSolver(Genie.Hipmf)
+    solver.actual.factorize(coo, par)
+    out = solver.actual.outputs()
+    _check_complex_det(A, out["determinant_coefficient"], out["determinant_exponent"])
+    # calling factorize again works, values through the device-side refresh (the determinant is fetched after it)
+    solver.actual.factorize(coo, None)
+    out2 = solver.actual.outputs()
+    assert out2["determinant_coefficient"] == out["determinant_coefficient"] and out2["determinant_exponent"] == out["determinant_exponent"]
+    # without the request the triple is zero (interface_complex_umfpack.c:196-200)
+    plain = ComplexLinSolver(Genie.Hipmf)
+    plain.actual.factorize(coo, None)
+    o = plain.actual.outputs()
+    assert o["determinant_coefficient"] == 0 and o["determinant_exponent"] == 0
+
+
+@pytest.mark.parametrize("case", ["helmholtz 60x50", "random weak diagonal 600", "symmetric lower helmholtz 30x28", "weak pivot blocks, natural order"])
+def test_determinant_of_larger_complex_matrices(case):
+    # tiled fronts, one-workgroup fronts, small fronts; matching on the moduli (weak diagonal); interchanges of complex rows inside the
+    # pivot blocks (natural order, no matching) -- through the C-ABI
+    import ctypes as C
+    import os
+    import scipy.sparse as sp
+    from russell_amd._capi import load
+    from test_complex_pairs_cpu import _helmholtz2d, _random_complex, _two_complex_leaves_and_a_root, _zcsr
+    symmetric, ordering, env = False, 0, {}
+    if case.startswith("helmholtz"):
+        A = _helmholtz2d(60, 50)
+    elif case.startswith("random"):
+        A = _random_complex(600, 0.01, seed=77, diag=0.05)
+    elif case.startswith("symmetric"):
+        A = _helmholtz2d(30, 28)
+        A = sp.csr_matrix((A + A.T) * 0.5)
+        symmetric = True
+    else:
+        A = _two_complex_leaves_and_a_root(40, 60, seed=460)
+        ordering, env = 2, {"HIPMF_MATCHING": "0"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        lib = load()
+        h = lib.complex_solver_hipmf_new()
+        n = A.shape[0]
+        rp, ci, zv = _zcsr(sp.tril(A).tocsr() if symmetric else A)
+        assert lib.complex_solver_hipmf_initialize(h, ordering, 1, -1.0, -1, 0, int(symmetric), n, rp, ci, zv.ctypes.data) == 0
+    finally:
+        for k, val in old.items():
+            os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
+    npert, dre, dim, dex = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
+    assert lib.complex_solver_hipmf_factorize(h, None, None, C.byref(npert), None, C.byref(dre), C.byref(dim), C.byref(dex), 1, 0, zv) == 0
+    assert npert.value == 0
+    _check_complex_det(sp.csr_matrix(A).toarray(), complex(dre.value, dim.value), dex.value)
+    rng = np.random.default_rng(3)
+    xs = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    b = sp.csr_matrix(A) @ xs
+    x = np.zeros(2 * n)
+    assert lib.complex_solver_hipmf_solve(h, x, np.ascontiguousarray(np.stack([b.real, b.imag], axis=1).ravel()), 0) == 0
+    assert np.max(np.abs(x[0::2] + 1j * x[1::2] - xs)) < 1e-9 * max(1.0, np.max(np.abs(xs)))
+    lib.complex_solver_hipmf_drop(h)

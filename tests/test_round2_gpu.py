@@ -291,8 +291,7 @@ def test_complex_cabi_direct(symmetric):
     assert lib.complex_solver_hipmf_initialize(h, 0, 1, -1.0, -1, 0, int(symmetric), n, rp, ci, zv.ctypes.data) == 0
     assert lib.complex_solver_hipmf_initialize(h, 0, 1, -1.0, -1, 0, int(symmetric), n, rp, ci, None) == 700000
     eo, es, npert, rc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
-    assert lib.complex_solver_hipmf_factorize(h, C.byref(eo), C.byref(es), C.byref(npert), C.byref(rc), 1, 0, zv) == 400000  # no determinant
-    assert lib.complex_solver_hipmf_factorize(h, C.byref(eo), C.byref(es), C.byref(npert), C.byref(rc), 0, 0, zv) == 0
+    assert lib.complex_solver_hipmf_factorize(h, C.byref(eo), C.byref(es), C.byref(npert), C.byref(rc), None, None, None, 0, 0, zv) == 0
     x = np.zeros(2 * n)
     assert lib.complex_solver_hipmf_solve(h, x, rhs, 0) == 0
     xz = x[0::2] + 1j * x[1::2]
@@ -319,7 +318,7 @@ def test_complex_cabi_direct(symmetric):
     xz2 = x[0::2] + 1j * x[1::2]
     assert np.max(np.abs(xz2 - xd / scale)) < 1e-11
     # plain CSR values again: the identity map comes back
-    assert lib.complex_solver_hipmf_factorize(h, None, None, None, None, 0, 0, zv) == 0
+    assert lib.complex_solver_hipmf_factorize(h, None, None, None, None, None, None, None, 0, 0, zv) == 0
     assert lib.complex_solver_hipmf_solve(h, x, rhs, 0) == 0
     assert np.array_equal(x[0::2] + 1j * x[1::2], xz)
     lib.complex_solver_hipmf_drop(h)

@@ -19,7 +19,7 @@ assert lib.complex_solver_hipmf_initialize(hd, 0, 1, -1.0, -1, 0, 0, n, rp, ci, 
 print("initialize %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 for rep in range(4):
     t0 = time.perf_counter()
-    assert lib.complex_solver_hipmf_factorize(hd, None, None, None, None, 0, 0, zv) == 0
+    assert lib.complex_solver_hipmf_factorize(hd, None, None, None, None, None, None, None, 0, 0, zv) == 0
     t1 = time.perf_counter()
     i, d = np.zeros(16, np.int64), np.zeros(16)
     lib.complex_solver_hipmf_get_stats(hd, i, d)
