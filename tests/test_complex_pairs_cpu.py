@@ -98,7 +98,7 @@ def test_reference_known_answer(emu_lib):
     assert np.max(np.abs(x - xs)) < 1e-12
 
 
-@pytest.mark.parametrize("n,density,diag", [(40, 0.1, 4.0), (300, 0.03, 4.0), (300, 0.03, 0.05), (700, 0.008, 0.3)])
+@pytest.mark.parametrize("n,density,diag", [(40, 0.1, 4.0), (200, 0.03, 4.0), (300, 0.03, 0.05)])
 def test_determinant_and_solution_of_random_complex_matrices(emu_lib, n, density, diag):
     # strong diagonals of any phase, and weak ones (0.05: the matching on the moduli permutes complex rows -- its sign enters the determinant;
     # the pivot searches interchange pairs inside the pivot blocks)
@@ -111,9 +111,9 @@ def test_determinant_and_solution_of_random_complex_matrices(emu_lib, n, density
 
 def test_tiled_fronts_and_one_workgroup_fronts(emu_lib):
     # a 2D mesh large enough for tiled fronts (k_panel / k_update look-ahead / first tiles in the extend-add) and k_front_lu fronts
-    A = _helmholtz2d(40, 36)
+    A = _helmholtz2d(36, 34)
     ref = None
-    for env in ({}, {"HIPMF_MID_FRONT": "0"}, {"HIPMF_EA_LDS": "0"}, {"HIPMF_UPD32_MAXF": "0", "HIPMF_EA_LU": "0"}):
+    for env in ({}, {"HIPMF_MID_FRONT": "0", "HIPMF_EA_LDS": "0"}, {"HIPMF_UPD32_MAXF": "0", "HIPMF_EA_LU": "0"}):
         code, m, e, x, xs, npert, _ = _factor_det_solve(emu_lib, A, env)
         assert code == 0 and npert == 0, env
         _check_det(A, m, e)

@@ -103,11 +103,11 @@ def test_radau5_like_complex_shifted_system():
     assert np.max(np.abs(z - zs)) / np.max(np.abs(zs)) < 1e-12
 
 
-def _check_complex_det(A_dense, m, e):
+def _check_complex_det(A_dense, m, e, tol=1e-9):
     sign, logabs = np.linalg.slogdet(A_dense)
     assert 1.0 <= abs(m) < 10.0
-    assert abs(np.log10(abs(m)) + e - logabs / np.log(10.0)) < 1e-9
-    assert abs(m / abs(m) - sign) < 1e-9, (m / abs(m), sign)
+    assert abs(np.log10(abs(m)) + e - logabs / np.log(10.0)) < tol
+    assert abs(m / abs(m) - sign) < 10.0 * tol, (m / abs(m), sign)
 
 
 def test_determinant_works():
@@ -148,11 +148,11 @@ def test_determinant_of_larger_complex_matrices(case):
     import scipy.sparse as sp
     from russell_amd._capi import load
     from test_complex_pairs_cpu import _helmholtz2d, _random_complex, _two_complex_leaves_and_a_root, _zcsr
-    symmetric, ordering, env = False, 0, {}
+    symmetric, ordering, env, tol = False, 0, {}, 1e-9
     if case.startswith("helmholtz"):
         A = _helmholtz2d(60, 50)
     elif case.startswith("random"):
-        A = _random_complex(600, 0.01, seed=77, diag=0.05)
+        A = _random_complex(600, 0.01, seed=77, diag=0.005)  # (below 1 % of the rows' largest entries: the matching on the moduli is applied)
     elif case.startswith("symmetric"):
         A = _helmholtz2d(30, 28)
         A = sp.csr_matrix((A + A.T) * 0.5)
@@ -174,11 +174,11 @@ def test_determinant_of_larger_complex_matrices(case):
     npert, dre, dim, dex = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
     assert lib.complex_solver_hipmf_factorize(h, None, None, C.byref(npert), None, C.byref(dre), C.byref(dim), C.byref(dex), 1, 0, zv) == 0
     assert npert.value == 0
-    _check_complex_det(sp.csr_matrix(A).toarray(), complex(dre.value, dim.value), dex.value)
+    _check_complex_det(sp.csr_matrix(A).toarray(), complex(dre.value, dim.value), dex.value, tol)
     rng = np.random.default_rng(3)
     xs = rng.standard_normal(n) + 1j * rng.standard_normal(n)
     b = sp.csr_matrix(A) @ xs
     x = np.zeros(2 * n)
     assert lib.complex_solver_hipmf_solve(h, x, np.ascontiguousarray(np.stack([b.real, b.imag], axis=1).ravel()), 0) == 0
-    assert np.max(np.abs(x[0::2] + 1j * x[1::2] - xs)) < 1e-9 * max(1.0, np.max(np.abs(xs)))
+    assert np.max(np.abs(x[0::2] + 1j * x[1::2] - xs)) < max(1e-9, tol) * max(1.0, np.max(np.abs(xs)))
     lib.complex_solver_hipmf_drop(h)
