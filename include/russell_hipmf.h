@@ -82,7 +82,9 @@ void solver_hipmf_drop(struct InterfaceHIPMF *solver);
  * get a maximum-product matching + row/column scaling pre-permutation, which stays in force for every later
  * factorisation with this handle.  A symmetric-lower matrix with such a diagonal (indefinite: the Lagrange rows of
  * CooMatrix::put_lagrange_block, coo_matrix.rs:823-857) is mirrored to general storage inside the handle and takes the same
- * path (HIPMF_COUNTER_SYM_EXPANDED); the caller keeps passing lower-triangle values and lower-triangle value maps. */
+ * path (HIPMF_COUNTER_SYM_EXPANDED); the caller keeps passing lower-triangle values and lower-triangle value maps.  Round 4: a
+ * symmetric-lower handle initialised WITHOUT values makes that decision at its first solver_hipmf_factorize (one more analysis inside
+ * that call when the diagonal is weak; handles with a value map installed keep the L D L^T path). */
 int32_t solver_hipmf_initialize(struct InterfaceHIPMF *solver,
                                 int32_t ordering,
                                 int32_t scaling,

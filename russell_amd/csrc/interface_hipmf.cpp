@@ -34,6 +34,9 @@ struct InterfaceHIPMF {
     // the caller keeps handing over lower-triangle values, entry k of the handle's CSR is entry emap[k] of the caller's
     bool expanded = false;
     int64_t nnz_lower = 0;
+    // a symmetric-lower handle that was initialised WITHOUT values looks at the first values it is asked to factorise (see factorize_body)
+    bool sym_unchecked = false;
+    SymbolicOptions so_keep;
     // device words of solver_hipmf_broadcast_factor's plan check (8 x int64 header, 2 x int32 status), allocated at initialize: no rank
     // can fail an allocation between two collectives
     int64_t *d_hdr = nullptr;
@@ -89,6 +92,61 @@ void solver_hipmf_drop(struct InterfaceHIPMF *h) {
     delete h;
 }
 
+// true when the matrix given as its LOWER triangle has a weak diagonal somewhere: missing, zero or < 1 % of the largest entry of the
+// row / column (the criterion of the general path, matching.cpp); false as well when an entry above the diagonal is met
+static bool sym_lower_diagonal_is_weak(int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
+    std::vector<double> rmax((size_t)ndim, 0.0), dg((size_t)ndim, 0.0);
+    for (int32_t i = 0; i < ndim; i++)
+        for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+            const int32_t j = col_indices[k];
+            if (j > i) return false;
+            const double a = std::fabs(values[k]);
+            rmax[(size_t)i] = std::max(rmax[(size_t)i], a), rmax[(size_t)j] = std::max(rmax[(size_t)j], a);
+            if (j == i) dg[(size_t)i] = a;
+        }
+    for (int32_t i = 0; i < ndim; i++)
+        if (dg[(size_t)i] < 0.01 * rmax[(size_t)i] || rmax[(size_t)i] == 0.0) return true;
+    return false;
+}
+
+// the lower triangle mirrored to general storage, analysed with these values (matching + scaling), the expansion map installed: the
+// caller keeps handing over lower-triangle values
+static int32_t initialize_expanded(struct InterfaceHIPMF *h, int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values,
+                                   const SymbolicOptions &so, const NumericOptions &no) {
+    const int64_t nl = row_pointers[ndim];
+    std::vector<int64_t> cnt((size_t)ndim + 1, 0);
+    for (int32_t i = 0; i < ndim; i++)
+        for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+            cnt[(size_t)i + 1]++;
+            if (col_indices[k] != i) cnt[(size_t)col_indices[k] + 1]++;
+        }
+    for (int32_t i = 0; i < ndim; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
+    if (cnt[(size_t)ndim] > 0x7fffffffLL) return ERROR_HIPMF_INVALID_MATRIX;
+    std::vector<int32_t> rpf((size_t)ndim + 1), cif((size_t)cnt[(size_t)ndim]), emap((size_t)cnt[(size_t)ndim]);
+    std::vector<double> vf((size_t)cnt[(size_t)ndim]);
+    for (int32_t i = 0; i <= ndim; i++) rpf[(size_t)i] = (int32_t)cnt[(size_t)i];
+    // row i of the full matrix: its stored lower entries (columns ascending, <= i), then the mirrored ones (rows r > i ascending):
+    // filling row by row in ascending order of the source row keeps every row's columns ascending
+    std::vector<int64_t> w(cnt.begin(), cnt.end() - 1);
+    for (int32_t i = 0; i < ndim; i++)
+        for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+            const int64_t q = w[(size_t)i]++;
+            cif[(size_t)q] = col_indices[k], vf[(size_t)q] = values[k], emap[(size_t)q] = k;
+        }
+    for (int32_t i = 0; i < ndim; i++)
+        for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
+            const int32_t j = col_indices[k];
+            if (j == i) continue;
+            const int64_t q = w[(size_t)j]++;
+            cif[(size_t)q] = i, vf[(size_t)q] = values[k], emap[(size_t)q] = k;
+        }
+    int32_t code = h->solver.initialize(ndim, rpf.data(), cif.data(), false, so, no, vf.data());
+    if (code == SUCCESSFUL_EXIT) code = h->solver.set_expansion(nl, emap);
+    if (code == SUCCESSFUL_EXIT) h->expanded = true, h->nnz_lower = nl;
+    else h->solver.release();
+    return code;
+}
+
 static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32_t scaling, double pivot_epsilon,
                                 int32_t refinement_nstep, C_BOOL verbose, C_BOOL general_symmetric, C_BOOL positive_definite,
                                 int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values) {
@@ -133,56 +191,12 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
     bool expand = false;
     if (sym_lower && values && ndim > 1 && no.matching > 0 && row_pointers[0] == 0 && validate_csr(ndim, row_pointers, col_indices) == 0) {
         const char *e = getenv("HIPMF_SYM_EXPAND");
-        if (!e || atoi(e) != 0) {
-            std::vector<double> rmax((size_t)ndim, 0.0), dg((size_t)ndim, 0.0);
-            bool lower_only = true;
-            for (int32_t i = 0; i < ndim && lower_only; i++)
-                for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
-                    const int32_t j = col_indices[k];
-                    if (j > i) {
-                        lower_only = false;
-                        break;
-                    }
-                    const double a = std::fabs(values[k]);
-                    rmax[(size_t)i] = std::max(rmax[(size_t)i], a), rmax[(size_t)j] = std::max(rmax[(size_t)j], a);
-                    if (j == i) dg[(size_t)i] = a;
-                }
-            if (lower_only)
-                for (int32_t i = 0; i < ndim && !expand; i++) expand = dg[(size_t)i] < 0.01 * rmax[(size_t)i] || rmax[(size_t)i] == 0.0;
-        }
+        if (!e || atoi(e) != 0) expand = sym_lower_diagonal_is_weak(ndim, row_pointers, col_indices, values);
     }
+    h->so_keep = so;
+    h->sym_unchecked = sym_lower && !values && no.matching > 0; // (no values yet: the first factorize looks at the diagonal)
     if (expand) {
-        const int64_t nl = row_pointers[ndim];
-        std::vector<int64_t> cnt((size_t)ndim + 1, 0);
-        for (int32_t i = 0; i < ndim; i++)
-            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
-                cnt[(size_t)i + 1]++;
-                if (col_indices[k] != i) cnt[(size_t)col_indices[k] + 1]++;
-            }
-        for (int32_t i = 0; i < ndim; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
-        if (cnt[(size_t)ndim] > 0x7fffffffLL) return ERROR_HIPMF_INVALID_MATRIX;
-        std::vector<int32_t> rpf((size_t)ndim + 1), cif((size_t)cnt[(size_t)ndim]), emap((size_t)cnt[(size_t)ndim]);
-        std::vector<double> vf((size_t)cnt[(size_t)ndim]);
-        for (int32_t i = 0; i <= ndim; i++) rpf[(size_t)i] = (int32_t)cnt[(size_t)i];
-        // row i of the full matrix: its stored lower entries (columns ascending, <= i), then the mirrored ones (rows r > i ascending):
-        // filling row by row in ascending order of the source row keeps every row's columns ascending
-        std::vector<int64_t> w(cnt.begin(), cnt.end() - 1);
-        for (int32_t i = 0; i < ndim; i++)
-            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
-                const int64_t q = w[(size_t)i]++;
-                cif[(size_t)q] = col_indices[k], vf[(size_t)q] = values[k], emap[(size_t)q] = k;
-            }
-        for (int32_t i = 0; i < ndim; i++)
-            for (int32_t k = row_pointers[i]; k < row_pointers[i + 1]; k++) {
-                const int32_t j = col_indices[k];
-                if (j == i) continue;
-                const int64_t q = w[(size_t)j]++;
-                cif[(size_t)q] = i, vf[(size_t)q] = values[k], emap[(size_t)q] = k;
-            }
-        code = h->solver.initialize(ndim, rpf.data(), cif.data(), false, so, no, vf.data());
-        if (code == SUCCESSFUL_EXIT) code = h->solver.set_expansion(nl, emap);
-        if (code == SUCCESSFUL_EXIT) h->expanded = true, h->nnz_lower = nl;
-        else h->solver.release();
+        code = initialize_expanded(h, ndim, row_pointers, col_indices, values, so, no);
     } else {
         code = h->solver.initialize(ndim, row_pointers, col_indices, sym_lower, so, no, values);
     }
@@ -268,6 +282,26 @@ static int32_t factorize_body(struct InterfaceHIPMF *h, int32_t *effective_order
     if (!h || !values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     h->solver.opt.verbose = verbose == 1;
+    if (h->sym_unchecked) {
+        // A symmetric-lower handle analysed WITHOUT values (round 4): these are the first numbers it sees.  A weak diagonal (saddle-point /
+        // KKT matrices) sends it where initialize would have sent it with values -- mirrored to general storage, maximum-product matching,
+        // LU with pivoting inside the pivot blocks -- at the price of one more analysis, inside this call (HIPMF_COUNTER_SYM_EXPANDED
+        // tells).  Once per handle; a value map installed meanwhile speaks of the lower triangle's entries and is not carried over:
+        // such handles keep the L D L^T path.
+        h->sym_unchecked = false;
+        const char *e = getenv("HIPMF_SYM_EXPAND");
+        const Solver &sv = h->solver;
+        if ((!e || atoi(e) != 0) && sv.S.sym_lower && !h->expanded && sv.nnz_in_values() == 0 && sv.S.n > 1 &&
+            sym_lower_diagonal_is_weak(sv.S.n, sv.kept_row_pointers().data(), sv.kept_col_indices().data(), values)) {
+            const std::vector<int32_t> rp = sv.kept_row_pointers(), ci = sv.kept_col_indices();
+            const NumericOptions no = sv.opt;
+            const int32_t ndim = sv.S.n;
+            h->solver.release();
+            const int32_t c = initialize_expanded(h, ndim, rp.data(), ci.data(), values, h->so_keep, no);
+            if (c != SUCCESSFUL_EXIT) return c;
+            if (verbose == 1) printf("solver_hipmf_factorize: weak diagonal of a symmetric matrix: analysed again as a general matrix with matching\n");
+        }
+    }
     int32_t code = h->solver.factorize(values, false);
     if (verbose == 1 && h->solver.n_perturbed > 0)
         printf("solver_hipmf_factorize: WARNING: %d pivot(s) perturbed (matrix may be (nearly) singular)\n", h->solver.n_perturbed);

@@ -154,3 +154,33 @@ def test_host_mirror_put_lagrange_block_lower_storage(emu_lib):
             assert np.max(np.abs(x - xs)) <= 1e-10
     finally:
         lib.rh_set_hipmf_library(b"")
+
+
+def test_saddle_point_without_values_at_initialize_is_sent_to_the_general_path_by_the_first_factorize(emu_lib):
+    # round 4: initialize(values = NULL) analyses the lower triangle for L D L^T; the first factorize sees the zero (2,2) block and redoes
+    # the analysis on the mirrored matrix with the matching -- inside the call, once per handle
+    A, L = saddle_point(12, 30)
+    n = A.shape[0]
+    rp, ci, v = _csr(L)
+    rng = np.random.default_rng(1)
+    xs = rng.standard_normal(n)
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci, general_symmetric=True) == 0
+    assert s.counter("sym_expanded") == 0 and s.counter("symmetric_ldlt") == 1
+    assert s.factorize(v, compute_determinant=True) == 0
+    assert s.counter("sym_expanded") == 1 and s.counter("symmetric_ldlt") == 0 and s.stats()["matched"] == 1
+    assert s.num_perturbed == 0
+    sign, logdet = np.linalg.slogdet(A.toarray())
+    assert np.sign(s.det_coefficient) == sign and abs(np.log10(abs(s.det_coefficient)) + s.det_exponent - logdet / np.log(10.0)) < 1e-9
+    x = s.solve(A @ xs)
+    assert np.max(np.abs(x - xs)) <= 1e-10 * np.max(np.abs(xs))
+    assert s.factorize(v * 1.5) == 0  # (the handle stays where it is: lower-triangle values as before)
+    assert np.max(np.abs(s.solve(1.5 * (A @ xs)) - xs)) <= 1e-10 * np.max(np.abs(xs))
+    s.close()
+    # a definite matrix handed over the same way keeps its L D L^T fronts
+    K = sp.tril(A[:144, :144], format="csr")
+    K.sort_indices()
+    s = Hipmf(emu_lib)
+    assert s.initialize(144, *_csr(K)[:2], general_symmetric=True) == 0
+    assert s.factorize(_csr(K)[2]) == 0 and s.counter("sym_expanded") == 0 and s.counter("symmetric_ldlt") == 1
+    s.close()
