@@ -156,6 +156,11 @@ int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *solver, int32_t *per
  * ERROR_HIPMF_INVALID_MATRIX when the matrix is structurally singular. */
 int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, const int32_t *col_indices, const double *values,
                                    int32_t *matched_row, double *row_scale, double *col_scale);
+/* The same for the REAL-EQUIVALENT form (order ndim2 = 2 n: rows / columns 2 k, 2 k + 1 = real and imaginary part of complex row /
+ * column k, entry a + i b -> [a -b; b a]) of a complex matrix, as the complex twin applies it (round 4): the matching runs on the
+ * moduli of the complex entries, a pair of rows moves as a whole (matched_row[2 k + 1] = matched_row[2 k] + 1) and shares its scales. */
+int32_t hipmf_paired_matching(int32_t ndim2, const int32_t *row_pointers, const int32_t *col_indices, const double *values, int32_t *matched_row,
+                              double *row_scale, double *col_scale);
 
 /* istats[16]: 0 ndim, 1 nnz(A), 2 nsuper, 3 nlevels, 4 nnz(L) strict, 5 nnz(U) incl. diag, 6 max front,
  *             7 max pivots, 8 perturbed pivots, 9 zero pivots, 10 refinement steps, 11 factor launches,

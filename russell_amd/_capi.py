@@ -37,6 +37,7 @@ SYMBOLS = {
                                                   C.c_int32, f64p]),
     "solver_hipmf_factorize_mapped_device": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "hipmf_max_product_matching": (C.c_int32, [C.c_int32, i32p, i32p, f64p, i32p, f64p, f64p]),
+    "hipmf_paired_matching": (C.c_int32, [C.c_int32, i32p, i32p, f64p, i32p, f64p, f64p]),
     "solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
     "solver_hipmf_reset_timers": (C.c_int32, [C.c_void_p]),
     "complex_solver_hipmf_new": (C.c_void_p, []),

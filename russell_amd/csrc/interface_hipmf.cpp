@@ -443,6 +443,19 @@ int32_t hipmf_max_product_matching(int32_t ndim, const int32_t *row_pointers, co
     return SUCCESSFUL_EXIT;
 }
 
+int32_t hipmf_paired_matching(int32_t ndim2, const int32_t *row_pointers, const int32_t *col_indices, const double *values, int32_t *matched_row,
+                              double *row_scale, double *col_scale) {
+    if (!row_pointers || !col_indices || !values || !matched_row || !row_scale || !col_scale) return ERROR_NULL_POINTER;
+    if (ndim2 < 2 || ndim2 % 2 != 0 || validate_csr(ndim2, row_pointers, col_indices) != 0) return ERROR_HIPMF_INVALID_MATRIX;
+    return guarded(nullptr, [&]() {
+        std::vector<int32_t> mrow;
+        std::vector<double> dr, dc;
+        if (paired_matching(ndim2, row_pointers, col_indices, values, mrow, dr, dc) != 0) return (int32_t)ERROR_HIPMF_INVALID_MATRIX;
+        for (int32_t i = 0; i < ndim2; i++) matched_row[i] = mrow[i], row_scale[i] = dr[i], col_scale[i] = dc[i];
+        return (int32_t)SUCCESSFUL_EXIT;
+    });
+}
+
 int32_t solver_hipmf_get_permutation(struct InterfaceHIPMF *h, int32_t *perm) {
     if (!h || !perm) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
