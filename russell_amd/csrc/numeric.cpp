@@ -48,8 +48,20 @@ struct DeviceScope {
 
 constexpr int32_t MAX_LDS_DOUBLES = 7936; // 62 KiB of dynamic LDS for the w1 / v vectors of the big-front solves
 
-template <class T>
-static hipError_t dev_upload(T **dptr, const std::vector<T> &v) {
+// vector whose resize() leaves trivially constructible elements uninitialised: the extend-add task lists (gigabytes for a 3D problem) are
+// sized once and filled by the planning threads, which then also take the first-touch page faults
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+
+template <class T, class A>
+static hipError_t dev_upload(T **dptr, const std::vector<T, A> &v) {
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     hipError_t e = hipMalloc((void **)dptr, bytes);
     if (e != hipSuccess) return e;
@@ -1110,8 +1122,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     std::vector<ChainTask> chain;
     chain_words = 0;
     std::vector<FrontDesc> bigfd;
-    std::vector<EaTask> ea;
-    std::vector<EaRange> ear;
+    std::vector<EaTask, NoInitAlloc<EaTask>> ea;
+    std::vector<EaRange, NoInitAlloc<EaRange>> ear;
+    std::vector<int32_t> tiled_slot((size_t)S.nsuper, -1); // s -> slot among the tiled fronts of its level
     int32_t max_big = 0;
     std::vector<SolveTask> stasks;
     levels.assign((size_t)S.nlevels, LevelPlan());
@@ -1332,70 +1345,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                 L.chain_cnt = (int32_t)((int64_t)chain.size() - L.chain_off);
             }
         }
-        // extend-add tasks: 32-column x 256-row tiles of the parent (k_extend_add_lds: EA_TILE_C x EA_TILE_R, every tile, and the first tile
-        // of a tiled LU front also factorises the front's first diagonal tile -- those tasks lead the level's list: they are the long ones)
-        L.ea_off = (int32_t)ea.size();
-        std::vector<int32_t> tiled_slot; // (s -> slot among the level's tiled fronts)
-        if (ea_lds_active()) {
-            tiled_slot.assign((size_t)S.nsuper, -1);
-            for (size_t q = 0; q < big.size(); q++) tiled_slot[(size_t)big[q]] = (int32_t)q;
-        }
-        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
-            int32_t s = S.level_sn[k];
-            bool any = false;
-            for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
-            const bool all_tiles = ea_lds_active(); // k_extend_add_lds writes the working block: every tile of every big front has a task
-            if (!any && !all_tiles) continue;
-            if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
-            int32_t f = S.fsize(s);
-            const int32_t cstep = f <= 64 ? f : (all_tiles ? EA_TILE_C : 32), rstep = f <= 64 ? f : (all_tiles ? EA_TILE_R : 256);
-            // where every child's (ascending) relative indices cross the tile boundaries: computed once per child, not per tile (a front of
-            // 76 000 rows has 716 000 tiles; four binary searches per tile and child made `initialize` of such a matrix take minutes)
-            const int32_t nch_s = S.child_ptr[s + 1] - S.child_ptr[s];
-            const int32_t ncc = (f + cstep - 1) / cstep + 1, nrc = (f + rstep - 1) / rstep + 1;
-            std::vector<int32_t> ccut((size_t)nch_s * ncc), rcut((size_t)nch_s * nrc);
-            for (int32_t q = 0; q < nch_s; q++) {
-                const int32_t ch = S.child_idx[S.child_ptr[s] + q];
-                const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
-                for (int32_t k = 0; k < ncc; k++) ccut[(size_t)q * ncc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * cstep)) - rb);
-                for (int32_t k = 0; k < nrc; k++) rcut[(size_t)q * nrc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * rstep)) - rb);
-            }
-            for (int32_t c0 = 0; c0 < f; c0 += cstep)
-                for (int32_t r0 = 0; r0 < f; r0 += rstep) {
-                    EaTask tk;
-                    tk.f_off = S.front_off[s];
-                    tk.ld = S.front_ld[s];
-                    tk.piece_begin = (int32_t)ear.size();
-                    tk.sym = S.sym_mode ? 1 : 0; // L D L^T parent: lower triangle only
-                    const int32_t c1 = std::min(f, c0 + cstep), r1 = std::min(f, r0 + rstep);
-                    if (S.sym_mode && r1 <= c0) continue; // tile strictly above the diagonal
-                    for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
-                        int32_t ch = S.child_idx[c];
-                        const int32_t q = c - S.child_ptr[s];
-                        EaRange rg;
-                        rg.jlo = ccut[(size_t)q * ncc + c0 / cstep];
-                        rg.jhi = ccut[(size_t)q * ncc + c0 / cstep + 1];
-                        rg.ilo = rcut[(size_t)q * nrc + r0 / rstep];
-                        rg.ihi = rcut[(size_t)q * nrc + r0 / rstep + 1];
-                        if (rg.jlo >= rg.jhi || rg.ilo >= rg.ihi) continue;
-                        rg.ldc = S.front_ld[ch];
-                        rg.cb_off = S.front_off[ch] + S.npiv(ch) + (int64_t)S.npiv(ch) * rg.ldc;
-                        rg.rel_off = S.sn_rowptr[ch];
-                        rg.pad = 0;
-                        ear.push_back(rg);
-                    }
-                    tk.piece_end = (int32_t)ear.size();
-                    tk.c0 = c0, tk.r0 = r0, tk.nc = c1 - c0, tk.nr = r1 - r0;
-                    tk.lu_slot = -1, tk.lu_first = 0, tk.lu_nb = 0, tk.pad = 0;
-                    if (all_tiles && c0 == 0 && r0 == 0) {
-                        tk.pad = 1; // (first tile of its front: sorted to the head of the level below)
-                        if (tiled_slot[(size_t)s] >= 0 && ea_lu_active()) tk.lu_slot = tiled_slot[(size_t)s], tk.lu_first = S.sn_first[s], tk.lu_nb = std::min<int32_t>(NB, S.npiv(s));
-                    }
-                    if (tk.piece_end > tk.piece_begin || all_tiles) ea.push_back(tk);
-                }
-        }
-        L.ea_cnt = (int32_t)ea.size() - L.ea_off;
-        if (ea_lds_active()) std::stable_partition(ea.begin() + L.ea_off, ea.end(), [](const EaTask &t) { return t.pad == 1; });
+        for (size_t q = 0; q < big.size(); q++) tiled_slot[(size_t)big[q]] = (int32_t)q;
         // solve tasks of the big fronts: 64-row slabs of the f rows (forward) / of the p pivot rows (backward)
         L.fwd_off = (int32_t)stasks.size();
         int64_t nslab = 0;
@@ -1426,6 +1376,141 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         }
     }
     if (S.sym_mode && !allbig.empty()) level_path_ok = false; // the level-set solve kernels have no L D L^T instance: same remedy
+    // ---- extend-add tasks of every level ---------------------------------------------------------------------------------------------
+    // EA_TILE_C x EA_TILE_R tiles of the parent (k_extend_add_lds: every tile of every front above SMALL_F has a task, and the first tile of
+    // a tiled LU front also factorises the front's first diagonal tile -- those tasks lead the level's list: they are the long ones); the
+    // legacy kernel (k_extend_add) gets 32 x 256 tiles, only the ones a child reaches.  With the first-touch extend-add a 3D problem has
+    // tens of millions of tiles (200^3: 22.6 M tasks + 30.4 M child pieces, 2.4 GB; built serially they were 1.7 of the 1.9 s of the launch
+    // plans): the lists are laid out by a counting pass and filled by a second one, both spread over host threads front by front.  The
+    // arrays do not depend on the number of threads (every front writes its own, precomputed ranges).
+    {
+        const bool all_tiles = ea_lds_active();
+        struct EaParent {
+            int32_t s, level;
+            int64_t ntask, nhead, nrange; // tasks (nhead of them lead the level's list), child pieces
+            int64_t head_pos, tail_pos, range_pos;
+        };
+        std::vector<EaParent> eap;
+        for (int32_t l = 0; l < S.nlevels; l++)
+            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+                const int32_t s = S.level_sn[k];
+                if (S.fsize(s) <= SMALL_F) continue; // small parents pull their children's blocks themselves (k_small_factor)
+                bool any = false;
+                for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) any |= S.nrow(S.child_idx[c]) > 0;
+                if (!any && !all_tiles) continue;
+                eap.push_back({s, l, 0, 0, 0, 0, 0, 0});
+            }
+        struct EaScratch {
+            std::vector<int32_t> ccut, rcut;
+        };
+        // one front: FILL = false counts (P.ntask / nhead / nrange), FILL = true writes the tasks at the positions of P
+        auto ea_front = [&](EaParent &P, EaScratch &t, const bool FILL) {
+            const int32_t s = P.s, f = S.fsize(s);
+            const int32_t cstep = f <= 64 ? f : (all_tiles ? EA_TILE_C : 32), rstep = f <= 64 ? f : (all_tiles ? EA_TILE_R : 256);
+            // where every child's (ascending) relative indices cross the tile boundaries: computed once per child, not per tile (a front of
+            // 76 000 rows has 716 000 tiles; four binary searches per tile and child made `initialize` of such a matrix take minutes)
+            const int32_t cb = S.child_ptr[s], nch_s = S.child_ptr[s + 1] - cb;
+            const int32_t ncc = (f + cstep - 1) / cstep + 1, nrc = (f + rstep - 1) / rstep + 1;
+            t.ccut.resize((size_t)nch_s * ncc), t.rcut.resize((size_t)nch_s * nrc);
+            for (int32_t q = 0; q < nch_s; q++) {
+                const int32_t ch = S.child_idx[cb + q];
+                const int32_t *rb = S.rel.data() + S.sn_rowptr[ch], *re = S.rel.data() + S.sn_rowptr[ch + 1];
+                for (int32_t k = 0; k < ncc; k++) t.ccut[(size_t)q * ncc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * cstep)) - rb);
+                for (int32_t k = 0; k < nrc; k++) t.rcut[(size_t)q * nrc + k] = (int32_t)(std::lower_bound(rb, re, std::min(f, k * rstep)) - rb);
+            }
+            int64_t ntask = 0, nhead = 0, nrange = 0;
+            int64_t tail_pos = P.tail_pos, range_pos = P.range_pos;
+            for (int32_t c0 = 0; c0 < f; c0 += cstep)
+                for (int32_t r0 = 0; r0 < f; r0 += rstep) {
+                    const int32_t c1 = std::min(f, c0 + cstep), r1 = std::min(f, r0 + rstep);
+                    if (S.sym_mode && r1 <= c0) continue; // tile strictly above the diagonal
+                    const int64_t piece_begin = range_pos + nrange;
+                    for (int32_t q = 0; q < nch_s; q++) {
+                        const int32_t jlo = t.ccut[(size_t)q * ncc + c0 / cstep], jhi = t.ccut[(size_t)q * ncc + c0 / cstep + 1];
+                        const int32_t ilo = t.rcut[(size_t)q * nrc + r0 / rstep], ihi = t.rcut[(size_t)q * nrc + r0 / rstep + 1];
+                        if (jlo >= jhi || ilo >= ihi) continue;
+                        if (FILL) {
+                            const int32_t ch = S.child_idx[cb + q];
+                            EaRange &rg = ear[(size_t)(range_pos + nrange)];
+                            rg.jlo = jlo, rg.jhi = jhi, rg.ilo = ilo, rg.ihi = ihi;
+                            rg.ldc = S.front_ld[ch];
+                            rg.cb_off = S.front_off[ch] + S.npiv(ch) + (int64_t)S.npiv(ch) * rg.ldc;
+                            rg.rel_off = S.sn_rowptr[ch];
+                            rg.pad = 0;
+                        }
+                        nrange++;
+                    }
+                    const int64_t piece_end = range_pos + nrange;
+                    if (!(piece_end > piece_begin || all_tiles)) continue;
+                    const bool head = all_tiles && c0 == 0 && r0 == 0; // (first tile of its front: at the head of the level's list)
+                    if (FILL) {
+                        EaTask &tk = ea[(size_t)(head ? P.head_pos : tail_pos++)];
+                        tk.f_off = S.front_off[s];
+                        tk.ld = S.front_ld[s];
+                        tk.piece_begin = (int32_t)piece_begin, tk.piece_end = (int32_t)piece_end;
+                        tk.sym = S.sym_mode ? 1 : 0; // L D L^T parent: lower triangle only
+                        tk.c0 = c0, tk.r0 = r0, tk.nc = c1 - c0, tk.nr = r1 - r0;
+                        tk.lu_slot = -1, tk.lu_first = 0, tk.lu_nb = 0, tk.pad = head ? 1 : 0;
+                        if (head && tiled_slot[(size_t)s] >= 0 && ea_lu_active())
+                            tk.lu_slot = tiled_slot[(size_t)s], tk.lu_first = S.sn_first[s], tk.lu_nb = std::min<int32_t>(NB, S.npiv(s));
+                    }
+                    ntask++, nhead += head ? 1 : 0;
+                }
+            if (!FILL) P.ntask = ntask, P.nhead = nhead, P.nrange = nrange;
+        };
+        // the fronts are handed out one at a time, largest (the last levels) first
+        std::atomic<bool> ea_oom{false};
+        auto ea_pass = [&](const bool FILL, int nthreads) {
+            std::atomic<size_t> next{0};
+            auto body = [&]() {
+                try {
+                    EaScratch t;
+                    for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < eap.size();) ea_front(eap[eap.size() - 1 - i], t, FILL);
+                } catch (const std::bad_alloc &) { // (an exception must not leave a thread)
+                    ea_oom.store(true);
+                }
+            };
+            if (nthreads <= 1) {
+                body();
+                return;
+            }
+            std::vector<std::thread> pool;
+            for (int i = 0; i < nthreads; i++) pool.emplace_back(body);
+            for (auto &th : pool) th.join();
+        };
+        int64_t tiles_bound = 0;
+        for (const EaParent &P : eap) {
+            const int64_t f = S.fsize(P.s);
+            tiles_bound += f <= 64 ? 1 : ((f + 31) / 32) * ((f + 63) / 64);
+        }
+        int ea_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = getenv("HIPMF_ND_THREADS")) ea_threads = std::max(1, atoi(e));
+        if (tiles_bound < 200000) ea_threads = 1; // (not worth the thread start-up)
+        ea_pass(false, ea_threads);
+        if (ea_oom.load()) return ERROR_MALLOC;
+        // layout: level by level, a level's first tiles (nhead) in front of its other tasks, both in the order of the level's fronts
+        int64_t task_pos = 0, range_pos = 0;
+        size_t i0 = 0;
+        for (int32_t l = 0; l < S.nlevels; l++) {
+            LevelPlan &L = levels[l];
+            size_t i1 = i0;
+            int64_t heads = 0, total = 0;
+            while (i1 < eap.size() && eap[i1].level == l) heads += eap[i1].nhead, total += eap[i1].ntask, i1++;
+            int64_t hp = task_pos, tp = task_pos + heads;
+            for (size_t i = i0; i < i1; i++) {
+                EaParent &P = eap[i];
+                P.head_pos = hp, P.tail_pos = tp, P.range_pos = range_pos;
+                hp += P.nhead, tp += P.ntask - P.nhead, range_pos += P.nrange;
+            }
+            if (task_pos + total > 0x7fffffffLL || range_pos > 0x7fffffffLL) return ERROR_HIPMF_SYMBOLIC;
+            L.ea_off = (int32_t)task_pos, L.ea_cnt = (int32_t)total;
+            task_pos += total;
+            i0 = i1;
+        }
+        ea.resize((size_t)task_pos), ear.resize((size_t)range_pos);
+        ea_pass(true, ea_threads);
+        if (ea_oom.load()) return ERROR_MALLOC;
+    }
     if (ea_lds_active()) {
         HIPMF_ALLOW_LDS(k_extend_add_lds<false>, sizeof(double) * EA_TILE_C * EA_TILE_R);
         HIPMF_ALLOW_LDS(k_extend_add_lds<true>, sizeof(double) * EA_TILE_C * EA_TILE_R);

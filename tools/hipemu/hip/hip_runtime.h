@@ -7,6 +7,7 @@
 // Blocks run one after another; streams and events are synchronous.
 #pragma once
 #include <ucontext.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -16,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <unordered_map>
 #include <vector>
 
 struct dim3 {
@@ -257,7 +259,21 @@ inline int atomicOr(int *p, int v) {
 }
 
 // ---- host runtime --------------------------------------------------------------------------------
+// (development: an allocation beyond HIPEMU_LAZY_GB -- the pool of a large problem whose PLAN is being timed -- is address space only:
+// untouched pages cost nothing, no poison)
+inline std::unordered_map<void *, size_t> &hipemu_lazy_blocks() {
+    static std::unordered_map<void *, size_t> m;
+    return m;
+}
 inline hipError_t hipMalloc(void **p, size_t bytes) {
+    const char *lz = getenv("HIPEMU_LAZY_GB");
+    if (lz && bytes > ((size_t)atoi(lz) << 30)) {
+        void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (q == MAP_FAILED) return hipErrorOutOfMemory;
+        hipemu_lazy_blocks()[q] = bytes;
+        *p = q;
+        return hipSuccess;
+    }
     *p = malloc(bytes ? bytes : 1);
     if (*p) memset(*p, 0xCD, bytes); // poison: catches reads of uninitialised device memory
     return *p ? hipSuccess : hipErrorOutOfMemory;
@@ -267,6 +283,13 @@ inline hipError_t hipMalloc(T **p, size_t bytes) {
     return hipMalloc((void **)p, bytes);
 }
 inline hipError_t hipFree(void *p) {
+    auto &lz = hipemu_lazy_blocks();
+    auto it = lz.find(p);
+    if (it != lz.end()) {
+        munmap(p, it->second);
+        lz.erase(it);
+        return hipSuccess;
+    }
     free(p);
     return hipSuccess;
 }
