@@ -50,14 +50,39 @@ inline dim3 g_blockDim, g_gridDim;
 inline std::vector<char> g_dynshared;
 
 enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+// Fiber switch.  glibc's swapcontext saves and restores the signal mask -- one system call per switch, two per yield: a third of the
+// wall time of the emulated kernels went to the kernel.  On x86-64 the switch is done by hand (callee-saved registers + stack pointer; the
+// fibers neither change the signal mask nor the floating-point control words); other hosts keep ucontext.
+#if defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+asm(".text\n"
+    ".weak hipemu_switch\n"
+    ".type hipemu_switch,@function\n"
+    "hipemu_switch:\n"
+    "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq %rsi, %rsp\n"
+    "    popq %r15\n    popq %r14\n    popq %r13\n    popq %r12\n    popq %rbx\n    popq %rbp\n"
+    "    ret\n"
+    ".size hipemu_switch, .-hipemu_switch\n");
+#endif
 struct Fiber {
+#ifdef HIPEMU_FAST_SWITCH
+    void *sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     char *stack = nullptr;
     int state = DONE;
     hipemu_uint3 tid;
 };
 inline std::vector<Fiber> g_fibers;
+#ifdef HIPEMU_FAST_SWITCH
+inline void *g_sched_sp = nullptr;
+#else
 inline ucontext_t g_sched;
+#endif
 inline int g_cur = 0;
 inline std::function<void()> g_body;
 inline unsigned long long g_wave_buf[16][64];
@@ -68,7 +93,11 @@ inline int linear_tid() { return (int)(g_threadIdx.x + g_blockDim.x * (g_threadI
 inline void yield_with(int state) {
     Fiber &f = g_fibers[g_cur];
     f.state = state;
+#ifdef HIPEMU_FAST_SWITCH
+    hipemu_switch(&f.sp, g_sched_sp);
+#else
     swapcontext(&f.ctx, &g_sched);
+#endif
     g_threadIdx = f.tid; // restored by the scheduler as well; keep both for clarity
 }
 inline void sync_block() { yield_with(WAIT_BLOCK); }
@@ -77,7 +106,11 @@ inline void sync_wave() { yield_with(WAIT_WAVE); }
 inline void fiber_entry() {
     g_body();
     g_fibers[g_cur].state = DONE;
+#ifdef HIPEMU_FAST_SWITCH
+    hipemu_switch(&g_fibers[g_cur].sp, g_sched_sp);
+#else
     swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+#endif
 }
 
 inline void run_block(int nthreads) {
@@ -85,11 +118,23 @@ inline void run_block(int nthreads) {
     for (int t = 0; t < nthreads; t++) {
         Fiber &f = g_fibers[t];
         if (!f.stack) f.stack = (char *)malloc(STACK_BYTES);
+#ifdef HIPEMU_FAST_SWITCH
+        {
+            // what hipemu_switch pops: six registers, then the entry point as its return address; the entry then finds the stack pointer
+            // 8 bytes below a 16-byte boundary, as after a call (its own return address is never used: fiber_entry does not return)
+            void **top = (void **)(((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15);
+            top[-1] = nullptr;
+            top[-2] = (void *)fiber_entry;
+            for (int r = 3; r <= 8; r++) top[-r] = nullptr;
+            f.sp = (void *)(top - 8);
+        }
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = STACK_BYTES;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
         f.state = RUNNABLE;
         f.tid.x = t % g_blockDim.x;
         f.tid.y = (t / g_blockDim.x) % g_blockDim.y;
@@ -102,7 +147,11 @@ inline void run_block(int nthreads) {
             if (g_fibers[t].state != RUNNABLE) continue;
             g_cur = t;
             g_threadIdx = g_fibers[t].tid;
+#ifdef HIPEMU_FAST_SWITCH
+            hipemu_switch(&g_sched_sp, g_fibers[t].sp);
+#else
             swapcontext(&g_sched, &g_fibers[t].ctx);
+#endif
             ran = true;
         }
         int done = 0, wblock = 0;
