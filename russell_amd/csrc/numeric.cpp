@@ -48,18 +48,6 @@ struct DeviceScope {
 
 constexpr int32_t MAX_LDS_DOUBLES = 7936; // 62 KiB of dynamic LDS for the w1 / v vectors of the big-front solves
 
-// vector whose resize() leaves trivially constructible elements uninitialised: the extend-add task lists (gigabytes for a 3D problem) are
-// sized once and filled by the planning threads, which then also take the first-touch page faults
-template <class T> struct NoInitAlloc : std::allocator<T> {
-    template <class U> struct rebind {
-        using other = NoInitAlloc<U>;
-    };
-    template <class U, class... A> void construct(U *p, A &&...a) {
-        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
-        else ::new ((void *)p) U(std::forward<A>(a)...);
-    }
-};
-
 template <class T, class A>
 static hipError_t dev_upload(T **dptr, const std::vector<T, A> &v) {
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
@@ -1546,9 +1534,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     HIPC(dev_upload(&d_rows, S.sn_rows), ERROR_HIP_MALLOC);
     {
         // (+ 64 entries: the solve kernels read relative indices and workspace entries from clamped addresses, unconditionally)
-        std::vector<int32_t> relp(S.rel);
-        relp.resize(S.rel.size() + 64, 0);
-        HIPC(dev_upload(&d_rel, relp), ERROR_HIP_MALLOC);
+        // (no padded copy of the array on the host: at 200^3 it holds hundreds of megabytes)
+        HIPC(hipMalloc((void **)&d_rel, sizeof(int32_t) * (S.rel.size() + 64)), ERROR_HIP_MALLOC);
+        if (!S.rel.empty()) HIPC(hipMemcpy(d_rel, S.rel.data(), sizeof(int32_t) * S.rel.size(), hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
+        HIPC(hipMemset(d_rel + S.rel.size(), 0, sizeof(int32_t) * 64), ERROR_HIP_MEMCPY);
     }
     HIPC(dev_upload(&d_child, S.child_idx), ERROR_HIP_MALLOC);
     pl_lap("descriptor / index uploads");

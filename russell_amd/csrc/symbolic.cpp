@@ -811,13 +811,41 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
 
     S.seconds_phase[3] = since(t_phase), t_phase = clk::now();
     // ---- row structure of every supernode ----------------------------------------------------
+    // A supernode's rows are the entries of A below its pivots merged with its children's rows: a subtree needs nothing from outside,
+    // and in the postorder it is a contiguous range of supernodes.  The maximal subtrees below a size bound ("chunks") are built on host
+    // threads into buffers of their own, the few supernodes above them afterwards, and the pieces are copied to their places once all sizes
+    // are known (the lists themselves are what the serial sweep produced: sorted unions).
     S.sn_rowptr.assign((size_t)S.nsuper + 1, 0);
     S.sn_rows.clear();
     {
-        std::vector<int32_t> mark((size_t)n, -1);
-        std::vector<int32_t> rows, merged;
-        for (int32_t s = 0; s < S.nsuper; s++) {
-            int32_t last = S.sn_first[s + 1] - 1;
+        struct Chunk {
+            int32_t lo, hi; // supernodes [lo, hi]
+            std::vector<int32_t> rows;
+            std::vector<int64_t> ptr; // hi - lo + 2 offsets into rows
+        };
+        std::vector<Chunk> chunks;
+        std::vector<int32_t> chunk_of((size_t)S.nsuper, -1);
+        if (threads > 1 && n >= 200000) {
+            std::vector<int32_t> desc_first((size_t)S.nsuper);
+            std::iota(desc_first.begin(), desc_first.end(), 0);
+            for (int32_t s = 0; s < S.nsuper; s++)
+                if (S.sn_parent[s] >= 0) desc_first[S.sn_parent[s]] = std::min(desc_first[S.sn_parent[s]], desc_first[s]);
+            const int64_t bound = std::max<int64_t>(4096, (int64_t)n / (8 * threads)); // columns of a chunk
+            auto weight = [&](int32_t s) { return (int64_t)S.sn_first[s + 1] - S.sn_first[desc_first[s]]; };
+            for (int32_t s = 0; s < S.nsuper; s++)
+                if (weight(s) <= bound && (S.sn_parent[s] < 0 || weight(S.sn_parent[s]) > bound)) {
+                    for (int32_t k = desc_first[s]; k <= s; k++) chunk_of[k] = (int32_t)chunks.size();
+                    chunks.push_back({desc_first[s], s, {}, {}});
+                }
+        }
+        struct Scratch {
+            std::vector<int32_t> mark, rows, merged;
+        };
+        // rows of supernode s into t.rows; child(ch) gives the [begin, end) of a child's finished list
+        auto sn_struct = [&](int32_t s, Scratch &t, auto &&child) {
+            if (t.mark.empty()) t.mark.assign((size_t)n, -1);
+            std::vector<int32_t> &mark = t.mark, &rows = t.rows, &merged = t.merged;
+            const int32_t last = S.sn_first[s + 1] - 1;
             rows.clear();
             for (int32_t j = S.sn_first[s]; j <= last; j++)
                 for (int64_t p = gp.ptr[j + 1] - 1; p >= gp.ptr[j]; p--) {
@@ -835,9 +863,8 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
                 // large supernodes were most of this phase: 0.8 s at 200^3).
                 std::sort(rows.begin(), rows.end());
                 for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
-                    const int32_t ch = S.child_idx[c];
-                    const int32_t *cb = S.sn_rows.data() + S.sn_rowptr[ch], *ce = S.sn_rows.data() + S.sn_rowptr[ch + 1];
-                    cb = std::upper_bound(cb, ce, last); // the child's rows beyond this supernode's pivots
+                    const std::pair<const int32_t *, const int32_t *> cr = child(S.child_idx[c]);
+                    const int32_t *cb = std::upper_bound(cr.first, cr.second, last), *ce = cr.second; // the child's rows beyond this supernode's pivots
                     if (cb == ce) continue;
                     merged.clear();
                     merged.reserve(rows.size() + (size_t)(ce - cb));
@@ -846,9 +873,9 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
                 }
             } else {
                 for (int32_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; c++) {
-                    int32_t ch = S.child_idx[c];
-                    for (int64_t p = S.sn_rowptr[ch]; p < S.sn_rowptr[ch + 1]; p++) {
-                        int32_t i = S.sn_rows[p];
+                    const std::pair<const int32_t *, const int32_t *> cr = child(S.child_idx[c]);
+                    for (const int32_t *q = cr.first; q < cr.second; q++) {
+                        const int32_t i = *q;
                         if (i > last && mark[i] != s) {
                             mark[i] = s;
                             rows.push_back(i);
@@ -857,12 +884,87 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
                 }
                 std::sort(rows.begin(), rows.end());
             }
-            S.sn_rows.insert(S.sn_rows.end(), rows.begin(), rows.end());
-            S.sn_rowptr[s + 1] = (int64_t)S.sn_rows.size();
+        };
+        std::atomic<bool> oom{false};
+        if (!chunks.empty()) {
+            std::atomic<size_t> next{0};
+            auto body = [&]() {
+                try {
+                    Scratch t;
+                    for (size_t ci; (ci = next.fetch_add(1, std::memory_order_relaxed)) < chunks.size();) {
+                        Chunk &C = chunks[ci];
+                        C.ptr.assign(1, 0);
+                        auto child = [&](int32_t ch) { // (a chunk is closed under children)
+                            return std::make_pair((const int32_t *)C.rows.data() + C.ptr[(size_t)(ch - C.lo)], (const int32_t *)C.rows.data() + C.ptr[(size_t)(ch - C.lo) + 1]);
+                        };
+                        for (int32_t s = C.lo; s <= C.hi; s++) {
+                            sn_struct(s, t, child);
+                            C.rows.insert(C.rows.end(), t.rows.begin(), t.rows.end());
+                            C.ptr.push_back((int64_t)C.rows.size());
+                        }
+                    }
+                } catch (const std::bad_alloc &) { // (an exception must not leave a thread)
+                    oom.store(true);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int i = 0; i < threads; i++) pool.emplace_back(body);
+            for (auto &th : pool) th.join();
+            if (oom.load()) return -41;
         }
+        // the supernodes above the chunks, in order (all of them when nothing was chunked)
+        std::vector<int32_t> top_rows;
+        std::vector<int64_t> top_ptr((size_t)S.nsuper + 1, 0); // offsets of the top supernodes (entries of chunked ones unused)
+        {
+            Scratch t;
+            auto child = [&](int32_t ch) {
+                const int32_t c = chunk_of[ch];
+                if (c >= 0) {
+                    const Chunk &C = chunks[(size_t)c];
+                    return std::make_pair((const int32_t *)C.rows.data() + C.ptr[(size_t)(ch - C.lo)], (const int32_t *)C.rows.data() + C.ptr[(size_t)(ch - C.lo) + 1]);
+                }
+                return std::make_pair((const int32_t *)top_rows.data() + top_ptr[ch], (const int32_t *)top_rows.data() + top_ptr[ch] + S.sn_rowptr[ch + 1]);
+            };
+            // (S.sn_rowptr[s + 1] holds the SIZE of s until the prefix sum below)
+            for (int32_t s = 0; s < S.nsuper; s++) {
+                const int32_t c = chunk_of[s];
+                if (c >= 0) {
+                    const Chunk &C = chunks[(size_t)c];
+                    S.sn_rowptr[s + 1] = C.ptr[(size_t)(s - C.lo) + 1] - C.ptr[(size_t)(s - C.lo)];
+                    continue;
+                }
+                top_ptr[s] = (int64_t)top_rows.size();
+                sn_struct(s, t, child);
+                top_rows.insert(top_rows.end(), t.rows.begin(), t.rows.end());
+                S.sn_rowptr[s + 1] = (int64_t)t.rows.size();
+            }
+        }
+        for (int32_t s = 0; s < S.nsuper; s++) S.sn_rowptr[s + 1] += S.sn_rowptr[s];
+        S.sn_rows.resize((size_t)S.sn_rowptr[S.nsuper]);
+        // copies: every chunk is one contiguous piece of the final array; the top supernodes one piece each
+        auto place_top = [&]() {
+            for (int32_t s = 0; s < S.nsuper; s++)
+                if (chunk_of[s] < 0 && S.sn_rowptr[s + 1] > S.sn_rowptr[s])
+                    std::memcpy(S.sn_rows.data() + S.sn_rowptr[s], top_rows.data() + top_ptr[s], sizeof(int32_t) * (size_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]));
+        };
+        if (!chunks.empty()) {
+            std::atomic<size_t> next{0};
+            auto body = [&]() {
+                for (size_t ci; (ci = next.fetch_add(1, std::memory_order_relaxed)) < chunks.size();) {
+                    Chunk &C = chunks[ci];
+                    if (!C.rows.empty()) std::memcpy(S.sn_rows.data() + S.sn_rowptr[C.lo], C.rows.data(), sizeof(int32_t) * C.rows.size());
+                    std::vector<int32_t>().swap(C.rows);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int i = 0; i < threads; i++) pool.emplace_back(body);
+            place_top();
+            for (auto &th : pool) th.join();
+        } else
+            place_top();
     }
     // relative indices into the parent's front
-    S.rel.assign(S.sn_rows.size(), -1);
+    S.rel.resize(S.sn_rows.size()); // (every entry is written below, or the analysis fails)
     {
         // (every supernode writes its own range of rel and reads its parent's rows: independent, spread over the host threads)
         std::atomic<int> rel_err{0};

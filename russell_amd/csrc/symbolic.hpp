@@ -9,9 +9,24 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace hipmf {
+
+// vector whose resize() leaves trivially constructible elements uninitialised: arrays of hundreds of megabytes (row structures, task
+// lists of a 3D problem) are sized once and filled by host threads, which then also take the first-touch page faults
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using noinit_vector = std::vector<T, NoInitAlloc<T>>;
 
 enum OrderingKind : int32_t {
     ORDERING_NESTED_DISSECTION = 0, // level-structure nested dissection + minimum degree on the leaves
@@ -50,7 +65,7 @@ struct Symbolic {
     std::vector<int32_t> sn_first;   // nsuper+1: first permuted column of each supernode
     std::vector<int32_t> sn_of;      // n: supernode of a permuted column
     std::vector<int64_t> sn_rowptr;  // nsuper+1
-    std::vector<int32_t> sn_rows;    // off-diagonal row structure (permuted indices, ascending)
+    noinit_vector<int32_t> sn_rows;  // off-diagonal row structure (permuted indices, ascending)
     std::vector<int32_t> sn_parent;  // parent supernode or -1
     std::vector<int32_t> sn_level;   // 0 = leaves
     int32_t nlevels = 0;
@@ -58,7 +73,7 @@ struct Symbolic {
     std::vector<int32_t> level_sn;   // supernodes grouped by level
     std::vector<int32_t> child_ptr;  // nsuper+1
     std::vector<int32_t> child_idx;  // children of each supernode, ascending
-    std::vector<int32_t> rel;        // aligned with sn_rows: position of the row in the PARENT's front
+    noinit_vector<int32_t> rel;      // aligned with sn_rows: position of the row in the PARENT's front
     // Pool layout (offsets in doubles into ONE device allocation): [0, persist_doubles) holds what the solves need (the small
     // fronts' f x f blocks, the big fronts' E / E' panels); [persist_doubles, persist_doubles + temp_doubles) is the arena of the
     // big fronts' f x f working blocks, whose storage is re-used once the parent has consumed the contribution block.
