@@ -194,9 +194,11 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
  *   HIPMF_OPTION_PIVOTING            lin_sol_params.rs:16 / enums.rs Pivoting: 1 = Auto / LocalBlock (partial pivoting inside the pivot
  *                                    block of a small front / the 32-row diagonal tile of a tiled one, tiny pivots perturbed and counted);
  *                                    None / GlobalCol / GlobalRow / Diagonal are not available: ERROR_NOT_AVAILABLE
- *   HIPMF_OPTION_HYBRID_MEMORY       lin_sol_params.rs:39 (cuDSS hybrid memory, factor 0.01 .. 0.99): accepted and recorded; this
- *                                    backend has no out-of-core path, a factor that does not fit HBM is refused by initialize with the
- *                                    "Not enough memory" string the reference's harness recognises (stats_lin_sol.rs:334-340)
+ *   HIPMF_OPTION_HYBRID_MEMORY       lin_sol_params.rs:39 (cuDSS hybrid memory, factor 0.01 .. 0.99): the DEVICE half of the reference's
+ *                                    meaning -- factor x the device's total memory is the most the factor + working arena may take
+ *                                    (interface_cudss.cu:364-372 sets cuDSS's device memory limit the same way).  The host half does not
+ *                                    exist here (no out-of-core path): a factor that does not fit the limit is refused by initialize with
+ *                                    the "Not enough memory" string the reference's harness recognises (stats_lin_sol.rs:334-340)
  *   HIPMF_OPTION_ERROR_ESTIMATES     lin_sol_params.rs:50: the componentwise backward error omega of the last solve is always kept
  *   HIPMF_OPTION_CONDITION_NUMBERS   lin_sol_params.rs:55: min|u_ii| / max|u_ii| is always reported by factorize (rcond_estimate)
  * (both readable with solver_hipmf_get_option after solve / factorize: the value, not the flag). */

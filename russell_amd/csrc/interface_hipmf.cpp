@@ -179,6 +179,7 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
     if (refinement_nstep >= 0) no.refinement_nstep = refinement_nstep;
     no.verbose = verbose == 1;
     no.matching = h->opt_matching;
+    no.device_memory_factor = h->opt_hybrid;
     h->ordering_requested = ordering;
     h->effective_ordering = (ordering == HIPMF_ORDERING_NONE) ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_NESTED_DISSECTION;
     int32_t code;

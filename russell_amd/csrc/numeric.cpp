@@ -238,7 +238,11 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         }
         {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) live_pool_limit.store(0.95 * (double)free_b);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+                double limit = 0.95 * (double)free_b;
+                if (opt.device_memory_factor > 0.0) limit = std::min(limit, opt.device_memory_factor * (double)total_b);
+                live_pool_limit.store(limit);
+            }
             if (const char *e = getenv("HIPMF_POOL_LIMIT_GB")) live_pool_limit.store(0.95e9 * atof(e)); // (tests: force the refusal)
         }
         // matrix structure (kept for the refinement SpMV) and per-entry row/col indices
@@ -400,8 +404,12 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     lap("wait for the device set-up");
     if (rc == -40) {
         char msg[256];
-        snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free)", S.pool_estimate_bytes / 1e9,
-                 so.pool_limit_bytes / 0.95 / 1e9);
+        if (opt.device_memory_factor > 0.0)
+            snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (limit: %.1f GB = min(free device memory, hybrid_memory_factor %.2f x total))",
+                     S.pool_estimate_bytes / 1e9, so.pool_limit_bytes / 1e9, opt.device_memory_factor);
+        else
+            snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free)", S.pool_estimate_bytes / 1e9,
+                     so.pool_limit_bytes / 0.95 / 1e9);
         last_error = msg;
         return ERROR_HIP_MALLOC;
     }

@@ -50,6 +50,9 @@ struct NumericOptions {
     double pivot_epsilon = 1e-13;   // relative to max|scaled a_ij| (cuDSS documents 1e-13 as its f64 default)
     int32_t refinement_nstep = 2;   // UMFPACK's default UMFPACK_IRSTEP is 2
     int32_t matching = 1;           // maximum-product matching + scaling at initialize: 0 never, 1 when the diagonal is weak, 2 always
+    double device_memory_factor = 0.0; // > 0: the factor + arena may take at most this share of the device's TOTAL memory (the device limit the
+                                    // reference derives from hybrid_memory_factor, interface_cudss.cu:364-372); there is no host spill here: a pool
+                                    // beyond the limit is refused by initialize with the out-of-memory status
                                     // (needs the values at initialize; general storage only)
     bool complex_pairs = false;     // the system is the real-equivalent form of a complex matrix (rows / columns 2 k, 2 k + 1 = Re, Im of complex
                                     // row / column k; interface_complex_hipmf.cpp): ordering, matching and pivot searches keep the pairs together,

@@ -99,3 +99,25 @@ def test_set_option_before_and_after_initialize(emu_lib):
     assert lib.solver_hipmf_get_option(s.h, 4, C.byref(val)) == 0 and 0.0 < val.value <= 1.0
     assert lib.solver_hipmf_get_option(s.h, 3, C.byref(val)) == 0 and 0.0 <= val.value < 1e-10
     s.close()
+
+
+def test_hybrid_memory_factor_limits_the_device_memory(emu_lib, monkeypatch):
+    # lin_sol_params.rs:39 / interface_cudss.cu:364-372: the reference turns the factor into a device memory limit (factor x total).  Here
+    # the factor + arena must fit that limit -- there is no host spill -- and a matrix that does not is refused with the out-of-memory
+    # status and the "Not enough memory" text the reference's harness looks for (stats_lin_sol.rs:334-340).
+    monkeypatch.setenv("HIPEMU_DEVICE_GB", "1")  # the emulated device: 1 GiB in total
+    n, rp, ci, v = P.poisson2d(120, 110)
+    s = Hipmf(emu_lib)
+    assert s.lib.solver_hipmf_set_option(s.h, 2, 0.01) == 0  # ~10.7 MB
+    code = s.initialize(n, rp, ci)
+    assert code != 0
+    msg = (s.lib.solver_hipmf_last_error(s.h) or b"").decode()
+    assert "Not enough memory" in msg and "hybrid_memory_factor" in msg, msg
+    s.close()
+    s = Hipmf(emu_lib)
+    assert s.lib.solver_hipmf_set_option(s.h, 2, 0.99) == 0
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    xs = P.manufactured_solution(n)
+    assert np.max(np.abs(s.solve(P.csr_matvec(n, rp, ci, v, xs)) - xs)) < 1e-10
+    s.close()
