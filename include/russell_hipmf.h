@@ -60,6 +60,8 @@ extern "C" {
 #define HIPMF_ORDERING_DEFAULT 0            /* nested dissection */
 #define HIPMF_ORDERING_NESTED_DISSECTION 1
 #define HIPMF_ORDERING_NONE 2               /* natural order (Ordering::No) */
+#define HIPMF_ORDERING_AMD 3                /* approximate minimum degree on A + A^T (Ordering::Amd / Amf / Qamd; own implementation of the
+                                               published method, symbolic.cpp) -- the better choice for patterns without small separators */
 /* scaling argument (same numbering as UMFPACK_SCALE_*) */
 #define HIPMF_SCALE_NONE 0
 #define HIPMF_SCALE_SUM 1

@@ -806,8 +806,17 @@ void set_hipmf_library_path(const std::string &path) {
     g_backend.tried = false;
 }
 
-// Ordering -> C-ABI constant (all fill-reducing requests map to nested dissection, the only one implemented)
-static int32_t hipmf_ordering(Ordering o) { return o == Ordering::No ? HIPMF_ORDERING_NONE : HIPMF_ORDERING_DEFAULT; }
+// Ordering -> C-ABI constant, in the manner of umfpack_ordering (solver_umfpack.rs:457-472): the minimum-degree family (Amd, Amf, Qamd)
+// selects the backend's approximate minimum degree, No the natural order, everything else its default, the nested dissection
+static int32_t hipmf_ordering(Ordering o) {
+    switch (o) {
+    case Ordering::No: return HIPMF_ORDERING_NONE;
+    case Ordering::Amd:
+    case Ordering::Amf:
+    case Ordering::Qamd: return HIPMF_ORDERING_AMD;
+    default: return HIPMF_ORDERING_DEFAULT;
+    }
+}
 // Scaling -> C-ABI constant, same mapping as umfpack_scaling (solver_umfpack.rs:475-487)
 static int32_t hipmf_scaling(Scaling s) {
     switch (s) {
@@ -1151,7 +1160,7 @@ void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.initialize_ns.push_back(time_initialize_ns);
     stats.factorize_ns.push_back(time_factorize_ns);
     stats.solve_ns.push_back(time_solve_ns);
-    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Nd"; // the backend's own nested dissection, whatever of Amd / Colamd / Metis / ... was asked for (none of those libraries is used)
+    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : (effective_ordering == HIPMF_ORDERING_AMD ? "Amd" : "Nd"); // what ran: the backend's own minimum degree / nested dissection (none of the ordering libraries is used)
     stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
     stats.rcond_estimate = rcond_estimate;
     // (complex_solver_umfpack.rs:411-414)
@@ -1177,7 +1186,7 @@ void SolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.initialize_ns.push_back(time_initialize_ns);
     stats.factorize_ns.push_back(time_factorize_ns);
     stats.solve_ns.push_back(time_solve_ns);
-    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : "Nd"; // the backend's own nested dissection, whatever of Amd / Colamd / Metis / ... was asked for (none of those libraries is used)
+    stats.effective_ordering = effective_ordering == HIPMF_ORDERING_NONE ? "No" : (effective_ordering == HIPMF_ORDERING_AMD ? "Amd" : "Nd"); // what ran: the backend's own minimum degree / nested dissection (none of the ordering libraries is used)
     stats.effective_scaling = effective_scaling == HIPMF_SCALE_MAX ? "Max" : (effective_scaling == HIPMF_SCALE_NONE ? "No" : "Sum");
     stats.rcond_estimate = rcond_estimate;
     stats.det_mantissa = determinant_coefficient;

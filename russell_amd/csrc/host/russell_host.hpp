@@ -39,9 +39,10 @@ enum class Matching : int32_t { None = 0, Auto, MaxDiagCount, MaxMinDiag, MaxMin
 enum class Pivoting : int32_t { Auto = 0, None, GlobalCol, GlobalRow, Diagonal, LocalBlock };
 
 // lin_sol_params.rs:5-82; the MUMPS / UMFPACK-only fields have no meaning for this backend and are not mirrored.
-//   ordering   Ordering::No -> natural order; every other variant (Auto, Amd, Amf, Cholmod, Colamd, Metis, Pord, Qamd, Scotch, Best)
-//              -> this backend's nested dissection with dense leaves (the reference maps unknown variants to the backend's default
-//              the same way, solver_umfpack.rs:457-472); the effective ordering is reported by update_stats
+//   ordering   Ordering::No -> natural order; Amd / Amf / Qamd -> this backend's approximate minimum degree; every other variant (Auto,
+//              Cholmod, Colamd, Metis, Pord, Scotch, Best) -> its nested dissection with dense leaves (the reference maps variants a
+//              backend does not have to that backend's default the same way, solver_umfpack.rs:457-472); the effective ordering
+//              ("No" / "Amd" / "Nd") is reported by update_stats
 //   matching   None -> never; Auto -> when the diagonal is weak; any named variant -> always (there is one matching: maximum product
 //              + scaling, what cuDSS calls MaxDiagProduct)
 //   pivoting   Auto / LocalBlock -> partial pivoting inside the pivot block (the only strategy); others: factorize returns an error

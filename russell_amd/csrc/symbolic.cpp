@@ -474,6 +474,267 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Approximate minimum degree on the pattern of A + A^T (Ordering::Amd of the reference's enum, enums.rs:71-155).
+// The method of Amestoy, Davis & Duff (SIAM J. Matrix Anal. Appl. 17, 1996), written for this code's data structures: the
+// elimination graph is kept as a QUOTIENT graph in one workspace -- a variable's list holds the elements (eliminated pivots) it
+// touches, then the variables it is still directly adjacent to; an element's list holds its variables -- with
+//   * element absorption (an element reachable through the new pivot, or whose variables all lie in the new element, dies),
+//   * approximate external degrees  d_i = min(n - k, d_i + |L_me \ i|, |A_i \ i| + |L_me \ i| + sum_e |L_e \ L_me|),
+//   * mass elimination (a variable whose only neighbour is the new element is eliminated with it),
+//   * indistinguishable variables merged into supervariables (found by hashing the lists of the variables of the new element).
+// Ties are broken by list position only (no hashing of pointers, no threads): the permutation is reproducible.
+// Hub vertices are taken out first and ordered last, as in the dissection.
+// ------------------------------------------------------------------------------------------------
+static void approximate_minimum_degree(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm) {
+    const int32_t n = g.n;
+    perm.assign((size_t)n, -1);
+    const double avg_deg = n > 0 ? (double)g.ptr[n] / (double)n : 0.0;
+    const int64_t dense_deg =
+        std::max<int64_t>(32, (int64_t)std::min(opt.dense_row_factor * std::sqrt((double)n), 4.0 * opt.dense_row_factor * std::max(avg_deg, 1.0)));
+    enum : uint8_t { VAR = 0, ELEM = 1, DEAD = 2, HUB = 3 };
+    std::vector<uint8_t> kind((size_t)n, VAR);
+    int32_t nhub = 0;
+    if (opt.dense_row_factor > 0.0)
+        for (int32_t v = 0; v < n; v++)
+            if (g.ptr[v + 1] - g.ptr[v] > dense_deg) kind[v] = HUB, nhub++;
+    if (nhub == n) std::fill(kind.begin(), kind.end(), (uint8_t)VAR), nhub = 0;
+    const int32_t nact = n - nhub;
+
+    // workspace: the lists never grow in total (a variable that gains the new element loses the pivot or an absorbed element; a new
+    // element is no longer than the lists it replaces), so the initial size + room for one element built at the end is enough
+    std::vector<int64_t> pe((size_t)n, 0);
+    std::vector<int32_t> len((size_t)n, 0), elen((size_t)n, 0), nv((size_t)n, 1), degree((size_t)n, 0), parent((size_t)n, -1);
+    int64_t nz = 0;
+    for (int32_t v = 0; v < n; v++)
+        if (kind[v] == VAR)
+            for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) nz += kind[g.adj[p]] == VAR;
+    const int64_t iwlen = nz + nz / 5 + 2 * (int64_t)n + 16;
+    std::vector<int32_t> iw((size_t)iwlen);
+    int64_t pfree = 0;
+    for (int32_t v = 0; v < n; v++) {
+        if (kind[v] != VAR) continue;
+        pe[v] = pfree;
+        for (int64_t p = g.ptr[v]; p < g.ptr[v + 1]; p++)
+            if (kind[g.adj[p]] == VAR) iw[(size_t)pfree++] = g.adj[p];
+        len[v] = (int32_t)(pfree - pe[v]);
+        degree[v] = len[v];
+    }
+    // degree lists
+    std::vector<int32_t> head((size_t)n + 1, -1), nxt((size_t)n, -1), prv((size_t)n, -1);
+    auto dl_insert = [&](int32_t i, int32_t d) {
+        nxt[i] = head[d], prv[i] = -1;
+        if (head[d] >= 0) prv[head[d]] = i;
+        head[d] = i;
+    };
+    auto dl_remove = [&](int32_t i, int32_t d) {
+        if (prv[i] >= 0) nxt[prv[i]] = nxt[i];
+        else head[d] = nxt[i];
+        if (nxt[i] >= 0) prv[nxt[i]] = prv[i];
+    };
+    // (inserted in descending vertex order: the head of a list is its smallest vertex)
+    for (int32_t v = n - 1; v >= 0; v--)
+        if (kind[v] == VAR) dl_insert(v, degree[v]);
+    std::vector<int32_t> inl((size_t)n, -1);            // inl[i] == pivot step: variable i lies in the current element
+    std::vector<int32_t> wstep((size_t)n, -1), wext((size_t)n, 0); // element e, at the current step: |L_e \ L_me| (weighted)
+    std::vector<int32_t> esize((size_t)n, 0);            // weighted size of an element when it was formed
+    std::vector<int32_t> hhead((size_t)n, -1), hnext((size_t)n, -1), cmp((size_t)n, -1);
+    std::vector<uint32_t> hval((size_t)n, 0);
+    std::vector<int32_t> order;
+    order.reserve((size_t)nact);
+    std::vector<char> is_pivot((size_t)n, 0);
+
+    auto collect_garbage = [&]() {
+        // live lists keep their order in the workspace; the first entry of each is swapped for a tag while the workspace is swept
+        for (int32_t i = 0; i < n; i++)
+            if ((kind[i] == VAR || kind[i] == ELEM) && len[i] > 0) {
+                const int32_t first = iw[(size_t)pe[i]];
+                iw[(size_t)pe[i]] = -(i + 1);
+                pe[i] = first; // (parked)
+            }
+        int64_t dst = 0;
+        for (int64_t src = 0; src < pfree;) {
+            const int32_t tag = iw[(size_t)src];
+            if (tag >= 0) {
+                src++;
+                continue;
+            }
+            const int32_t i = -tag - 1;
+            iw[(size_t)dst] = (int32_t)pe[i];
+            pe[i] = dst;
+            for (int32_t k = 1; k < len[i]; k++) iw[(size_t)(dst + k)] = iw[(size_t)(src + k)];
+            dst += len[i], src += len[i];
+        }
+        pfree = dst;
+    };
+
+    int32_t nel = 0, mindeg = 0;
+    for (int32_t step = 0; nel < nact; step++) {
+        while (mindeg < n && head[mindeg] < 0) mindeg++;
+        const int32_t me = head[mindeg];
+        dl_remove(me, mindeg);
+        int32_t nvpiv = nv[me];
+        nel += nvpiv;
+        order.push_back(me);
+        is_pivot[me] = 1;
+        inl[me] = step; // (keeps the pivot itself out of its element)
+        // ---- the new element: variables of the pivot's lists and of the elements it touches --------------------------------------
+        bool has_elem = false;
+        for (int64_t p = pe[me]; p < pe[me] + elen[me]; p++) has_elem |= kind[iw[(size_t)p]] == ELEM;
+        int64_t pme1, pme2;
+        int32_t degme = 0;
+        auto take = [&](int32_t i, int64_t &wr) {
+            if (kind[i] != VAR || inl[i] == step) return;
+            inl[i] = step;
+            iw[(size_t)wr++] = i;
+            degme += nv[i];
+            dl_remove(i, degree[i]);
+        };
+        if (!has_elem) {
+            // in place: the pivot's own variable list, filtered
+            pme1 = pe[me];
+            int64_t wr = pme1;
+            for (int64_t p = pe[me] + elen[me]; p < pe[me] + len[me]; p++) take(iw[(size_t)p], wr);
+            pme2 = wr;
+        } else {
+            if (pfree + (int64_t)(nact - nel) + 1 > iwlen) collect_garbage();
+            pme1 = pfree;
+            int64_t wr = pfree;
+            const int64_t pb = pe[me]; // (re-read after a possible compaction)
+            for (int64_t p = pb; p < pb + elen[me]; p++) {
+                const int32_t e = iw[(size_t)p];
+                if (kind[e] != ELEM) continue;
+                for (int64_t q = pe[e]; q < pe[e] + len[e]; q++) take(iw[(size_t)q], wr);
+                kind[e] = DEAD, parent[e] = me; // absorbed
+            }
+            for (int64_t p = pb + elen[me]; p < pb + len[me]; p++) take(iw[(size_t)p], wr);
+            pme2 = wr;
+            pfree = wr;
+        }
+        kind[me] = ELEM;
+        pe[me] = pme1, len[me] = (int32_t)(pme2 - pme1), elen[me] = 0;
+        // ---- |L_e \ L_me| for every element a variable of L_me touches -------------------------------------------------------------
+        for (int64_t pm = pme1; pm < pme2; pm++) {
+            const int32_t i = iw[(size_t)pm];
+            for (int64_t p = pe[i]; p < pe[i] + elen[i]; p++) {
+                const int32_t e = iw[(size_t)p];
+                if (kind[e] != ELEM) continue;
+                if (wstep[e] != step) wstep[e] = step, wext[e] = esize[e];
+                wext[e] -= nv[i];
+            }
+        }
+        // ---- degrees, list clean-up, mass elimination, hash ------------------------------------------------------------------------
+        for (int64_t pm = pme1; pm < pme2; pm++) {
+            const int32_t i = iw[(size_t)pm];
+            const int64_t p1 = pe[i];
+            int64_t pn = p1;
+            int64_t deg = 0;
+            uint32_t h = 0;
+            for (int64_t p = p1; p < p1 + elen[i]; p++) {
+                const int32_t e = iw[(size_t)p];
+                if (kind[e] != ELEM) continue;
+                const int32_t ext = std::max(wext[e], 0);
+                if (ext > 0) {
+                    deg += ext;
+                    iw[(size_t)pn++] = e;
+                    h += (uint32_t)e;
+                } else {
+                    kind[e] = DEAD, parent[e] = me; // every variable of e lies in the new element: aggressive absorption
+                }
+            }
+            const int64_t p3 = pn;
+            for (int64_t p = p1 + elen[i]; p < p1 + len[i]; p++) {
+                const int32_t j = iw[(size_t)p];
+                if (kind[j] != VAR || inl[j] == step) continue; // (the pivot, dead variables, variables the new element covers)
+                deg += nv[j];
+                iw[(size_t)pn++] = j;
+                h += (uint32_t)j;
+            }
+            if (deg == 0) {
+                // nothing outside the new element: eliminated together with the pivot
+                kind[i] = DEAD, parent[i] = me;
+                nvpiv += nv[i], degme -= nv[i], nel += nv[i];
+                len[i] = 0;
+                continue;
+            }
+            degree[i] = (int32_t)std::min<int64_t>(degree[i], deg);
+            // the new element leads the list (one entry at least was dropped above: the pivot or an absorbed element)
+            iw[(size_t)pn] = iw[(size_t)p3];
+            iw[(size_t)p3] = iw[(size_t)p1];
+            iw[(size_t)p1] = me;
+            elen[i] = (int32_t)(p3 - p1) + 1;
+            len[i] = (int32_t)(pn - p1) + 1;
+            h += (uint32_t)me;
+            hval[i] = h;
+            const int32_t b = (int32_t)(h % (uint32_t)n);
+            hnext[i] = hhead[b], hhead[b] = i;
+        }
+        // ---- supervariables: variables of the new element with identical lists ------------------------------------------------------
+        for (int64_t pm = pme1; pm < pme2; pm++) {
+            const int32_t i0 = iw[(size_t)pm];
+            if (kind[i0] != VAR) continue;
+            const int32_t b = (int32_t)(hval[i0] % (uint32_t)n);
+            int32_t i = hhead[b];
+            hhead[b] = -1; // (the bucket is worked off once)
+            for (; i >= 0 && hnext[i] >= 0; i = hnext[i]) {
+                if (kind[i] != VAR) continue;
+                for (int64_t p = pe[i] + 1; p < pe[i] + len[i]; p++) cmp[iw[(size_t)p]] = i;
+                int32_t jprev = i;
+                for (int32_t j = hnext[i]; j >= 0;) {
+                    bool same = kind[j] == VAR && hval[j] == hval[i] && len[j] == len[i] && elen[j] == elen[i];
+                    for (int64_t p = pe[j] + 1; same && p < pe[j] + len[j]; p++) same = cmp[iw[(size_t)p]] == i;
+                    if (same) {
+                        nv[i] += nv[j];
+                        kind[j] = DEAD, parent[j] = i, len[j] = 0;
+                        j = hnext[j];
+                        hnext[jprev] = j;
+                    } else {
+                        jprev = j;
+                        j = hnext[j];
+                    }
+                }
+            }
+        }
+        // ---- the element's final list, the degrees of its variables ----------------------------------------------------------------
+        int64_t wr = pme1;
+        for (int64_t pm = pme1; pm < pme2; pm++) {
+            const int32_t i = iw[(size_t)pm];
+            if (kind[i] != VAR) continue;
+            int64_t d = (int64_t)degree[i] + degme - nv[i];
+            d = std::max<int64_t>(0, std::min<int64_t>(d, (int64_t)nact - nel - nv[i]));
+            degree[i] = (int32_t)d;
+            dl_insert(i, degree[i]);
+            if (degree[i] < mindeg) mindeg = degree[i];
+            iw[(size_t)wr++] = i;
+        }
+        nv[me] = nvpiv;
+        esize[me] = degme;
+        len[me] = (int32_t)(wr - pme1);
+        if (len[me] == 0) kind[me] = DEAD; // (a root of the assembly forest: no variable refers to it)
+        if (has_elem) pfree = wr;
+    }
+    // ---- permutation: pivots in elimination order, each followed by the variables eliminated with it (ascending) --------------------
+    std::vector<int32_t> owner((size_t)n, -1), cnt((size_t)n + 1, 0);
+    for (int32_t v = 0; v < n; v++) {
+        if (kind[v] == HUB || is_pivot[v]) continue;
+        int32_t r = v;
+        while (!is_pivot[r]) r = parent[r];
+        owner[v] = r;
+        cnt[r]++;
+    }
+    int32_t k = 0;
+    std::vector<int32_t> start((size_t)n, 0);
+    for (int32_t me : order) {
+        perm[(size_t)k++] = me;
+        start[me] = k;
+        k += cnt[me];
+    }
+    for (int32_t v = 0; v < n; v++)
+        if (owner[v] >= 0) perm[(size_t)start[owner[v]]++] = v;
+    for (int32_t v = 0; v < n; v++)
+        if (kind[v] == HUB) perm[(size_t)k++] = v;
+}
+
 // elimination tree of the permuted symmetric pattern (Liu's algorithm with path compression)
 static void etree(const Graph &gp, std::vector<int32_t> &parent) {
     int32_t n = gp.n;
@@ -647,12 +908,15 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             if (w != gc.ptr[(size_t)k + 1]) return -11;
         }
         std::vector<int32_t> permc, leafc;
-        nested_dissection(gc, opt, permc, leafc);
+        if (opt.ordering == ORDERING_MIN_DEGREE) approximate_minimum_degree(gc, opt, permc);
+        else nested_dissection(gc, opt, permc, leafc);
         for (int32_t k = 0; k < n / 2; k++) perm0[2 * k] = 2 * permc[k], perm0[2 * k + 1] = 2 * permc[k] + 1;
         if (!leafc.empty()) {
             leaf_of.resize((size_t)n);
             for (int32_t k = 0; k < n / 2; k++) leaf_of[2 * k] = leaf_of[2 * k + 1] = leafc[k];
         }
+    } else if (opt.ordering == ORDERING_MIN_DEGREE) {
+        approximate_minimum_degree(g, opt, perm0);
     } else {
         nested_dissection(g, opt, perm0, leaf_of);
     }

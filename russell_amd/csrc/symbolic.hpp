@@ -31,7 +31,7 @@ template <class T> using noinit_vector = std::vector<T, NoInitAlloc<T>>;
 enum OrderingKind : int32_t {
     ORDERING_NESTED_DISSECTION = 0, // level-structure nested dissection + minimum degree on the leaves
     ORDERING_NATURAL = 1,           // identity (Ordering::No in the reference's enum)
-    ORDERING_MIN_DEGREE = 2,        // nested dissection with one-vertex separators disabled: leaves only (small n)
+    ORDERING_MIN_DEGREE = 2,        // approximate minimum degree on A + A^T (Ordering::Amd / Amf / Qamd)
 };
 
 struct SymbolicOptions {
