@@ -62,6 +62,8 @@ extern "C" {
 #define HIPMF_ORDERING_NONE 2               /* natural order (Ordering::No) */
 #define HIPMF_ORDERING_AMD 3                /* approximate minimum degree on A + A^T (Ordering::Amd / Amf / Qamd; own implementation of the
                                                published method, symbolic.cpp) -- the better choice for patterns without small separators */
+#define HIPMF_ORDERING_BEST 4               /* both orderings, the one whose factorisation needs fewer flops is kept (Ordering::Best, UMFPACK's
+                                               meaning of the word); the effective ordering reports which one that was */
 /* scaling argument (same numbering as UMFPACK_SCALE_*) */
 #define HIPMF_SCALE_NONE 0
 #define HIPMF_SCALE_SUM 1

@@ -807,13 +807,15 @@ void set_hipmf_library_path(const std::string &path) {
 }
 
 // Ordering -> C-ABI constant, in the manner of umfpack_ordering (solver_umfpack.rs:457-472): the minimum-degree family (Amd, Amf, Qamd)
-// selects the backend's approximate minimum degree, No the natural order, everything else its default, the nested dissection
+// selects the backend's approximate minimum degree, Best tries both orderings, No is the natural order, everything else the default
+// (nested dissection)
 static int32_t hipmf_ordering(Ordering o) {
     switch (o) {
     case Ordering::No: return HIPMF_ORDERING_NONE;
     case Ordering::Amd:
     case Ordering::Amf:
     case Ordering::Qamd: return HIPMF_ORDERING_AMD;
+    case Ordering::Best: return HIPMF_ORDERING_BEST; // both, the sparser one (UMFPACK_ORDERING_BEST's meaning)
     default: return HIPMF_ORDERING_DEFAULT;
     }
 }

@@ -157,7 +157,8 @@ static int32_t c_initialize_body(struct InterfaceComplexHIPMF *h, int32_t orderi
     int32_t code = build_real_equivalent(h, row_pointers, col_indices, rp2, ci2);
     if (code != SUCCESSFUL_EXIT) return code;
     SymbolicOptions so;
-    so.ordering = (ordering == HIPMF_ORDERING_NONE) ? ORDERING_NATURAL : (ordering == HIPMF_ORDERING_AMD ? ORDERING_MIN_DEGREE : ORDERING_NESTED_DISSECTION);
+    so.ordering = (ordering == HIPMF_ORDERING_NONE) ? ORDERING_NATURAL
+                  : (ordering == HIPMF_ORDERING_AMD ? ORDERING_MIN_DEGREE : (ordering == HIPMF_ORDERING_BEST ? ORDERING_BEST : ORDERING_NESTED_DISSECTION));
     NumericOptions no;
     no.scaling = (scaling < 0 || scaling > 2) ? HIPMF_SCALE_SUM : scaling;
     if (pivot_epsilon >= 0.0) no.pivot_epsilon = pivot_epsilon;
@@ -165,7 +166,7 @@ static int32_t c_initialize_body(struct InterfaceComplexHIPMF *h, int32_t orderi
     no.verbose = verbose == 1;
     no.complex_pairs = true;
     if (const char *e = getenv("HIPMF_COMPLEX_PAIRS")) no.complex_pairs = atoi(e) != 0;
-    h->effective_ordering = (ordering == HIPMF_ORDERING_NONE || ordering == HIPMF_ORDERING_AMD) ? ordering : HIPMF_ORDERING_NESTED_DISSECTION;
+    h->effective_ordering = (ordering == HIPMF_ORDERING_NONE || ordering == HIPMF_ORDERING_AMD || ordering == HIPMF_ORDERING_BEST) ? ordering : HIPMF_ORDERING_NESTED_DISSECTION; // (BEST: resolved once the analysis has chosen)
     // the values (when given) let the analysis apply the maximum-product matching to a weak diagonal, as for real matrices
     std::vector<double> v2;
     if (values) {
@@ -205,7 +206,10 @@ int32_t complex_solver_hipmf_set_value_map(struct InterfaceComplexHIPMF *h, int3
 
 static int32_t finish(struct InterfaceComplexHIPMF *h, int32_t code, int32_t *effective_ordering, int32_t *effective_scaling, int32_t *num_perturbed,
                       double *rcond) {
-    if (effective_ordering) *effective_ordering = h->effective_ordering;
+    if (effective_ordering) {
+        *effective_ordering = h->effective_ordering;
+        if (h->effective_ordering == HIPMF_ORDERING_BEST) *effective_ordering = h->solver.S.best_chose_min_degree ? HIPMF_ORDERING_AMD : HIPMF_ORDERING_NESTED_DISSECTION;
+    }
     if (effective_scaling) *effective_scaling = h->solver.opt.scaling;
     if (num_perturbed) *num_perturbed = h->solver.n_perturbed;
     if (rcond) {

@@ -172,7 +172,8 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
     if (h->solver.initialized) return ERROR_ALREADY_INITIALIZED;
     if (ndim < 1) return ERROR_HIPMF_INVALID_MATRIX;
     SymbolicOptions so;
-    so.ordering = (ordering == HIPMF_ORDERING_NONE) ? ORDERING_NATURAL : (ordering == HIPMF_ORDERING_AMD ? ORDERING_MIN_DEGREE : ORDERING_NESTED_DISSECTION);
+    so.ordering = (ordering == HIPMF_ORDERING_NONE) ? ORDERING_NATURAL
+                  : (ordering == HIPMF_ORDERING_AMD ? ORDERING_MIN_DEGREE : (ordering == HIPMF_ORDERING_BEST ? ORDERING_BEST : ORDERING_NESTED_DISSECTION));
     NumericOptions no;
     no.scaling = (scaling < 0 || scaling > 2) ? HIPMF_SCALE_SUM : scaling;
     if (pivot_epsilon >= 0.0) no.pivot_epsilon = pivot_epsilon;
@@ -181,7 +182,7 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
     no.matching = h->opt_matching;
     no.device_memory_factor = h->opt_hybrid;
     h->ordering_requested = ordering;
-    h->effective_ordering = (ordering == HIPMF_ORDERING_NONE || ordering == HIPMF_ORDERING_AMD) ? ordering : HIPMF_ORDERING_NESTED_DISSECTION;
+    h->effective_ordering = (ordering == HIPMF_ORDERING_NONE || ordering == HIPMF_ORDERING_AMD || ordering == HIPMF_ORDERING_BEST) ? ordering : HIPMF_ORDERING_NESTED_DISSECTION; // (BEST: resolved once the analysis has chosen)
     int32_t code;
     // Symmetric INDEFINITE input (saddle-point / KKT matrices: put_lagrange_block, coo_matrix.rs:823-857): the L D L^T fronts never
     // interchange rows and the matching needs general storage, so a weak diagonal used to rest on perturbed pivots + refinement.  When
@@ -259,7 +260,10 @@ int32_t solver_hipmf_get_option(struct InterfaceHIPMF *h, int32_t option, double
 
 static int32_t finish_factorize(struct InterfaceHIPMF *h, int32_t code, int32_t *effective_ordering, int32_t *effective_scaling,
                                 int32_t *num_perturbed, double *rcond, double *det_c, double *det_e, C_BOOL compute_determinant) {
-    if (effective_ordering) *effective_ordering = h->effective_ordering;
+    if (effective_ordering) {
+        *effective_ordering = h->effective_ordering;
+        if (h->effective_ordering == HIPMF_ORDERING_BEST) *effective_ordering = h->solver.S.best_chose_min_degree ? HIPMF_ORDERING_AMD : HIPMF_ORDERING_NESTED_DISSECTION;
+    }
     if (effective_scaling) *effective_scaling = h->solver.opt.scaling;
     if (num_perturbed) *num_perturbed = h->solver.n_perturbed;
     if (rcond) *rcond = 0.0;

@@ -917,6 +917,53 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         }
     } else if (opt.ordering == ORDERING_MIN_DEGREE) {
         approximate_minimum_degree(g, opt, perm0);
+    } else if (opt.ordering == ORDERING_BEST) {
+        // Ordering::Best (UMFPACK's meaning, umfpack_ordering in solver_umfpack.rs:457-472: try several, keep the sparsest): both orderings,
+        // the one whose factorisation needs fewer flops by the column counts wins (the minimum degree runs on a thread of its own beside
+        // the dissection; the winner's elimination tree is built once more below)
+        std::vector<int32_t> perm_md;
+        std::atomic<bool> md_oom{false};
+        std::thread md([&]() {
+            try {
+                approximate_minimum_degree(g, opt, perm_md);
+            } catch (const std::bad_alloc &) {
+                md_oom.store(true);
+            }
+        });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() {
+                if (t.joinable()) t.join();
+            }
+        } joiner{md};
+        nested_dissection(g, opt, perm0, leaf_of);
+        md.join();
+        if (md_oom.load()) return -41;
+        auto flops_of = [&](const std::vector<int32_t> &pm) -> double {
+            std::vector<int32_t> pi((size_t)n);
+            for (int32_t k = 0; k < n; k++) {
+                if (pm[k] < 0 || pm[k] >= n) return -1.0;
+                pi[pm[k]] = k;
+            }
+            Graph q;
+            permute_graph(g, pm, pi, q, threads);
+            std::vector<int32_t> par, po;
+            etree(q, par);
+            postorder(par, po);
+            std::vector<int32_t> pm2((size_t)n), pi2((size_t)n), poi((size_t)n), par2((size_t)n);
+            for (int32_t k = 0; k < n; k++) pm2[k] = pm[po[k]], poi[po[k]] = k;
+            for (int32_t k = 0; k < n; k++) pi2[pm2[k]] = k, par2[k] = par[po[k]] < 0 ? -1 : poi[par[po[k]]];
+            permute_graph(g, pm2, pi2, q, threads);
+            std::vector<int64_t> c;
+            column_counts(q, par2, c);
+            double fl = 0.0;
+            for (int32_t k = 0; k < n; k++) fl += (double)c[k] * (double)c[k];
+            return fl;
+        };
+        const double f_nd = flops_of(perm0), f_md = flops_of(perm_md);
+        if (f_nd < 0.0 || f_md < 0.0) return -10;
+        S.best_chose_min_degree = f_md < f_nd;
+        if (S.best_chose_min_degree) perm0.swap(perm_md), leaf_of.clear();
     } else {
         nested_dissection(g, opt, perm0, leaf_of);
     }

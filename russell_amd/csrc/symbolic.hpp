@@ -32,6 +32,7 @@ enum OrderingKind : int32_t {
     ORDERING_NESTED_DISSECTION = 0, // level-structure nested dissection + minimum degree on the leaves
     ORDERING_NATURAL = 1,           // identity (Ordering::No in the reference's enum)
     ORDERING_MIN_DEGREE = 2,        // approximate minimum degree on A + A^T (Ordering::Amd / Amf / Qamd)
+    ORDERING_BEST = 3,              // both of the above, the one with fewer factorisation flops (Ordering::Best)
 };
 
 struct SymbolicOptions {
@@ -57,6 +58,7 @@ struct Symbolic {
     int32_t n = 0;
     int64_t nnz_a = 0;          // entries of the input CSR
     bool sym_lower = false;     // input holds the lower triangle of a symmetric matrix
+    bool best_chose_min_degree = false; // ORDERING_BEST: the minimum degree won
 
     std::vector<int32_t> perm;  // perm[new] = old   (applied to rows and columns)
     std::vector<int32_t> pinv;  // pinv[old] = new

@@ -116,3 +116,32 @@ def test_host_mirror_maps_the_minimum_degree_family_and_reports_what_ran(host_on
         x = solver.actual.solve(b)
         assert np.max(np.abs(x - xs)) < 1e-11
         assert solver.actual.stats()["output"]["effective_ordering"] == name, (o, solver.actual.stats()["output"])
+
+
+def test_ordering_best_keeps_the_sparser_of_the_two(emu_lib, host_on_emu):
+    # Ordering::Best (UMFPACK_ORDERING_BEST: try several orderings, keep the sparsest): dissection on the grid, minimum degree on the
+    # pattern without separators; the effective ordering says which
+    ORDERING_BEST = 4
+    n, rp, ci, v = P.poisson2d(60, 60)
+    _, rrp, rci, rv = _random_pattern(900, 7)
+    for (nn, p, c, vals, want) in ((n, rp, ci, v, ORDERING_DEFAULT), (900, rrp, rci, rv, ORDERING_AMD)):
+        fill = {}
+        for o in (ORDERING_DEFAULT, ORDERING_AMD, ORDERING_BEST):
+            s = Hipmf(emu_lib)
+            assert s.initialize(nn, p, c, ordering=o) == 0
+            fill[o] = s.stats()["nnz_l"]
+            if o == ORDERING_BEST:
+                xs = P.manufactured_solution(nn)
+                assert s.factorize(vals) == 0
+                assert np.max(np.abs(s.solve(P.csr_matvec(nn, p, c, vals, xs)) - xs)) < 1e-10
+            s.close()
+        assert fill[ORDERING_BEST] == fill[want], fill
+    # through the mirror: the reported name is the winner's
+    rows = np.repeat(np.arange(900), np.diff(rrp))
+    coo = RS.CooMatrix(900, 900, len(rv))
+    coo.put_many(rows.astype(np.int32), rci.astype(np.int32), rv.astype(np.float64))
+    par = RS.LinSolParams()
+    par.ordering = RS.Ordering.Best
+    solver = RS.LinSolver(RS.Genie.Hipmf)
+    solver.actual.factorize(coo, par)
+    assert solver.actual.stats()["output"]["effective_ordering"] == "Amd"
