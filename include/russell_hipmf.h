@@ -305,6 +305,16 @@ int32_t hipmf_fdm_dims(const void *fdm, int64_t *nu, int64_t *np, int64_t *nnz_b
 int32_t hipmf_fdm_structure_device(const void *fdm, int32_t *d_bar_i, int32_t *d_bar_j, int32_t *d_check_i, int32_t *d_check_j);
 int32_t hipmf_fdm_values_device(const void *fdm, double dx, double dy, double dz, double kx, double ky, double kz, double alpha,
                                 double *d_bar_values, double *d_check_values);
+/* The Lagrange-multiplier form of the same operator: replaces Fdm2d::get_matrices_lmm (fdm_2d.rs:672-748) -- the augmented matrix
+ *   M = [K C^T; C 0]  of order neq + nlag  (neq = nx*ny*nz: every node keeps its equation; nlag = prescribed nodes)
+ * as COO triplets in the reference's order: the molecule of every node ascending (entries above / below the diagonal skipped for
+ * lower / upper storage), then per prescribed node, ascending, the entry of C (row neq + ip, column m) and / or of C^T (lower storage
+ * keeps C, upper C^T, general storage both, C first); global node numbers as indices.  The matrix is a saddle-point system: handed to
+ * solver_hipmf_initialize WITH values (or to a symmetric-lower handle) it takes the matched path, no perturbed pivots.  The constraint
+ * matrix C of the reference's second return value is the (row - neq, column) view of the C entries.  The first call builds the offsets. */
+int32_t hipmf_fdm_lmm_dims(void *fdm, int64_t *neq, int64_t *nlag, int64_t *nnz);
+int32_t hipmf_fdm_lmm_structure_device(void *fdm, int32_t *d_i, int32_t *d_j);
+int32_t hipmf_fdm_lmm_values_device(void *fdm, double dx, double dy, double dz, double kx, double ky, double kz, double alpha, double *d_values);
 
 #ifdef __cplusplus
 }

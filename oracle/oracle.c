@@ -618,3 +618,56 @@ int64_t oracle_fdm_sps(int32_t nx, int32_t ny, int32_t nz, int32_t px, int32_t p
     *nnz_check = nchk;
     return nbar;
 }
+
+/* ---- finite-difference Laplacian, Lagrange-multiplier form: the triplets of Fdm2d::get_matrices_lmm --------------------------
+ * Plain restatement of /root/reference/russell_pde/src/fdm_2d.rs:672-748: M = [K C^T; C 0] of order neq + nlag -- every node's
+ * molecule (fdm_2d.rs:692-710: entries above / below the diagonal skipped for lower / upper storage, alpha on the diagonal, rows
+ * of boundary nodes halved), then per prescribed node, ascending (equation_handler.rs:153-190), the entries of C (row neq + ip,
+ * column m) and C^T (fdm_2d.rs:713-728: lower storage keeps C, upper C^T, general both, C first).
+ * nz > 1: the 7-point analogue.  Pinned on the dense M / C the reference's own test prints (fdm_2d.rs:1094-1131 ->
+ * tests/golden/fdm2d_reference_cases.json).  Output arrays must hold 7 ntot + 2 nlag entries; returns nnz(M); local = ip of the
+ * prescribed nodes (others untouched). */
+int64_t oracle_fdm_lmm(int32_t nx, int32_t ny, int32_t nz, int32_t px, int32_t py, int32_t pz, int32_t sym, const uint8_t *presc,
+                       double dx, double dy, double dz, double kx, double ky, double kz, double alpha, int32_t *mm_i, int32_t *mm_j,
+                       double *mm_v, int64_t *nlag_out) {
+    const int64_t nxy = (int64_t)nx * ny, ntot = nxy * nz;
+    const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+    double mol[7];
+    mol[0] = 2.0 * (kx / dx2 + ky / dy2 + (nz > 1 ? kz / dz2 : 0.0));
+    mol[1] = mol[2] = -kx / dx2;
+    mol[3] = mol[4] = -ky / dy2;
+    mol[5] = mol[6] = nz > 1 ? -kz / dz2 : 0.0;
+    const int nb = nz > 1 ? 7 : 5;
+    int64_t nnz = 0;
+    for (int64_t m = 0; m < ntot; m++) {
+        const int32_t i = (int32_t)(m % nx), j = (int32_t)((m / nx) % ny), k = (int32_t)(m / nxy);
+        int64_t nn[7];
+        nn[0] = m;
+        nn[1] = px ? (i != 0 ? m - 1 : m + (nx - 1)) : (i != 0 ? m - 1 : m + 1);
+        nn[2] = px ? (i != nx - 1 ? m + 1 : m - (nx - 1)) : (i != nx - 1 ? m + 1 : m - 1);
+        nn[3] = py ? (j != 0 ? m - nx : m + (int64_t)(ny - 1) * nx) : (j != 0 ? m - nx : m + nx);
+        nn[4] = py ? (j != ny - 1 ? m + nx : m - (int64_t)(ny - 1) * nx) : (j != ny - 1 ? m + nx : m - nx);
+        nn[5] = pz ? (k != 0 ? m - nxy : m + (int64_t)(nz - 1) * nxy) : (k != 0 ? m - nxy : m + nxy);
+        nn[6] = pz ? (k != nz - 1 ? m + nxy : m - (int64_t)(nz - 1) * nxy) : (k != nz - 1 ? m + nxy : m - nxy);
+        for (int b = 0; b < nb; b++) {
+            const int64_t n = nn[b];
+            if ((sym == 1 && m < n) || (sym == 2 && m > n)) continue;
+            double val = mol[b];
+            if (m == n) val += alpha;
+            if (!px && (i == 0 || i == nx - 1)) val /= 2.0;
+            if (!py && (j == 0 || j == ny - 1)) val /= 2.0;
+            if (nz > 1 && !pz && (k == 0 || k == nz - 1)) val /= 2.0;
+            mm_i[nnz] = (int32_t)m, mm_j[nnz] = (int32_t)n, mm_v[nnz] = val;
+            nnz++;
+        }
+    }
+    int64_t ip = 0;
+    for (int64_t m = 0; m < ntot; m++) {
+        if (!(presc && presc[m])) continue;
+        if (sym != 2) mm_i[nnz] = (int32_t)(ntot + ip), mm_j[nnz] = (int32_t)m, mm_v[nnz] = 1.0, nnz++; /* C */
+        if (sym != 1) mm_i[nnz] = (int32_t)m, mm_j[nnz] = (int32_t)(ntot + ip), mm_v[nnz] = 1.0, nnz++; /* C^T */
+        ip++;
+    }
+    *nlag_out = ip;
+    return nnz;
+}

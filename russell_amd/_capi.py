@@ -81,6 +81,9 @@ SYMBOLS = {
     "hipmf_fdm_structure_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hipmf_fdm_values_device": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                             C.c_void_p, C.c_void_p]),
+    "hipmf_fdm_lmm_dims": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hipmf_fdm_lmm_structure_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hipmf_fdm_lmm_values_device": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
 }
 
 _cache = {}

@@ -174,7 +174,51 @@ __global__ void __launch_bounds__(FDM_T) k_fdm_fill(FdmGrid g, const uint8_t *__
     }
 }
 
+// Lagrange-multiplier form (Fdm2d::get_matrices_lmm, fdm_2d.rs:672-748): M = [K C^T; C 0].  The molecule of EVERY node at off_all[m]
+// (the offsets of a numbering without prescribed nodes), then per prescribed node the entries of C (row neq + ip, column m) and / or
+// C^T at  nnz(K) + ip * per_presc  (lower storage keeps C, upper C^T, general storage both, C first).
+template <bool VALUES>
+__global__ void __launch_bounds__(FDM_T) k_fdm_lmm_fill(FdmGrid g, const uint8_t *__restrict__ presc, int64_t ntot, const int32_t *__restrict__ local,
+                                                       const int64_t *__restrict__ off_all, int64_t nnz_k, int32_t *__restrict__ mm_i, int32_t *__restrict__ mm_j,
+                                                       double *__restrict__ mm_v, double mol0, double molx, double moly, double molz, double alpha) {
+    const int64_t m = (int64_t)blockIdx.x * FDM_T + threadIdx.x;
+    if (m >= ntot) return;
+    const int i = (int)(m % g.nx), j = (int)((m / g.nx) % g.ny), k = (int)(m / ((int64_t)g.nx * g.ny));
+    const int nb = g.nz > 1 ? 7 : 5;
+    int64_t o = off_all[m];
+    double scale = 1.0;
+    if (!g.px && (i == 0 || i == g.nx - 1)) scale *= 0.5;
+    if (!g.py && (j == 0 || j == g.ny - 1)) scale *= 0.5;
+    if (g.nz > 1 && !g.pz && (k == 0 || k == g.nz - 1)) scale *= 0.5;
+    for (int b = 0; b < nb; b++) {
+        const int64_t n = fdm_neighbour(g, m, i, j, k, b);
+        if (fdm_skip(g, m, n)) continue;
+        if (VALUES) {
+            double val = b == 0 ? mol0 : (b <= 2 ? molx : (b <= 4 ? moly : molz));
+            if (m == n) val += alpha;
+            mm_v[o] = val * scale;
+        } else
+            mm_i[o] = (int32_t)m, mm_j[o] = (int32_t)n;
+        o++;
+    }
+    if (presc && presc[m]) {
+        const int64_t ip = local[m];
+        int64_t q = nnz_k + ip * (g.sym == 0 ? 2 : 1);
+        if (g.sym != 2) { // C
+            if (VALUES) mm_v[q] = 1.0;
+            else mm_i[q] = (int32_t)(ntot + ip), mm_j[q] = (int32_t)m;
+            q++;
+        }
+        if (g.sym != 1) { // C^T
+            if (VALUES) mm_v[q] = 1.0;
+            else mm_i[q] = (int32_t)m, mm_j[q] = (int32_t)(ntot + ip);
+        }
+    }
+}
+
 struct FdmHandle {
+    int64_t *d_off_all = nullptr; // Lagrange-multiplier form: offsets of every node's molecule (built at the first hipmf_fdm_lmm_* call)
+    int64_t nnz_k_all = 0;
     FdmGrid g;
     int64_t ntot = 0, totals[4] = {0, 0, 0, 0}; // nu, np, nnz(K-bar), nnz(K-check)
     uint8_t *d_presc = nullptr;
@@ -203,7 +247,40 @@ void fdm_free(FdmHandle *h) {
     if (h->d_local) (void)hipFree(h->d_local);
     if (h->d_off_bar) (void)hipFree(h->d_off_bar);
     if (h->d_off_chk) (void)hipFree(h->d_off_chk);
+    if (h->d_off_all) (void)hipFree(h->d_off_all);
     delete h;
+}
+
+// offsets of the molecules of ALL nodes (the counting kernels run without the prescribed mask); 0 or a status code
+int32_t fdm_ensure_lmm(FdmHandle *h) {
+    if (h->d_off_all) return 0;
+    if ((int64_t)h->ntot + h->totals[1] > 0x7fffffffLL) return 803; // rows neq + ip are int32 in the triplets
+    const int64_t nblocks = (h->ntot + FDM_T - 1) / FDM_T;
+    int64_t *d_bsum = nullptr, *d_tot = nullptr, *d_chk = nullptr, *d_all = nullptr;
+    int32_t *d_loc = nullptr;
+    bool ok = hipMalloc((void **)&d_bsum, sizeof(int64_t) * 4 * (size_t)nblocks) == hipSuccess;
+    ok = ok && hipMalloc((void **)&d_tot, sizeof(int64_t) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&d_loc, sizeof(int32_t) * (size_t)h->ntot) == hipSuccess;
+    ok = ok && hipMalloc((void **)&d_chk, sizeof(int64_t) * (size_t)h->ntot) == hipSuccess;
+    ok = ok && hipMalloc((void **)&d_all, sizeof(int64_t) * (size_t)h->ntot) == hipSuccess;
+    int64_t tot[4] = {0, 0, 0, 0};
+    if (ok) {
+        hipLaunchKernelGGL(k_fdm_block_sums, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, (const uint8_t *)nullptr, h->ntot, d_bsum);
+        hipLaunchKernelGGL(k_fdm_scan_blocks, dim3(1), dim3(1024), 0, 0, nblocks, d_bsum, d_tot);
+        hipLaunchKernelGGL(k_fdm_node_offsets, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, (const uint8_t *)nullptr, h->ntot, d_bsum, d_loc, d_all, d_chk);
+        ok = hipMemcpy(tot, d_tot, sizeof(int64_t) * 4, hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess;
+    }
+    if (d_bsum) (void)hipFree(d_bsum);
+    if (d_tot) (void)hipFree(d_tot);
+    if (d_loc) (void)hipFree(d_loc);
+    if (d_chk) (void)hipFree(d_chk);
+    if (!ok) {
+        if (d_all) (void)hipFree(d_all);
+        return 200000; // ERROR_MALLOC's neighbour on the device side would be ERROR_HIP_MALLOC; the shared code says "memory"
+    }
+    h->d_off_all = d_all;
+    h->nnz_k_all = tot[2];
+    return 0;
 }
 
 } // namespace
@@ -284,6 +361,46 @@ int32_t hipmf_fdm_values_device(const void *handle, double dx, double dy, double
     hipLaunchKernelGGL(k_fdm_fill<true>, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, h->d_presc, h->ntot, h->d_local, h->d_off_bar, h->d_off_chk,
                        (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, d_bar_values, d_check_values, 2.0 * (bx + by + bz), -bx, -by, -bz,
                        alpha);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return 350;
+    return 0;
+}
+
+// ---- Lagrange-multiplier form (Fdm2d::get_matrices_lmm, fdm_2d.rs:672-748) -----------------------------------------------------------
+int32_t hipmf_fdm_lmm_dims(void *handle, int64_t *neq, int64_t *nlag, int64_t *nnz) {
+    FdmHandle *h = (FdmHandle *)handle;
+    if (!h || !neq || !nlag || !nnz) return 100000;
+    FdmDeviceScope scope(h->device);
+    const int32_t rc = fdm_ensure_lmm(h);
+    if (rc != 0) return rc;
+    *neq = h->ntot, *nlag = h->totals[1];
+    *nnz = h->nnz_k_all + h->totals[1] * (h->g.sym == 0 ? 2 : 1);
+    return 0;
+}
+
+int32_t hipmf_fdm_lmm_structure_device(void *handle, int32_t *d_i, int32_t *d_j) {
+    FdmHandle *h = (FdmHandle *)handle;
+    if (!h || !d_i || !d_j) return 100000;
+    FdmDeviceScope scope(h->device);
+    const int32_t rc = fdm_ensure_lmm(h);
+    if (rc != 0) return rc;
+    const int64_t nblocks = (h->ntot + FDM_T - 1) / FDM_T;
+    hipLaunchKernelGGL(k_fdm_lmm_fill<false>, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, h->d_presc, h->ntot, h->d_local, h->d_off_all, h->nnz_k_all, d_i, d_j,
+                       (double *)nullptr, 0.0, 0.0, 0.0, 0.0, 0.0);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return 350;
+    return 0;
+}
+
+int32_t hipmf_fdm_lmm_values_device(void *handle, double dx, double dy, double dz, double kx, double ky, double kz, double alpha, double *d_values) {
+    FdmHandle *h = (FdmHandle *)handle;
+    if (!h || !d_values) return 100000;
+    if (!(dx > 0.0) || !(dy > 0.0) || (h->g.nz > 1 && !(dz > 0.0))) return 803;
+    FdmDeviceScope scope(h->device);
+    const int32_t rc = fdm_ensure_lmm(h);
+    if (rc != 0) return rc;
+    const double bx = kx / (dx * dx), by = ky / (dy * dy), bz = h->g.nz > 1 ? kz / (dz * dz) : 0.0;
+    const int64_t nblocks = (h->ntot + FDM_T - 1) / FDM_T;
+    hipLaunchKernelGGL(k_fdm_lmm_fill<true>, dim3((unsigned)nblocks), dim3(FDM_T), 0, 0, h->g, h->d_presc, h->ntot, h->d_local, h->d_off_all, h->nnz_k_all,
+                       (int32_t *)nullptr, (int32_t *)nullptr, d_values, 2.0 * (bx + by + bz), -bx, -by, -bz, alpha);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return 350;
     return 0;
 }

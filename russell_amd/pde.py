@@ -57,6 +57,31 @@ class FdmDevice:
             raise RuntimeError("hipmf_fdm_values_device failed with status %d" % code)
         return bv, cv
 
+    # ---- Lagrange-multiplier form: M = [K C^T; C 0] of Fdm2d::get_matrices_lmm (fdm_2d.rs:672-748) ----
+    def lmm_dims(self):
+        """(neq, nlag, nnz) of the augmented matrix; its order is neq + nlag."""
+        neq, nlag, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        code = self.lib.hipmf_fdm_lmm_dims(self.h, C.byref(neq), C.byref(nlag), C.byref(nnz))
+        if code != 0:
+            raise RuntimeError("hipmf_fdm_lmm_dims failed with status %d" % code)
+        return neq.value, nlag.value, nnz.value
+
+    def lmm_structure_device(self):
+        """Device arrays (i, j) of the triplets of M (global node numbers; multiplier ip is row / column neq + ip)."""
+        nnz = self.lmm_dims()[2]
+        di, dj = self._alloc(4 * nnz), self._alloc(4 * nnz)
+        code = self.lib.hipmf_fdm_lmm_structure_device(self.h, di, dj)
+        if code != 0:
+            raise RuntimeError("hipmf_fdm_lmm_structure_device failed with status %d" % code)
+        return di, dj
+
+    def lmm_values_device(self, d=(1.0, 1.0, 1.0), k=(1.0, 1.0, 1.0), alpha=0.0, out=None):
+        dv = out if out is not None else self._alloc(8 * self.lmm_dims()[2])
+        code = self.lib.hipmf_fdm_lmm_values_device(self.h, d[0], d[1], d[2], k[0], k[1], k[2], alpha, dv)
+        if code != 0:
+            raise RuntimeError("hipmf_fdm_lmm_values_device failed with status %d" % code)
+        return dv
+
     def to_host(self, dptr, count, dtype):
         a = np.zeros(max(count, 1), dtype)
         if count > 0:

@@ -45,6 +45,8 @@ def _load():
     lib.oracle_lu_determinant.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.oracle_lu_rcond.restype = C.c_double
     lib.oracle_lu_rcond.argtypes = [C.c_void_p]
+    lib.oracle_fdm_lmm.restype = C.c_int64
+    lib.oracle_fdm_lmm.argtypes = [C.c_int32] * 7 + [C.c_void_p] + [C.c_double] * 7 + [i32p, i32p, f64p, C.POINTER(C.c_int64)]
     lib.oracle_fdm_sps.restype = C.c_int64
     lib.oracle_fdm_sps.argtypes = [C.c_int32] * 7 + [C.c_void_p] + [C.c_double] * 7 + [i32p, i32p, i32p, f64p, i32p, i32p, f64p, C.POINTER(C.c_int64)]
     return lib
@@ -177,3 +179,16 @@ def fdm_sps(nx, ny, nz=1, periodic=(False, False, False), sym=0, prescribed=None
     nu = ntot if mask is None else int(ntot - np.count_nonzero(mask))
     return {"nu": nu, "np": ntot - nu, "local": local, "bar": (bi[:nbar].copy(), bj[:nbar].copy(), bv[:nbar].copy()),
             "check": (ci[:nchk.value].copy(), cj[:nchk.value].copy(), cv[:nchk.value].copy())}
+
+
+def fdm_lmm(nx, ny, nz=1, periodic=(False, False, False), sym=0, prescribed=None, d=(1.0, 1.0, 1.0), k=(1.0, 1.0, 1.0), alpha=0.0):
+    """Triplets of the augmented matrix M = [K C^T; C 0] of Fdm2d::get_matrices_lmm (and its 7-point analogue) in the reference's order."""
+    ntot = nx * ny * nz
+    mask = None if prescribed is None else np.ascontiguousarray(prescribed, dtype=np.uint8)
+    cap = 7 * ntot + 2 * (0 if mask is None else int(np.count_nonzero(mask)))
+    mi, mj, mv = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap)
+    nlag = C.c_int64(0)
+    nnz = LIB.oracle_fdm_lmm(nx, ny, nz, int(periodic[0]), int(periodic[1]), int(periodic[2]), sym,
+                             None if mask is None else mask.ctypes.data_as(C.c_void_p), d[0], d[1], d[2], k[0], k[1], k[2], alpha, mi, mj, mv,
+                             C.byref(nlag))
+    return {"neq": ntot, "nlag": nlag.value, "ndim": ntot + nlag.value, "mm": (mi[:nnz].copy(), mj[:nnz].copy(), mv[:nnz].copy())}

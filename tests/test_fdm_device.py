@@ -153,3 +153,112 @@ def test_poisson_solved_with_device_assembled_values():
         assert np.max(np.abs(x - xs)) < 1e-9
     s.close()
     f.close()
+
+
+# ---- Lagrange-multiplier form: M = [K C^T; C 0] of Fdm2d::get_matrices_lmm (fdm_2d.rs:672-748) --------------------------------------
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+@pytest.mark.parametrize("sym", [0, 1, 2])
+def test_oracle_reproduces_the_reference_lmm_matrices(case, sym):
+    # the reference asserts the same dense M for Sym::No, YesLower, YesUpper and YesFull (fdm_2d.rs:1094-1131) and C apart
+    r = O.fdm_lmm(case["nx"], case["ny"], 1, (case["periodic_x"], case["periodic_y"], False), sym, mask_of(case),
+                  (case["dx"], case["dy"], 1.0), (case["kx"], case["ky"], 0.0), case["alpha"])
+    assert (r["neq"], r["nlag"], r["ndim"]) == (case["nx"] * case["ny"], case["np"], case["nx"] * case["ny"] + case["np"])
+    mm = dense_from(r["ndim"], r["ndim"], r["mm"], sym)
+    assert np.array_equal(mm, np.array(case["lmm_mm_dense"]))  # exact: small integers
+    if case["lmm_cc_dense"] is not None:
+        i, j, v = r["mm"]
+        sel = (i >= r["neq"]) if sym != 2 else (j >= r["neq"])  # the C entries (the C^T ones for upper storage)
+        ci, cj = (i[sel] - r["neq"], j[sel]) if sym != 2 else (j[sel] - r["neq"], i[sel])
+        assert np.array_equal(dense_from(r["nlag"], r["neq"], (ci, cj, v[sel])), np.array(case["lmm_cc_dense"]))
+    # triplet budget of the reference: band * neq + 2 nlag entries allocated (fdm_2d.rs:688-689)
+    assert len(r["mm"][0]) <= (3 if sym else 5) * r["neq"] + 2 * r["nlag"]
+
+
+def _device_lmm_vs_oracle(lib_path, nx, ny, nz, periodic, sym, mask, d, k, alpha):
+    from russell_amd.pde import FdmDevice
+    want = O.fdm_lmm(nx, ny, nz, periodic, sym, mask, d, k, alpha)
+    f = FdmDevice(nx, ny, nz, periodic, sym, mask, lib_path=lib_path)
+    neq, nlag, nnz = f.lmm_dims()
+    assert (neq, nlag, nnz) == (want["neq"], want["nlag"], len(want["mm"][0]))
+    di, dj = f.lmm_structure_device()
+    dv = f.lmm_values_device(d, k, alpha)
+    assert np.array_equal(f.to_host(di, nnz, np.int32), want["mm"][0])
+    assert np.array_equal(f.to_host(dj, nnz, np.int32), want["mm"][1])
+    assert np.array_equal(f.to_host(dv, nnz, np.float64), want["mm"][2])  # bit-exact
+    f.close()
+
+
+def test_device_lmm_kernels_match_oracle_in_the_emulator(emu_lib):
+    rng = np.random.default_rng(6)
+    for case in CASES:
+        for sym in (0, 1, 2):
+            _device_lmm_vs_oracle(emu_lib, case["nx"], case["ny"], 1, (case["periodic_x"], case["periodic_y"], False), sym, mask_of(case),
+                                  (case["dx"], case["dy"], 1.0), (case["kx"], case["ky"], 0.0), 0.0)
+    mask = (rng.random(23 * 17) < 0.2).astype(np.uint8)
+    _device_lmm_vs_oracle(emu_lib, 23, 17, 1, (False, True, False), 1, mask, (0.5, 0.25, 1.0), (3.0, 7.0, 0.0), 1.5)
+    _device_lmm_vs_oracle(emu_lib, 23, 17, 1, (True, False, False), 2, mask, (0.5, 0.25, 1.0), (3.0, 7.0, 0.0), 0.0)
+    mask3 = (rng.random(9 * 7 * 5) < 0.15).astype(np.uint8)
+    _device_lmm_vs_oracle(emu_lib, 9, 7, 5, (True, False, False), 0, mask3, (0.5, 0.25, 2.0), (3.0, 7.0, 11.0), 0.0)
+
+
+def _solve_lmm(lib_path, nx, ny):
+    """Dirichlet problem in its Lagrange-multiplier form, assembled on the device as the lower triangle and solved as the saddle-point
+    system it is (weak diagonal in the multiplier rows: the handle mirrors it to general storage and matches); against the oracle's LU."""
+    from russell_amd.backend import Hipmf
+    from russell_amd.pde import FdmDevice, SYM_LOWER
+    mask = np.zeros((ny, nx), np.uint8)
+    mask[0, :] = mask[-1, :] = mask[:, 0] = mask[:, -1] = 1
+    f = FdmDevice(nx, ny, 1, (False, False, False), SYM_LOWER, mask.ravel(), lib_path=lib_path)
+    neq, nlag, nnz = f.lmm_dims()
+    di, dj = f.lmm_structure_device()
+    dv = f.lmm_values_device((1.0 / (nx - 1), 1.0 / (ny - 1), 1.0), (1.0, 1.0, 0.0), 0.0)
+    ti, tj, tv = f.to_host(di, nnz, np.int32), f.to_host(dj, nnz, np.int32), f.to_host(dv, nnz, np.float64)
+    f.close()
+    import scipy.sparse as sp
+    ndim = neq + nlag
+    L = sp.coo_matrix((tv, (ti, tj)), shape=(ndim, ndim)).tocsr()  # duplicates (mirrored ghost nodes) summed, as COO -> CSR does
+    L.sort_indices()
+    assert (sp.triu(L, 1)).nnz == 0
+    rng = np.random.default_rng(3)
+    xs = rng.uniform(-1.0, 1.0, ndim)
+    full = (L + sp.tril(L, -1).T).tocsr()
+    b = full @ xs
+    s = Hipmf(lib_path)
+    assert s.initialize(ndim, L.indptr.astype(np.int32), L.indices.astype(np.int32), general_symmetric=True, values=L.data) == 0
+    assert s.factorize(L.data) == 0
+    x = s.solve(b)
+    st = s.stats()
+    s.close()
+    assert st["n_perturbed"] == 0
+    assert np.max(np.abs(x - xs)) <= 1e-9 * np.max(np.abs(xs))
+    return ndim
+
+
+def test_lagrange_form_is_solved_as_a_saddle_point_system_in_the_emulator(emu_lib):
+    assert _solve_lmm(emu_lib, 14, 11) == 14 * 11 + 2 * (14 + 11) - 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 3, 1), (257, 129, 1), (1000, 1000, 1), (41, 37, 29)])
+def test_device_lmm_assembly_equals_oracle_bitwise(shape):
+    nx, ny, nz = shape
+    rng = np.random.default_rng(nx * 5 + ny)
+    ntot = nx * ny * nz
+    for sym, periodic, dens in ((0, (False, False, False), 0.05), (1, (False, True, False), 0.1), (2, (True, False, nz > 1), 0.3)):
+        mask = (rng.random(ntot) < dens).astype(np.uint8)
+        _device_lmm_vs_oracle(None, nx, ny, nz, periodic, sym, mask, (0.1, 0.3, 0.7), (2.0, 5.0, 11.0), 0.25)
+
+
+@pytest.mark.gpu
+def test_reference_lmm_matrices_on_the_device_and_a_saddle_point_solve():
+    from russell_amd.pde import FdmDevice
+    for case in CASES:
+        for sym in (0, 1, 2):
+            f = FdmDevice(case["nx"], case["ny"], 1, (case["periodic_x"], case["periodic_y"], False), sym, mask_of(case))
+            neq, nlag, nnz = f.lmm_dims()
+            di, dj = f.lmm_structure_device()
+            dv = f.lmm_values_device((case["dx"], case["dy"], 1.0), (case["kx"], case["ky"], 0.0), case["alpha"])
+            trip = (f.to_host(di, nnz, np.int32), f.to_host(dj, nnz, np.int32), f.to_host(dv, nnz, np.float64))
+            assert np.array_equal(dense_from(neq + nlag, neq + nlag, trip, sym), np.array(case["lmm_mm_dense"]))
+            f.close()
+    _solve_lmm(None, 300, 200)
