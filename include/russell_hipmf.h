@@ -188,6 +188,8 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
                                             * handing over lower-triangle values */
 #define HIPMF_COUNTER_MID_FRONTS 8        /* fronts one workgroup factorises in one launch per level (k_front_lu: f > 64, at most 32 pivots and 192 off-diagonal rows, LU mode; k_front where switched on) */
 #define HIPMF_COUNTER_CHAIN_FALLBACKS 7    /* factorisations repeated with one launch per tiled step after a hand-off of a chained launch timed out */
+#define HIPMF_COUNTER_PLAN_DIGEST 9       /* diagnostic: digest of the row structures, pool layout and extend-add task lists of the last initialize
+                                             (computed only when HIPMF_PLAN_DIGEST is set in the environment, else 0): equal for every thread count */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

@@ -333,6 +333,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SPLIT_PIVOTS")) so.split_pivots = std::max(0, atoi(e)); // tuning knob: chain links of the big supernodes
     if (const char *e = getenv("HIPMF_DENSE_ROWS")) so.dense_row_factor = atof(e); // degree threshold factor of the hub vertices (0: off)
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
+    if (const char *e = getenv("HIPMF_PAR_MIN")) so.parallel_min_n = std::max(0, atoi(e)); // (tests: the threaded pieces of the analysis on small matrices)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
@@ -1481,7 +1482,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         }
         int ea_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *e = getenv("HIPMF_ND_THREADS")) ea_threads = std::max(1, atoi(e));
-        if (tiles_bound < 200000) ea_threads = 1; // (not worth the thread start-up)
+        int64_t ea_par_min = 200000; // (below: not worth the thread start-up)
+        if (const char *e = getenv("HIPMF_PAR_MIN")) ea_par_min = std::max(0, atoi(e));
+        if (tiles_bound < ea_par_min) ea_threads = 1;
         ea_pass(false, ea_threads);
         if (ea_oom.load()) return ERROR_MALLOC;
         // layout: level by level, a level's first tiles (nhead) in front of its other tasks, both in the order of the level's fronts
@@ -1506,6 +1509,21 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         ea.resize((size_t)task_pos), ear.resize((size_t)range_pos);
         ea_pass(true, ea_threads);
         if (ea_oom.load()) return ERROR_MALLOC;
+    }
+    plan_digest = 0;
+    if (getenv("HIPMF_PLAN_DIGEST")) {
+        // (diagnostic / tests: one number over what the threaded pieces of initialize produce -- row structures, relative indices, pool
+        //  layout, extend-add task lists -- to compare thread counts and builds; a pass over gigabytes at 200^3, hence opt-in)
+        uint64_t h = 1469598103934665603ull;
+        auto eat = [&](const void *p, size_t bytes) {
+            const unsigned char *b = (const unsigned char *)p;
+            for (size_t i = 0; i < bytes; i++) h = (h ^ b[i]) * 1099511628211ull;
+        };
+        eat(S.sn_rowptr.data(), S.sn_rowptr.size() * sizeof(int64_t)), eat(S.sn_rows.data(), S.sn_rows.size() * sizeof(int32_t));
+        eat(S.rel.data(), S.rel.size() * sizeof(int32_t)), eat(S.front_off.data(), S.front_off.size() * sizeof(int64_t));
+        eat(ea.data(), ea.size() * sizeof(EaTask)), eat(ear.data(), ear.size() * sizeof(EaRange));
+        for (const LevelPlan &L : levels) eat(&L.ea_off, sizeof L.ea_off), eat(&L.ea_cnt, sizeof L.ea_cnt);
+        plan_digest = (int64_t)(h & 0x7fffffffffffffffull);
     }
     if (ea_lds_active()) {
         HIPMF_ALLOW_LDS(k_extend_add_lds<false>, sizeof(double) * EA_TILE_C * EA_TILE_R);

@@ -141,6 +141,7 @@ class Solver {
     // layout of the pool (computed at initialize / after a re-matching factorize)
     uint64_t plan_signature() const { return plan_sig; }
     uint64_t plan_sig = 0;
+    int64_t plan_digest = 0; // HIPMF_PLAN_DIGEST set at initialize: digest of the row structures, pool layout and extend-add task lists (else 0)
     int64_t nnz_in_values() const { return nnz_in; } // inputs the installed value map reads (0: none)
     const std::vector<int32_t> &kept_row_pointers() const { return h_rp_keep; } // the caller's CSR structure as handed to initialize
     const std::vector<int32_t> &kept_col_indices() const { return h_ci_keep; }

@@ -1136,7 +1136,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         };
         std::vector<Chunk> chunks;
         std::vector<int32_t> chunk_of((size_t)S.nsuper, -1);
-        if (threads > 1 && n >= 200000) {
+        if (threads > 1 && n >= opt.parallel_min_n) {
             std::vector<int32_t> desc_first((size_t)S.nsuper);
             std::iota(desc_first.begin(), desc_first.end(), 0);
             for (int32_t s = 0; s < S.nsuper; s++)

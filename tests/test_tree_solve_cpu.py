@@ -125,3 +125,31 @@ def test_golden_ordering_is_pinned(emu_lib, grid, monkeypatch):
             break  # (one analysis of the 1M-DOF matrix is enough for the CPU suite's time budget)
     for g in got:
         assert g == want
+
+
+@pytest.mark.parametrize("case", ["poisson2d 150x140", "poisson3d 24 lower", "poisson3d 20"])
+def test_threaded_pieces_of_initialize_do_not_depend_on_the_thread_count(emu_lib, case, monkeypatch):
+    # round 4: row structures are built subtree by subtree and the extend-add task lists front by front on host threads.  Forced on for
+    # small matrices (HIPMF_PAR_MIN=0), the digest of everything they produce equals the serial build's for every thread count.
+    monkeypatch.setenv("HIPMF_PLAN_DIGEST", "1")
+    if case.startswith("poisson2d"):
+        n, rp, ci, v = P.poisson2d(150, 140)
+        sym = False
+    else:
+        n, rp, ci, v = P.poisson3d(int(case.split()[1]))
+        sym = "lower" in case
+        if sym:
+            rp, ci, v = P.lower_triangle(n, rp, ci, v)
+    digests = {}
+    for threads, par_min in (("1", None), ("2", "0"), ("5", "0"), ("16", "0")):
+        monkeypatch.setenv("HIPMF_ND_THREADS", threads)
+        if par_min is None:
+            monkeypatch.delenv("HIPMF_PAR_MIN", raising=False)
+        else:
+            monkeypatch.setenv("HIPMF_PAR_MIN", par_min)
+        s = Hipmf(emu_lib)
+        assert s.initialize(n, rp, ci, general_symmetric=sym) == 0
+        digests[threads] = (s.counter("plan_digest"), s.stats()["nnz_l"], s.stats()["nsuper"])
+        s.close()
+    assert digests["1"][0] != 0
+    assert len(set(digests.values())) == 1, digests
