@@ -568,7 +568,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         AL.zero_off.assign((size_t)S.nlevels, 0), AL.zero_n.assign((size_t)S.nlevels, 0);
         for (int32_t l = 0; l < S.nlevels; l++) {
             AL.zero_off[(size_t)l] = (int32_t)zt.size();
-            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            // (the first-touch extend-add writes every working block whole: no per-level zero-fill launches, no tasks for them -- at 200^3
+            //  they were 2.8 M records built and uploaded for nothing)
+            for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1] && !ea_lds_active(); k++) {
                 const int32_t s = S.level_sn[k];
                 if (S.fsize(s) > SMALL_F) zero_range(S.front_off[s], (int64_t)S.front_ld[s] * S.fsize(s));
             }
