@@ -438,6 +438,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         std::vector<uint16_t> sc_pos;
         std::vector<ZeroTask> zt;
         int32_t zero_cnt = 0, status = 0;
+        double seconds = 0.0; // (verbose: how long the thread below worked)
     } AL;
     struct Joiner { // (every early return below must not leave the thread running)
         std::thread &t;
@@ -447,17 +448,26 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     };
     std::thread asm_thread([this, &AL]() {
       try {
+        const auto t_asm = std::chrono::steady_clock::now();
+        struct Stop {
+            double &out;
+            std::chrono::steady_clock::time_point t0;
+            ~Stop() { out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+        } stop{AL.seconds, t_asm};
         const int32_t ns = S.nsuper;
         std::vector<int32_t> &sa_ptr = AL.sa_ptr;
         std::vector<int64_t> &sc_cnt = AL.sc_cnt;
         sa_ptr.assign((size_t)ns + 1, 0);
         sc_cnt.assign((size_t)S.nlevels + 1, 0);
+        // (front size per supernode once: S.fsize reads four entries of two arrays, and both passes below ask it per matrix entry)
+        std::vector<int32_t> fsz((size_t)ns);
+        for (int32_t s = 0; s < ns; s++) fsz[(size_t)s] = S.fsize(s);
         for (int pass = 0; pass < 2; pass++) {
             const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
             for (int64_t k = 0; k < (int64_t)am.size(); k++)
                 if (am[k] >= 0) {
                     const int32_t s = S.amap_sn[(size_t)k];
-                    if (S.fsize(s) <= SMALL_F) sa_ptr[(size_t)s + 1]++;
+                    if (fsz[(size_t)s] <= SMALL_F) sa_ptr[(size_t)s + 1]++;
                     else sc_cnt[(size_t)S.sn_level[s] + 1]++;
                 }
         }
@@ -478,13 +488,13 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             for (int64_t k = 0; k < (int64_t)am.size(); k++)
                 if (am[k] >= 0) {
                     const int32_t s = S.amap_sn[(size_t)k];
-                    if (S.fsize(s) > SMALL_F) {
+                    if (fsz[(size_t)s] > SMALL_F) {
                         const size_t q = (size_t)wl[(size_t)S.sn_level[s]]++;
                         AL.sc_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
                         AL.sc_at[q] = am[k];
                         continue;
                     }
-                    const int64_t off = am[k] - S.front_off[s], f = S.fsize(s);
+                    const int64_t off = am[k] - S.front_off[s], f = fsz[(size_t)s];
                     const size_t q = (size_t)w[s]++;
                     AL.sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
                     AL.sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
@@ -536,7 +546,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             for (size_t e = 0; e < ne; e++) {
                 const int32_t k = AL.sc_k[e] < 0 ? ~AL.sc_k[e] : AL.sc_k[e];
                 const int32_t s = S.amap_sn[(size_t)k];
-                const int64_t off = AL.sc_at[e] - S.front_off[s], ld = S.front_ld[s], f = S.fsize(s);
+                const int64_t off = AL.sc_at[e] - S.front_off[s], ld = S.front_ld[s], f = fsz[(size_t)s];
                 const int64_t r = off % ld, c = off / ld;
                 const int64_t lin = ea_tile_index(f, c / EA_TILE_C, r / EA_TILE_R);
                 task_of[e] = lin == 0 ? ea_first[(size_t)s] : ea_base[(size_t)s] + (int32_t)lin;
@@ -631,6 +641,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         {
             // (joined below: the lists were computed beside upload_plan)
             if (asm_thread.joinable()) asm_thread.join();
+            if (opt.verbose) fprintf(stderr, "hipmf: initialize: the assembly-list thread worked %.3f s beside the launch plans\n", AL.seconds);
             if (AL.status == 1) {
                 last_error = "too many entries in the tiled fronts";
                 return ERROR_HIPMF_SYMBOLIC;
