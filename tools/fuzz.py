@@ -11,6 +11,7 @@ from russell_amd.backend import Hipmf
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+ORDERING = int(os.environ.get("FUZZ_ORDERING", "0"))  # 0 nested dissection, 3 approximate minimum degree, 4 best of both (include/russell_hipmf.h)
 
 
 def make(rng):
@@ -58,7 +59,7 @@ for c in range(cases):
     XS = rng.standard_normal((nr, n))
     B = XS @ full.T
     s = Hipmf()
-    code = s.initialize(n, rp, ci, general_symmetric=sym, values=None if sym else v)
+    code = s.initialize(n, rp, ci, ordering=ORDERING, general_symmetric=sym, values=None if sym else v)
     assert code == 0, (seed0 + c, kind, n, "initialize", code)
     code = s.factorize(v, compute_determinant=True)
     assert code == 0, (seed0 + c, kind, n, "factorize", code)

@@ -46,7 +46,7 @@ for c in range(cases):
     XS = rng.standard_normal((nr, n))
     B = (A @ XS.T).T
     s = Hipmf()
-    assert s.initialize(n, rp, ci, general_symmetric=sym, values=v if (rng.random() < 0.5 and not sym) else None) == 0
+    assert s.initialize(n, rp, ci, ordering=int(os.environ.get("FUZZ_ORDERING", "0")), general_symmetric=sym, values=v if (rng.random() < 0.5 and not sym) else None) == 0
     code = s.factorize(v)
     assert code == 0, (seed0 + c, code)
     X = s.solve_many(B) if nr > 1 else s.solve(B[0])[None, :]
