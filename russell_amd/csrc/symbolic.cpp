@@ -131,6 +131,12 @@ struct NDShared {
     std::unique_ptr<NDVertex[]> vx;
     std::vector<int32_t> verts;                   // region vertex lists (disjoint segments)
     std::atomic<int32_t> cur_stamp{0}, next_id{1};
+    // Regions of at most `interval_cutoff` vertices whose parent is larger, as (first position, size) in the new numbering.  Every neighbour
+    // of a region's vertex that is numbered BEFORE it lies in the region itself (what is outside are separators and hubs, numbered after):
+    // the elimination tree of such an interval can be built without looking at anything else (etree below).
+    int32_t interval_cutoff = 0;
+    std::mutex interval_mu;
+    std::vector<std::pair<int32_t, int32_t>> intervals;
     explicit NDShared(const Graph &gr) : g(gr) {}
     int32_t region_of(int32_t v) const { return vx[v].part.load(std::memory_order_relaxed); }
     void set_region(int32_t v, int32_t id) { vx[v].part.store(id, std::memory_order_relaxed); }
@@ -150,6 +156,7 @@ struct NDScratch {
 struct NDRegion {
     int32_t begin, end, pos, id;
     bool connected;
+    int32_t parent_size; // vertices of the region this one was cut out of (the whole graph: INT32_MAX)
 };
 
 // BFS inside region `id` from `root`; fills t.queue[0..count) in visit order, w.lev, t.lvl_ptr.
@@ -236,6 +243,10 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
     const Graph &g = w.g;
     const int32_t size = R.end - R.begin;
     if (size <= 0) return;
+    if (size <= w.interval_cutoff && R.parent_size > w.interval_cutoff) {
+        std::lock_guard<std::mutex> lk(w.interval_mu);
+        w.intervals.emplace_back(R.pos, size);
+    }
     t.reserve(size);
     // A region that is not known to be connected and is going to be split: the first breadth-first search of the pseudo-peripheral
     // iteration (from the region's first vertex) visits exactly what the component sweep below would visit first, in the same order.
@@ -278,7 +289,7 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
                 int32_t b = R.begin + t.comp_ptr[c], e = R.begin + t.comp_ptr[c + 1];
                 int32_t id = w.next_id.fetch_add(1, std::memory_order_relaxed);
                 for (int32_t k = b; k < e; k++) w.set_region(w.verts[k], id);
-                out.push_back({b, e, R.pos + t.comp_ptr[c], id, true});
+                out.push_back({b, e, R.pos + t.comp_ptr[c], id, true, size});
             }
             return;
         }
@@ -373,15 +384,17 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
         w.set_region(v, -1);
     }
     std::copy(t.tmp.begin(), t.tmp.begin() + nA + nB, w.verts.begin() + R.begin);
-    out.push_back({R.begin + nA, R.begin + nA + nB, R.pos + nA, idB, false});
-    out.push_back({R.begin, R.begin + nA, R.pos, idA, false});
+    out.push_back({R.begin + nA, R.begin + nA + nB, R.pos + nA, idB, false, size});
+    out.push_back({R.begin, R.begin + nA, R.pos, idA, false, size});
 }
 
-static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm, std::vector<int32_t> &leaf_of) {
+static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm, std::vector<int32_t> &leaf_of,
+                              std::vector<std::pair<int32_t, int32_t>> *intervals = nullptr) {
     int32_t n = g.n;
     perm.assign((size_t)n, -1);
     leaf_of.assign((size_t)n, -1);
     NDShared w(g);
+    if (intervals && n >= opt.parallel_min_n) w.interval_cutoff = std::max<int32_t>(std::min(64, opt.parallel_chunk_min), n / (8 * std::max(1, host_threads(opt))));
     w.vx.reset(new NDVertex[(size_t)n]);
     for (int32_t v = 0; v < n; v++) {
         w.vx[v].part.store(0, std::memory_order_relaxed);
@@ -425,7 +438,7 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
     std::condition_variable cv;
     std::vector<NDRegion> shared;
     int busy = 0;
-    shared.push_back({0, nsparse, 0, 0, false});
+    shared.push_back({0, nsparse, 0, 0, false, INT32_MAX});
     auto worker = [&]() {
         NDScratch t;
         std::vector<NDRegion> local, out;
@@ -471,6 +484,10 @@ static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::v
         std::vector<std::thread> pool;
         for (int i = 0; i < nthreads; i++) pool.emplace_back(worker);
         for (auto &th : pool) th.join();
+    }
+    if (intervals) {
+        std::sort(w.intervals.begin(), w.intervals.end());
+        intervals->swap(w.intervals);
     }
 }
 
@@ -736,24 +753,49 @@ static void approximate_minimum_degree(const Graph &g, const SymbolicOptions &op
 }
 
 // elimination tree of the permuted symmetric pattern (Liu's algorithm with path compression)
-static void etree(const Graph &gp, std::vector<int32_t> &parent) {
+// `closed`: disjoint intervals (first column, size), ascending, whose columns have no neighbour with a smaller number outside the
+// interval (regions of the dissection): their parts of the tree are built on host threads, the remaining columns (separators above
+// them, hubs) afterwards in ascending order.  The tree does not depend on the split -- it is a function of the pattern.
+static void etree(const Graph &gp, std::vector<int32_t> &parent, const std::vector<std::pair<int32_t, int32_t>> *closed = nullptr, int threads = 1) {
     int32_t n = gp.n;
     parent.assign((size_t)n, -1);
     std::vector<int32_t> anc((size_t)n, -1);
-    for (int32_t j = 0; j < n; j++)
-        for (int64_t p = gp.ptr[j]; p < gp.ptr[j + 1]; p++) {
-            int32_t r = gp.adj[p];
-            if (r >= j) break; // ascending lists
-            while (anc[r] != -1 && anc[r] != j) {
-                int32_t next = anc[r];
-                anc[r] = j;
-                r = next;
+    int32_t *par = parent.data(), *an = anc.data();
+    auto columns = [&](int32_t j0, int32_t j1) {
+        for (int32_t j = j0; j < j1; j++)
+            for (int64_t p = gp.ptr[j]; p < gp.ptr[j + 1]; p++) {
+                int32_t r = gp.adj[p];
+                if (r >= j) break; // ascending lists
+                while (an[r] != -1 && an[r] != j) {
+                    int32_t next = an[r];
+                    an[r] = j;
+                    r = next;
+                }
+                if (an[r] == -1) {
+                    an[r] = j;
+                    par[r] = j;
+                }
             }
-            if (anc[r] == -1) {
-                anc[r] = j;
-                parent[r] = j;
-            }
-        }
+    };
+    if (!closed || closed->empty() || threads <= 1) {
+        columns(0, n);
+        return;
+    }
+    {
+        std::atomic<size_t> next{0};
+        auto body = [&]() {
+            for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < closed->size();) columns((*closed)[i].first, (*closed)[i].first + (*closed)[i].second);
+        };
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; i++) pool.emplace_back(body);
+        for (auto &th : pool) th.join();
+    }
+    int32_t j = 0;
+    for (const auto &iv : *closed) {
+        columns(j, iv.first);
+        j = iv.first + iv.second;
+    }
+    columns(j, n);
 }
 
 static void postorder(const std::vector<int32_t> &parent, std::vector<int32_t> &post) {
@@ -785,7 +827,15 @@ static void postorder(const std::vector<int32_t> &parent, std::vector<int32_t> &
 
 // column counts of the Cholesky factor of the (postordered) symmetric pattern
 // (skeleton / least-common-ancestor method of Gilbert, Ng & Peyton, 1994)
-static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, std::vector<int64_t> &cc) {
+//
+// threads > 1: in the postorder a subtree is a contiguous range of columns [first[r], r], and everything the method does for a column of
+// the subtree stays inside it -- its own counts, the leaves of the row subtrees of rows INSIDE the range, the disjoint-set links -- except
+// for the rows above the subtree's root: there the first leaf the subtree contributes needs the row's previous leaf (in an earlier
+// subtree) and the last one must be left behind for later columns.  So the maximal subtrees below a size bound are processed on host
+// threads with private state for those rows, and each hands back, per row above it, (first leaf, last leaf, its `first`); the columns
+// above the subtrees are then processed in order, a subtree's records applied where its columns stand.  Same counts as the serial sweep.
+static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, std::vector<int64_t> &cc, int threads = 1, int32_t parallel_min_n = 0,
+                          int32_t chunk_min = 4096) {
     int32_t n = gp.n;
     std::vector<int32_t> first((size_t)n, -1), maxfirst((size_t)n, -1), prevleaf((size_t)n, -1), anc((size_t)n);
     std::iota(anc.begin(), anc.end(), 0);
@@ -795,7 +845,18 @@ static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, s
         cc[j] = (first[j] == -1) ? 1 : 0;
         for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
     }
-    for (int32_t j = 0; j < n; j++) {
+    auto find = [&](int32_t x) {
+        int32_t q = x;
+        while (q != anc[q]) q = anc[q];
+        for (int32_t s = x; s != q;) {
+            int32_t sp = anc[s];
+            anc[s] = q;
+            s = sp;
+        }
+        return q;
+    };
+    // one column with the shared (serial) state
+    auto column = [&](int32_t j) {
         if (parent[j] != -1) cc[parent[j]]--;
         for (int64_t p = gp.ptr[j]; p < gp.ptr[j + 1]; p++) {
             int32_t i = gp.adj[p];
@@ -804,18 +865,114 @@ static void column_counts(const Graph &gp, const std::vector<int32_t> &parent, s
             int32_t jprev = prevleaf[i];
             prevleaf[i] = j;
             cc[j]++;
-            if (jprev != -1) {
-                int32_t q = jprev;
-                while (q != anc[q]) q = anc[q];
-                for (int32_t s = jprev; s != q;) {
-                    int32_t sp = anc[s];
-                    anc[s] = q;
-                    s = sp;
-                }
-                cc[q]--;
-            }
+            if (jprev != -1) cc[find(jprev)]--;
         }
         if (parent[j] != -1) anc[j] = parent[j];
+    };
+    struct Rec {
+        int32_t row, first_leaf, last_leaf, last_first;
+    };
+    struct Chunk {
+        int32_t lo, hi;
+        std::vector<Rec> recs;
+    };
+    std::vector<Chunk> chunks;
+    if (threads > 1 && n >= parallel_min_n && n > 1) {
+        const int64_t bound = std::max<int64_t>(chunk_min, (int64_t)n / (8 * threads));
+        auto weight = [&](int32_t j) { return (int64_t)j - first[j] + 1; };
+        for (int32_t j = 0; j < n; j++)
+            if (weight(j) <= bound && (parent[j] < 0 || weight(parent[j]) > bound)) chunks.push_back({first[j], j, {}});
+    }
+    if (chunks.empty()) {
+        for (int32_t j = 0; j < n; j++) column(j);
+    } else {
+        std::atomic<size_t> next{0};
+        std::atomic<bool> oom{false};
+        auto body = [&]() {
+            try {
+                struct Out {
+                    int32_t maxfirst, prevleaf, first_leaf;
+                };
+                std::vector<int32_t> mf_in, pl_in; // rows inside the chunk, by (row - lo)
+                std::vector<std::pair<int32_t, Out>> outs;  // rows above the chunk's root: few (open-addressing table below)
+                std::vector<int32_t> slot;
+                for (size_t ci; (ci = next.fetch_add(1, std::memory_order_relaxed)) < chunks.size();) {
+                    Chunk &C = chunks[ci];
+                    const int32_t lo = C.lo, hi = C.hi, w = hi - lo + 1;
+                    mf_in.assign((size_t)w, -1), pl_in.assign((size_t)w, -1);
+                    outs.clear();
+                    size_t cap = 64;
+                    slot.assign(cap, -1);
+                    auto out_of = [&](int32_t row) -> Out & { // find or insert
+                        for (;;) {
+                            size_t h = ((size_t)(uint32_t)row * 2654435761u) & (cap - 1);
+                            while (slot[h] >= 0 && outs[(size_t)slot[h]].first != row) h = (h + 1) & (cap - 1);
+                            if (slot[h] >= 0) return outs[(size_t)slot[h]].second;
+                            if (2 * (outs.size() + 1) > cap) { // grow and rehash
+                                cap *= 2;
+                                slot.assign(cap, -1);
+                                for (size_t q = 0; q < outs.size(); q++) {
+                                    size_t g = ((size_t)(uint32_t)outs[q].first * 2654435761u) & (cap - 1);
+                                    while (slot[g] >= 0) g = (g + 1) & (cap - 1);
+                                    slot[g] = (int32_t)q;
+                                }
+                                continue;
+                            }
+                            slot[h] = (int32_t)outs.size();
+                            outs.push_back({row, Out{-1, -1, -1}});
+                            return outs.back().second;
+                        }
+                    };
+                    for (int32_t j = lo; j <= hi; j++) {
+                        if (j != hi && parent[j] != -1) cc[parent[j]]--; // (the root's parent lies outside: left to the serial part)
+                        for (int64_t p = gp.ptr[j]; p < gp.ptr[j + 1]; p++) {
+                            const int32_t i = gp.adj[p];
+                            if (i <= j) continue;
+                            int32_t jprev;
+                            if (i <= hi) {
+                                if (first[j] <= mf_in[(size_t)(i - lo)]) continue;
+                                mf_in[(size_t)(i - lo)] = first[j];
+                                jprev = pl_in[(size_t)(i - lo)];
+                                pl_in[(size_t)(i - lo)] = j;
+                            } else {
+                                Out &o = out_of(i);
+                                if (first[j] <= o.maxfirst) continue;
+                                o.maxfirst = first[j];
+                                jprev = o.prevleaf;
+                                o.prevleaf = j;
+                                if (jprev == -1) o.first_leaf = j; // its least common ancestor with the row's earlier leaf: serial part
+                            }
+                            cc[j]++;
+                            if (jprev != -1) cc[find(jprev)]--; // (both leaves inside the chunk: so is their least common ancestor)
+                        }
+                        if (parent[j] != -1) anc[j] = parent[j];
+                    }
+                    C.recs.reserve(outs.size());
+                    for (const auto &o : outs) C.recs.push_back({o.first, o.second.first_leaf, o.second.prevleaf, o.second.maxfirst});
+                }
+            } catch (const std::bad_alloc &) { // (an exception must not leave a thread)
+                oom.store(true);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; i++) pool.emplace_back(body);
+        for (auto &th : pool) th.join();
+        if (oom.load()) throw std::bad_alloc();
+        size_t c = 0;
+        for (int32_t j = 0; j < n; j++) {
+            if (c < chunks.size() && chunks[c].lo == j) {
+                const Chunk &C = chunks[c++];
+                for (const Rec &r : C.recs) {
+                    const int32_t jprev = prevleaf[r.row];
+                    if (jprev != -1) cc[find(jprev)]--;
+                    prevleaf[r.row] = r.last_leaf, maxfirst[r.row] = r.last_first;
+                }
+                if (parent[C.hi] != -1) cc[parent[C.hi]]--;
+                j = C.hi;
+                continue;
+            }
+            column(j);
+        }
     }
     for (int32_t j = 0; j < n; j++)
         if (parent[j] != -1) cc[parent[j]] += cc[j];
@@ -891,6 +1048,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     // ---- ordering --------------------------------------------------------------------------
     auto t_ord = clk::now();
     std::vector<int32_t> perm0((size_t)n), pinv0((size_t)n), leaf_of;
+    std::vector<std::pair<int32_t, int32_t>> closed; // intervals of the dissection's numbering that the elimination tree can take apart
     bool single_front = n <= opt.dense_n;
     if (single_front || opt.ordering == ORDERING_NATURAL) {
         std::iota(perm0.begin(), perm0.end(), 0);
@@ -909,7 +1067,8 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         }
         std::vector<int32_t> permc, leafc;
         if (opt.ordering == ORDERING_MIN_DEGREE) approximate_minimum_degree(gc, opt, permc);
-        else nested_dissection(gc, opt, permc, leafc);
+        else nested_dissection(gc, opt, permc, leafc, &closed);
+        for (auto &iv : closed) iv.first *= 2, iv.second *= 2; // (pairs: two columns per vertex of the ordered graph)
         for (int32_t k = 0; k < n / 2; k++) perm0[2 * k] = 2 * permc[k], perm0[2 * k + 1] = 2 * permc[k] + 1;
         if (!leafc.empty()) {
             leaf_of.resize((size_t)n);
@@ -965,7 +1124,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         S.best_chose_min_degree = f_md < f_nd;
         if (S.best_chose_min_degree) perm0.swap(perm_md), leaf_of.clear();
     } else {
-        nested_dissection(g, opt, perm0, leaf_of);
+        nested_dissection(g, opt, perm0, leaf_of, &closed);
     }
     for (int32_t k = 0; k < n; k++) {
         if (perm0[k] < 0 || perm0[k] >= n) return -10;
@@ -978,7 +1137,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     Graph gp;
     permute_graph(g, perm0, pinv0, gp, threads);
     std::vector<int32_t> parent0, post;
-    etree(gp, parent0);
+    etree(gp, parent0, &closed, threads);
     postorder(parent0, post);
     S.perm.resize((size_t)n);
     S.pinv.resize((size_t)n);
@@ -993,7 +1152,11 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.seconds_phase[2] = since(t_phase), t_phase = clk::now();
     // ---- column counts and supernodes --------------------------------------------------------
     std::vector<int64_t> cc;
-    column_counts(gp, parent, cc);
+    try {
+        column_counts(gp, parent, cc, threads, opt.parallel_min_n, opt.parallel_chunk_min);
+    } catch (const std::bad_alloc &) {
+        return -41;
+    }
 
     std::vector<int32_t> fs_first; // fundamental supernodes
     if (single_front) {
@@ -1141,7 +1304,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
             std::iota(desc_first.begin(), desc_first.end(), 0);
             for (int32_t s = 0; s < S.nsuper; s++)
                 if (S.sn_parent[s] >= 0) desc_first[S.sn_parent[s]] = std::min(desc_first[S.sn_parent[s]], desc_first[s]);
-            const int64_t bound = std::max<int64_t>(4096, (int64_t)n / (8 * threads)); // columns of a chunk
+            const int64_t bound = std::max<int64_t>(opt.parallel_chunk_min, (int64_t)n / (8 * threads)); // columns of a chunk
             auto weight = [&](int32_t s) { return (int64_t)S.sn_first[s + 1] - S.sn_first[desc_first[s]]; };
             for (int32_t s = 0; s < S.nsuper; s++)
                 if (weight(s) <= bound && (S.sn_parent[s] < 0 || weight(S.sn_parent[s]) > bound)) {

@@ -41,6 +41,7 @@ struct SymbolicOptions {
     bool dense_leaves = false;    // every nested-dissection leaf region becomes one dense supernode
     int32_t nd_threads = 0;       // host threads of the nested dissection (0: min(16, hardware threads)); the result does not depend on it
     int32_t parallel_min_n = 200000; // below this order the row structures are built serially (thread start-up); tests set 0 (HIPMF_PAR_MIN)
+    int32_t parallel_chunk_min = 4096; // smallest size bound of the subtrees handed to host threads (tests: small, so that small matrices split)
     double dense_row_factor = 10.0; // vertices of degree > max(32, min(factor sqrt(n), 4 factor x average degree)) are ordered last (0: never)
     int32_t dense_n = 32;         // n <= dense_n: one dense front, i.e. LU with full partial pivoting
     int32_t split_pivots = 4096;  // supernodes with more pivots are split into a chain of supernodes (0: never); see symbolic.cpp

@@ -129,7 +129,8 @@ def test_golden_ordering_is_pinned(emu_lib, grid, monkeypatch):
 
 @pytest.mark.parametrize("case", ["poisson2d 150x140", "poisson3d 24 lower", "poisson3d 20"])
 def test_threaded_pieces_of_initialize_do_not_depend_on_the_thread_count(emu_lib, case, monkeypatch):
-    # round 4: row structures are built subtree by subtree and the extend-add task lists front by front on host threads.  Forced on for
+    # round 4: elimination tree, column counts and row structures are built subtree by subtree and the extend-add task lists front by
+    # front on host threads.  Forced on for
     # small matrices (HIPMF_PAR_MIN=0), the digest of everything they produce equals the serial build's for every thread count.
     monkeypatch.setenv("HIPMF_PLAN_DIGEST", "1")
     if case.startswith("poisson2d"):
@@ -145,8 +146,10 @@ def test_threaded_pieces_of_initialize_do_not_depend_on_the_thread_count(emu_lib
         monkeypatch.setenv("HIPMF_ND_THREADS", threads)
         if par_min is None:
             monkeypatch.delenv("HIPMF_PAR_MIN", raising=False)
+            monkeypatch.delenv("HIPMF_PAR_CHUNK", raising=False)
         else:
             monkeypatch.setenv("HIPMF_PAR_MIN", par_min)
+            monkeypatch.setenv("HIPMF_PAR_CHUNK", "24")  # many subtrees per thread: records across them in the column counts
         s = Hipmf(emu_lib)
         assert s.initialize(n, rp, ci, general_symmetric=sym) == 0
         digests[threads] = (s.counter("plan_digest"), s.stats()["nnz_l"], s.stats()["nsuper"])

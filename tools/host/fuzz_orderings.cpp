@@ -1,5 +1,6 @@
 // Differential / sanity fuzzing of the orderings without a device: random small patterns (empty, dense, hubs, two components, rows without a
-// diagonal entry, up to 3 000 vertices) through analyse() with Ordering::Amd and Ordering::Best -- every result must be a permutation.
+// diagonal entry, up to 3 000 vertices) through analyse() with the dissection, Ordering::Amd and Ordering::Best -- every result must be a
+// permutation, and the analysis with host threads (subtree-parallel elimination tree, column counts, row structures) must equal the serial one.
 //   g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -I russell_amd/csrc tools/host/fuzz_orderings.cpp russell_amd/csrc/symbolic.cpp -o build/fuzz_orderings && build/fuzz_orderings 3000
 #include <cstdio>
 #include <cstdlib>
@@ -26,11 +27,21 @@ int main(int argc, char **argv) {
         std::vector<int32_t> rp(n + 1, 0), ci;
         for (int i = 0; i < n; i++) { std::sort(rows[i].begin(), rows[i].end()); rows[i].erase(std::unique(rows[i].begin(), rows[i].end()), rows[i].end()); for (int32_t j : rows[i]) ci.push_back(j); rp[i + 1] = (int32_t)ci.size(); }
         if (ci.empty()) ci.push_back(0);
-        for (int ord : {2, 3}) {
-            SymbolicOptions so; so.nd_leaf = 16, so.dense_leaves = true; so.ordering = ord; so.parallel_min_n = 0; so.nd_threads = 1 + c % 4;
+        for (int ord : {0, 2, 3}) {
+            SymbolicOptions so; so.nd_leaf = 16, so.dense_leaves = true; so.ordering = ord; so.parallel_min_n = 0; so.nd_threads = 2 + c % 4;
+            so.parallel_chunk_min = 1 + c % 40; // (small subtrees: many chunks, records across them)
             if (c % 5 == 0) so.dense_row_factor = 0.0;
-            Symbolic S;
+            Symbolic S, S1;
             int rc = analyse(n, rp.data(), ci.data(), false, so, S);
+            {
+                // the same analysis without host threads: elimination tree, column counts and row structures in their serial form
+                SymbolicOptions s1 = so;
+                s1.nd_threads = 1;
+                const int rc1 = analyse(n, rp.data(), ci.data(), false, s1, S1);
+                const bool same = rc1 == rc && (rc != 0 || (S.perm == S1.perm && S.sn_first == S1.sn_first && S.sn_rowptr == S1.sn_rowptr && S.sn_rows == S1.sn_rows &&
+                                                            S.rel == S1.rel && S.front_off == S1.front_off && S.sn_parent == S1.sn_parent));
+                if (!same) { bad++; printf("case %d kind %d n %d ordering %d: threaded analysis differs from the serial one\n", c, kind, n, ord); }
+            }
             bool ok = rc == 0;
             std::vector<char> seen(n, 0);
             if (ok) for (int k = 0; k < n; k++) { int32_t v = S.perm[k]; if (v < 0 || v >= n || seen[v]) { ok = false; break; } seen[v] = 1; }
