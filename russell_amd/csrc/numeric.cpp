@@ -463,17 +463,87 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         // (front size per supernode once: S.fsize reads four entries of two arrays, and both passes below ask it per matrix entry)
         std::vector<int32_t> fsz((size_t)ns);
         for (int32_t s = 0; s < ns; s++) fsz[(size_t)s] = S.fsize(s);
-        for (int pass = 0; pass < 2; pass++) {
-            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
-            for (int64_t k = 0; k < (int64_t)am.size(); k++)
-                if (am[k] >= 0) {
-                    const int32_t s = S.amap_sn[(size_t)k];
-                    if (fsz[(size_t)s] <= SMALL_F) sa_ptr[(size_t)s + 1]++;
-                    else sc_cnt[(size_t)S.sn_level[s] + 1]++;
-                }
+        // The lists are stable bucket sorts of the entry sequence (all of amap, then all of amap2): small fronts by supernode, big ones by
+        // level.  The sequence is cut into pieces; every piece counts its entries per bucket, the pieces' counts are turned into start
+        // positions bucket by bucket (piece order = sequence order: the lists come out as the serial sweep wrote them), and every piece
+        // then writes its entries from its own cursors.  Pieces run on host threads when the matrix is large enough.
+        const int64_t nnz_a = (int64_t)S.amap.size();
+        const bool two = !S.amap2.empty();
+        int npiece = 1;
+        {
+            int thr = (int)std::min<unsigned>(4u, std::max(1u, std::thread::hardware_concurrency()));
+            if (const char *e = getenv("HIPMF_ND_THREADS")) thr = std::max(1, std::min(4, atoi(e)));
+            int64_t par_min = 200000;
+            if (const char *e = getenv("HIPMF_PAR_MIN")) par_min = std::max(0, atoi(e));
+            if (nnz_a >= par_min && nnz_a >= 64) npiece = thr;
         }
-        for (int32_t s = 0; s < ns; s++) sa_ptr[(size_t)s + 1] += sa_ptr[s];
-        for (int32_t l = 0; l < S.nlevels; l++) sc_cnt[(size_t)l + 1] += sc_cnt[l];
+        const int passes = two ? 2 : 1, P = npiece * passes;
+        auto piece_range = [&](int q, const std::vector<int64_t> *&am, int &pass, int64_t &k0, int64_t &k1) {
+            pass = q / npiece;
+            am = pass == 0 ? &S.amap : &S.amap2;
+            const int t = q % npiece;
+            k0 = nnz_a * t / npiece, k1 = nnz_a * (t + 1) / npiece;
+        };
+        std::vector<std::vector<int32_t>> cnt_s((size_t)P);
+        std::vector<std::vector<int64_t>> cnt_l((size_t)P);
+        auto run_pieces = [&](auto &&fn) {
+            if (npiece == 1) {
+                for (int q = 0; q < P; q++) fn(q);
+                return;
+            }
+            std::vector<std::thread> pool;
+            std::atomic<bool> oom{false};
+            for (int q = 0; q < P; q++)
+                pool.emplace_back([&, q]() {
+                    try {
+                        fn(q);
+                    } catch (const std::bad_alloc &) { // (an exception must not leave a thread)
+                        oom.store(true);
+                    }
+                });
+            for (auto &th : pool) th.join();
+            if (oom.load()) throw std::bad_alloc();
+        };
+        run_pieces([&](int q) {
+            const std::vector<int64_t> *am;
+            int pass;
+            int64_t k0, k1;
+            piece_range(q, am, pass, k0, k1);
+            cnt_s[(size_t)q].assign((size_t)ns, 0), cnt_l[(size_t)q].assign((size_t)S.nlevels, 0);
+            for (int64_t k = k0; k < k1; k++)
+                if ((*am)[(size_t)k] >= 0) {
+                    const int32_t s = S.amap_sn[(size_t)k];
+                    if (fsz[(size_t)s] <= SMALL_F) cnt_s[(size_t)q][(size_t)s]++;
+                    else cnt_l[(size_t)q][(size_t)S.sn_level[s]]++;
+                }
+        });
+        // counts -> start positions (cnt becomes the piece's cursor), totals -> sa_ptr / sc_cnt
+        {
+            int64_t run = 0;
+            for (int32_t s = 0; s < ns; s++) {
+                sa_ptr[(size_t)s] = (int32_t)run;
+                for (int q = 0; q < P; q++) {
+                    const int32_t c = cnt_s[(size_t)q][(size_t)s];
+                    cnt_s[(size_t)q][(size_t)s] = (int32_t)run;
+                    run += c;
+                }
+                if (run > 0x7fffffffLL) {
+                    AL.status = 1;
+                    return;
+                }
+            }
+            sa_ptr[(size_t)ns] = (int32_t)run;
+            int64_t runl = 0;
+            for (int32_t l = 0; l < S.nlevels; l++) {
+                sc_cnt[(size_t)l] = runl;
+                for (int q = 0; q < P; q++) {
+                    const int64_t c = cnt_l[(size_t)q][(size_t)l];
+                    cnt_l[(size_t)q][(size_t)l] = runl;
+                    runl += c;
+                }
+            }
+            sc_cnt[(size_t)S.nlevels] = runl;
+        }
         if (sc_cnt[(size_t)S.nlevels] > 0x7fffffffLL) {
             AL.status = 1;
             return;
@@ -482,25 +552,30 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         AL.sa_pos.resize((size_t)sa_ptr[ns]);
         AL.sc_k.resize((size_t)sc_cnt[(size_t)S.nlevels]);
         AL.sc_at.resize((size_t)sc_cnt[(size_t)S.nlevels]);
-        std::vector<int32_t> w(sa_ptr.begin(), sa_ptr.end() - 1);
-        std::vector<int64_t> wl(sc_cnt.begin(), sc_cnt.end() - 1);
-        for (int pass = 0; pass < 2; pass++) {
-            const std::vector<int64_t> &am = pass == 0 ? S.amap : S.amap2;
-            for (int64_t k = 0; k < (int64_t)am.size(); k++)
-                if (am[k] >= 0) {
+        run_pieces([&](int q) {
+            const std::vector<int64_t> *amp;
+            int pass;
+            int64_t k0, k1;
+            piece_range(q, amp, pass, k0, k1);
+            const std::vector<int64_t> &am = *amp;
+            std::vector<int32_t> &w = cnt_s[(size_t)q];
+            std::vector<int64_t> &wl = cnt_l[(size_t)q];
+            for (int64_t k = k0; k < k1; k++)
+                if (am[(size_t)k] >= 0) {
                     const int32_t s = S.amap_sn[(size_t)k];
                     if (fsz[(size_t)s] > SMALL_F) {
-                        const size_t q = (size_t)wl[(size_t)S.sn_level[s]]++;
-                        AL.sc_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
-                        AL.sc_at[q] = am[k];
+                        const size_t qq = (size_t)wl[(size_t)S.sn_level[s]]++;
+                        AL.sc_k[qq] = pass == 0 ? (int32_t)k : ~(int32_t)k;
+                        AL.sc_at[qq] = am[(size_t)k];
                         continue;
                     }
-                    const int64_t off = am[k] - S.front_off[s], f = fsz[(size_t)s];
-                    const size_t q = (size_t)w[s]++;
-                    AL.sa_k[q] = pass == 0 ? (int32_t)k : ~(int32_t)k;
-                    AL.sa_pos[q] = (uint16_t)((off % f) | ((off / f) << 8));
+                    const int64_t off = am[(size_t)k] - S.front_off[s], f = fsz[(size_t)s];
+                    const size_t qq = (size_t)w[(size_t)s]++;
+                    AL.sa_k[qq] = pass == 0 ? (int32_t)k : ~(int32_t)k;
+                    AL.sa_pos[qq] = (uint16_t)((off % f) | ((off / f) << 8));
                 }
-        }
+        });
+        cnt_s.clear(), cnt_l.clear();
         if (ea_lds_active()) {
             // linear index of tile (ct, rt) of a front with f rows among the tiles that have a task, tile columns outer, tile rows inner
             // (L D L^T fronts: the tiles strictly above the diagonal have none: rows (rt + 1) R <= ct C)
@@ -643,6 +718,18 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             // (joined below: the lists were computed beside upload_plan)
             if (asm_thread.joinable()) asm_thread.join();
             if (opt.verbose) fprintf(stderr, "hipmf: initialize: the assembly-list thread worked %.3f s beside the launch plans\n", AL.seconds);
+            if (getenv("HIPMF_PLAN_DIGEST")) { // (the thread's lists join the digest of the plans: thread-count independence test)
+                uint64_t h = (uint64_t)plan_digest ^ 1469598103934665603ull;
+                auto eat = [&](const void *p, size_t bytes) {
+                    const unsigned char *b = (const unsigned char *)p;
+                    for (size_t i = 0; i < bytes; i++) h = (h ^ b[i]) * 1099511628211ull;
+                };
+                eat(AL.sa_ptr.data(), AL.sa_ptr.size() * sizeof(int32_t)), eat(AL.sa_k.data(), AL.sa_k.size() * sizeof(int32_t));
+                eat(AL.sa_pos.data(), AL.sa_pos.size() * sizeof(AL.sa_pos[0])), eat(AL.sc_k.data(), AL.sc_k.size() * sizeof(int32_t));
+                eat(AL.sc_cnt.data(), AL.sc_cnt.size() * sizeof(int64_t)), eat(AL.sc_pos.data(), AL.sc_pos.size() * sizeof(AL.sc_pos[0]));
+                eat(AL.ea_sc.data(), AL.ea_sc.size() * sizeof(AL.ea_sc[0]));
+                plan_digest = (int64_t)(h & 0x7fffffffffffffffull);
+            }
             if (AL.status == 1) {
                 last_error = "too many entries in the tiled fronts";
                 return ERROR_HIPMF_SYMBOLIC;
