@@ -334,6 +334,13 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_DENSE_ROWS")) so.dense_row_factor = atof(e); // degree threshold factor of the hub vertices (0: off)
     if (const char *e = getenv("HIPMF_ND_THREADS")) so.nd_threads = std::max(1, atoi(e)); // host threads of the ordering (same result for any count)
     if (const char *e = getenv("HIPMF_PAR_MIN")) so.parallel_min_n = std::max(0, atoi(e)); // (tests: the threaded pieces of the analysis on small matrices)
+    if (const char *e = getenv("HIPMF_RELAX")) { // "n0,n1,n2,z0,z1,z2": relaxed amalgamation (columns of the merged supernode, share of explicit zeros it may hold)
+        int a, b, c;
+        double x, y, z;
+        if (sscanf(e, "%d,%d,%d,%lf,%lf,%lf", &a, &b, &c, &x, &y, &z) == 6)
+            so.relax_ncol[0] = a, so.relax_ncol[1] = b, so.relax_ncol[2] = c, so.relax_zeros[0] = x, so.relax_zeros[1] = y, so.relax_zeros[2] = z;
+    }
+    if (const char *e = getenv("HIPMF_RELAX_BIG")) so.relax_big_front = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_PAR_CHUNK")) so.parallel_chunk_min = std::max(1, atoi(e)); // (tests: several subtrees per thread on small matrices)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;

@@ -1210,7 +1210,7 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
         if (nc <= opt.relax_ncol[0]) accept = true;
         else if (nc <= opt.relax_ncol[1]) accept = z < opt.relax_zeros[0];
         else if (nc <= opt.relax_ncol[2]) accept = z < opt.relax_zeros[1];
-        else accept = z < opt.relax_zeros[2];
+        else accept = z < opt.relax_zeros[2] && (opt.relax_big_front <= 0 || nc + s_m[t] >= opt.relax_big_front);
         if (accept) {
             s_first[t] = s_first[s];
             s_ncol[t] = (int32_t)nc;

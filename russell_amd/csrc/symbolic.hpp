@@ -52,8 +52,15 @@ struct SymbolicOptions {
     bool pair_blocks = false;     // n even, rows / columns 2 k and 2 k + 1 belong together (real and imaginary part of complex unknown k,
                                   // interface_complex_hipmf.cpp): the ordering runs on the graph of the pairs, a pair stays adjacent (2 k' , 2 k' + 1
                                   // in the permuted numbering) and inside one supernode, every front has an even number of pivots and of rows
-    int32_t relax_ncol[3] = {4, 16, 48};
+    // relaxed amalgamation (a supernode absorbs the child that ends right before it): merged supernodes of up to relax_ncol[0] columns always,
+    // up to [1] / [2] columns when the share of explicit zeros stays below relax_zeros[0] / [1]; larger ones below relax_zeros[2] AND only
+    // into fronts of at least relax_big_front rows (0: any).  Late round 4 (profiles/r04_relax_sweep.txt): every pivot merged into a
+    // front near the root is one more step of a sequential chain, which is what the 2D factorisation is bound by -- merging large
+    // supernodes pays only where the front is big enough to be bound by arithmetic (3D).  48 / any -> 64 / 2 048: 1000^2 LU 6.55 -> 6.19 ms
+    // (292 -> 263 launches), L D L^T 5.65 -> 5.29 ms, 100^3 136 -> 140 ms.
+    int32_t relax_ncol[3] = {4, 16, 64};
     double relax_zeros[3] = {0.8, 0.1, 0.05};
+    int32_t relax_big_front = 2048;
 };
 
 struct Symbolic {

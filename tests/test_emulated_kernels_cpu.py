@@ -87,6 +87,10 @@ def test_emulated_value_map_refresh_with_duplicates(emu_lib):
 def test_emulated_grouped_updates_and_chain_split(emu_lib, monkeypatch):
     # tiled path with 4 / 8 / 16 panels per pass over the trailing matrix, and big supernodes split into chains: same solution
     # (to rounding) and same determinant as the default two-panel schedule
+    # (the amalgamation of rounds 1 - 4: large supernodes merged whatever the front size, so that this small problem has a front with
+    #  more than 128 pivots -- the default since late round 4 merges them only into fronts of 2 048 rows and more)
+    monkeypatch.setenv("HIPMF_RELAX", "4,16,48,0.8,0.1,0.05")
+    monkeypatch.setenv("HIPMF_RELAX_BIG", "0")
     n, rp, ci, v = P.poisson3d(13)
     xs = P.manufactured_solution(n)
     b = P.csr_matvec(n, rp, ci, v, xs)

@@ -77,7 +77,8 @@ def test_split_full_updates_give_the_same_factor_bit_for_bit(emu_lib, case):
     # panels touch) and the other tiles (on a side stream on the device).  Same tiles, same arithmetic: the same bits.  64 x 64 tiles
     # only (HIPMF_UPD32_MAXF=0), every full step with a follower (threshold 1), no one-workgroup fronts so that the tiled path has work.
     _, (n, rp, ci, v), kw = case
-    base = {"HIPMF_UPD32_MAXF": "0", "HIPMF_MID_LU": "0", "HIPMF_MID_FRONT": "0"}
+    # (HIPMF_RELAX / _BIG: the amalgamation of rounds 1 - 4, which gives these small problems fronts with enough full steps)
+    base = {"HIPMF_UPD32_MAXF": "0", "HIPMF_MID_LU": "0", "HIPMF_MID_FRONT": "0", "HIPMF_RELAX": "4,16,48,0.8,0.1,0.05", "HIPMF_RELAX_BIG": "0"}
     ref = _run(emu_lib, n, rp, ci, v, dict(base, HIPMF_UPD_SPLIT="0"), **kw)
     got = _run(emu_lib, n, rp, ci, v, dict(base, HIPMF_UPD_SPLIT="1"), **kw)
     assert np.array_equal(ref[0], got[0])
