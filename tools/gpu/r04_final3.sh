@@ -1,6 +1,6 @@
 # round 4, after the threaded launch plans / row structures, the device memory limit and Ordering::Amd: the driver's round-end sequence + initialize phases
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r04f4
+OUT=gpurun_out/r04f5
 mkdir -p $OUT
 export TMPDIR=/tmp
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest_gpu.txt 2>&1
@@ -9,8 +9,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -
 ( time timeout 900 python bench.py --steps 10 --warmup 3 ) > $OUT/bench.json 2> $OUT/bench.err
 python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r04f4/bench.json').read().strip().split('\n')[0])
+d=json.loads(open('gpurun_out/r04f5/bench.json').read().strip().split('\n')[0])
 print('value', d['value'], d['phases_ms'], 'frac', d['roofline']['frac'], 'cpu', d['cpu_baseline']['value'], d.get('speedup_repeat_call'), 'total_ifs', d.get('total_ifs_ms'))
 PY
-{ python tools/init_phases.py 1000; INIT_REPS=3 timeout 600 python tools/init_phases.py 200 3d sym; } 2>&1 | grep -v "^solver_hipmf" > $OUT/init_phases.txt
+python tools/init_phases.py 1000 2>&1 | grep -v "^solver_hipmf" > $OUT/init_phases.txt
 grep "initialize wall" $OUT/init_phases.txt | tr '\n' ' '
