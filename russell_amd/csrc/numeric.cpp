@@ -2433,8 +2433,9 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     }
     if (KB > 1) block_cols = KB;
     const int32_t nblocks = (nrhs + KB - 1) / KB;
-    // Two blocks in flight hide the host round trips of the refinement (residual norms) behind the other block's kernels: worth 10 - 20 %
-    // while a pass lasts a millisecond.  When the factor is tens of gigabytes a pass lasts 0.1 s, the round trips vanish, and two
+    // (rounds 2 - 3: two blocks in flight hid the host round trips of the refinement behind the other block's kernels, worth 10 - 20 % while
+    //  a pass lasted a millisecond.  With the kernels of round 4 one lane is as fast or faster and two concurrently resident
+    //  dependency-driven launches time out every few runs: the default is one lane, HIPMF_SOLVE_LANES asks for more.)  When the factor is tens of gigabytes a pass lasts 0.1 s, the round trips vanish, and two
     // launches full of waiting workgroups only get in each other's way (200^3, 256 right-hand sides: 3.0 - 3.7 s on two lanes from run
     // to run, 3.3 s on one; each lane also holds its own block and workspace buffers, 25 GB there): one lane from 64 GB of factor on.
     const int32_t lanes_here = (solve_lanes_auto && 8.0 * (double)S.persist_doubles > 64e9) ? 1 : solve_lanes;

@@ -327,7 +327,10 @@ class Solver {
     std::vector<LaneBuffers> extra_lanes;
     double *h_nrm = nullptr;   // pinned: norms of every lane
     double *h_stage = nullptr; // pinned: rhs | x of a single host-pointer solve
-    int32_t solve_lanes = 2;   // HIPMF_SOLVE_LANES (1..4)
+    int32_t solve_lanes = 1;   // HIPMF_SOLVE_LANES (1..4).  One since late round 4: two launches full of workgroups that wait for each other's
+                               // lower-numbered tasks no longer pay (0.304 against 0.307 - 0.313 ms per right-hand side at 1000^2 with 256
+                               // right-hand sides, 0.307 against 0.365 with 64) and, concurrently resident, every few runs one of them ran
+                               // into a hand-off time-out (3.7 s; profiles/r04_solve_lanes.txt)
     bool solve_lanes_auto = true; // no HIPMF_SOLVE_LANES given: one lane when the factor exceeds 64 GB (solve())
     int32_t block_cols = 0;    // columns per block of the many-RHS driver once its buffers exist (8 or 16; HIPMF_BLOCK_COLS forces one)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
