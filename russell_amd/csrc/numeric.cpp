@@ -422,6 +422,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         last_error = msg;
         return ERROR_HIP_MALLOC;
     }
+    if (rc == -41) { // a host thread of the analysis ran out of memory (row structures, column counts, Ordering::Best)
+        last_error = "Not enough memory: a host allocation failed in the analysis";
+        return ERROR_MALLOC;
+    }
     if (rc != 0) {
         last_error = "symbolic analysis failed (" + std::to_string(rc) + ")";
         return rc <= -30 || rc >= -2 ? ERROR_HIPMF_INVALID_MATRIX : ERROR_HIPMF_SYMBOLIC;
