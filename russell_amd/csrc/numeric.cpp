@@ -344,6 +344,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_PAR_CHUNK")) so.parallel_chunk_min = std::max(1, atoi(e)); // (tests: several subtrees per thread on small matrices)
     if (const char *e = getenv("HIPMF_FUSED_SOLVE")) use_fused = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_OVERLAP_SMALL")) overlap_small = atoi(e) != 0;
+    small_pair = false;
+    if (const char *e = getenv("HIPMF_SMALL_PAIR")) small_pair = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
@@ -1906,11 +1908,20 @@ int32_t Solver::run_factor() {
                 sst = (hipStream_t)stream2;
             }
             const SmallAsm sasm = {d_sd, d_sa_k, d_sa_pos, d_vs, d_vs2, d_child, d_rel, d_lists};
+            // (HIPMF_SMALL_PAIR=1: the two launches of an all-small level side by side -- the first on the third stream)
+            const bool pair = small_pair && L.small_cnt_a > 0 && !forked && !use_graph && L.steps.empty() && !has_mid;
             if (L.small_cnt_a > 0) {
                 const size_t shmem_a = sizeof(double) * (size_t)L.small_ld_a * (size_t)L.small_ld_a;
-                hipLaunchKernelGGL((PZ ? k_small_factor<1, true> : k_small_factor<1, false>), dim3(L.small_cnt_a), dim3(64), shmem_a, sst, d_lists + L.small_off, d_fd, d_pool, d_lperm,
+                hipStream_t ast = sst;
+                if (pair) {
+                    HIPC(hipEventRecord((hipEvent_t)ev_fork3, STREAM), ERROR_HIP_SYNCHRONIZE);
+                    HIPC(hipStreamWaitEvent((hipStream_t)stream3, (hipEvent_t)ev_fork3, 0), ERROR_HIP_SYNCHRONIZE);
+                    ast = (hipStream_t)stream3;
+                }
+                hipLaunchKernelGGL((PZ ? k_small_factor<1, true> : k_small_factor<1, false>), dim3(L.small_cnt_a), dim3(64), shmem_a, ast, d_lists + L.small_off, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld_a, sasm, d_diag);
                 launches++;
+                if (pair) HIPC(hipEventRecord((hipEvent_t)ev_join3, (hipStream_t)stream3), ERROR_HIP_SYNCHRONIZE);
             }
             // few fronts in the launch: four wavefronts per front (the launch lasts as long as one front's LU)
             const int32_t cnt_b = L.small_cnt - L.small_cnt_a;
@@ -1921,6 +1932,7 @@ int32_t Solver::run_factor() {
                 hipLaunchKernelGGL((PZ ? k_small_factor<1, true> : k_small_factor<1, false>), dim3(cnt_b), dim3(64), shmem, sst, d_lists + L.small_off + L.small_cnt_a, d_fd, d_pool, d_lperm,
                                    d_scalar, opt.pivot_epsilon, d_info, L.small_ld, sasm, d_diag);
             launches++;
+            if (pair) HIPC(hipStreamWaitEvent(STREAM, (hipEvent_t)ev_join3, 0), ERROR_HIP_SYNCHRONIZE);
         } else if (forked) {
             HIPC(hipEventRecord((hipEvent_t)ev_fork, STREAM), ERROR_HIP_SYNCHRONIZE);
             HIPC(hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)ev_fork, 0), ERROR_HIP_SYNCHRONIZE);

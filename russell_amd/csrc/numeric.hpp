@@ -261,6 +261,7 @@ class Solver {
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream
+    bool small_pair = false;                // HIPMF_SMALL_PAIR=1: the two k_small_factor launches of an all-small level side by side (third stream)
     int32_t sf_big_rows = 6, sf_big_front = 2048; // forward solve: fronts with at least sf_big_front rows use slabs of 2^sf_big_rows rows
     int32_t sf_asm_front = 2048;                  // forward solve: fronts with at least this many rows assemble their vector once, in tasks of their own (0: never; then sf_big_rows applies)
     // levels with few tiled steps (the middle of the tree): all steps of a level in one launch with in-launch hand-offs (kernels_factor_chain.hpp)
