@@ -190,6 +190,10 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 #define HIPMF_COUNTER_CHAIN_FALLBACKS 7    /* factorisations repeated with one launch per tiled step after a hand-off of a chained launch timed out */
 #define HIPMF_COUNTER_PLAN_DIGEST 9       /* diagnostic: digest of the row structures, pool layout and extend-add task lists of the last initialize
                                              (computed only when HIPMF_PLAN_DIGEST is set in the environment, else 0): equal for every thread count */
+#define HIPMF_COUNTER_TAGGED_SOLVE 10     /* 1: the triangular solves of one right-hand side hand their vectors from front to front as data-tagged
+                                             words above the wave-subtrees (no completion counters; HIPMF_TAG_SOLVE=0 or fronts of >= 2 048 rows: 0) */
+#define HIPMF_COUNTER_GATE_WAITS 11       /* solves of this handle that found the device's gate held by another handle (dependency-driven
+                                             launches of two handles are never resident together) */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

@@ -501,6 +501,8 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
     case HIPMF_COUNTER_CHAIN_FALLBACKS: return s.chain_fallbacks;
     case HIPMF_COUNTER_MID_FRONTS: return s.mid_front_count;
     case HIPMF_COUNTER_PLAN_DIGEST: return s.plan_digest;
+    case HIPMF_COUNTER_TAGGED_SOLVE: return s.tagged_solve() ? 1 : 0;
+    case HIPMF_COUNTER_GATE_WAITS: return s.gate_waits;
     default: return -1;
     }
 }

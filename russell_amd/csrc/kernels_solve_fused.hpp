@@ -87,6 +87,39 @@ __device__ __forceinline__ void sf_publish_front(int s, const int32_t *__restric
     }
 }
 
+// ---- data-tagged hand-offs (TAG instances: single right-hand side above the wave-subtrees) ----
+// A hand-off through a completion counter costs the producer a drain of its stores and an atomic, and the consumer a poll of the counter
+// FOLLOWED by a dependent round trip for the data (measured per level of the 1M-DOF Poisson factor: ~0.5-1 us publish, 1.5-2.5 us until
+// the waiter sees the counter, 2-3 us to gather the children's vectors -- profiles/r04_solve_trace.txt).  In the TAG instances the data
+// ARE the flag (MI355X_MICROARCH.md, handoff-1to1 against handoff-flag): every 8-byte word a task of the launch hands to another one
+// (forward: the update part of a front's vector in `work`; backward: the solved pivot entries, in a shadow copy `xt` of x) is set to
+// SF_TAG_BITS by a memset on the stream before the launch; producers store each word once (one aligned 8-byte write-through store, never
+// torn); consumers load the words they need and re-load the ones that still hold the tag.  No drain, no counter, no second round trip.
+// SF_TAG_BITS is a NaN no arithmetic produces (all ones; generated NaNs are the canonical quiet NaN, and k_perm_in canonicalises the
+// NaNs of a right-hand side), so a value never looks like "not yet written"; every re-load loop is bounded like sf_wait.
+constexpr long long SF_TAG_BITS = -1LL;
+__device__ __forceinline__ bool sf_is_tag(double v) { return __double_as_longlong(v) == SF_TAG_BITS; }
+__device__ __forceinline__ double sf_tag_wait(const double *p, double v, int *err) {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    while (sf_is_tag(v)) {
+        poll_nap();
+        v = ld_agent(p);
+        spins++;
+        if ((spins & 1023u) == 0) {
+            if (flag_load(err) != 0) return 0.0;
+            const unsigned long long now = dev_clock();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > SF_WAIT_TICKS) {
+                flag_store(err, 1);
+                return 0.0;
+            }
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ double sf_tag_load(const double *p, int *err) { return sf_tag_wait(p, ld_agent(p), err); }
+
 // One entry per column of a block of right-hand sides, column c < nk at base + c * cstr + off: K agent-scope loads issued back to back.
 // The compiler never speculates an agent-scope load: written as `cond ? ld_agent(p) : 0` (or under `if (c < nk)`) every load sits in a
 // branch of its own and waits for its own round trip -- sixteen columns cost sixteen round trips (measured on the blocked small-front
@@ -104,7 +137,7 @@ template <int K> __device__ __forceinline__ void ld_cols(double (&v)[K], const d
 // big-front slabs of the blocked instances run on MFMA tiles (sf_mma_chunk): another summation order, equal to rounding.
 
 // ---- forward step of one small front by one wavefront; w = K x 64 doubles of LDS owned by this wave ----
-template <int K>
+template <int K, bool TAG = false>
 __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
                                              const int32_t *__restrict__ lperm, const int32_t *__restrict__ child_idx,
                                              const int32_t *__restrict__ rel, const int32_t *__restrict__ need, int *done, int *err,
@@ -137,7 +170,7 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             const int ch = child_idx[fd.child_begin + c0 + lane];
             const FrontDesc cd = FD[ch];
             c_woff = cd.woff, c_rowptr = cd.rowptr, c_p = cd.p, c_m = cd.m;
-            sf_wait(done + ch, need[ch], err);
+            if constexpr (!TAG) sf_wait(done + ch, need[ch], err); // (TAG: the gathered words themselves say when they are there)
         }
         wave_sync();
         const int nbatch = nch - c0 < 64 ? nch - c0 : 64;
@@ -147,6 +180,9 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             const int myr = (lane < nbatch && c_m == 1) ? rel[c_rowptr] : -1;
             double myv[K];
             ld_cols<K>(myv, work, wstr, myr >= 0 ? c_woff + c_p : 0, nk);
+            if constexpr (TAG) {
+                if (myr >= 0) myv[0] = sf_tag_wait(work + c_woff + c_p, myv[0], err);
+            }
 #pragma unroll
             for (int c = 0; c < K; c++) myv[c] = (c < nk && myr >= 0) ? myv[c] : 0.0;
             double add[K]; // starts from the row's current value: the same association order as adding child after child
@@ -171,7 +207,9 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             const int64_t woff = wave_bcast_i64(c_woff, cl), rowptr = wave_bcast_i64(c_rowptr, cl);
             const int cp = wave_bcast_i32(c_p, cl), cm = wave_bcast_i32(c_m, cl);
             if constexpr (K == 1) {
-                if (lane < cm) w[0][rel[rowptr + lane]] += ld_agent(work + woff + cp + lane); // cm <= f <= 64
+                if constexpr (TAG) {
+                    if (lane < cm) w[0][rel[rowptr + lane]] += sf_tag_load(work + woff + cp + lane, err);
+                } else if (lane < cm) w[0][rel[rowptr + lane]] += ld_agent(work + woff + cp + lane); // cm <= f <= 64
             } else if (cm > 0) { // (wave-uniform)
                 const int gl = lane < cm ? lane : 0;
                 const int r = rel[rowptr + gl];
@@ -216,15 +254,17 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             if (lane < p) st_agent(xs + c * xstr + lane, v[c]);
             else if (lane < f) st_agent(W + c * wstr + lane, v[c]);
         }
-    drain_stores();
-    if (lane == 0) flag_add(done + s, 1);
+    if constexpr (!TAG) {
+        drain_stores();
+        if (lane == 0) flag_add(done + s, 1);
+    }
 }
 
 // ---- backward step of one small front by one wavefront; xg = K x 64 doubles of LDS owned by this wave ----
-template <int K>
+template <int K, bool TAG = false>
 __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
                                              const int32_t *__restrict__ rows, const int32_t *__restrict__ need, int *done, int *err,
-                                             double *x, int nk, int64_t xstr) {
+                                             double *x, int nk, int64_t xstr, double *xt = nullptr) {
     const FrontDesc fd = FD[s];
     const int p = fd.p, m = fd.m, f = fd.p + fd.m;
     const double *F = pool + fd.off;
@@ -254,11 +294,17 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     // the reciprocal of the lane's own pivot, once (a division per pivot step was the larger part of the substitution's instructions);
     // requested and formed before the wait
     const double inv_d = (lane < p) ? 1.0 / Ub[lane + (int64_t)lane * us] : 1.0;
-    if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
+    if constexpr (!TAG) {
+        if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
+    }
     wave_sync();
     {
         double xv[K];
-        ld_cols<K>(xv, x, xstr, myrow, nk); // (myrow = 0 for the lanes past the front's rows: a valid address, the value is dropped)
+        if constexpr (TAG) { // the ancestors' solved entries come from the tagged shadow of x
+            xv[0] = ld_agent(xt + myrow);
+            if (lane < m) xv[0] = sf_tag_wait(xt + myrow, xv[0], err);
+        } else
+            ld_cols<K>(xv, x, xstr, myrow, nk); // (myrow = 0 for the lanes past the front's rows: a valid address, the value is dropped)
         if (lane < m) {
 #pragma unroll
             for (int c = 0; c < K; c++)
@@ -316,9 +362,12 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
 #pragma unroll
         for (int c = 0; c < K; c++)
             if (c < nk) st_agent(xs + c * xstr + lane, v[c]);
+        if constexpr (TAG) st_agent(xt + fd.first + lane, v[0]);
     }
-    drain_stores();
-    if (lane == 0) flag_add(done + s, 1);
+    if constexpr (!TAG) {
+        drain_stores();
+        if (lane == 0) flag_add(done + s, 1);
+    }
 }
 
 // Strided dot products against K LDS vector chunks (column c at w + c * wld):
@@ -376,11 +425,12 @@ __device__ __forceinline__ void sf_dot(double (&acc0)[K], double (&acc1)[K], con
 // the first chunk, into the slab's own rows wsl (column c at wsl + c * 128): NK children at a time, NE entries per
 // thread and child fetched together (one round trip), then added child by child in ascending order (the order fixes
 // the floating-point sums).  Longer children finish in a plain loop.
-template <int NK, int NE, int K>
+template <int NK, int NE, int K, bool TAG = false>
 __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int64_t *cd_woff, const int64_t *cd_rel, const int32_t *cd_m,
                                             const FrontDesc &fd, const FrontDesc *__restrict__ FD, const int32_t *__restrict__ child_idx,
                                             const int32_t *__restrict__ rel, const double *work, double *wc, int wld, double *wsl, int c0, int c1,
-                                            int p, int r0, int r1, int nk, int64_t wstr) {
+                                            int p, int r0, int r1, int nk, int64_t wstr, int *err = nullptr) {
+    static_assert(!TAG || K == 1, "the tagged hand-offs carry one right-hand side");
     for (int cb = 0; cb < nch; cb += NK) {
         int qv[NK][NE];
         double uv[NK][NE][K];
@@ -425,6 +475,16 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
                     const int q = qv[k][e];
+                    if constexpr (TAG) {
+                        // (a word that still holds the tag is re-loaded until the producing task has stored it; only the words this
+                        //  thread is going to use are waited for)
+                        const bool used = (q >= c0 && q < c1) || (c0 == 0 && q >= p && q >= r0 && q < r1);
+                        if (used && sf_is_tag(uv[k][e][0])) {
+                            const int c = cb + k;
+                            const int64_t woff = c < ncd ? cd_woff[c] : FD[child_idx[fd.child_begin + c]].woff + FD[child_idx[fd.child_begin + c]].p;
+                            uv[k][e][0] = sf_tag_wait(work + woff + tid + 256 * e, uv[k][e][0], err);
+                        }
+                    }
                     if (q >= c0 && q < c1) {
 #pragma unroll
                         for (int cc = 0; cc < K; cc++)
@@ -448,6 +508,9 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
                         const int q = rel[relo + i];
                         double tv[K];
                         ld_cols<K>(tv, work, wstr, woff + i, nk);
+                        if constexpr (TAG) {
+                            if ((q >= c0 && q < c1) || (c0 == 0 && q >= p && q >= r0 && q < r1)) tv[0] = sf_tag_wait(work + woff + i, tv[0], err);
+                        }
                         if (q >= c0 && q < c1) {
 #pragma unroll
                             for (int cc = 0; cc < K; cc++)
@@ -558,7 +621,9 @@ __device__ __forceinline__ double sf_mma_sum(const double *mt, int nsub, int rr,
 // doubles, slot [u][tid]: private to the thread, no barrier, conflict-free -- BEFORE it waits; after the wait the dot product reads
 // them back in the same order and with the same two accumulators as sf_dot (bit-identical sums).  Registers cannot hold them: the
 // kernel also runs thousands of small fronts, whose occupancy pays for every VGPR (measured in round 2: 108 -> 152 VGPRs, slower).
-template <bool SMALL_ONLY, int K, bool STG = false>
+// TAG (K = 1 only): data-tagged hand-offs (see sf_tag_wait) -- no completion counters, no drains; the task list then holds no
+// ASSEMBLE tasks (their intermediate result would sit where the parent looks for the final one).
+template <bool SMALL_ONLY, int K, bool STG = false, bool TAG = false>
 __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
@@ -566,6 +631,7 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace, int stage,
                                                    const int32_t *__restrict__ rep_idx, int *rep) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
+    static_assert(!TAG || (K == 1 && !SMALL_ONLY), "the tagged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles
     constexpr int CHK = K > 8 ? SF_CHUNK / 4 : (K > 4 ? SF_CHUNK / 2 : SF_CHUNK); // chunk of w1 per right-hand side
     // One LDS buffer, three uses that never overlap in time: a workgroup either runs four small fronts (wv: K x 64 doubles per wave)
@@ -587,11 +653,11 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
     if (SMALL_ONLY || t.kind == 0) {
         // (wave-uniform: the front's descriptor then lives in scalar registers and the panel loads use scalar bases)
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
-        if (s >= 0) sf_fwd_small<K>(s, lane, wv[wave], FD, pool, lperm, child_idx, rel, need, done, err, work, x, nk, xstr, wstr);
+        if (s >= 0) sf_fwd_small<K, TAG>(s, lane, wv[wave], FD, pool, lperm, child_idx, rel, need, done, err, work, x, nk, xstr, wstr);
         return;
     }
     if (SMALL_ONLY) return; // (never reached: the small-only instance is launched on all-small bands)
-    if (t.kind == 1) {
+    if (!TAG && t.kind == 1) {
         // ---- assemble rows [q0, q1) of the big front t.a: w = b (pivot rows) + the children's updates, once for all slabs.  Every
         //      slab used to gather all children itself: hundreds of redundant gathers on fronts of thousands of rows.  The pivot part
         //      goes back into x (the slabs read their w1 from there), the rest into the front's work vector (the slabs add E w1). ----
@@ -738,15 +804,17 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         }
         const int mx = (int)wave_max_u32((unsigned)mym);
         if (lane == 0) cm_max_s = nch > 64 ? 0x7fffffff : mx;
-        if (lane < ncd) {
-            const int ch = child_idx[fd.child_begin + lane];
-            sf_wait_front(ch, need, done, STG ? rep_idx : nullptr, rep, err);
-        }
-        for (int c0 = 64; c0 < nch; c0 += 64)
-            if (c0 + lane < nch) {
-                const int ch = child_idx[fd.child_begin + c0 + lane];
+        if constexpr (!TAG) {
+            if (lane < ncd) {
+                const int ch = child_idx[fd.child_begin + lane];
                 sf_wait_front(ch, need, done, STG ? rep_idx : nullptr, rep, err);
             }
+            for (int c0 = 64; c0 < nch; c0 += 64)
+                if (c0 + lane < nch) {
+                    const int ch = child_idx[fd.child_begin + c0 + lane];
+                    sf_wait_front(ch, need, done, STG ? rep_idx : nullptr, rep, err);
+                }
+        }
     }
     __syncthreads();
     if (trace && tid == 0) tr1 = dev_clock();
@@ -769,9 +837,9 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
             __syncthreads();
         }
         if (cm_max <= 256)
-            sf_children<(K == 1 ? 8 : (K <= 8 ? 4 : 2)), 1, K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+            sf_children<(K == 1 ? 8 : (K <= 8 ? 4 : 2)), 1, K, TAG>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr, err);
         else // (top-level instance: six entries per thread and child in one round trip -- 1 536 rows)
-            sf_children<2, (STG ? 6 : (K == 1 ? 4 : (K <= 8 ? 2 : 1))), K>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+            sf_children<2, (STG ? 6 : (K == 1 ? 4 : (K <= 8 ? 2 : 1))), K, TAG>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr, err);
         if (nch == 0) __syncthreads();
         if (trace && tid == 0 && c0 == 0) tr_g = dev_clock();
         // the group's columns of this chunk: g, g + G, ... continue across chunks (CHK is a multiple of every G)
@@ -834,9 +902,11 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         }
     }
     if (trace && tid == 0) tr2 = dev_clock();
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
+    if constexpr (!TAG) {
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
+    }
     if (trace && tid == 0) {
         unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;
         tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock(), tr[4] = tr_g, tr[5] = tr_d;
@@ -845,13 +915,16 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
 
 // Backward pass, one launch per band of levels (tasks ordered root first).
 // SYM: instance for factors whose big fronts are L D L^T (x1 = E^T [D^{-1} y1; x2], transposed GEMV); the LU instance carries none of it.
-template <bool SMALL_ONLY, int K, bool SYM, bool STG = false>
+// TAG (K = 1 only): data-tagged hand-offs -- a front's solved pivot entries also go to the tagged shadow `xt` of x (all tag words before
+// the launch), and that is where the fronts below read their x2 from, re-loading what is not there yet (see sf_tag_wait).
+template <bool SMALL_ONLY, int K, bool SYM, bool STG = false, bool TAG = false>
 __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag,
-                                                   int stage, const int32_t *__restrict__ rep_idx, int *rep) {
+                                                   int stage, const int32_t *__restrict__ rep_idx, int *rep, double *xt) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
+    static_assert(!TAG || (K == 1 && !SMALL_ONLY), "the tagged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles (see k_fwd_fused)
     constexpr int CHK = K > 8 ? SF_CHUNK / 4 : (K > 4 ? SF_CHUNK / 2 : SF_CHUNK);
     // (one LDS buffer for the small fronts' vectors, the chunk of a big front's vectors and its MFMA tiles: see k_fwd_fused)
@@ -866,7 +939,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     const SfTask t = tasks[blockIdx.x];
     if (SMALL_ONLY || t.kind == 0) {
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
-        if (s >= 0) sf_bwd_small<K>(s, lane, wv[wave], FD, pool, rows, need, done, err, x, nk, xstr);
+        if (s >= 0) sf_bwd_small<K, TAG>(s, lane, wv[wave], FD, pool, rows, need, done, err, x, nk, xstr, xt);
         return;
     }
     if (SMALL_ONLY) return;
@@ -917,11 +990,21 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
             for (int q = 0; q < 8; q++) els[(u0 + q) * 256 + tid] = t[q];
         }
     }
-    if (fd.parent >= 0 && tid == 0) sf_wait_front(fd.parent, need, done, STG ? rep_idx : nullptr, rep, err);
+    if constexpr (!TAG) {
+        if (fd.parent >= 0 && tid == 0) sf_wait_front(fd.parent, need, done, STG ? rep_idx : nullptr, rep, err);
+    }
     __syncthreads();
     if (trace && tid == 0) tr1 = dev_clock();
     // ---- after the wait ----
-    if constexpr (K == 1) {
+    if constexpr (TAG) {
+        // all (up to four) words of x2 requested at once; the ones that still hold the tag are re-loaded until they are there
+        double xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) xv[k] = ld_agent(xt + (xrow[k] >= 0 ? xrow[k] : 0));
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (xrow[k] >= 0) wc[tid + 256 * k] = sf_tag_wait(xt + xrow[k], xv[k], err);
+    } else if constexpr (K == 1) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (xrow[k] >= 0) wc[tid + 256 * k] = ld_agent(x + xrow[k]);
@@ -967,7 +1050,8 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
                 const int row = (j < p) ? 0 : rws[j - p];
                 const double dj = (sym && j < p) ? diag[fd.first + j] : 1.0;
                 double xv[K];
-                ld_cols<K>(xv, x, xstr, row, nk);
+                if constexpr (TAG) xv[0] = (j < p) ? 0.0 : sf_tag_load(xt + row, err);
+                else ld_cols<K>(xv, x, xstr, row, nk);
 #pragma unroll
                 for (int c = 0; c < K; c++)
                     if (c < nk) wc[c * CHK + j - c0] = (j < p) ? (sym ? W[c * wstr + j] / dj : W[c * wstr + j]) : xv[c];
@@ -1048,17 +1132,26 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
             const int col = r0 + wave + 4 * q;
             double v = sacc[(SYM && K == 1) ? q : 0][0];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && col < r1) st_agent(x + fd.first + col, v);
+            if (lane == 0 && col < r1) {
+                st_agent(x + fd.first + col, v);
+                if constexpr (TAG) st_agent(xt + fd.first + col, v);
+            }
         }
     } else {
         red[g * (1 << sh) + rr] = acc0[0] + acc1[0];
         __syncthreads();
-        if (g == 0 && i < r1) st_agent(x + fd.first + i, sf_group_sum(red, 1 << sh, rr, G));
+        if (g == 0 && i < r1) {
+            const double xi = sf_group_sum(red, 1 << sh, rr, G);
+            st_agent(x + fd.first + i, xi);
+            if constexpr (TAG) st_agent(xt + fd.first + i, xi);
+        }
     }
     if (trace && tid == 0) tr2 = dev_clock();
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
+    if constexpr (!TAG) {
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
+    }
     if (trace && tid == 0) {
         unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;
         tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock(), tr[4] = tr_g, tr[5] = tr_d;

@@ -8,7 +8,13 @@ namespace hipmf {
 __global__ void k_perm_in(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ rs,
                           const double *__restrict__ b, double *__restrict__ xp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) xp[i] = rs[perm[i]] * b[perm[i]];
+    if (i < n) {
+        double v = rs[perm[i]] * b[perm[i]];
+        // (a NaN of the right-hand side enters the solves as THE quiet NaN: the data-tagged hand-offs of kernels_solve_fused.hpp use
+        //  another NaN pattern as "not yet written", and NaN payloads propagate through the arithmetic)
+        if (v != v) v = __longlong_as_double(0x7ff8000000000000LL);
+        xp[i] = v;
+    }
 }
 
 // out[perm[j]] = cs[perm[j]] * xp[j] (mode 0), += (mode 1), -= (mode 2); cs == nullptr: no column scaling

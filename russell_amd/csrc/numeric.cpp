@@ -97,7 +97,7 @@ void Solver::release() {
     for (void *p : {(void *)d_emap, (void *)d_vlow})
         if (p) (void)hipFree(p);
     d_emap = nullptr, d_vlow = nullptr, nnz_low = 0;
-    wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false;
+    wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false, tag_active = false, work_up = 0;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
             if (p) (void)hipFree(p);
@@ -324,7 +324,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         so.nd_leaf = v > 0 ? std::min(v, 64) : 64;
     }
     solve_lanes_auto = true;
-    if (const char *e = getenv("HIPMF_SOLVE_LANES")) solve_lanes = std::max(1, std::min(MAX_SOLVE_LANES, atoi(e))), solve_lanes_auto = false;
+    // (HIPMF_SOLVE_LANES: read and ignored since round 5 -- two lanes are two dependency-driven launches resident together, the very thing
+    //  the device gate of solve() rules out; one lane has been as fast since round 4, profiles/r04_solve_lanes.txt)
+    solve_lanes = 1, solve_lanes_auto = false;
     if (const char *e = getenv("HIPMF_SMALL_WIDE")) small_wide_max = atoi(e);
     if (const char *e = getenv("HIPMF_SMALL_SPLIT")) small_split = atoi(e);
     if (const char *e = getenv("HIPMF_UPD_G4")) upd_g4 = std::max(65, atoi(e));
@@ -347,6 +349,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     small_pair = false;
     if (const char *e = getenv("HIPMF_SMALL_PAIR")) small_pair = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_TAG_SOLVE")) use_tag = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_UP_STAGE")) up_stage = std::max(0, std::min(64, atoi(e) / 8 * 8));
@@ -848,13 +851,80 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         pl_log += buf;
         pl_t = now;
     };
-    std::vector<FrontDesc> fd((size_t)ns);
+    // ---- bottom of the tree: one wavefront per subtree of small fronts (kernels_solve_tree.hpp) ----
+    // A front is "closed" when it and all its descendants are small fronts and the subtree stays within the caps (fronts, panel
+    // bytes, pivots = the part of x the wave keeps in LDS, LDS stack = sum of f over a root-to-leaf path of fronts with children);
+    // the wave-subtrees are the maximal closed ones.  Planned here, before the descriptors: the fronts strictly inside a wave-subtree
+    // never touch the global solve workspace on that path, which decides the layout of the workspace (below).
+    struct WtPlan {
+        bool ok_tree = false;
+        std::vector<char> ok;
+        std::vector<int32_t> cnt, roots;
+        std::vector<int64_t> bytes;
+    } WP;
+    WP.ok_tree = use_tree && S.n >= 4;
+    if (WP.ok_tree) {
+        bool tree_ok = true;
+        std::vector<char> &ok = WP.ok;
+        std::vector<int32_t> &cnt = WP.cnt;
+        std::vector<int64_t> &bytes = WP.bytes;
+        ok.assign((size_t)ns, 0), cnt.assign((size_t)ns, 0), bytes.assign((size_t)ns, 0);
+        std::vector<int32_t> dl((size_t)ns, 0), piv((size_t)ns, 0);
+        for (int32_t s = 0; s < ns && tree_ok; s++) { // (supernodes are numbered in postorder: children first)
+            const int32_t f = S.fsize(s), p = S.npiv(s);
+            bool good = f <= SMALL_F && (int64_t)f * p <= WT_NCH * WT_CHUNK && S.nrow(s) <= WT_MI - 16 * WT_NREC;
+            int32_t c = 1, d = 0, pv = p;
+            int64_t b = (int64_t)f * p * 8;
+            for (int32_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; q++) {
+                const int32_t ch = S.child_idx[q];
+                if (ch >= s) tree_ok = false;
+                else good = good && ok[(size_t)ch], c += cnt[(size_t)ch], b += bytes[(size_t)ch], d = std::max(d, dl[(size_t)ch]), pv += piv[(size_t)ch];
+            }
+            if (S.child_ptr[s + 1] > S.child_ptr[s]) d += f;
+            cnt[(size_t)s] = c, bytes[(size_t)s] = b, dl[(size_t)s] = d, piv[(size_t)s] = pv;
+            ok[(size_t)s] = good && c <= wt_max_fronts && b <= (int64_t)wt_max_kb * 1024 && d <= WT_STACK && pv <= WT_X;
+        }
+        if (tree_ok) {
+            for (int32_t s = 0; s < ns; s++)
+                if (ok[(size_t)s] && (S.sn_parent[s] < 0 || !ok[(size_t)S.sn_parent[s]])) WP.roots.push_back(s);
+            // the longest subtrees first: workgroups start in index order, the short ones fill the tail
+            std::stable_sort(WP.roots.begin(), WP.roots.end(), [&](int32_t a, int32_t b) { return bytes[(size_t)a] > bytes[(size_t)b]; });
+            // the subtree of root R is the supernode range [R - cnt + 1, R] (postorder numbering)
+            for (size_t ri = 0; ri < WP.roots.size() && tree_ok; ri++) {
+                const int32_t R = WP.roots[ri], lo = R - cnt[(size_t)R] + 1;
+                for (int32_t s = lo; s < R; s++)
+                    if (S.sn_parent[s] < lo || S.sn_parent[s] > R) tree_ok = false;
+            }
+        }
+        WP.ok_tree = tree_ok;
+    }
+    // Layout of a solve workspace (one per right-hand side of a block): the f-vectors of the fronts that talk to other workgroups
+    // through it first -- everything but the interiors of the wave-subtrees --, then (tagged hand-offs only) a shadow copy of x, then
+    // the interiors' vectors (used by the schedules without wave-subtrees only).  The data-tagged instances of the solve kernels
+    // (kernels_solve_fused.hpp, sf_tag_wait) arm the first two parts with ONE memset before a pass pair.
+    // Tagged hand-offs need a task list without ASSEMBLE tasks: matrices with fronts of sf_asm_front rows or more (3D: bound by
+    // bandwidth, not by the hand-offs) keep the completion counters.
+    const bool tag_plan = use_tag && WP.ok_tree && !WP.roots.empty() && (sf_asm_front <= 0 || S.max_front < sf_asm_front);
+    std::vector<char> interior((size_t)ns, 0);
+    if (tag_plan)
+        for (int32_t R : WP.roots)
+            for (int32_t s = R - WP.cnt[(size_t)R] + 1; s < R; s++) interior[(size_t)s] = 1;
+    std::vector<int64_t> woff_of((size_t)ns, 0);
     work_doubles = 0;
+    for (int32_t s = 0; s < ns; s++)
+        if (!interior[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
+    work_up = work_doubles;
+    if (tag_plan) {
+        work_doubles += S.n; // xt
+        for (int32_t s = 0; s < ns; s++)
+            if (interior[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
+    }
+    std::vector<FrontDesc> fd((size_t)ns);
     for (int32_t s = 0; s < ns; s++) {
         FrontDesc &d = fd[s];
         d.off = S.front_off[s];
         d.rowptr = S.sn_rowptr[s];
-        d.woff = work_doubles;
+        d.woff = woff_of[(size_t)s];
         d.p = S.npiv(s);
         d.m = S.nrow(s);
         d.first = S.sn_first[s];
@@ -866,7 +936,6 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         d.eoff = S.e_off[s], d.epoff = S.ep_off[s];
         d.flags = S.fsize(s) > SMALL_F ? (FD_BIG | (S.sym_mode ? FD_SYM : 0) | (is_mid(s) ? FD_DENSE_TOP : 0)) : 0;
         d.pad = 0;
-        work_doubles += d.p + d.m;
     }
     pool_doubles = S.persist_doubles + S.temp_doubles;
 
@@ -922,7 +991,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                 // forward pass of the largest fronts: the front's vector (right-hand side + children's updates) is assembled ONCE by
                 // tasks of their own, 512 rows each (the chunk the blocked instances stage in LDS); the slabs wait for those
                 int32_t nasm = 0;
-                if (forward && sf_asm_front > 0 && S.fsize(s) >= sf_asm_front && S.child_ptr[s + 1] > S.child_ptr[s]) {
+                if (forward && sf_asm_front > 0 && S.fsize(s) >= sf_asm_front && S.child_ptr[s + 1] > S.child_ptr[s] && !(tree && tag_plan)) {
                     for (int32_t q0 = 0; q0 < ext; q0 += SF_ASM_ROWS) sf.push_back({1, s, q0, std::min(ext, q0 + SF_ASM_ROWS), 0, 0}), nasm++;
                 }
                 need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows + nasm;
@@ -1013,31 +1082,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         // the wave-subtrees are the maximal closed ones.
         wt_waves = wt_recs = 0;
         sf2_fwd_cnt = sf2_bwd_cnt = 0;
-        bool tree_ok = use_tree && S.n >= 4;
+        bool tree_ok = WP.ok_tree; // (the wave-subtrees were planned before the descriptors: WtPlan above)
         if (tree_ok) {
-            std::vector<char> ok((size_t)ns, 0);
-            std::vector<int32_t> cnt((size_t)ns, 0), dl((size_t)ns, 0), piv((size_t)ns, 0);
-            std::vector<int64_t> bytes((size_t)ns, 0);
-            for (int32_t s = 0; s < ns && tree_ok; s++) { // (supernodes are numbered in postorder: children first)
-                const int32_t f = S.fsize(s), p = S.npiv(s);
-                bool good = f <= SMALL_F && (int64_t)f * p <= WT_NCH * WT_CHUNK && S.nrow(s) <= WT_MI - 16 * WT_NREC;
-                int32_t c = 1, d = 0, pv = p;
-                int64_t b = (int64_t)f * p * 8;
-                for (int32_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; q++) {
-                    const int32_t ch = S.child_idx[q];
-                    if (ch >= s) tree_ok = false;
-                    else good = good && ok[(size_t)ch], c += cnt[(size_t)ch], b += bytes[(size_t)ch], d = std::max(d, dl[(size_t)ch]), pv += piv[(size_t)ch];
-                }
-                if (S.child_ptr[s + 1] > S.child_ptr[s]) d += f;
-                cnt[(size_t)s] = c, bytes[(size_t)s] = b, dl[(size_t)s] = d, piv[(size_t)s] = pv;
-                ok[(size_t)s] = good && c <= wt_max_fronts && b <= (int64_t)wt_max_kb * 1024 && d <= WT_STACK && pv <= WT_X;
-            }
-            if (tree_ok) {
-                std::vector<int32_t> roots;
-                for (int32_t s = 0; s < ns; s++)
-                    if (ok[(size_t)s] && (S.sn_parent[s] < 0 || !ok[(size_t)S.sn_parent[s]])) roots.push_back(s);
-                // the longest subtrees first: workgroups start in index order, the short ones fill the tail
-                std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return bytes[(size_t)a] > bytes[(size_t)b]; });
+            const std::vector<int32_t> &cnt = WP.cnt, &roots = WP.roots;
+            {
                 std::vector<WtHdr> hdr_f, hdr_b;
                 std::vector<int32_t> meta_f, meta_b;
                 std::vector<WtWave> wav_f, wav_b;
@@ -1200,9 +1248,12 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             }
         }
         tree_active = tree_ok && (wt_waves > 0 || sf2_fwd_cnt > 0);
+        tag_active = tree_active && tag_plan;
         if (tree_active && up_stage > 0) {
             HIPMF_ALLOW_LDS((k_fwd_fused<false, 1, true>), sizeof(double) * 256 * (size_t)up_stage);
             HIPMF_ALLOW_LDS((k_bwd_fused<false, 1, false, true>), sizeof(double) * 256 * (size_t)up_stage_bwd);
+            HIPMF_ALLOW_LDS((k_fwd_fused<false, 1, true, true>), sizeof(double) * 256 * (size_t)up_stage);
+            HIPMF_ALLOW_LDS((k_bwd_fused<false, 1, false, true, true>), sizeof(double) * 256 * (size_t)up_stage_bwd);
         }
         HIPC(dev_upload(&d_need, need), ERROR_HIP_MALLOC);
         HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
@@ -1815,6 +1866,18 @@ int32_t Solver::factorize_mapped(const double *input, bool on_device) {
     return n_zero_pivot > 0 ? WARNING_SINGULAR_MATRIX : SUCCESSFUL_EXIT;
 }
 
+// The dependency-driven launches are safe ONE AT A TIME on a device: a task waits for tasks with lower workgroup indices of its own
+// launch, which the hardware has placed before it.  Two such launches resident together (two handles on two host threads: the real
+// and the complex system of russell_ode's Radau5, radau5.rs:270-296) can fill the compute units with each other's waiting
+// workgroups and stall until a wait gives up (seen in round 4 with two solve lanes of one handle, profiles/r04_solve_lanes.txt).
+// One gate per device, process-wide: a solve holds it from its first launch to its last synchronisation, so at most one handle's
+// dependency-driven launches are in flight on a device; the other handle's solve waits (a solve takes a millisecond).  Launches that wait
+// for nothing inside themselves (factorisations, products, the level-set solves) are not gated: they cannot hold anything up.
+static std::mutex &device_gate(int device) {
+    static std::mutex gates[64];
+    return gates[device >= 0 && device < 64 ? device : 0];
+}
+
 int32_t Solver::run_factor() {
     const int32_t n = S.n;
     const int64_t nnz = S.nnz_a;
@@ -1826,6 +1889,8 @@ int32_t Solver::run_factor() {
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     const bool chained = use_chain && d_chain_cnt != nullptr;
+    std::unique_lock<std::mutex> gate(device_gate(device), std::defer_lock); // (the chained tiled steps wait inside their launch: see device_gate)
+    if (chained) gate.lock();
     const bool PZ = opt.complex_pairs; // the pivot searches keep the (real, imaginary) rows of a complex row together (tile_lu32_z)
     if (chained) HIPC(hipMemsetAsync(d_chain_cnt, 0, sizeof(int32_t) * (size_t)chain_words, STREAM), ERROR_HIP_MEMCPY);
     int gs = (int)std::min<int64_t>(2048, (nnz + 255) / 256);
@@ -2124,6 +2189,7 @@ int32_t Solver::run_factor() {
         use_chain = false;
         chain_fallbacks++;
         if (opt.verbose) fprintf(stderr, "hipmf: factorize: a hand-off of the chained tiled steps timed out; repeating with one launch per step\n");
+        if (gate.owns_lock()) gate.unlock();
         return run_factor();
     }
     n_perturbed = hinfo.n_perturbed;
@@ -2158,48 +2224,70 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
         if (tree_active && nk == 1) {
+            // (inside the timed pass pair: arming the tagged words is part of what a pass pair costs)
+            if (tag_active) HIPC(hipMemsetAsync(wrk, 0xFF, sizeof(double) * (size_t)(work_up + S.n), LST), ERROR_HIP_MEMCPY);
+            else if (d_rep)
+                HIPC(hipMemsetAsync(d_rep + 2 * (size_t)rep_words * (size_t)lane_id, 0, sizeof(int32_t) * 2 * (size_t)rep_words, LST), ERROR_HIP_MEMCPY);
+        }
+        if (tree_active && nk == 1) {
             int32_t *const d_rep = this->d_rep ? this->d_rep + 2 * (size_t)rep_words * (size_t)lane_id : nullptr; // this lane's replicas
-            if (d_rep) HIPC(hipMemsetAsync(d_rep, 0, sizeof(int32_t) * 2 * (size_t)rep_words, LST), ERROR_HIP_MEMCPY);
+            // data-tagged hand-offs (kernels_solve_fused.hpp, sf_tag_wait): the words the tasks above the wave-subtrees hand to each other --
+            // the vectors of those fronts in `wrk` and the shadow copy xt of x behind them -- hold the tag when the launches start
+            const bool tag = tag_active;
+            double *const xt = wrk + work_up;
             // one wavefront per subtree of small fronts at the bottom (k_wt_fwd / k_wt_bwd), LDS-staged dependency-driven tasks above
             const int32_t wg = (wt_waves + WT_WAVES - 1) / WT_WAVES;
             const size_t dyn = sizeof(double) * 256 * (size_t)up_stage;
             unsigned long long *no_tr = (timed && d_trace) ? d_trace : nullptr;
+            const int32_t *const no_rep_idx = nullptr;
+            int *const no_rep = nullptr;
             if (wg > 0)
                 hipLaunchKernelGGL(k_wt_fwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave, d_wt_hdr, d_wt_meta, d_pool, d_lperm, sync_f, wrk, xp);
             // the fronts above the wave-subtrees: the many mid-level tasks at full occupancy, then the top levels (a chain of
             // hand-offs between few, large fronts) with their shares of E / E' parked in LDS before the wait
             const int32_t f_mid = sf2_fwd_mid, f_top = sf2_fwd_cnt - sf2_fwd_mid, b_top = sf2_bwd_top, b_mid = sf2_bwd_cnt - sf2_bwd_top;
-            if (f_mid > 0)
-                hipLaunchKernelGGL((k_fwd_fused<false, 1, false>), dim3(f_mid), dim3(256), 0, LST, d_sf2, d_fd, d_pool, d_lperm, d_child, d_rel, d_need2,
-                                   sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr, 0, (const int32_t *)nullptr, (int *)nullptr);
-            if (f_top > 0)
-                hipLaunchKernelGGL((k_fwd_fused<false, 1, true>), dim3(f_top), dim3(256), dyn, LST, d_sf2 + f_mid, d_fd, d_pool, d_lperm, d_child, d_rel,
-                                   d_need2, sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr ? no_tr + 8 * (size_t)f_mid : no_tr, up_stage,
-                                   (const int32_t *)d_rep_idx, d_rep);
+#define HIPMF_TREE_FWD(STGV, TAGV, CNT, DYN, TASKS, TRACE, STAGE, RIDX, REP)                                                                  \
+    hipLaunchKernelGGL((k_fwd_fused<false, 1, STGV, TAGV>), dim3(CNT), dim3(256), DYN, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need2, \
+                       sync_f, sync_err, wrk, xp, 1, xstr, wstr, TRACE, STAGE, RIDX, REP)
+#define HIPMF_TREE_BWD(SYMV, STGV, TAGV, CNT, DYN, TASKS, TRACE, STAGE, RIDX, REP)                                                            \
+    hipLaunchKernelGGL((k_bwd_fused<false, 1, SYMV, STGV, TAGV>), dim3(CNT), dim3(256), DYN, LST, TASKS, d_fd, d_pool, d_rows, d_need2 + ns,   \
+                       sync_b, sync_err, wrk, xp, 1, xstr, wstr, TRACE, d_diag, STAGE, RIDX, REP, TAGV ? xt : (double *)nullptr)
+            unsigned long long *tr_top = no_tr ? no_tr + 8 * (size_t)f_mid : no_tr;
+            if (f_mid > 0) {
+                if (tag) HIPMF_TREE_FWD(false, true, f_mid, 0, d_sf2, no_tr, 0, no_rep_idx, no_rep);
+                else HIPMF_TREE_FWD(false, false, f_mid, 0, d_sf2, no_tr, 0, no_rep_idx, no_rep);
+            }
+            if (f_top > 0) {
+                if (tag) HIPMF_TREE_FWD(true, true, f_top, dyn, d_sf2 + f_mid, tr_top, up_stage, no_rep_idx, no_rep);
+                else HIPMF_TREE_FWD(true, false, f_top, dyn, d_sf2 + f_mid, tr_top, up_stage, (const int32_t *)d_rep_idx, d_rep);
+            }
             if (timed) HIPC(hipEventRecord((hipEvent_t)ev[4], LST), ERROR_HIP_SYNCHRONIZE);
             {
                 const SfTask *tb = d_sf2 + sf2_fwd_cnt;
                 unsigned long long *tr_b = no_tr ? no_tr + 8 * (size_t)sf2_fwd_cnt : nullptr;
-                const size_t dyn_b = sizeof(double) * 256 * (size_t)up_stage_bwd;
+                unsigned long long *tr_bm = tr_b ? tr_b + 8 * (size_t)b_top : tr_b;
+                const size_t dyn_b = sizeof(double) * 256 * (size_t)up_stage_bwd, dyn_m = sizeof(double) * 256 * (size_t)up_stage_mid;
                 if (S.sym_mode) {
-                    if (sf2_bwd_cnt > 0)
-                        hipLaunchKernelGGL((k_bwd_fused<false, 1, true, false>), dim3(sf2_bwd_cnt), dim3(256), 0, LST, tb, d_fd, d_pool, d_rows,
-                                           d_need2 + ns, sync_b, sync_err, wrk, xp, 1, xstr, wstr, tr_b, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr);
+                    if (sf2_bwd_cnt > 0) {
+                        if (tag) HIPMF_TREE_BWD(true, false, true, sf2_bwd_cnt, 0, tb, tr_b, 0, no_rep_idx, no_rep);
+                        else HIPMF_TREE_BWD(true, false, false, sf2_bwd_cnt, 0, tb, tr_b, 0, no_rep_idx, no_rep);
+                    }
                 } else {
-                    if (b_top > 0)
-                        hipLaunchKernelGGL((k_bwd_fused<false, 1, false, true>), dim3(b_top), dim3(256), dyn_b, LST, tb, d_fd, d_pool, d_rows, d_need2 + ns,
-                                           sync_b, sync_err, wrk, xp, 1, xstr, wstr, tr_b, d_diag, up_stage_bwd, (const int32_t *)d_rep_idx,
-                                           d_rep ? d_rep + rep_words : d_rep);
-                    if (b_mid > 0 && up_stage_mid > 0) // (the backward slabs have no register prefetch of E': a small parked share pays)
-                        hipLaunchKernelGGL((k_bwd_fused<false, 1, false, true>), dim3(b_mid), dim3(256), sizeof(double) * 256 * (size_t)up_stage_mid, LST,
-                                           tb + b_top, d_fd, d_pool, d_rows, d_need2 + ns, sync_b, sync_err, wrk, xp, 1, xstr, wstr,
-                                           tr_b ? tr_b + 8 * (size_t)b_top : tr_b, d_diag, up_stage_mid, (const int32_t *)nullptr, (int *)nullptr);
-                    else if (b_mid > 0)
-                        hipLaunchKernelGGL((k_bwd_fused<false, 1, false, false>), dim3(b_mid), dim3(256), 0, LST, tb + b_top, d_fd, d_pool, d_rows,
-                                           d_need2 + ns, sync_b, sync_err, wrk, xp, 1, xstr, wstr, tr_b ? tr_b + 8 * (size_t)b_top : tr_b, d_diag, 0,
-                                           (const int32_t *)nullptr, (int *)nullptr);
+                    if (b_top > 0) {
+                        if (tag) HIPMF_TREE_BWD(false, true, true, b_top, dyn_b, tb, tr_b, up_stage_bwd, no_rep_idx, no_rep);
+                        else HIPMF_TREE_BWD(false, true, false, b_top, dyn_b, tb, tr_b, up_stage_bwd, (const int32_t *)d_rep_idx, d_rep ? d_rep + rep_words : d_rep);
+                    }
+                    if (b_mid > 0 && up_stage_mid > 0) { // (the backward slabs have no register prefetch of E': a small parked share pays)
+                        if (tag) HIPMF_TREE_BWD(false, true, true, b_mid, dyn_m, tb + b_top, tr_bm, up_stage_mid, no_rep_idx, no_rep);
+                        else HIPMF_TREE_BWD(false, true, false, b_mid, dyn_m, tb + b_top, tr_bm, up_stage_mid, no_rep_idx, no_rep);
+                    } else if (b_mid > 0) {
+                        if (tag) HIPMF_TREE_BWD(false, false, true, b_mid, 0, tb + b_top, tr_bm, 0, no_rep_idx, no_rep);
+                        else HIPMF_TREE_BWD(false, false, false, b_mid, 0, tb + b_top, tr_bm, 0, no_rep_idx, no_rep);
+                    }
                 }
             }
+#undef HIPMF_TREE_FWD
+#undef HIPMF_TREE_BWD
             if (wg > 0)
                 hipLaunchKernelGGL(k_wt_bwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave + (size_t)wg * WT_WAVES, d_wt_hdr + wt_hdr_fwd,
                                    d_wt_meta + wt_meta_fwd, d_pool, xp);
@@ -2220,7 +2308,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
                        sync_err, wrk, xp, nk, xstr, wstr, TRACE, 0, (const int32_t *)nullptr, (int *)nullptr)
 #define HIPMF_BWD1(SMALL, KK, SYMM, CNT, TASKS, TRACE)                                                                                     \
     hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, NEED + ns, sync_b,        \
-                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr)
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr)
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     do {                                                                                                                                  \
         if (!SMALL && S.sym_mode) HIPMF_BWD1(false, KK, true, CNT, TASKS, TRACE);                                                          \
@@ -2281,10 +2369,10 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             if (cnt <= 0) continue;
             if (S.sym_mode)
                 hipLaunchKernelGGL((k_bwd_fused<false, 1, true, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
-                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr);
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr);
             else
                 hipLaunchKernelGGL((k_bwd_fused<false, 1, false, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
-                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr);
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr);
             launches++;
         }
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
@@ -2416,6 +2504,13 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     if (!x || !rhs) return ERROR_NULL_POINTER;
     if (nrhs < 1 || ldx < S.n) return ERROR_HIPMF_INVALID_VALUE;
     DeviceScope dev_scope(device);
+    std::unique_lock<std::mutex> gate(device_gate(device), std::defer_lock);
+    if (use_fused) {
+        if (!gate.try_lock()) {
+            gate_waits++;
+            gate.lock();
+        }
+    }
     const int32_t n = S.n;
     const dim3 g((n + 255) / 256), b(256);
     const double EPS = 2.220446049250313e-16;
@@ -2674,6 +2769,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         for (LaneBuffers &lb : extra_lanes) (void)hipMemset(lb.sync + sync_words - 1, 0, sizeof(int32_t));
         last_error = "dependency-driven solve timed out; level-set path used instead";
         if (opt.verbose) fprintf(stderr, "hipmf: %s\n", last_error.c_str());
+        gate.unlock();
         return solve(x, rhs, nrhs, ldx, on_device);
     }
     if (staged) memcpy(x, h_stage + n, sizeof(double) * (size_t)n);

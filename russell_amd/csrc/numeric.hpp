@@ -158,6 +158,8 @@ class Solver {
     int32_t refinement_steps_done = 0;
     int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
     int64_t mid_front_count = 0; // fronts of this plan that one workgroup factorises in one launch (k_front)
+    int64_t gate_waits = 0;      // solves that waited for another handle's solve on the same device (device_gate, numeric.cpp)
+    bool tagged_solve() const { return tag_active && use_fused; }
     int64_t chain_fallbacks = 0; // factorisations repeated with one launch per tiled step after a hand-off timeout of a chained launch (never expected)
     int64_t persist_bytes() const { return S.persist_doubles * 8; }
     double last_residual_inf = 0.0, last_omega = 0.0;
@@ -258,6 +260,10 @@ class Solver {
     bool use_rep = true;                    // HIPMF_UP_REPLICAS=0: every waiter polls the front's counter
     int32_t *d_need2 = nullptr;             // completed-task counts of that list (the slabs are cut differently)
     bool tree_active = false;               // the plan above exists for this matrix
+    bool use_tag = true;                    // HIPMF_TAG_SOLVE=0: completion counters instead of data-tagged hand-offs above the wave-subtrees
+    bool tag_active = false;                // the launches above the wave-subtrees run their TAG instances (kernels_solve_fused.hpp, sf_tag_wait)
+    int64_t work_up = 0;                    // doubles at the head of a solve workspace: the vectors of the fronts outside the wave-subtrees' interiors
+                                            // (tag_active: followed by n doubles, the tagged shadow of x)
     int32_t *d_need = nullptr;              // completed-task counts that mark a front as done: [0, ns) forward, [ns, 2 ns) backward
     int32_t *d_sync = nullptr;              // 2 x (SF_SYNC_HEADER + ns) ints: ticket, error word, counters; zeroed before every pass
     bool overlap_small = true;              // HIPMF_OVERLAP_SMALL=0: everything on one stream

@@ -67,6 +67,73 @@ def test_tree_schedule_equals_level_set_bitwise(emu_lib, case):
         assert np.array_equal(ref, x), env
 
 
+def _solve_counter(lib, n, rp, ci, v, b, env, name, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = Hipmf(lib)
+        assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+        assert s.factorize(v) == 0
+        x = s.solve(b)
+        c = s.counter(name)
+        assert s.counter("fused_fallbacks") == 0
+        s.close()
+        return x, c
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_tagged_handoffs_equal_completion_counters_bitwise(emu_lib, case):
+    # round 5: above the wave-subtrees the vectors travel as data-tagged words (HIPMF_TAG_SOLVE, the default) instead of behind
+    # completion counters; the arithmetic and its order are untouched
+    _, n, rp, ci, v, kw = case
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    x_tag, c_tag = _solve_counter(emu_lib, n, rp, ci, v, b, dict(TREE, HIPMF_TAG_SOLVE="1"), "tagged_solve", **kw)
+    x_cnt, c_cnt = _solve_counter(emu_lib, n, rp, ci, v, b, dict(TREE, HIPMF_TAG_SOLVE="0"), "tagged_solve", **kw)
+    x_lvl, c_lvl = _solve_counter(emu_lib, n, rp, ci, v, b, LEVEL, "tagged_solve", **kw)
+    assert (c_tag, c_cnt, c_lvl) == (1, 0, 0)
+    assert np.array_equal(x_tag, x_cnt)
+    assert np.array_equal(x_tag, x_lvl)
+    # fronts that would assemble their vector in tasks of their own keep the counters
+    x_asm, c_asm = _solve_counter(emu_lib, n, rp, ci, v, b, dict(TREE, HIPMF_SF_ASM_FRONT="40", HIPMF_SF_BIG_FRONT="40"), "tagged_solve", **kw)
+    assert c_asm == 0 and np.array_equal(x_tag, x_asm)
+
+
+def test_tagged_handoffs_survive_nan_right_hand_sides(emu_lib):
+    # the tag is a NaN pattern: a right-hand side with NaNs still comes back (as NaNs), and the next solve of the handle is clean
+    n, rp, ci, v = P.poisson2d(44, 40)
+    b = P.csr_matvec(n, rp, ci, v, P.manufactured_solution(n))
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci, refinement_nstep=0) == 0
+    assert s.factorize(v) == 0
+    assert s.counter("tagged_solve") == 1
+    x = s.solve(b)
+    bn = b.copy()
+    bn[n // 2] = np.nan
+    bn[7] = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFFFF).tobytes(), dtype=np.float64)[0]  # the tag pattern itself
+    assert np.isnan(s.solve(bn)).any()
+    assert np.array_equal(s.solve(b), x)
+    assert s.counter("fused_fallbacks") == 0
+    s.close()
+
+
+def test_tagged_handoffs_symmetric_lower_ldlt(emu_lib):
+    n, rp, ci, v = P.poisson2d(48, 44)
+    xs = P.manufactured_solution(n)
+    b = P.csr_matvec(n, rp, ci, v, xs)
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    x_tag, c_tag = _solve_counter(emu_lib, n, lrp, lci, lv, b, dict(TREE, HIPMF_TAG_SOLVE="1"), "tagged_solve", general_symmetric=True)
+    x_cnt, c_cnt = _solve_counter(emu_lib, n, lrp, lci, lv, b, dict(TREE, HIPMF_TAG_SOLVE="0"), "tagged_solve", general_symmetric=True)
+    assert (c_tag, c_cnt) == (1, 0)
+    assert np.array_equal(x_tag, x_cnt)
+
+
 def test_tree_schedule_symmetric_lower_ldlt(emu_lib):
     n, rp, ci, v = P.poisson2d(48, 44)
     xs = P.manufactured_solution(n)

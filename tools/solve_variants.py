@@ -26,17 +26,18 @@ else:
     kw = {}
 
 VARIANTS = [
+    ("tagged hand-offs (defaults)", {}),
+    ("completion counters (HIPMF_TAG_SOLVE=0)", {"HIPMF_TAG_SOLVE": "0"}),
+    ("tagged, no top launch (stage 0)", {"HIPMF_UP_STAGE": "0"}),
+    ("tagged, top = levels with <= 120 fronts", {"HIPMF_UP_TOP_FRONTS": "120"}),
+    ("tagged, top = levels with <= 16 fronts", {"HIPMF_UP_TOP_FRONTS": "16"}),
+    ("tagged, stage 24 / 32", {"HIPMF_UP_STAGE": "24", "HIPMF_UP_STAGE_BWD": "32"}),
+    ("tagged, mid stage 16", {"HIPMF_UP_STAGE_MID": "16"}),
+    ("tagged, mid stage 0", {"HIPMF_UP_STAGE_MID": "0"}),
     ("round-2 schedule (HIPMF_TREE_SOLVE=0)", {"HIPMF_TREE_SOLVE": "0"}),
-    ("tree (defaults)", {}),
-    ("tree, no top launch (stage 0)", {"HIPMF_UP_STAGE": "0"}),
-    ("tree, top = levels with <= 120 fronts", {"HIPMF_UP_TOP_FRONTS": "120"}),
-    ("tree, top = levels with <= 300 fronts", {"HIPMF_UP_TOP_FRONTS": "300"}),
-    ("tree, top = levels with <= 16 fronts", {"HIPMF_UP_TOP_FRONTS": "16"}),
-    ("tree, stage 40 / 64", {"HIPMF_UP_STAGE": "40", "HIPMF_UP_STAGE_BWD": "64"}),
-    ("tree, stage 24 / 32", {"HIPMF_UP_STAGE": "24", "HIPMF_UP_STAGE_BWD": "32"}),
-    ("tree, stage 16 / 24, top <= 120", {"HIPMF_UP_STAGE": "16", "HIPMF_UP_STAGE_BWD": "24", "HIPMF_UP_TOP_FRONTS": "120"}),
-    ("tree, caps 40 fronts / 128 KB", {"HIPMF_WT_FRONTS": "40", "HIPMF_WT_KB": "128"}),
 ]
+if os.environ.get("SOLVE_VARIANTS_SHORT"):
+    VARIANTS = VARIANTS[:2]
 LIB = next((a[4:] for a in sys.argv[2:] if a.startswith("lib=")), None)
 ONLY = next((a[5:] for a in sys.argv[2:] if a.startswith("only=")), None)
 extra = [a for a in sys.argv[2:] if "=" in a and not a.startswith("lib=") and not a.startswith("only=")]
