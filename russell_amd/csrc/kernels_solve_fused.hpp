@@ -43,6 +43,8 @@ struct SfTask {
                         //       ASSEMBLE tasks of the front (0: the slab gathers the children's vectors itself)
                         // 1:    forward pass only, fronts of thousands of rows: assemble rows [b, c) of front a's vector ONCE
                         //       (right-hand side + the children's updates, children in ascending order) for all of its slabs
+                        // 2:    forward pass, single right-hand side: group of WAVE FRONTS (a, b, c, d; -1 = none) -- big fronts (stored as
+                        //       E) of at most SF_WF_ROWS rows and SF_WF_PIV pivots, one per wavefront (sf_fwd_wave)
     int32_t a, b, c, d;
     int32_t pad;
 };
@@ -254,6 +256,126 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             if (lane < p) st_agent(xs + c * xstr + lane, v[c]);
             else if (lane < f) st_agent(W + c * wstr + lane, v[c]);
         }
+    if constexpr (!TAG) {
+        drain_stores();
+        if (lane == 0) flag_add(done + s, 1);
+    }
+}
+
+// ---- forward step of one WAVE FRONT by one wavefront (round 5) ----
+// The levels right above the wave-subtrees hold thousands of big fronts that are big in name only: f = 65 ... 128 rows, ~16 pivots, two to
+// six children (1000 x 1000 Poisson: 2 700 of them on levels 3 - 5).  As 256-thread slab tasks they fill the device's workgroup slots
+// (four workgroups per compute unit) several times over, each task a chain of dependent round trips for a few hundred multiply-adds:
+// those levels were bound by slots x task latency, 11 - 15 us per level (profiles/r05_solve_trace_step1_tagged.txt).  Here such a front is the
+// work of ONE wavefront, four fronts per workgroup: the lane owns rows lane and lane + 64; the first SF_WF_PRE columns of its rows of E
+// are requested before anything is waited for (registers), the children's update vectors are gathered four children at a time (all
+// loads of a batch in flight together) into the wave's LDS copy of the front's vector, in child order; then
+//   [y1; -delta] = E w1  (columns one after the other, even ones into one accumulator, odd ones into another),  u = w2 + (E w1)_2.
+// Same result as the slab tasks to rounding (another summation order); HIPMF_SOLVE_SLAB64=1 / HIPMF_WAVE_FRONTS=0 keep the slab tasks.
+constexpr int SF_WF_ROWS = 128, SF_WF_PIV = 32, SF_WF_PRE = 16;
+template <bool TAG>
+__device__ __forceinline__ void sf_fwd_wave(int s, int lane, double *w, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
+                                            const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
+                                            const int32_t *__restrict__ need, int *done, int *err, double *work, const double *x) {
+    const FrontDesc fd = FD[s];
+    const int p = fd.p, f = fd.p + fd.m;
+    const int64_t ld = fd.ld;
+    const double *E = pool + fd.eoff;
+    double *W = work + fd.woff;
+    const int r0 = lane, r1 = lane + 64;
+    const bool h1 = r1 < f; // (r0 < f always: f > 64)
+    // the front's vector: b1 on the pivot rows, zeros below (x is set before the launch: the children write `work`)
+    const double b1 = x[fd.first + (r0 < p ? r0 : 0)];
+    // the lane's rows of E, first SF_WF_PRE columns (clamped addresses: unconditional loads, all in flight at once)
+    double e0[SF_WF_PRE], e1[SF_WF_PRE];
+    {
+        const double *E0 = E + r0, *E1 = E + (h1 ? r1 : r0);
+#pragma unroll
+        for (int c = 0; c < SF_WF_PRE; c++) {
+            const int64_t cc = (int64_t)(c < p ? c : p - 1) * ld;
+            e0[c] = E0[cc], e1[c] = E1[cc];
+        }
+    }
+    w[r0] = (r0 < p) ? b1 : 0.0;
+    w[r1] = 0.0;
+    // lane c looks after child c (at most 64 children: the planner sends other fronts to the slab tasks)
+    const int nch = fd.child_end - fd.child_begin;
+    int64_t c_src = 0, c_rel = 0;
+    int c_m = 0;
+    if (lane < nch) {
+        const int ch = child_idx[fd.child_begin + lane];
+        const FrontDesc cd = FD[ch];
+        c_src = cd.woff + cd.p, c_rel = cd.rowptr, c_m = cd.m;
+        if constexpr (!TAG) sf_wait(done + ch, need[ch], err);
+    }
+    wave_sync();
+    for (int cb = 0; cb < nch; cb += 4) {
+        int q[4][2];
+        double v[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cl = cb + k < nch ? cb + k : cb; // (wave-uniform; a batch's unused places re-read its first child and drop the values)
+            const int64_t src = wave_bcast_i64(c_src, cl), rl = wave_bcast_i64(c_rel, cl);
+            const int m = cb + k < nch ? wave_bcast_i32(c_m, cl) : 0;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int i = lane + 64 * e, ic = i < m ? i : 0;
+                const int qq = rel[rl + ic];
+                v[k][e] = ld_agent(work + src + ic); // (`work` and `rel` are padded: index 0 of a child without update rows is inside the allocation)
+                q[k][e] = i < m ? qq : -1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (cb + k < nch) { // (wave-uniform) children in ascending order: the order fixes the floating-point sums
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    if (q[k][e] >= 0) {
+                        if constexpr (TAG) {
+                            if (sf_is_tag(v[k][e])) v[k][e] = sf_tag_wait(work + wave_bcast_i64(c_src, cb + k) + lane + 64 * e, v[k][e], err);
+                        }
+                        w[q[k][e]] += v[k][e];
+                    }
+                wave_sync();
+            }
+        }
+    }
+    wave_sync();
+    // E w1: even columns into a, odd ones into b
+    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1s = 0.0;
+#pragma unroll
+    for (int c = 0; c < SF_WF_PRE; c += 2) {
+        if (c < p) { // (wave-uniform)
+            const double wj = w[c];
+            a0 += e0[c] * wj, a1 += e1[c] * wj;
+        }
+        if (c + 1 < p) {
+            const double wj = w[c + 1];
+            b0 += e0[c + 1] * wj, b1s += e1[c + 1] * wj;
+        }
+    }
+    if (p > SF_WF_PRE) { // (wave-uniform) the columns past the prefetched ones
+        const double *E0 = E + r0, *E1 = E + (h1 ? r1 : r0);
+#pragma unroll
+        for (int c = 0; c < SF_WF_PIV - SF_WF_PRE; c++) {
+            const int64_t cc = (int64_t)(SF_WF_PRE + c < p ? SF_WF_PRE + c : p - 1) * ld;
+            e0[c] = E0[cc], e1[c] = E1[cc];
+        }
+#pragma unroll
+        for (int c = 0; c < SF_WF_PIV - SF_WF_PRE; c += 2) {
+            if (SF_WF_PRE + c < p) {
+                const double wj = w[SF_WF_PRE + c];
+                a0 += e0[c] * wj, a1 += e1[c] * wj;
+            }
+            if (SF_WF_PRE + c + 1 < p) {
+                const double wj = w[SF_WF_PRE + c + 1];
+                b0 += e0[c + 1] * wj, b1s += e1[c + 1] * wj;
+            }
+        }
+    }
+    const double t0 = a0 + b0, t1 = a1 + b1s;
+    st_agent(W + r0, (r0 < p) ? t0 : w[r0] + t0);
+    if (h1) st_agent(W + r1, w[r1] + t1);
     if constexpr (!TAG) {
         drain_stores();
         if (lane == 0) flag_add(done + s, 1);
@@ -623,8 +745,11 @@ __device__ __forceinline__ double sf_mma_sum(const double *mt, int nsub, int rr,
 // kernel also runs thousands of small fronts, whose occupancy pays for every VGPR (measured in round 2: 108 -> 152 VGPRs, slower).
 // TAG (K = 1 only): data-tagged hand-offs (see sf_tag_wait) -- no completion counters, no drains; the task list then holds no
 // ASSEMBLE tasks (their intermediate result would sit where the parent looks for the final one).
+#ifndef HIPMF_SF_FWD_WGS
+#define HIPMF_SF_FWD_WGS 3 // workgroups per compute unit the single-column forward instances above the wave-subtrees are compiled for (A/B builds)
+#endif
 template <bool SMALL_ONLY, int K, bool STG = false, bool TAG = false>
-__global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
+__global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WGS : 3) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
                                                    const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int nk,
@@ -657,6 +782,13 @@ __global__ void __launch_bounds__(256, 3) k_fwd_fused(const SfTask *__restrict__
         return;
     }
     if (SMALL_ONLY) return; // (never reached: the small-only instance is launched on all-small bands)
+    if constexpr (K == 1 && !SMALL_ONLY) {
+        if (t.kind == 2) { // wave fronts: one big front of few rows and pivots per wavefront
+            const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
+            if (s >= 0) sf_fwd_wave<TAG>(s, lane, lds + SF_WF_ROWS * wave, FD, pool, child_idx, rel, need, done, err, work, x);
+            return;
+        }
+    }
     if (!TAG && t.kind == 1) {
         // ---- assemble rows [q0, q1) of the big front t.a: w = b (pivot rows) + the children's updates, once for all slabs.  Every
         //      slab used to gather all children itself: hundreds of redundant gathers on fronts of thousands of rows.  The pivot part

@@ -74,7 +74,7 @@ static_assert(sizeof(WtRec) == 64, "16 words");
 struct WtHdr {                 // one batch: 16 8-byte words, fetched by 16 lanes
     int64_t src[WT_NCH];       // pool offsets of the batch's pieces (unused ones repeat src[0])
     int64_t meta;              // word offset of the batch's meta block
-    int32_t nrec, pad;
+    int32_t nrec, words;       // fronts of the batch; words of its meta block that hold something (records + index lists)
     int64_t pad2[16 - WT_NCH - 2];
 };
 static_assert(sizeof(WtHdr) == 128, "16 words");
@@ -82,7 +82,7 @@ static_assert(sizeof(WtHdr) == 128, "16 words");
 struct WtWave {
     int32_t b0, b1;  // batches of the wave
     int32_t xfirst;  // first pivot column of the subtree
-    int32_t pad;
+    int32_t npiv;    // its pivot columns (<= WT_X)
 };
 
 // the loads of one batch: 8 pieces of factor, 2 of meta (all unconditional: the batch after this one is requested before this one
@@ -92,8 +92,12 @@ __device__ __forceinline__ void wt_issue(long long hw, int lane, const double *_
 #pragma unroll
     for (int c = 0; c < WT_NCH; c++) pc[c] = pool[wave_bcast_i64(hw, c) + lane];
     const int64_t mo = wave_bcast_i64(hw, WT_NCH);
-#pragma unroll
-    for (int c = 0; c < 2; c++) mc[c] = ld_i32x4(meta + mo + 256 * c + 4 * lane);
+    // (a meta block that ends inside its first 256 words -- most do -- is not fetched beyond them: the second load re-reads the first
+    //  chunk, a cache hit; still unconditional, see above)
+    const int words = (int)(unsigned)((unsigned long long)wave_bcast_i64(hw, WT_NCH + 1) >> 32);
+    const int second = words > 256 ? 256 : 0;
+    mc[0] = ld_i32x4(meta + mo + 4 * lane);
+    mc[1] = ld_i32x4(meta + mo + second + 4 * lane);
 }
 __device__ __forceinline__ void wt_park(double *L, int lane, const double (&pc)[WT_NCH], const i32x4 (&mc)[2]) {
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restri
     __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const WtWave wv = waves[blockIdx.x * WT_WAVES + wave];
-    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst);
+    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst), npiv = wave_uniform(wv.npiv);
     if (b0 >= b1) return;
     HIPMF_STAMP((int)blockIdx.x / 6, 0);
     HIPMF_STAMP_VAL((int)blockIdx.x / 6, 4, b1 - b0);
@@ -196,12 +200,14 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restri
     long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
     long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
     // the subtree's part of the right-hand side and of the interchanges (the vectors are allocated with room for the over-read)
+    // (chunks of 128 entries of x / 256 of the interchanges; a chunk past the subtree's pivots re-reads chunk 0 -- a cache hit -- instead
+    //  of dragging the neighbouring subtrees' entries in: the average subtree has ~60 pivots)
     f64x2 xc[WT_X / 128];
     i32x4 lc[WT_X / 256];
 #pragma unroll
-    for (int c = 0; c < WT_X / 128; c++) xc[c] = ld_f64x2(x + xfirst + 128 * c + 2 * lane);
+    for (int c = 0; c < WT_X / 128; c++) xc[c] = ld_f64x2(x + xfirst + (128 * c < npiv ? 128 * c : 0) + 2 * lane);
 #pragma unroll
-    for (int c = 0; c < WT_X / 256; c++) lc[c] = ld_i32x4(lperm + xfirst + 256 * c + 4 * lane);
+    for (int c = 0; c < WT_X / 256; c++) lc[c] = ld_i32x4(lperm + xfirst + (256 * c < npiv ? 256 * c : 0) + 4 * lane);
     double pc[WT_NCH];
     i32x4 mc[2];
     wt_issue(h0, lane, pool, meta, pc, mc);
@@ -316,7 +322,7 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_bwd(const WtWave *__restri
     __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const WtWave wv = waves[blockIdx.x * WT_WAVES + wave];
-    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst);
+    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst), npiv = wave_uniform(wv.npiv);
     if (b0 >= b1) return;
     double *L = lds[wave];
     L[WT_OFF_Z + lane] = 0.0;
@@ -325,7 +331,7 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_bwd(const WtWave *__restri
     long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
     f64x2 xc[WT_X / 128];
 #pragma unroll
-    for (int c = 0; c < WT_X / 128; c++) xc[c] = ld_f64x2(x + xfirst + 128 * c + 2 * lane);
+    for (int c = 0; c < WT_X / 128; c++) xc[c] = ld_f64x2(x + xfirst + (128 * c < npiv ? 128 * c : 0) + 2 * lane);
     double pc[WT_NCH];
     i32x4 mc[2];
     wt_issue(h0, lane, pool, meta, pc, mc);

@@ -350,6 +350,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SMALL_PAIR")) small_pair = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TAG_SOLVE")) use_tag = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_UP_STAGE")) up_stage = std::max(0, std::min(64, atoi(e) / 8 * 8));
@@ -979,12 +980,22 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
         };
         auto emit_level = [&](int32_t l, bool forward) {
-            std::vector<int32_t> small;
+            std::vector<int32_t> small, wavef;
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                 int32_t s = S.level_sn[k];
                 if (tree && in_w[(size_t)s]) continue;
                 if (S.fsize(s) <= SMALL_F) {
                     small.push_back(s);
+                    continue;
+                }
+                // forward pass above the wave-subtrees: big fronts of few rows and pivots are the work of one wavefront each
+                // (kind 2, sf_fwd_wave) instead of 256-thread slab tasks
+                // (below the top levels only: a top-level front publishes through its replicas, sf_publish_front)
+                if (tree && forward && wave_fronts && !slab64 && S.sn_level[s] < top_level && S.fsize(s) <= SF_WF_ROWS && S.npiv(s) <= SF_WF_PIV &&
+                    S.child_ptr[s + 1] - S.child_ptr[s] <= 64) {
+                    wavef.push_back(s);
+                    need[(size_t)s] = 1;
+                    wave_front_count++;
                     continue;
                 }
                 const int32_t kind = kind_of(s, forward), rows = 1 << kind, ext = forward ? S.fsize(s) : S.npiv(s);
@@ -1007,6 +1018,13 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                     for (size_t g0 = 0; g0 + 16 <= cnt; g0 += 16)
                         for (size_t j = 0; j < 8; j++) sf[first_slab + g0 + j] = tmp[g0 + 2 * j], sf[first_slab + g0 + 8 + j] = tmp[g0 + 2 * j + 1];
                 }
+            }
+            for (size_t k = 0; k < wavef.size(); k += 4) {
+                SfTask t = {2, wavef[k], -1, -1, -1, 0};
+                if (k + 1 < wavef.size()) t.b = wavef[k + 1];
+                if (k + 2 < wavef.size()) t.c = wavef[k + 2];
+                if (k + 3 < wavef.size()) t.d = wavef[k + 3];
+                sf.push_back(t);
             }
             for (size_t k = 0; k < small.size(); k += 4) {
                 SfTask t = {0, small[k], -1, -1, -1, 0};
@@ -1082,6 +1100,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         // the wave-subtrees are the maximal closed ones.
         wt_waves = wt_recs = 0;
         sf2_fwd_cnt = sf2_bwd_cnt = 0;
+        wave_front_count = 0;
         bool tree_ok = WP.ok_tree; // (the wave-subtrees were planned before the descriptors: WtPlan above)
         if (tree_ok) {
             const std::vector<int32_t> &cnt = WP.cnt, &roots = WP.roots;
@@ -1105,7 +1124,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                         std::vector<int32_t> &meta = dir == 0 ? meta_f : meta_b;
                         std::vector<WtWave> &wav = dir == 0 ? wav_f : wav_b;
                         WtWave w;
-                        w.b0 = (int32_t)hdr.size(), w.xfirst = xfirst, w.pad = 0;
+                        w.b0 = (int32_t)hdr.size(), w.xfirst = xfirst, w.npiv = S.sn_first[R + 1] - xfirst;
                         int32_t s = dir == 0 ? lo : R;
                         const int32_t send = dir == 0 ? R + 1 : lo - 1, step = dir == 0 ? 1 : -1;
                         while (s != send) {
@@ -1157,6 +1176,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                                 memcpy(meta.data() + m0 + (size_t)16 * k, &r, sizeof r);
                             }
                             for (int32_t c = ci; c < WT_NCH; c++) h.src[c] = h.src[0];
+                            h.words = lst;
                             hdr.push_back(h);
                             s = e;
                         }

@@ -158,6 +158,7 @@ class Solver {
     int32_t refinement_steps_done = 0;
     int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
     int64_t mid_front_count = 0; // fronts of this plan that one workgroup factorises in one launch (k_front)
+    int64_t wave_front_count = 0; // big fronts that are wave-front tasks in the forward pass of this plan (sf_fwd_wave)
     int64_t gate_waits = 0;      // solves that waited for another handle's solve on the same device (device_gate, numeric.cpp)
     bool tagged_solve() const { return tag_active && use_fused; }
     int64_t chain_fallbacks = 0; // factorisations repeated with one launch per tiled step after a hand-off timeout of a chained launch (never expected)
@@ -261,6 +262,7 @@ class Solver {
     int32_t *d_need2 = nullptr;             // completed-task counts of that list (the slabs are cut differently)
     bool tree_active = false;               // the plan above exists for this matrix
     bool use_tag = true;                    // HIPMF_TAG_SOLVE=0: completion counters instead of data-tagged hand-offs above the wave-subtrees
+    bool wave_fronts = true;                // HIPMF_WAVE_FRONTS=0: the big fronts of few rows / pivots right above the wave-subtrees stay 256-thread slab tasks in the forward pass
     bool tag_active = false;                // the launches above the wave-subtrees run their TAG instances (kernels_solve_fused.hpp, sf_tag_wait)
     int64_t work_up = 0;                    // doubles at the head of a solve workspace: the vectors of the fronts outside the wave-subtrees' interiors
                                             // (tag_active: followed by n doubles, the tagged shadow of x)

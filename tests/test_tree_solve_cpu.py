@@ -123,6 +123,23 @@ def test_tagged_handoffs_survive_nan_right_hand_sides(emu_lib):
     s.close()
 
 
+@pytest.mark.parametrize("tag", ["1", "0"])
+def test_wave_fronts_agree_with_slab_tasks(emu_lib, tag):
+    # round 5: big fronts of at most 128 rows / 32 pivots below the top levels are the work of one wavefront each in the forward pass
+    # (sf_fwd_wave): another summation order than the slab tasks', equal to rounding, reproducible from solve to solve
+    for n, rp, ci, v in (P.poisson2d(150, 140), P.convection_diffusion2d(90, peclet=30.0, scale_decades=0.0), P.poisson3d(14)):
+        xs = P.manufactured_solution(n)
+        b = P.csr_matvec(n, rp, ci, v, xs)
+        base = {"HIPMF_TAG_SOLVE": tag, "HIPMF_UP_TOP_FRONTS": "1"}  # (top levels = the last ones: wave fronts on every level below)
+        x_w, n_w = _solve_counter(emu_lib, n, rp, ci, v, b, dict(base, HIPMF_WAVE_FRONTS="1"), "wave_fronts")
+        x_w2, _ = _solve_counter(emu_lib, n, rp, ci, v, b, dict(base, HIPMF_WAVE_FRONTS="1"), "wave_fronts")
+        x_s, n_s = _solve_counter(emu_lib, n, rp, ci, v, b, dict(base, HIPMF_WAVE_FRONTS="0"), "wave_fronts")
+        assert n_w > 0 and n_s == 0
+        assert np.array_equal(x_w, x_w2)
+        assert np.max(np.abs(x_w - x_s)) <= 1e-13 * np.max(np.abs(x_s))
+        assert np.max(np.abs(x_w - xs)) < 1e-11
+
+
 def test_tagged_handoffs_symmetric_lower_ldlt(emu_lib):
     n, rp, ci, v = P.poisson2d(48, 44)
     xs = P.manufactured_solution(n)

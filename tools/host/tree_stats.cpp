@@ -50,6 +50,18 @@ int main(int argc, char **argv) {
         printf("%3d %7lld %7lld %6lld | %8lld %5lld %5lld | %8.2f %8.2f %8.2f | %9lld %9lld %4lld\n", l, (long long)(ns + nb), (long long)ns, (long long)nb, (long long)sp,
                (long long)pmax, (long long)fmax, sb / 1e6, eb / 1e6, epb / 1e6, (long long)sf, (long long)sm, (long long)ncm);
     }
+    printf("big fronts per level: count | f<=128&p<=32 | f<=192&p<=48 | f<=256&p<=64 | avg f, avg p, avg children\n");
+    for (int l = 0; l < S.nlevels; l++) {
+        int64_t nb = 0, c1 = 0, c2 = 0, c3 = 0, sf = 0, sp = 0, sc = 0;
+        for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+            const int s = S.level_sn[k];
+            const int64_t p = S.npiv(s), f = p + S.nrow(s);
+            if (f <= 64) continue;
+            nb++, sf += f, sp += p, sc += S.child_ptr[s + 1] - S.child_ptr[s];
+            c1 += f <= 128 && p <= 32, c2 += f <= 192 && p <= 48, c3 += f <= 256 && p <= 64;
+        }
+        if (nb) printf("%3d %6lld | %6lld %6lld %6lld | %6.1f %6.1f %5.2f\n", l, (long long)nb, (long long)c1, (long long)c2, (long long)c3, (double)sf / nb, (double)sp / nb, (double)sc / nb);
+    }
     printf("total small (both passes) %.1f MB, E %.1f MB, E' %.1f MB\n", tot_s / 1e6, tot_e / 1e6, tot_ep / 1e6);
     return 0;
 }

@@ -26,15 +26,14 @@ else:
     kw = {}
 
 VARIANTS = [
-    ("tagged hand-offs (defaults)", {}),
+    ("defaults (tagged hand-offs, wave fronts)", {}),
+    ("slab tasks instead of wave fronts", {"HIPMF_WAVE_FRONTS": "0"}),
     ("completion counters (HIPMF_TAG_SOLVE=0)", {"HIPMF_TAG_SOLVE": "0"}),
-    ("tagged, no top launch (stage 0)", {"HIPMF_UP_STAGE": "0"}),
-    ("tagged, top = levels with <= 120 fronts", {"HIPMF_UP_TOP_FRONTS": "120"}),
-    ("tagged, top = levels with <= 16 fronts", {"HIPMF_UP_TOP_FRONTS": "16"}),
-    ("tagged, stage 24 / 32", {"HIPMF_UP_STAGE": "24", "HIPMF_UP_STAGE_BWD": "32"}),
-    ("tagged, mid stage 16", {"HIPMF_UP_STAGE_MID": "16"}),
-    ("tagged, mid stage 0", {"HIPMF_UP_STAGE_MID": "0"}),
-    ("round-2 schedule (HIPMF_TREE_SOLVE=0)", {"HIPMF_TREE_SOLVE": "0"}),
+    ("counters, no wave fronts (round 4)", {"HIPMF_TAG_SOLVE": "0", "HIPMF_WAVE_FRONTS": "0"}),
+    ("top = levels with <= 16 fronts", {"HIPMF_UP_TOP_FRONTS": "16"}),
+    ("top = levels with <= 120 fronts", {"HIPMF_UP_TOP_FRONTS": "120"}),
+    ("mid stage 0", {"HIPMF_UP_STAGE_MID": "0"}),
+    ("caps 40 fronts / 128 KB per wave-subtree", {"HIPMF_WT_FRONTS": "40", "HIPMF_WT_KB": "128"}),
 ]
 if os.environ.get("SOLVE_VARIANTS_SHORT"):
     VARIANTS = VARIANTS[:2]
