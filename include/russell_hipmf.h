@@ -205,11 +205,20 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
  *   HIPMF_OPTION_PIVOTING            lin_sol_params.rs:16 / enums.rs Pivoting: 1 = Auto / LocalBlock (partial pivoting inside the pivot
  *                                    block of a small front / the 32-row diagonal tile of a tiled one, tiny pivots perturbed and counted);
  *                                    None / GlobalCol / GlobalRow / Diagonal are not available: ERROR_NOT_AVAILABLE
- *   HIPMF_OPTION_HYBRID_MEMORY       lin_sol_params.rs:39 (cuDSS hybrid memory, factor 0.01 .. 0.99): the DEVICE half of the reference's
- *                                    meaning -- factor x the device's total memory is the most the factor + working arena may take
- *                                    (interface_cudss.cu:364-372 sets cuDSS's device memory limit the same way).  The host half does not
- *                                    exist here (no out-of-core path): a factor that does not fit the limit is refused by initialize with
- *                                    the "Not enough memory" string the reference's harness recognises (stats_lin_sol.rs:334-340)
+ *   HIPMF_OPTION_HYBRID_MEMORY       lin_sol_params.rs:39 (cuDSS hybrid memory, factor 0.01 .. 0.99; interface_cudss.cu:347-380: the factor spills
+ *                                    to host memory, factor x total is the device share).  Accepted, range-checked and kept (get_option
+ *                                    returns it), and WITHOUT effect on what fits: this backend has no out-of-core path, the factor +
+ *                                    working arena live in HBM (288 GB), so the option can neither let a larger matrix through nor --
+ *                                    since round 5 -- refuse one that fits the device (rounds 3 - 4 applied factor x total as a cap,
+ *                                    which refused matrices the reference accepts).  A matrix that does not fit the free device memory
+ *                                    is refused by initialize with the "Not enough memory" string the reference's harness recognises
+ *                                    (stats_lin_sol.rs:334-340); the message names the option when it was set
+ *   HIPMF_OPTION_SYM_RECHECK         (no reference counterpart) 1: a symmetric-lower handle initialised WITHOUT values looks at the diagonal
+ *                                    of the first values it is asked to factorise (solver_hipmf_factorize or _factorize_device) and, when
+ *                                    it is weak, redoes the analysis on the mirrored matrix with the matching inside that call (what
+ *                                    initialize does when it is handed values).  0 (default since round 5): it keeps its L D L^T plan --
+ *                                    the re-analysis changes the plan of this handle only, so peers waiting for its factor
+ *                                    (solver_hipmf_broadcast_factor) would be refused and a permutation fetched earlier goes stale
  *   HIPMF_OPTION_ERROR_ESTIMATES     lin_sol_params.rs:50: the componentwise backward error omega of the last solve is always kept
  *   HIPMF_OPTION_CONDITION_NUMBERS   lin_sol_params.rs:55: min|u_ii| / max|u_ii| is always reported by factorize (rcond_estimate)
  * (both readable with solver_hipmf_get_option after solve / factorize: the value, not the flag). */
@@ -218,6 +227,7 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 #define HIPMF_OPTION_HYBRID_MEMORY 2
 #define HIPMF_OPTION_ERROR_ESTIMATES 3
 #define HIPMF_OPTION_CONDITION_NUMBERS 4
+#define HIPMF_OPTION_SYM_RECHECK 5
 int32_t solver_hipmf_set_option(struct InterfaceHIPMF *solver, int32_t option, double value);
 int32_t solver_hipmf_get_option(struct InterfaceHIPMF *solver, int32_t option, double *value);
 
@@ -276,6 +286,8 @@ int32_t complex_solver_hipmf_set_value_map(struct InterfaceComplexHIPMF *solver,
 int32_t complex_solver_hipmf_factorize_mapped(struct InterfaceComplexHIPMF *solver, int32_t *effective_ordering, int32_t *effective_scaling,
                                               int32_t *num_perturbed_pivots, double *rcond_estimate, C_BOOL verbose, const double *input_values);
 int32_t complex_solver_hipmf_get_stats(struct InterfaceComplexHIPMF *solver, int64_t *istats, double *dstats); /* istats[0..1]: complex n, nnz */
+/* the HIPMF_COUNTER_* values of solver_hipmf_get_counter for the complex twin's handle (-1: unknown counter / not initialized) */
+int64_t complex_solver_hipmf_get_counter(struct InterfaceComplexHIPMF *solver, int32_t which);
 const char *complex_solver_hipmf_last_error(struct InterfaceComplexHIPMF *solver);
 
 /* plain device-memory helpers so that callers need no HIP binding of their own */
@@ -285,6 +297,7 @@ int32_t hipmf_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int32_t hipmf_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int32_t hipmf_device_synchronize(void);
 int32_t hipmf_device_count(void);
+int32_t hipmf_device_mem_info(size_t *free_bytes, size_t *total_bytes); /* hipMemGetInfo of the calling thread's device */
 /* Measured device-to-device copy rate in GB/s (read + written bytes over HIP-event time, `bytes` per copy, best of `reps`):
  * the achievable-HBM denominator bench.py reports beside the 8 TB/s spec. */
 int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_s);

@@ -53,6 +53,7 @@ SYMBOLS = {
     "complex_solver_hipmf_factorize_mapped": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                            C.POINTER(C.c_double), C.c_int32, f64p]),
     "complex_solver_hipmf_get_stats": (C.c_int32, [C.c_void_p, i64p, f64p]),
+    "complex_solver_hipmf_get_counter": (C.c_int64, [C.c_void_p, C.c_int32]),
     "complex_solver_hipmf_last_error": (C.c_char_p, [C.c_void_p]),
     "solver_hipmf_get_counter": (C.c_int64, [C.c_void_p, C.c_int32]),
     "solver_hipmf_set_option": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double]),
@@ -73,6 +74,7 @@ SYMBOLS = {
     "hipmf_device_synchronize": (C.c_int32, []),
     "hipmf_device_count": (C.c_int32, []),
     "hipmf_device_copy_bandwidth": (C.c_int32, [C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
+    "hipmf_device_mem_info": (C.c_int32, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hipmf_device_mfma_rate": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "hipmf_set_device": (C.c_int32, [C.c_int32]),
     "hipmf_fdm_new": (C.c_void_p, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

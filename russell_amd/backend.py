@@ -130,6 +130,12 @@ class Hipmf:
 
     COUNTERS = {"rematch": 0, "weak_diagonal_rows": 1, "fused_fallbacks": 2, "persistent_bytes": 3, "arena_bytes": 4, "symmetric_ldlt": 5, "sym_expanded": 6, "chain_fallbacks": 7, "mid_fronts": 8, "plan_digest": 9, "tagged_solve": 10, "gate_waits": 11, "wave_fronts": 12}
 
+    OPTIONS = {"matching": 0, "pivoting": 1, "hybrid_memory": 2, "error_estimates": 3, "condition_numbers": 4, "sym_recheck": 5}
+
+    def set_option(self, name, value):
+        """solver_hipmf_set_option (before initialize): the LinSolParams fields the initialize signature does not carry."""
+        return int(self.lib.solver_hipmf_set_option(self.h, self.OPTIONS[name], float(value)))
+
     def counter(self, name):
         return int(self.lib.solver_hipmf_get_counter(self.h, self.COUNTERS[name]))
 

@@ -409,6 +409,12 @@ class Radau5 {
         }
     }
 
+  public:
+    // the backend's diagnostic counters of the two handles (HIPMF_COUNTER_* of include/russell_hipmf.h)
+    long long counter_real(int which) const { return solver_real ? (long long)solver_real->get_counter(which) : -1; }
+    long long counter_comp(int which) const { return solver_comp ? (long long)solver_comp->get_counter(which) : -1; }
+
+  private:
     Params params;
     const Brusselator &system;
     size_t ndim;
@@ -539,16 +545,26 @@ int main(int argc, char **argv) {
     }
     const Stats &st = work.stats;
     const size_t ij_mid = (npoint - 1) / 2, m_mid = ij_mid + ij_mid * npoint;
+    // the backend's own counters of both handles (HIPMF_COUNTER_* of include/russell_hipmf.h): solves that fell back to the level-set
+    // launches (2), factorisations that fell back from the chained tiled steps (7), solves that found the device's gate held by the other
+    // handle (11: the real and the complex system are solved on two threads, radau5.rs:270-296) -- fallbacks are never expected
+    const long long fb_real = radau.counter_real(2);
+    const long long fb_comp = radau.counter_comp(2);
+    const long long cf_real = radau.counter_real(7);
+    const long long cf_comp = radau.counter_comp(7);
+    const long long gw_real = radau.counter_real(11);
+    const long long gw_comp = radau.counter_comp(11);
     if (json) {
         printf("{\"second_book\": %s, \"npoint\": %zu, \"ndim\": %zu, \"jac_nnz\": %zu, \"tolerance\": %.3e, \"concurrent\": %s, \"t1\": %.17g, "
                "\"n_function\": %zu, \"n_jacobian\": %zu, \"n_factor\": %zu, \"n_lin_sol\": %zu, \"n_steps\": %zu, \"n_accepted\": %zu, "
                "\"n_rejected\": %zu, \"n_iterations_max\": %zu, \"h_accepted\": %.17g, \"u_mid\": %.17g, \"v_mid\": %.17g, "
                "\"ms_total\": %.3f, \"ms_factor_max\": %.3f, \"ms_factor_avg\": %.3f, \"ms_lin_sol_max\": %.3f, \"ms_lin_sol_avg\": %.3f, "
-               "\"ms_jacobian_total\": %.3f}\n",
+               "\"ms_jacobian_total\": %.3f, \"fused_fallbacks\": [%lld, %lld], \"chain_fallbacks\": [%lld, %lld], \"gate_waits\": [%lld, %lld]}\n",
                first_book ? "false" : "true", npoint, sys.ndim, sys.jac_nnz(), tol, serial ? "false" : "true", t1, st.n_function, st.n_jacobian,
                st.n_factor, st.n_lin_sol, st.n_steps, st.n_accepted, st.n_rejected, st.n_iterations_max, st.h_accepted, yy[m_mid], yy[sys.s + m_mid],
                st.ns_total * 1e-6, st.ns_factor_max * 1e-6, st.n_factor ? st.ns_factor_total * 1e-6 / (double)st.n_factor : 0.0,
-               st.ns_lin_sol_max * 1e-6, st.n_lin_sol ? st.ns_lin_sol_total * 1e-6 / (double)st.n_lin_sol : 0.0, st.ns_jacobian_total * 1e-6);
+               st.ns_lin_sol_max * 1e-6, st.n_lin_sol ? st.ns_lin_sol_total * 1e-6 / (double)st.n_lin_sol : 0.0, st.ns_jacobian_total * 1e-6, fb_real,
+               fb_comp, cf_real, cf_comp, gw_real, gw_comp);
     } else {
         printf("Second-book problem              = %s\n", first_book ? "false" : "true");
         printf("Number of points along x and y   = %zu\n", npoint);
@@ -569,6 +585,9 @@ int main(int argc, char **argv) {
         printf("Max time spent on factorization  = %.3f ms\n", st.ns_factor_max * 1e-6);
         printf("Max time spent on lin solution   = %.3f ms\n", st.ns_lin_sol_max * 1e-6);
         printf("Total time                       = %.3f ms\n", st.ns_total * 1e-6);
+        printf("Solve fallbacks (real, complex)  = %lld, %lld\n", fb_real, fb_comp);
+        printf("Chain fallbacks (real, complex)  = %lld, %lld\n", cf_real, cf_comp);
+        printf("Waits at the device gate (r, c)  = %lld, %lld\n", gw_real, gw_comp);
         printf("u, v at the middle node          = %.15g %.15g\n", yy[m_mid], yy[sys.s + m_mid]);
     }
     return 0;

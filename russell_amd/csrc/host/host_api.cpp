@@ -744,6 +744,8 @@ struct Backend {
     decltype(&complex_solver_hipmf_factorize_mapped) zfactorize_mapped = nullptr;
     decltype(&complex_solver_hipmf_get_determinant) zget_determinant = nullptr;
     decltype(&complex_solver_hipmf_get_stats) zget_stats = nullptr;
+    decltype(&solver_hipmf_get_counter) get_counter = nullptr;
+    decltype(&complex_solver_hipmf_get_counter) zget_counter = nullptr;
     bool tried = false;
 };
 Backend g_backend;
@@ -793,6 +795,8 @@ bool load_backend() {
     BIND(zfactorize_mapped, "complex_solver_hipmf_factorize_mapped")
     BIND(zget_determinant, "complex_solver_hipmf_get_determinant")
     BIND(zget_stats, "complex_solver_hipmf_get_stats")
+    BIND(get_counter, "solver_hipmf_get_counter")
+    BIND(zget_counter, "complex_solver_hipmf_get_counter")
 #undef BIND
     g_backend.dl = dl;
     return true;
@@ -960,6 +964,9 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
     if (g_backend.get_stats((InterfaceHIPMF *)solver, istats, dstats) == SUCCESSFUL_EXIT) effective_matching = istats[14] != 0;
     return nullptr;
 }
+
+int64_t SolverHIPMF::get_counter(int32_t which) const { return solver ? g_backend.get_counter((InterfaceHIPMF *)solver, which) : -1; }
+int64_t ComplexSolverHIPMF::get_counter(int32_t which) const { return solver ? g_backend.zget_counter((InterfaceComplexHIPMF *)solver, which) : -1; }
 
 StrError SolverHIPMF::solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) {
     if (!factorized) return "the function factorize must be called before solve";

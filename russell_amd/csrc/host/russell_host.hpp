@@ -39,10 +39,12 @@ enum class Matching : int32_t { None = 0, Auto, MaxDiagCount, MaxMinDiag, MaxMin
 enum class Pivoting : int32_t { Auto = 0, None, GlobalCol, GlobalRow, Diagonal, LocalBlock };
 
 // lin_sol_params.rs:5-82; the MUMPS / UMFPACK-only fields have no meaning for this backend and are not mirrored.
-//   ordering   Ordering::No -> natural order; Amd / Amf / Qamd -> this backend's approximate minimum degree; every other variant (Auto,
-//              Cholmod, Colamd, Metis, Pord, Scotch, Best) -> its nested dissection with dense leaves (the reference maps variants a
-//              backend does not have to that backend's default the same way, solver_umfpack.rs:457-472); the effective ordering
-//              ("No" / "Amd" / "Nd") is reported by update_stats
+//   ordering   Ordering::No -> natural order; Amd / Amf / Qamd -> this backend's approximate minimum degree; Best -> BOTH orderings, the one
+//              whose column counts promise fewer factorisation flops is kept (UMFPACK's meaning of the word, solver_umfpack.rs:461; on
+//              complex handles -- paired rows -- the nested dissection alone); every other variant (Auto, Cholmod, Colamd, Metis, Pord,
+//              Scotch) -> its nested dissection with dense leaves (the reference maps variants a backend does not have to that
+//              backend's default the same way, solver_umfpack.rs:457-472); the effective ordering ("No" / "Amd" / "Nd"; for Best: the
+//              winner) is reported by update_stats
 //   matching   None -> never; Auto -> when the diagonal is weak; any named variant -> always (there is one matching: maximum product
 //              + scaling, what cuDSS calls MaxDiagProduct)
 //   pivoting   Auto / LocalBlock -> partial pivoting inside the pivot block (the only strategy); others: factorize returns an error
@@ -196,6 +198,8 @@ class SolverHIPMF : public LinSolTrait {
     uint64_t get_ns_solve() const override { return time_solve_ns; }
     // extension: many right-hand sides, column-major n x nrhs
     StrError solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs);
+    // extension: the backend's diagnostic counters (HIPMF_COUNTER_* of include/russell_hipmf.h; -1 before the first factorize)
+    int64_t get_counter(int32_t which) const;
 
     bool factorized = false;
     bool value_map_set = false, first_call = false; // repeat factorizations refresh the values on the device through a map
@@ -251,6 +255,7 @@ class ComplexSolverHIPMF {
     void get_determinant(double &re, double &im, double &exponent) const { re = determinant_coefficient_real, im = determinant_coefficient_imag, exponent = determinant_exponent; }
     double get_rcond() const { return rcond_estimate; }
     int32_t get_perturbed_pivots() const { return perturbed_pivots; }
+    int64_t get_counter(int32_t which) const; // (HIPMF_COUNTER_* of include/russell_hipmf.h)
 
   private:
     ComplexSolverHIPMF() {}

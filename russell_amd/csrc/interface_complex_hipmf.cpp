@@ -306,4 +306,23 @@ int32_t complex_solver_hipmf_get_stats(struct InterfaceComplexHIPMF *h, int64_t 
     return guarded(h, [&]() { return c_get_stats_body(h, is, ds); });
 }
 
+int64_t complex_solver_hipmf_get_counter(struct InterfaceComplexHIPMF *h, int32_t which) {
+    if (!h || !h->solver.initialized) return -1;
+    const Solver &s = h->solver;
+    switch (which) {
+    case HIPMF_COUNTER_REMATCH: return s.rematch_count;
+    case HIPMF_COUNTER_WEAK_DIAGONAL_ROWS: return s.n_weak_diag;
+    case HIPMF_COUNTER_FUSED_FALLBACKS: return s.fused_fallbacks;
+    case HIPMF_COUNTER_PERSISTENT_BYTES: return s.S.persist_doubles * 8;
+    case HIPMF_COUNTER_ARENA_BYTES: return s.S.temp_doubles * 8;
+    case HIPMF_COUNTER_SYMMETRIC_LDLT: return s.S.sym_mode ? 1 : 0;
+    case HIPMF_COUNTER_CHAIN_FALLBACKS: return s.chain_fallbacks;
+    case HIPMF_COUNTER_MID_FRONTS: return s.mid_front_count;
+    case HIPMF_COUNTER_TAGGED_SOLVE: return s.tagged_solve() ? 1 : 0;
+    case HIPMF_COUNTER_GATE_WAITS: return s.gate_waits;
+    case HIPMF_COUNTER_WAVE_FRONTS: return s.wave_front_count;
+    default: return -1;
+    }
+}
+
 } // extern "C"

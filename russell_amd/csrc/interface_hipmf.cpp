@@ -28,7 +28,7 @@ struct InterfaceHIPMF {
     int32_t ordering_requested = 0;
     int32_t effective_ordering = 0;
     // solver_hipmf_set_option (before initialize)
-    int32_t opt_matching = 1, opt_pivoting = 1;
+    int32_t opt_matching = 1, opt_pivoting = 1, opt_sym_recheck = 0;
     double opt_hybrid = 0.0;
     // a symmetric-lower matrix with a weak diagonal is analysed and factorised as the mirrored GENERAL matrix (with the matching):
     // the caller keeps handing over lower-triangle values, entry k of the handle's CSR is entry emap[k] of the caller's
@@ -196,7 +196,8 @@ static int32_t initialize_body(struct InterfaceHIPMF *h, int32_t ordering, int32
         if (!e || atoi(e) != 0) expand = sym_lower_diagonal_is_weak(ndim, row_pointers, col_indices, values);
     }
     h->so_keep = so;
-    h->sym_unchecked = sym_lower && !values && no.matching > 0; // (no values yet: the first factorize looks at the diagonal)
+    // (no values yet: with HIPMF_OPTION_SYM_RECHECK the first factorize looks at the diagonal)
+    h->sym_unchecked = h->opt_sym_recheck == 1 && sym_lower && !values && no.matching > 0;
     if (expand) {
         code = initialize_expanded(h, ndim, row_pointers, col_indices, values, so, no);
     } else {
@@ -237,6 +238,10 @@ int32_t solver_hipmf_set_option(struct InterfaceHIPMF *h, int32_t option, double
         if (!(value > 0.0 && value < 1.0)) return ERROR_HIPMF_INVALID_VALUE;
         h->opt_hybrid = value;
         return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_SYM_RECHECK:
+        if (value != 0.0 && value != 1.0) return ERROR_HIPMF_INVALID_VALUE;
+        h->opt_sym_recheck = (int32_t)value;
+        return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_ERROR_ESTIMATES:
     case HIPMF_OPTION_CONDITION_NUMBERS: return SUCCESSFUL_EXIT; // (always computed)
     default: return ERROR_HIPMF_INVALID_VALUE;
@@ -249,6 +254,7 @@ int32_t solver_hipmf_get_option(struct InterfaceHIPMF *h, int32_t option, double
     case HIPMF_OPTION_MATCHING: *value = h->solver.initialized ? h->solver.opt.matching : h->opt_matching; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_PIVOTING: *value = h->opt_pivoting; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_HYBRID_MEMORY: *value = h->opt_hybrid; return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_SYM_RECHECK: *value = h->opt_sym_recheck; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_ERROR_ESTIMATES: *value = h->solver.last_omega; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_CONDITION_NUMBERS: {
         if (!h->solver.factorized) return ERROR_NEED_FACTORIZATION;
@@ -281,31 +287,44 @@ static int32_t finish_factorize(struct InterfaceHIPMF *h, int32_t code, int32_t 
     return code;
 }
 
+// A symmetric-lower handle analysed WITHOUT values whose caller asked for it (HIPMF_OPTION_SYM_RECHECK = 1, set before initialize): the
+// first values it is asked to factorise -- through solver_hipmf_factorize or solver_hipmf_factorize_device alike -- are the first numbers
+// it sees.  A weak diagonal (saddle-point / KKT matrices) sends it where initialize would have sent it with values: mirrored to general
+// storage, maximum-product matching, LU with pivoting inside the pivot blocks, at the price of one more analysis inside this call
+// (HIPMF_COUNTER_SYM_EXPANDED tells).  Once per handle; a value map installed meanwhile speaks of the lower triangle's entries and is
+// not carried over: such handles (and solver_hipmf_factorize_mapped) keep the L D L^T path.
+// Opt-in since round 5: the re-analysis changes the plan of THIS handle only -- peers that are to receive its factor
+// (solver_hipmf_broadcast_factor / adopt_factor) hold the L D L^T plan and would be refused, a permutation fetched earlier goes stale,
+// and a full analysis lands in a timed factorize call.  A caller that has the values hands them to initialize (as the reference's
+// shims do, interface_cudss.cu:190-203) and every rank then takes the same decision; this option is for single-handle callers that
+// cannot.
+static int32_t recheck_symmetric_diagonal(struct InterfaceHIPMF *h, const double *host_values, bool verbose) {
+    if (!h->sym_unchecked) return SUCCESSFUL_EXIT;
+    h->sym_unchecked = false;
+    const char *e = getenv("HIPMF_SYM_EXPAND");
+    const Solver &sv = h->solver;
+    if ((!e || atoi(e) != 0) && sv.S.sym_lower && !h->expanded && sv.nnz_in_values() == 0 && sv.S.n > 1 &&
+        sym_lower_diagonal_is_weak(sv.S.n, sv.kept_row_pointers().data(), sv.kept_col_indices().data(), host_values)) {
+        const std::vector<int32_t> rp = sv.kept_row_pointers(), ci = sv.kept_col_indices();
+        const NumericOptions no = sv.opt;
+        const int32_t ndim = sv.S.n;
+        h->solver.release();
+        const int32_t c = initialize_expanded(h, ndim, rp.data(), ci.data(), host_values, h->so_keep, no);
+        if (c != SUCCESSFUL_EXIT) return c;
+        if (verbose) printf("solver_hipmf_factorize: weak diagonal of a symmetric matrix: analysed again as a general matrix with matching\n");
+    }
+    return SUCCESSFUL_EXIT;
+}
+
 static int32_t factorize_body(struct InterfaceHIPMF *h, int32_t *effective_ordering, int32_t *effective_scaling,
                                int32_t *num_perturbed_pivots, double *rcond_estimate, double *determinant_coefficient,
                                double *determinant_exponent, C_BOOL compute_determinant, C_BOOL verbose, const double *values) {
     if (!h || !values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
     h->solver.opt.verbose = verbose == 1;
-    if (h->sym_unchecked) {
-        // A symmetric-lower handle analysed WITHOUT values (round 4): these are the first numbers it sees.  A weak diagonal (saddle-point /
-        // KKT matrices) sends it where initialize would have sent it with values -- mirrored to general storage, maximum-product matching,
-        // LU with pivoting inside the pivot blocks -- at the price of one more analysis, inside this call (HIPMF_COUNTER_SYM_EXPANDED
-        // tells).  Once per handle; a value map installed meanwhile speaks of the lower triangle's entries and is not carried over:
-        // such handles keep the L D L^T path.
-        h->sym_unchecked = false;
-        const char *e = getenv("HIPMF_SYM_EXPAND");
-        const Solver &sv = h->solver;
-        if ((!e || atoi(e) != 0) && sv.S.sym_lower && !h->expanded && sv.nnz_in_values() == 0 && sv.S.n > 1 &&
-            sym_lower_diagonal_is_weak(sv.S.n, sv.kept_row_pointers().data(), sv.kept_col_indices().data(), values)) {
-            const std::vector<int32_t> rp = sv.kept_row_pointers(), ci = sv.kept_col_indices();
-            const NumericOptions no = sv.opt;
-            const int32_t ndim = sv.S.n;
-            h->solver.release();
-            const int32_t c = initialize_expanded(h, ndim, rp.data(), ci.data(), values, h->so_keep, no);
-            if (c != SUCCESSFUL_EXIT) return c;
-            if (verbose == 1) printf("solver_hipmf_factorize: weak diagonal of a symmetric matrix: analysed again as a general matrix with matching\n");
-        }
+    {
+        const int32_t c = recheck_symmetric_diagonal(h, values, verbose == 1);
+        if (c != SUCCESSFUL_EXIT) return c;
     }
     int32_t code = h->solver.factorize(values, false);
     if (verbose == 1 && h->solver.n_perturbed > 0)
@@ -362,6 +381,12 @@ static int32_t factorize_mapped_device_body(struct InterfaceHIPMF *h, const doub
 static int32_t factorize_device_body(struct InterfaceHIPMF *h, const double *d_values) {
     if (!h || !d_values) return ERROR_NULL_POINTER;
     if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    if (h->sym_unchecked) { // (the same decision as solver_hipmf_factorize takes: the values come to the host once)
+        std::vector<double> hv((size_t)h->solver.S.nnz_a);
+        if (hipMemcpy(hv.data(), d_values, sizeof(double) * hv.size(), hipMemcpyDeviceToHost) != hipSuccess) return ERROR_HIP_MEMCPY;
+        const int32_t c = recheck_symmetric_diagonal(h, hv.data(), false);
+        if (c != SUCCESSFUL_EXIT) return c;
+    }
     return h->solver.factorize(d_values, true);
 }
 
@@ -703,6 +728,10 @@ int32_t hipmf_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_MEMCPY;
 }
 int32_t hipmf_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIP_SYNCHRONIZE; }
+int32_t hipmf_device_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return ERROR_NULL_POINTER;
+    return hipMemGetInfo(free_bytes, total_bytes) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIPMF_NO_DEVICE;
+}
 int32_t hipmf_set_device(int32_t device) { return hipSetDevice(device) == hipSuccess ? SUCCESSFUL_EXIT : ERROR_HIPMF_NO_DEVICE; }
 int32_t hipmf_device_copy_bandwidth(int64_t bytes, int32_t reps, double *gb_per_s) {
     if (!gb_per_s || bytes < 1 || reps < 1) return ERROR_NULL_POINTER;

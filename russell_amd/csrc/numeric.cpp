@@ -158,8 +158,16 @@ void Solver::release() {
 int32_t Solver::initialize(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, const SymbolicOptions &sopt,
                            const NumericOptions &nopt, const double *values) {
     if (initialized) return ERROR_ALREADY_INITIALIZED;
-    // any failure leaves the handle as new: nothing allocated on the device, initialize may be tried again
-    const int32_t code = initialize_impl(n, rp, ci, sym_lower, sopt, nopt, values);
+    // any failure leaves the handle as new: nothing allocated on the device, initialize may be tried again -- also when the failure
+    // is an exception of the calling thread (a host allocation in the matching or the analysis: the device set-up thread has allocated
+    // streams, events and structure arrays by then)
+    int32_t code;
+    try {
+        code = initialize_impl(n, rp, ci, sym_lower, sopt, nopt, values);
+    } catch (...) {
+        release();
+        throw; // (the C boundary turns it into ERROR_MALLOC / ERROR_HIPMF_SYMBOLIC: guarded(), interface_hipmf.cpp)
+    }
     if (code != SUCCESSFUL_EXIT) {
         const std::string keep = last_error;
         release();
@@ -239,8 +247,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
-                double limit = 0.95 * (double)free_b;
-                if (opt.device_memory_factor > 0.0) limit = std::min(limit, opt.device_memory_factor * (double)total_b);
+                // (hybrid_memory_factor -- opt.device_memory_factor -- does NOT lower this limit: in the reference the option lets LARGER
+                //  problems through by spilling the factor to host memory, interface_cudss.cu:347-380; without a host half, capping
+                //  the device share would refuse matrices the reference accepts.  ADVICE r04.)
+                const double limit = 0.95 * (double)free_b;
                 live_pool_limit.store(limit);
             }
             if (const char *e = getenv("HIPMF_POOL_LIMIT_GB")) live_pool_limit.store(0.95e9 * atof(e)); // (tests: force the refusal)
@@ -420,8 +430,9 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (rc == -40) {
         char msg[256];
         if (opt.device_memory_factor > 0.0)
-            snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (limit: %.1f GB = min(free device memory, hybrid_memory_factor %.2f x total))",
-                     S.pool_estimate_bytes / 1e9, so.pool_limit_bytes / 1e9, opt.device_memory_factor);
+            snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free; hybrid_memory_factor %.2f was given, "
+                     "but this backend has no host half: the factor must fit the device)",
+                     S.pool_estimate_bytes / 1e9, so.pool_limit_bytes / 0.95 / 1e9, opt.device_memory_factor);
         else
             snprintf(msg, sizeof msg, "Not enough memory: the fronts of this matrix need about %.1f GB (device: %.1f GB free)", S.pool_estimate_bytes / 1e9,
                      so.pool_limit_bytes / 0.95 / 1e9);

@@ -101,19 +101,31 @@ def test_set_option_before_and_after_initialize(emu_lib):
     s.close()
 
 
-def test_hybrid_memory_factor_limits_the_device_memory(emu_lib, monkeypatch):
-    # lin_sol_params.rs:39 / interface_cudss.cu:364-372: the reference turns the factor into a device memory limit (factor x total).  Here
-    # the factor + arena must fit that limit -- there is no host spill -- and a matrix that does not is refused with the out-of-memory
-    # status and the "Not enough memory" text the reference's harness looks for (stats_lin_sol.rs:334-340).
+def test_hybrid_memory_factor_is_kept_and_never_refuses_what_fits(emu_lib, monkeypatch):
+    # lin_sol_params.rs:39 / interface_cudss.cu:347-380: in the reference the option lets LARGER problems through (the factor spills to
+    # host memory).  This backend has no host half: the option is kept and has no effect on what fits (rounds 3 - 4 used
+    # factor x total as a cap and refused matrices the reference accepts).  A matrix that does not fit the DEVICE is still refused with the
+    # "Not enough memory" text the reference's harness looks for (stats_lin_sol.rs:334-340), and the message names the option.
     monkeypatch.setenv("HIPEMU_DEVICE_GB", "1")  # the emulated device: 1 GiB in total
     n, rp, ci, v = P.poisson2d(120, 110)
+    xs = P.manufactured_solution(n)
     s = Hipmf(emu_lib)
-    assert s.lib.solver_hipmf_set_option(s.h, 2, 0.01) == 0  # ~10.7 MB
+    assert s.lib.solver_hipmf_set_option(s.h, 2, 0.01) == 0  # ~10.7 MB of the device: less than this factor needs
+    assert s.initialize(n, rp, ci) == 0
+    val = C.c_double(0.0)
+    assert s.lib.solver_hipmf_get_option(s.h, 2, C.byref(val)) == 0 and val.value == 0.01
+    assert s.factorize(v) == 0
+    assert np.max(np.abs(s.solve(P.csr_matvec(n, rp, ci, v, xs)) - xs)) < 1e-10
+    s.close()
+    monkeypatch.setenv("HIPMF_POOL_LIMIT_GB", "0.001")
+    s = Hipmf(emu_lib)
+    assert s.lib.solver_hipmf_set_option(s.h, 2, 0.5) == 0
     code = s.initialize(n, rp, ci)
     assert code != 0
     msg = (s.lib.solver_hipmf_last_error(s.h) or b"").decode()
     assert "Not enough memory" in msg and "hybrid_memory_factor" in msg, msg
     s.close()
+    monkeypatch.delenv("HIPMF_POOL_LIMIT_GB")
     s = Hipmf(emu_lib)
     assert s.lib.solver_hipmf_set_option(s.h, 2, 0.99) == 0
     assert s.initialize(n, rp, ci) == 0

@@ -142,6 +142,7 @@ def test_saddle_point_without_values_at_initialize_on_the_device():
     rp, ci, v = _csr(L)
     xs = np.random.default_rng(1).standard_normal(n)
     s = Hipmf()
+    assert s.set_option("sym_recheck", 1) == 0  # (opt-in since round 5: by default the handle keeps the plan its peers hold)
     assert s.initialize(n, rp, ci, general_symmetric=True) == 0
     assert s.counter("sym_expanded") == 0 and s.counter("symmetric_ldlt") == 1
     assert s.factorize(v) == 0

@@ -164,7 +164,14 @@ def test_saddle_point_without_values_at_initialize_is_sent_to_the_general_path_b
     rp, ci, v = _csr(L)
     rng = np.random.default_rng(1)
     xs = rng.standard_normal(n)
+    # (opt-in since round 5, HIPMF_OPTION_SYM_RECHECK: by default the handle keeps the plan its peers hold -- ADVICE r04)
     s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci, general_symmetric=True) == 0
+    s.factorize(v)  # (static pivoting on a zero (2,2) block: perturbed pivots or status 1 -- what the recheck is for)
+    assert s.counter("sym_expanded") == 0 and s.counter("symmetric_ldlt") == 1
+    s.close()
+    s = Hipmf(emu_lib)
+    assert s.set_option("sym_recheck", 1) == 0
     assert s.initialize(n, rp, ci, general_symmetric=True) == 0
     assert s.counter("sym_expanded") == 0 and s.counter("symmetric_ldlt") == 1
     assert s.factorize(v, compute_determinant=True) == 0
@@ -177,10 +184,22 @@ def test_saddle_point_without_values_at_initialize_is_sent_to_the_general_path_b
     assert s.factorize(v * 1.5) == 0  # (the handle stays where it is: lower-triangle values as before)
     assert np.max(np.abs(s.solve(1.5 * (A @ xs)) - xs)) <= 1e-10 * np.max(np.abs(xs))
     s.close()
+    # the device-values entry point takes the same decision (every factorize entry point or none)
+    s = Hipmf(emu_lib)
+    assert s.set_option("sym_recheck", 1) == 0
+    assert s.initialize(n, rp, ci, general_symmetric=True) == 0
+    d_v = s.dev_alloc(v.nbytes)
+    s.h2d(d_v, v)
+    assert s.factorize_device(d_v) == 0
+    assert s.counter("sym_expanded") == 1 and s.stats()["matched"] == 1
+    assert np.max(np.abs(s.solve(A @ xs) - xs)) <= 1e-10 * np.max(np.abs(xs))
+    s.dev_free(d_v)
+    s.close()
     # a definite matrix handed over the same way keeps its L D L^T fronts
     K = sp.tril(A[:144, :144], format="csr")
     K.sort_indices()
     s = Hipmf(emu_lib)
+    assert s.set_option("sym_recheck", 1) == 0
     assert s.initialize(144, *_csr(K)[:2], general_symmetric=True) == 0
     assert s.factorize(_csr(K)[2]) == 0 and s.counter("sym_expanded") == 0 and s.counter("symmetric_ldlt") == 1
     s.close()
