@@ -79,11 +79,16 @@ struct WtHdr {                 // one batch: 16 8-byte words, fetched by 16 lane
 };
 static_assert(sizeof(WtHdr) == 128, "16 words");
 
-struct WtWave {
-    int32_t b0, b1;  // batches of the wave
-    int32_t xfirst;  // first pivot column of the subtree
-    int32_t npiv;    // its pivot columns (<= WT_X)
+struct WtWave {       // 256 bytes (two 128-byte lines), fetched in one round trip
+    WtHdr h0;         // the header of the wave's FIRST batch (a copy): the pieces of that batch are requested as soon as the record is
+                      // there -- record -> header -> pieces was one dependent round trip more at the head of every wave, and a wave-subtree
+                      // is only ~8 fronts long (5 - 6 waves take turns on every slot of the device: the round trip was paid 5 - 6 times)
+    int32_t b0, b1;   // batches of the wave
+    int32_t xfirst;   // first pivot column of the subtree
+    int32_t npiv;     // its pivot columns (<= WT_X)
+    int64_t pad[14];
 };
+static_assert(sizeof(WtWave) == 256, "two lines");
 
 // the loads of one batch: 8 pieces of factor, 2 of meta (all unconditional: the batch after this one is requested before this one
 // is computed, and the compiler can only wait for "all but the last N loads" when N does not depend on predicates)
@@ -188,8 +193,12 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restri
                                                         const int32_t *__restrict__ lperm, int *sync, double *work, double *x) {
     __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
-    const WtWave wv = waves[blockIdx.x * WT_WAVES + wave];
-    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst), npiv = wave_uniform(wv.npiv);
+    // the wave's record: lanes 0 .. 15 hold the 16 words of its first batch's header, lanes 16 / 17 its four integers
+    const long long *WV = reinterpret_cast<const long long *>(waves + (blockIdx.x * WT_WAVES + wave));
+    const long long wrec = WV[lane & 31];
+    const long long w16 = wave_bcast_i64(wrec, 16), w17 = wave_bcast_i64(wrec, 17);
+    const int b0 = wave_uniform((int)(unsigned)(unsigned long long)w16), b1 = wave_uniform((int)(unsigned)((unsigned long long)w16 >> 32));
+    const int xfirst = wave_uniform((int)(unsigned)(unsigned long long)w17), npiv = wave_uniform((int)(unsigned)((unsigned long long)w17 >> 32));
     if (b0 >= b1) return;
     HIPMF_STAMP((int)blockIdx.x / 6, 0);
     HIPMF_STAMP_VAL((int)blockIdx.x / 6, 4, b1 - b0);
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restri
     L[WT_OFF_Z + lane] = 0.0;
     int *done = sync + 16; // (SF_SYNC_HEADER of kernels_solve_fused.hpp)
     const long long *H = reinterpret_cast<const long long *>(hdrs);
-    long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
+    long long h0 = __shfl(wrec, lane & 15); // (lanes l and l + 16, ... hold word l & 15, as a header load would leave them)
     long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
     // the subtree's part of the right-hand side and of the interchanges (the vectors are allocated with room for the over-read)
     // (chunks of 128 entries of x / 256 of the interchanges; a chunk past the subtree's pivots re-reads chunk 0 -- a cache hit -- instead
@@ -321,13 +330,16 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_bwd(const WtWave *__restri
                                                         const int32_t *__restrict__ meta, const double *__restrict__ pool, double *x) {
     __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
-    const WtWave wv = waves[blockIdx.x * WT_WAVES + wave];
-    const int b0 = wave_uniform(wv.b0), b1 = wave_uniform(wv.b1), xfirst = wave_uniform(wv.xfirst), npiv = wave_uniform(wv.npiv);
+    const long long *WV = reinterpret_cast<const long long *>(waves + (blockIdx.x * WT_WAVES + wave));
+    const long long wrec = WV[lane & 31]; // (see k_wt_fwd)
+    const long long w16 = wave_bcast_i64(wrec, 16), w17 = wave_bcast_i64(wrec, 17);
+    const int b0 = wave_uniform((int)(unsigned)(unsigned long long)w16), b1 = wave_uniform((int)(unsigned)((unsigned long long)w16 >> 32));
+    const int xfirst = wave_uniform((int)(unsigned)(unsigned long long)w17), npiv = wave_uniform((int)(unsigned)((unsigned long long)w17 >> 32));
     if (b0 >= b1) return;
     double *L = lds[wave];
     L[WT_OFF_Z + lane] = 0.0;
     const long long *H = reinterpret_cast<const long long *>(hdrs);
-    long long h0 = H[16 * (int64_t)b0 + (lane & 15)];
+    long long h0 = __shfl(wrec, lane & 15);
     long long h1 = H[16 * (int64_t)(b0 + 1 < b1 ? b0 + 1 : b0) + (lane & 15)];
     f64x2 xc[WT_X / 128];
 #pragma unroll

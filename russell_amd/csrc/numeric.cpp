@@ -97,7 +97,7 @@ void Solver::release() {
     for (void *p : {(void *)d_emap, (void *)d_vlow})
         if (p) (void)hipFree(p);
     d_emap = nullptr, d_vlow = nullptr, nnz_low = 0;
-    wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false, tag_active = false, work_up = 0;
+    wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false, tag_active = false, work_up = work_arm0 = 0;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
             if (p) (void)hipFree(p);
@@ -923,8 +923,14 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             for (int32_t s = R - WP.cnt[(size_t)R] + 1; s < R; s++) interior[(size_t)s] = 1;
     std::vector<int64_t> woff_of((size_t)ns, 0);
     work_doubles = 0;
+    // (the roots of the wave-subtrees first: their vectors are written by k_wt_fwd, a launch of its own BEFORE the tagged launches
+    //  start -- nothing to arm there)
+    std::vector<char> is_root((size_t)ns, 0);
+    if (tag_plan)
+        for (int32_t R : WP.roots) is_root[(size_t)R] = 1, woff_of[(size_t)R] = work_doubles, work_doubles += S.fsize(R);
+    work_arm0 = work_doubles;
     for (int32_t s = 0; s < ns; s++)
-        if (!interior[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
+        if (!interior[(size_t)s] && !is_root[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
     work_up = work_doubles;
     if (tag_plan) {
         work_doubles += S.n; // xt
@@ -1135,6 +1141,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                         std::vector<int32_t> &meta = dir == 0 ? meta_f : meta_b;
                         std::vector<WtWave> &wav = dir == 0 ? wav_f : wav_b;
                         WtWave w;
+                        memset(&w, 0, sizeof w);
                         w.b0 = (int32_t)hdr.size(), w.xfirst = xfirst, w.npiv = S.sn_first[R + 1] - xfirst;
                         int32_t s = dir == 0 ? lo : R;
                         const int32_t send = dir == 0 ? R + 1 : lo - 1, step = dir == 0 ? 1 : -1;
@@ -1192,6 +1199,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                             s = e;
                         }
                         w.b1 = (int32_t)hdr.size();
+                        if (w.b1 > w.b0) w.h0 = hdr[(size_t)w.b0]; // (the first batch's header rides in the wave's record)
                         wav.push_back(w);
                     }
                 }
@@ -1199,7 +1207,11 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                     for (size_t ri = 0; ri < roots.size(); ri++)
                         for (int32_t s = roots[ri] - cnt[(size_t)roots[ri]] + 1; s <= roots[ri]; s++) in_w[(size_t)s] = 1, wt_recs++;
                     wt_waves = (int32_t)roots.size();
-                    while (wav_f.size() % WT_WAVES != 0) wav_f.push_back({0, 0, 0, 0}), wav_b.push_back({0, 0, 0, 0});
+                    {
+                        WtWave none;
+                        memset(&none, 0, sizeof none);
+                        while (wav_f.size() % WT_WAVES != 0) wav_f.push_back(none), wav_b.push_back(none);
+                    }
                     // one array each: forward part, then backward part (the backward headers / waves index their own parts)
                     wt_hdr_fwd = (int32_t)hdr_f.size(), wt_hdr_bwd = (int32_t)hdr_b.size(), wt_meta_fwd = (int64_t)meta_f.size();
                     hdr_f.insert(hdr_f.end(), hdr_b.begin(), hdr_b.end());
@@ -1280,6 +1292,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         }
         tree_active = tree_ok && (wt_waves > 0 || sf2_fwd_cnt > 0);
         tag_active = tree_active && tag_plan;
+        // (the backward slabs below the top levels: with the tagged hand-offs the small parked share of E' no longer pays -- 217 against
+        //  221 us per backward pass at 1000 x 1000, profiles/r05_solve_variants_c2.txt; an explicit HIPMF_UP_STAGE_MID is kept)
+        if (tag_active && !getenv("HIPMF_UP_STAGE_MID")) up_stage_mid = 0;
         if (tree_active && up_stage > 0) {
             HIPMF_ALLOW_LDS((k_fwd_fused<false, 1, true>), sizeof(double) * 256 * (size_t)up_stage);
             HIPMF_ALLOW_LDS((k_bwd_fused<false, 1, false, true>), sizeof(double) * 256 * (size_t)up_stage_bwd);
@@ -2256,7 +2271,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
         if (tree_active && nk == 1) {
             // (inside the timed pass pair: arming the tagged words is part of what a pass pair costs)
-            if (tag_active) HIPC(hipMemsetAsync(wrk, 0xFF, sizeof(double) * (size_t)(work_up + S.n), LST), ERROR_HIP_MEMCPY);
+            if (tag_active) HIPC(hipMemsetAsync(wrk + work_arm0, 0xFF, sizeof(double) * (size_t)(work_up - work_arm0 + S.n), LST), ERROR_HIP_MEMCPY);
             else if (d_rep)
                 HIPC(hipMemsetAsync(d_rep + 2 * (size_t)rep_words * (size_t)lane_id, 0, sizeof(int32_t) * 2 * (size_t)rep_words, LST), ERROR_HIP_MEMCPY);
         }
