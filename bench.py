@@ -688,6 +688,16 @@ def main():
                         "replicate": {"factorize_ms": round(t_fact_rep * 1e3, 3), "total_ms": round((t_fact_rep + t_solve) * 1e3, 3),
                                       "rhs_per_s": round(args.nrhs / (t_fact_rep + t_solve), 1)},
                         "max_relative_error_all_columns": worst, "rhs": "default_rng([20260927, column]).standard_normal(n) per column (SURVEY.md 8d)"}
+                try:
+                    # replicate or broadcast, from THIS run's numbers: re-factorising on every rank against moving the
+                    # persistent factor over one xGMI link (ring broadcast: per-link bound, 153 GB/s) after the root's factorisation
+                    pb = s.counter("persistent_bytes")
+                    many["multi_gpu_model"] = {"persistent_factor_gb": round(pb / 1e9, 3), "broadcast_ms_at_153_gbs": round(pb / 153e9 * 1e3, 2),
+                                               "replicate_ms": round(t_fact_rep * 1e3, 2),
+                                               "decision": "broadcast" if pb / 153e9 < 0.5 * t_fact_rep else "replicate",
+                                               "note": "broadcast pays when moving the factor takes less than half a factorisation (the root still factorises once)"}
+                except Exception:
+                    pass
         # (b) north_star: ONE rank factorises, the factor goes to the others over RCCL / xGMI
         if ok and dist is not None:  # (also with ONE rank under BENCH_FORCE_DIST=1: the same collectives, nranks is data)
             import torch
