@@ -861,7 +861,8 @@ def main():
                           "solve_total_last": round(st["solve_total_ms"], 3)},
             "factor": {"nnz_l": st["nnz_l"], "nnz_u": st["nnz_u"], "nsuper": st["nsuper"], "nlevels": st["nlevels"],
                        "max_front": st["max_front"], "pool_gb": round(st["pool_bytes"] / 1e9, 3),
-                       "factor_launches": st["factor_launches"], "perturbed": st["n_perturbed"]},
+                       "factor_launches": st["factor_launches"], "solve_launches": st["solve_launches"], "perturbed": st["n_perturbed"],
+                       "tagged_solve": s.counter("tagged_solve"), "wave_fronts": s.counter("wave_fronts")},
             "relative_error": rel_err,
         }
         out.update(extras)

@@ -121,12 +121,12 @@ __global__ void __launch_bounds__(256) k_zero(const ZeroTask *__restrict__ tasks
 // identity blocks of the augmented big fronts: E(i, i) = 1 and E'(i, i) = 1 (the panels are zero-filled first)
 __global__ void k_set_identity(const int32_t *__restrict__ list, const FrontDesc *__restrict__ FD, double *__restrict__ pool) {
     FrontDesc fd = FD[list[blockIdx.x]];
-    const int64_t ld = fd.ld, p = fd.p;
+    const int64_t ld = fd.ld, ps = fd.ldp;
     double *E = pool + fd.eoff;
     double *Ep = fd.epoff >= 0 ? pool + fd.epoff : nullptr;
     for (int i = threadIdx.x; i < fd.p; i += blockDim.x) {
         E[i + i * ld] = 1.0;
-        if (Ep) Ep[i + i * p] = 1.0;
+        if (Ep) Ep[i + i * ps] = 1.0;
     }
 }
 

@@ -66,10 +66,10 @@ struct FrontDesc {
     int32_t parent;
     int32_t ld;     // column stride of the f x f block at `off` and of E (>= f; small fronts: f)
     int32_t ugroup; // tiled path: 32-pivot panels per read-modify-write pass over the trailing matrix (2, 4, 8 or 16)
-    int64_t eoff;   // big fronts: offset of E (f x p, ld f); -1 for small fronts
-    int64_t epoff;  // big fronts, LU mode: offset of E' (p x f, ld p); small fronts with m > 0: packed rows of U (p x f, ld p); else -1
+    int64_t eoff;   // big fronts: offset of E (f x p, stride ld); -1 for small fronts
+    int64_t epoff;  // big fronts, LU mode: offset of E' (p x f, stride ldp); small fronts with m > 0: packed rows of U (p x f, stride p); else -1
     int32_t flags;  // FD_BIG | FD_SYM
-    int32_t pad;
+    int32_t ldp;    // column stride of E' (big fronts: >= p, a multiple of 16 above 64 pivots) / of the packed rows of U (small fronts: p)
 };
 constexpr int32_t FD_BIG = 1; // tiled path (f > SMALL_F)
 constexpr int32_t FD_SYM = 2; // big front factorised as L D L^T: only the lower triangle of F (and of its contribution block) is valid
@@ -94,17 +94,19 @@ __device__ __forceinline__ void fd_resident(const FrontDesc &fd) {
 struct AugView {
     double *F;    // (r, c), r < f, c < f          at F[r + c ld]
     double *Esh;  // (r, c), r < f, c >= f         at Esh[r + c ld]    (Esh = E - f ld)
-    double *Epsh; // (r, c), r >= f, c < f         at Epsh[r + c p]    (Epsh = E' - f)
+    double *Epsh; // (r, c), r >= f, c < f         at Epsh[r + c ps]   (Epsh = E' - f)
     int64_t ld;   // column stride of F and of E (>= f)
     int32_t f, p;
+    int32_t ps;   // column stride of E' (>= p)
     __device__ __forceinline__ double *at(int r, int c) const {
-        if (r >= f) return Epsh + r + (int64_t)c * p;
+        if (r >= f) return Epsh + r + (int64_t)c * ps;
         return (c >= f ? Esh : F) + r + (int64_t)c * ld;
     }
 };
 __device__ __forceinline__ AugView aug_view(const FrontDesc &fd, double *pool) {
     AugView v;
     v.f = fd.p + fd.m, v.p = fd.p;
+    v.ps = fd.ldp;
     v.ld = fd.ld;
     v.F = pool + fd.off;
     v.Esh = pool + fd.eoff - (int64_t)v.f * v.ld;

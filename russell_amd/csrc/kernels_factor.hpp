@@ -535,9 +535,9 @@ __device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const i
     const bool from_dws = k0 > 0 || pre_lu != 0; // the factorised diagonal tile is in dws (look-ahead of the previous step / k_diag0)
     if (ext <= 0 && (from_dws || t != 0)) return; // (workgroup 0 of step 0 still factorises and parks the diagonal tile)
     double *Lrow = A.at(o0 + tid, k0);                      // L tile: column k0 + u of this thread's row at Lrow[u * lstr]
-    const int64_t lstr = (o0 + tid) >= f ? A.p : A.ld;
+    const int64_t lstr = (o0 + tid) >= f ? A.ps : A.ld;
     const bool lmixed = o0 < f && o0 + ext > f;             // (workgroup-uniform)
-    const int64_t lstr_u = o0 >= f ? A.p : A.ld;
+    const int64_t lstr_u = o0 >= f ? A.ps : A.ld;
     // 1. prefetch the tile, no interchange yet
     // (rows >= nb of T are zero: a partial tile is treated as a full one padded with identity)
     // (all 32 loads of a thread are issued before the first LDS store: one memory round trip, not four -- the step is a latency chain;
@@ -1024,10 +1024,10 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
     const int l15 = lane & 15, l4 = lane >> 4;
     double lreg[NE], ureg[NE];
     const double *Lb = rowsE ? A.Epsh : F;             // rows of the L slice: (r, k) at Lb[r + k * lstr]
-    const int64_t lstr = rowsE ? A.p : A.ld;
+    const int64_t lstr = rowsE ? A.ps : A.ld;
     const double *Ub = colsE ? A.Esh : F;              // columns of the U slice: (k, c) at Ub[k + c * ld]
     double *Cb = rowsE ? A.Epsh : (colsE ? A.Esh : F); // the tile itself: (r, c) at Cb[r + c * cstr]
-    const int64_t cstr = rowsE ? A.p : A.ld;
+    const int64_t cstr = rowsE ? A.ps : A.ld;
     // slice h of the panels: global -> registers, registers -> LDS
 #define HIPMF_FETCH_SLICE(h)                                                                                           \
     {                                                                                                                  \

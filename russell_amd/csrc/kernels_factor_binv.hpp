@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) k_dinv0(const FrontDesc *__restrict__ LFD,
         double *Ep = pool + fd.epoff;
 #pragma unroll
         for (int k = 0; k < NB; k++)
-            if (k < nb) Ep[step + (int64_t)fd.p * wave_uniform(rk[k])] = a[k]; // inv(D)(step, rk[k]): row = pivot step, column = the row chosen at step k
+            if (k < nb) Ep[step + (int64_t)fd.ldp * wave_uniform(rk[k])] = a[k]; // inv(D)(step, rk[k]): row = pivot step, column = the row chosen at step k
         lperm[fd.first + step] = tid;
         diag[fd.first + step] = dval;
     }
@@ -183,7 +183,7 @@ __device__ __forceinline__ void bstep_body(BstepLdsT<TS> &sh, const int t, const
     const AugView A = aug_view(fd, pool);
     double *F = A.F;
     double *Ep = pool + fd.epoff; // E'(i, c) at Ep[i + c p]; inv(D) of the step at column kh is its block (kh, kh)
-    const int64_t pstr = fd.p;
+    const int64_t pstr = fd.ldp;
     if (t == ntiles) {
         // ---- look-ahead workgroup (wave 0): rows [base, base + nb2) of W, the next diagonal tile, its inverse -> E'(base, base) ----
         if (tid >= 64) return;
@@ -298,10 +298,10 @@ __device__ __forceinline__ void bstep_body(BstepLdsT<TS> &sh, const int t, const
     const int l15 = lane & 15, l4 = lane >> 4;
     double lreg[NE], ureg[NE], dvreg[ND];
     double *Lb = rowsE ? A.Epsh : F;
-    const int64_t lstr = rowsE ? A.p : A.ld;
+    const int64_t lstr = rowsE ? A.ps : A.ld;
     const double *Ub = colsE ? A.Esh : F;
     double *Cb = rowsE ? A.Epsh : (colsE ? A.Esh : F);
-    const int64_t cstr = rowsE ? A.p : A.ld;
+    const int64_t cstr = rowsE ? A.ps : A.ld;
     // slice h: the block column A(rows of the tile, kh ..) as it is (rows kh .. of E' hold inv(D) where the identity of Ir was: taken as
     // the identity), the block row A(kh .., columns of the tile), inv(D_kh)
     // (addresses: a 64-bit base that is the same for the whole workgroup -- scalar registers -- plus ONE 32-bit per-lane offset per array,
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(64) k_eflush(const int32_t *__restrict__ pfx, 
     const int nbk = (p - k0) < NB ? (p - k0) : NB;
     const int lane = threadIdx.x;
     double *Ep = pool + fd.epoff;
-    const int64_t pstr = p;
+    const int64_t pstr = fd.ldp;
     const double *Dk = Ep + k0 + (int64_t)k0 * pstr;
     const int i = i0 + lane;
     const bool rowok = i < k0;

@@ -218,9 +218,9 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
 #pragma unroll
         for (int q = 0; q < CM; q++) {
             const int c = p + wave + MID_NW * q;
-            if (c < f) Ep[step + (int64_t)c * p] = -a[q];
+            if (c < f) Ep[step + (int64_t)c * fd.ldp] = -a[q];
         }
-        for (int j = wave; j < p; j += MID_NW) Ep[step + (int64_t)j * p] = (j == step) ? 1.0 : 0.0;
+        for (int j = wave; j < p; j += MID_NW) Ep[step + (int64_t)j * fd.ldp] = (j == step) ? 1.0 : 0.0;
         if (wave == 0) {
             diag[fd.first + step] = dval;
             lperm[fd.first + step] = lane;
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__re
                 Gs[step * ldd + k] = a[k], GsT[k * ldd + step] = a[k]; // (k >= p: zeros -- the padded columns of a real row stay zero)
                 if (k < p) {
                     E[step + (int64_t)sh.rk[k] * ld] = a[k];
-                    Ep[step + (int64_t)k * p] = (k == step) ? 1.0 : 0.0;
+                    Ep[step + (int64_t)k * fd.ldp] = (k == step) ? 1.0 : 0.0;
                 }
             }
             diag[fd.first + step] = dval;
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__re
                 if (j < m) {
 #pragma unroll
                     for (int c = 0; c < MIDL_P; c++)
-                        if (c < p) Ep[c + (int64_t)(p + j) * p] = -acc[c];
+                        if (c < p) Ep[c + (int64_t)(p + j) * fd.ldp] = -acc[c];
                 }
             }
         }

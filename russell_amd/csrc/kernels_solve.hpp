@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(SLAB *G) k_bwd_big(const SolveTask *__restrict
     SolveTask tk = tasks[blockIdx.x];
     FrontDesc fd = FD[tk.s];
     const int p = fd.p, f = fd.p + fd.m;
-    const int64_t ld = p;
+    const int64_t ld = fd.ldp;
     const double *Ep = pool + fd.epoff;
     const double *W = work + fd.woff;
     const int32_t *rws = rows + fd.rowptr;

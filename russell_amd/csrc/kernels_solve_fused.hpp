@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     const FrontDesc fd = FD[t.a];
     const int p = fd.p, f = fd.p + fd.m;
     const bool sym = SYM && (fd.flags & FD_SYM) != 0; // L D L^T front: x1 = E^T [D^{-1} y1; x2]
-    const int64_t ld = p;
+    const int64_t ld = fd.ldp;
     const double *Ep = sym ? pool + fd.eoff : pool + fd.epoff;
     const double *W = work + fd.woff; // y1: written by the forward launch
     const int32_t *rws = rows + fd.rowptr;

@@ -676,7 +676,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             if (S.fsize(s) <= SMALL_F || is_mid(s)) continue; // (k_front writes every entry of its E / E')
             const int64_t f = S.fsize(s), p = S.npiv(s);
             zero_range(S.e_off[s], (int64_t)S.front_ld[s] * p);
-            if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * p);
+            if (S.ep_off[s] >= 0) zero_range(S.ep_off[s], f * (int64_t)S.front_ldp[s]);
         }
         AL.zero_cnt = (int32_t)zt.size();
         AL.zero_off.assign((size_t)S.nlevels, 0), AL.zero_n.assign((size_t)S.nlevels, 0);
@@ -953,7 +953,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         d.ugroup = update_group(S.fsize(s));
         d.eoff = S.e_off[s], d.epoff = S.ep_off[s];
         d.flags = S.fsize(s) > SMALL_F ? (FD_BIG | (S.sym_mode ? FD_SYM : 0) | (is_mid(s) ? FD_DENSE_TOP : 0)) : 0;
-        d.pad = 0;
+        d.ldp = S.front_ldp[s];
     }
     pool_doubles = S.persist_doubles + S.temp_doubles;
 

@@ -1518,18 +1518,25 @@ int analyse(int32_t n, const int32_t *rp, const int32_t *ci, bool sym_lower, con
     S.front_ld.assign((size_t)S.nsuper, 0);
     S.e_off.assign((size_t)S.nsuper, -1);
     S.ep_off.assign((size_t)S.nsuper, -1);
+    S.front_ldp.assign((size_t)S.nsuper, 0);
     const bool arena_reuse = !(getenv("HIPMF_ARENA_REUSE") && atoi(getenv("HIPMF_ARENA_REUSE")) == 0); // (debug knob: 0 = every block keeps its own storage)
     auto round16 = [](int64_t v) { return (v + 15) / 16 * 16; }; // 128-byte granules for the large blocks
     // column stride of a big front's working block and of its E panel (measured: padding the stride to f + p, to a multiple of 16 or to
     // an odd multiple of 16 changes nothing on MI355X; the kernels take any stride >= f)
-    auto ld_of = [&](int64_t f, int64_t) -> int64_t { return f; };
+    // Round 5: the strides of a big front's E (and working block) and -- above 64 pivots -- of its E' are multiples of 16 doubles: the
+    // top-level solve slabs read 8 rows (64 bytes) of every column, and with odd strides those segments straddled 128-byte lines that
+    // the neighbouring slabs (other XCDs) fetched again -- the pass moved 1.76x the stored factor (profiles/r04_sptrsv_traffic.json).
+    // Fronts with few pivots keep E' packed (stride p): their backward slabs read whole columns, i.e. the block end to end.
+    const bool align_panels = !(getenv("HIPMF_ALIGN_PANELS") && atoi(getenv("HIPMF_ALIGN_PANELS")) == 0);
+    auto ld_of = [&](int64_t f, int64_t) -> int64_t { return align_panels ? (f + 15) / 16 * 16 : f; };
     int64_t pers = 0;
     for (int32_t s = 0; s < S.nsuper; s++) {
         int64_t p = S.npiv(s), m = S.nrow(s), f = p + m;
         S.front_ld[s] = (int32_t)(f > opt.augment_above ? ld_of(f, p) : f);
+        S.front_ldp[s] = (int32_t)((f > opt.augment_above && align_panels && p > 64) ? (p + 15) / 16 * 16 : p);
         if (f > opt.augment_above) {
             S.e_off[s] = pers, pers += round16((int64_t)S.front_ld[s] * p);
-            if (!S.sym_mode) S.ep_off[s] = pers, pers += round16(p * f);
+            if (!S.sym_mode) S.ep_off[s] = pers, pers += round16((int64_t)S.front_ldp[s] * f);
         } else {
             // (both blocks start on a 128-byte line: the wave-subtree solves fetch them as flat 512-byte pieces, and a piece that
             //  straddles lines costs a fifth line -- measured as HBM fetch bytes of k_wt_fwd / k_wt_bwd; +64 bytes per front on average)

@@ -91,7 +91,8 @@ struct Symbolic {
     std::vector<int64_t> front_off;  // nsuper: offset of the f x f block (small: persistent; big: arena)
     std::vector<int32_t> front_ld;   // nsuper: its leading dimension = f
     std::vector<int64_t> e_off;      // nsuper: big fronts: E (f x p, ld f), else -1
-    std::vector<int64_t> ep_off;     // nsuper: big fronts in LU mode: E' (p x f, ld p), else -1
+    std::vector<int64_t> ep_off;     // nsuper: big fronts in LU mode: E' (p x f, stride front_ldp), else -1
+    std::vector<int32_t> front_ldp;  // nsuper: column stride of E' (big fronts: p, rounded up to 128-byte lines above 64 pivots; small fronts: p = stride of the packed rows of U)
     int64_t persist_doubles = 0, temp_doubles = 0;
     bool sym_mode = false;           // big fronts are factorised as L D L^T (lower triangle only)
     std::vector<int64_t> amap;       // nnz_a: pool offset every input entry is added to

@@ -3,7 +3,9 @@
 HBM bytes of ONE SpTRSV pass pair = sum over the solve kernels of (FETCH_SIZE x 2 + WRITE_SIZE) KB per call x calls per pass pair.
 The x 2 on FETCH_SIZE is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, checked for this code's access shapes by
 tools/microbench/fetch_calib.hip (profiles/r04_fetch_calib.txt: the counter moves 64 bytes per 128-byte line for every shape).
-usage: sptrsv_traffic.py <pmc_hbm.txt> <pass pairs per timed step> <algorithmic bytes> <physical bytes> <source label>"""
+The file is STAMPED with the factor the counters were taken on (nnz(L), nnz(U), supernodes, solve launches: the `factor` object and
+roofline of the bench line of the SAME build): bench.py refuses a traffic figure whose stamp does not match the build it is timing.
+usage: sptrsv_traffic.py <pmc_hbm.txt> <pass pairs per timed step> <algorithmic bytes> <physical bytes> <source label> [<bench.json of the same build>]"""
 import json
 import re
 import sys
@@ -36,4 +38,7 @@ out = {
     "ratio_to_physical_bytes": round(traffic / physical, 3),
     "per_kernel_kb_per_pass": {k: {c: round(v[c][1] / steps, 2) for c in v} for k, v in per.items()},
 }
+if len(sys.argv) > 6:
+    d = json.loads(open(sys.argv[6]).read().strip().split("\n")[-1])
+    out["stamp"] = {"nnz_l": d["factor"]["nnz_l"], "nnz_u": d["factor"]["nnz_u"], "nsuper": d["factor"]["nsuper"], "solve_launches": d["factor"]["solve_launches"]}
 print(json.dumps(out, indent=1))
