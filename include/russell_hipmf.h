@@ -195,6 +195,7 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 #define HIPMF_COUNTER_GATE_WAITS 11       /* solves of this handle that found the device's gate held by another handle (dependency-driven
                                              launches of two handles are never resident together) */
 #define HIPMF_COUNTER_WAVE_FRONTS 12      /* big fronts (f > 64) whose forward solve step is the work of one wavefront (at most 128 rows, 32 pivots) */
+#define HIPMF_COUNTER_LEAF_FRONTS 13      /* leaves of the tree that the blocked (many-RHS) solves run in kernels of their own, sixteen columns per wavefront */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

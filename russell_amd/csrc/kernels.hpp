@@ -11,4 +11,5 @@
 #include "kernels_solve_fused.hpp"
 #include "kernels_factor_chain.hpp"
 #include "kernels_solve_tree.hpp"
+#include "kernels_solve_leaf.hpp"
 #include "kernels_vector.hpp"

@@ -1,0 +1,242 @@
+// kernels_solve_leaf.hpp -- the LEAVES of the assembly tree in the blocked (many-RHS) triangular solves: one wavefront, sixteen columns.
+//
+// The blocked instances of kernels_solve_fused.hpp run every small front as a task of its own, one wavefront per front with lane = row and
+// the K columns of the block in a loop: per front and column p substitution steps of two v_readlane and one multiply-add, six dependent
+// memory round trips per task.  Two thirds of the fronts of a 2D mesh are LEAVES (no children: 67 000 of the 113 000 fronts of the 1M-DOF
+// Poisson matrix, ~7 pivots x ~30 rows each), and the band they sit in is half of a blocked pass pair (profiles/r03_many_rhs_kernel_stats.txt).
+// A leaf depends on nothing (forward) / on ancestors that a launch of its own finds complete (backward), so here the leaves leave the
+// task lists: a wavefront owns LEAF_PER_WAVE consecutive leaves and walks them with
+//     lane = (column c of the block, row slice rs):  c = lane & 15, rs = lane >> 4,
+// i.e. ALL sixteen columns advance with every instruction.  The front's panel is fetched flat (64 lanes x 8 bytes per piece, whatever
+// its shape) into LDS; the four row slices share the rows of the front (row i belongs to slice i mod 4), a solved pivot entry travels to
+// the other slices through a 16 x 16 block of LDS (one write, one read per pivot and lane), and every panel entry is an LDS broadcast
+// to the sixteen lanes of a slice.  (A first version solved the p x p triangle redundantly in every slice, all p values of a column in
+// registers: 256 + 60 registers, one workgroup per compute unit.)  Per column the sums run in the order of sf_fwd_small (forward: bit-identical) / in plain column
+// order (backward: equal to rounding), so a column's result does not depend on what else is in its block.
+// The forward kernel publishes a leaf like a task would (update vector in `work`, completion counter); the backward kernel runs after the
+// dependency-driven launches of the pass.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hipmf {
+
+constexpr int LEAF_KC = 16;         // columns a wavefront carries (blocks of 8 use the first nk)
+constexpr int LEAF_PMAX = 16;       // pivots of a leaf at most
+constexpr int LEAF_MMAX = 48;       // off-diagonal rows at most
+constexpr int LEAF_PANEL = 768;     // doubles of panel at most (12 flat pieces of 64)
+constexpr int LEAF_PER_WAVE = 8;    // consecutive leaves per wavefront
+constexpr int LEAF_WAVES = 4;       // wavefronts per workgroup
+
+struct LeafRec { // 48 bytes: six 8-byte words, fetched by six lanes
+    int64_t off;    // forward: pool offset of the f x f block (its first p columns = [L11; L21], stride f); backward: of the p x f rows of U (stride p)
+    int64_t woff;   // offset of the front's vector in a solve workspace
+    int64_t rowptr; // offset of its row structure (global row numbers of the m off-diagonal rows)
+    int32_t first, p;
+    int32_t m, s;   // s: front number (completion counter)
+    int64_t pad;
+};
+static_assert(sizeof(LeafRec) == 48, "six words");
+
+// LDS of one wave (doubles): [ panel | pivot block 16 x 17 | zero | reciprocals 16 | ints | t 16 x 16 (backward) | update block 48 x 16 (backward) ]
+constexpr int LEAF_OFF_XB = LEAF_PANEL, LEAF_XB_LD = 17, LEAF_OFF_Z = LEAF_OFF_XB + 16 * LEAF_XB_LD, LEAF_OFF_INV = LEAF_OFF_Z + 2;
+constexpr int LEAF_OFF_I = LEAF_OFF_INV + 16, LEAF_OFF_T = LEAF_OFF_I + 32, LEAF_OFF_X2 = LEAF_OFF_T + 16 * 16, LEAF_LDS = LEAF_OFF_X2 + LEAF_MMAX * 16;
+constexpr int LEAF_LDS_FWD = LEAF_OFF_X2; // the forward kernel has no update block: 10.8 KB per wave (backward: 16.9 KB)
+
+__device__ __forceinline__ void leaf_rec(const LeafRec *__restrict__ recs, int i, int lane, int64_t &off, int64_t &woff, int64_t &rowptr, int &first, int &p,
+                                         int &m, int &s) {
+    const long long w = reinterpret_cast<const long long *>(recs + i)[lane < 6 ? lane : 0];
+    off = wave_bcast_i64(w, 0), woff = wave_bcast_i64(w, 1), rowptr = wave_bcast_i64(w, 2);
+    const long long fp = wave_bcast_i64(w, 3), ms = wave_bcast_i64(w, 4);
+    first = (int)(unsigned)(unsigned long long)fp, p = (int)(unsigned)((unsigned long long)fp >> 32);
+    m = (int)(unsigned)(unsigned long long)ms, s = (int)(unsigned)((unsigned long long)ms >> 32);
+}
+
+// forward: y = L11^{-1} (P b1), u = -L21 y.  Lane (c, rs) holds rows rs, rs + 4, rs + 8, rs + 12 of the pivot block for column c.
+__device__ __forceinline__ void leaf_fwd_body(double *L, int lane, int f, int p, int first, int64_t woff, double *xp, int64_t xstr, double *work,
+                                              int64_t wstr, int nk) {
+    const int c = lane & 15, rs = lane >> 4;
+    const double *Xb = L + LEAF_OFF_XB;
+    double *Yb = L + LEAF_OFF_T;
+    const int32_t *LPi = reinterpret_cast<const int32_t *>(L + LEAF_OFF_I);
+    double y[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = rs + 4 * q;
+        y[q] = (i < p) ? Xb[LPi[i] * LEAF_XB_LD + c] : 0.0; // (row interchanges inside the pivot block)
+    }
+#pragma unroll
+    for (int jq = 0; jq < 4; jq++) {
+        if (4 * jq < p) { // (wave-uniform)
+#pragma unroll
+            for (int js = 0; js < 4; js++) {
+                const int j = 4 * jq + js;
+                if (rs == js) Yb[j * 16 + c] = y[jq]; // y_j is final: steps 0 .. j - 1 have been applied to it
+                wave_sync();
+                const double yj = Yb[j * 16 + c];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = rs + 4 * q;
+                    const double a = L[(i > j && i < p && j < p) ? i + j * f : LEAF_OFF_Z]; // (zero: row i is not below pivot j of this front)
+                    y[q] -= a * yj;
+                }
+            }
+        }
+    }
+    const bool live = c < nk;
+    double *xc = xp + (int64_t)(live ? c : 0) * xstr + first;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (live && rs + 4 * q < p) st_agent(xc + rs + 4 * q, y[q]);
+    double *wc = work + (int64_t)(live ? c : 0) * wstr + woff;
+#pragma unroll 1
+    for (int r = p + rs; r < f; r += 4) { // the lane's off-diagonal rows: u_r = 0 - sum_j l_rj y_j, j ascending (sf_fwd_small's order)
+        double u = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < p; j++) u -= L[r + j * f] * Yb[j * 16 + c];
+        if (live) st_agent(wc + r, u);
+    }
+}
+
+__global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_fwd(const LeafRec *__restrict__ recs, int nleaf, const double *__restrict__ pool,
+                                                              const int32_t *__restrict__ lperm, double *xp, int64_t xstr, double *work, int64_t wstr,
+                                                              int *sync, int nk) {
+    __shared__ __attribute__((aligned(16))) double lds[LEAF_WAVES][LEAF_LDS_FWD];
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    double *L = lds[wave];
+    int *done = sync + 16; // (SF_SYNC_HEADER of kernels_solve_fused.hpp)
+    const int i0 = (blockIdx.x * LEAF_WAVES + wave) * LEAF_PER_WAVE;
+    if (i0 >= nleaf) return;
+    const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;
+    const int c = lane & 15, rs = lane >> 4;
+    L[LEAF_OFF_Z + (lane & 1)] = 0.0;
+#pragma unroll 1
+    for (int i = i0; i < i1; i++) {
+        int64_t off, woff, rowptr;
+        int first, p, m, s;
+        leaf_rec(recs, i, lane, off, woff, rowptr, first, p, m, s);
+        const int f = p + m, np = (f * p + 63) >> 6;
+        // everything the leaf needs, requested at once: the panel as flat pieces, the pivot rows of the block, the interchanges
+        double pc[LEAF_PANEL / 64];
+        const double *src = pool + off;
+#pragma unroll
+        for (int q = 0; q < LEAF_PANEL / 64; q++) pc[q] = src[(q < np ? 64 * q : 0) + lane];
+        double xb[4];
+        const double *xc = xp + (int64_t)(c < nk ? c : 0) * xstr + first;
+#pragma unroll
+        for (int q = 0; q < 4; q++) xb[q] = xc[rs + 4 * q < p ? rs + 4 * q : 0];
+        const int lp = lperm[first + (lane < p ? lane : 0)];
+        wave_sync(); // (the previous leaf's LDS reads are over)
+#pragma unroll
+        for (int q = 0; q < LEAF_PANEL / 64; q++)
+            if (q < np) L[64 * q + lane] = pc[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (rs + 4 * q < p) L[LEAF_OFF_XB + (rs + 4 * q) * LEAF_XB_LD + c] = xb[q];
+        if (lane < p) reinterpret_cast<int32_t *>(L + LEAF_OFF_I)[lane] = lp;
+        wave_sync();
+        leaf_fwd_body(L, lane, f, p, first, woff, xp, xstr, work, wstr, nk);
+        // the leaf's parent is a task of a later launch on the same stream; the counter is what that task looks at
+        drain_stores();
+        if (lane == 0) flag_add(done + s, 1);
+        (void)rowptr;
+    }
+}
+
+// backward: x1 = U11^{-1} (y1 - U12 x2); rows of U as a p x f block with stride p.  Lane (c, rs) holds pivot rows rs, rs + 4, ... of column c.
+__device__ __forceinline__ void leaf_bwd_body(double *L, int lane, int p, int m, int first, double *xp, int64_t xstr, int nk) {
+    const int c = lane & 15, rs = lane >> 4;
+    const double *Xb = L + LEAF_OFF_XB, *X2 = L + LEAF_OFF_X2, *INV = L + LEAF_OFF_INV;
+    double *Yb = L + LEAF_OFF_T;
+    double v[4];
+    // t_i = y1_i - sum_j u_i(p + j) x2_j for the lane's pivot rows
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = rs + 4 * q;
+        double acc = 0.0;
+        if (i < p) { // (uniform over the sixteen lanes of a row slice)
+            const double *Ui = L + i + p * p;
+#pragma unroll 4
+            for (int j = 0; j < m; j++) acc += Ui[j * p] * X2[j * 16 + c];
+        }
+        v[q] = (i < p) ? Xb[i * LEAF_XB_LD + c] - acc : 0.0;
+    }
+    // columns from right to left: x_j = t_j / u_jj, t_i -= u_ij x_j for i < j
+#pragma unroll
+    for (int jq = 3; jq >= 0; jq--) {
+        if (4 * jq < p) { // (wave-uniform)
+#pragma unroll
+            for (int js = 3; js >= 0; js--) {
+                const int j = 4 * jq + js;
+                if (rs == js) {
+                    v[jq] *= (j < p) ? INV[j] : 0.0;
+                    Yb[j * 16 + c] = v[jq];
+                }
+                wave_sync();
+                const double xj = Yb[j * 16 + c];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = rs + 4 * q;
+                    const double a = L[(i < j && j < p) ? i + j * p : LEAF_OFF_Z];
+                    v[q] -= a * xj;
+                }
+            }
+        }
+    }
+    const bool live = c < nk;
+    double *xc = xp + (int64_t)(live ? c : 0) * xstr + first;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (live && rs + 4 * q < p) xc[rs + 4 * q] = v[q];
+}
+
+__global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_bwd(const LeafRec *__restrict__ recs, int nleaf, const double *__restrict__ pool,
+                                                              const int32_t *__restrict__ rows, double *xp, int64_t xstr, int nk) {
+    __shared__ __attribute__((aligned(16))) double lds[LEAF_WAVES][LEAF_LDS];
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    double *L = lds[wave];
+    const int i0 = (blockIdx.x * LEAF_WAVES + wave) * LEAF_PER_WAVE;
+    if (i0 >= nleaf) return;
+    const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;
+    const int c = lane & 15, rs = lane >> 4;
+    L[LEAF_OFF_Z + (lane & 1)] = 0.0;
+#pragma unroll 1
+    for (int i = i0; i < i1; i++) {
+        int64_t off, woff, rowptr;
+        int first, p, m, s;
+        leaf_rec(recs, i, lane, off, woff, rowptr, first, p, m, s);
+        const int f = p + m, np = (f * p + 63) >> 6;
+        double pc[LEAF_PANEL / 64];
+        const double *src = pool + off;
+#pragma unroll
+        for (int q = 0; q < LEAF_PANEL / 64; q++) pc[q] = src[(q < np ? 64 * q : 0) + lane];
+        const double *xcol = xp + (int64_t)(c < nk ? c : 0) * xstr;
+        double xb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) xb[q] = xcol[first + (rs + 4 * q < p ? rs + 4 * q : 0)];
+        // x2: the solved entries of the ancestors, by global row number (every ancestor is complete: earlier launches of the pass)
+        const int32_t *rw = rows + rowptr;
+        double x2[LEAF_MMAX / 4];
+#pragma unroll
+        for (int q = 0; q < LEAF_MMAX / 4; q++) {
+            const int r = rs + 4 * q;
+            x2[q] = xcol[rw[r < m ? r : 0]];
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < LEAF_PANEL / 64; q++)
+            if (q < np) L[64 * q + lane] = pc[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (rs + 4 * q < p) L[LEAF_OFF_XB + (rs + 4 * q) * LEAF_XB_LD + c] = xb[q];
+#pragma unroll
+        for (int q = 0; q < LEAF_MMAX / 4; q++)
+            if (rs + 4 * q < m) L[LEAF_OFF_X2 + (rs + 4 * q) * 16 + c] = x2[q];
+        wave_sync();
+        if (lane < p) L[LEAF_OFF_INV + lane] = 1.0 / L[lane + lane * p];
+        wave_sync();
+        leaf_bwd_body(L, lane, p, m, first, xp, xstr, nk);
+        (void)woff, (void)s;
+    }
+}
+
+} // namespace hipmf

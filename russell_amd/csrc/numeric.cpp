@@ -88,8 +88,9 @@ void Solver::release() {
     if (d_chain_cnt) (void)hipFree(d_chain_cnt);
     d_chain = nullptr, d_chain_cnt = nullptr, chain_words = 0;
     for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep, (void *)d_sf3,
-                    (void *)d_need3, (void *)d_sfk, (void *)d_needk})
+                    (void *)d_need3, (void *)d_sfk, (void *)d_needk, (void *)d_leaf})
         if (p) (void)hipFree(p);
+    d_leaf = nullptr, leaf_cnt = 0;
     d_wt_hdr = nullptr, d_wt_meta = nullptr, d_wt_wave = nullptr, d_sf2 = nullptr, d_need2 = nullptr, d_rep_idx = nullptr, d_rep = nullptr;
     rep_words = 0;
     d_sf3 = nullptr, d_need3 = nullptr;
@@ -360,6 +361,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SMALL_PAIR")) small_pair = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TAG_SOLVE")) use_tag = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_LEAF_KERNELS")) leaf_kernels = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
@@ -996,11 +998,17 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             }
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
         };
+        bool skip_leaves = false;              // ... the one of the blocked instances when the leaves have kernels of their own
+        auto is_leaf_front = [&](int32_t s) {
+            const int64_t p = S.npiv(s), m = S.nrow(s), f = p + m;
+            return S.child_ptr[s + 1] == S.child_ptr[s] && f <= SMALL_F && p >= 1 && p <= LEAF_PMAX && m <= LEAF_MMAX && f * p <= LEAF_PANEL;
+        };
         auto emit_level = [&](int32_t l, bool forward) {
             std::vector<int32_t> small, wavef;
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                 int32_t s = S.level_sn[k];
                 if (tree && in_w[(size_t)s]) continue;
+                if (skip_leaves && is_leaf_front(s)) continue;
                 if (S.fsize(s) <= SMALL_F) {
                     small.push_back(s);
                     continue;
@@ -1077,13 +1085,34 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         }
         if (band == 0) sf_bwd_top = (int32_t)sf.size() - sf_fwd_cnt;
         sf_bwd_cnt = (int32_t)sf.size() - sf_fwd_cnt;
-        if (blocked_slabs) {
-            // the same levels once more with the slab shapes of the blocked instances (the small fronts' tasks are the same)
+        leaf_cnt = 0;
+        if (leaf_kernels && use_fused) {
+            std::vector<LeafRec> lf, lb;
+            for (int32_t s = 0; s < ns; s++) {
+                if (!is_leaf_front(s)) continue;
+                LeafRec r;
+                memset(&r, 0, sizeof r);
+                r.off = fd[(size_t)s].off, r.woff = fd[(size_t)s].woff, r.rowptr = fd[(size_t)s].rowptr;
+                r.first = fd[(size_t)s].first, r.p = fd[(size_t)s].p, r.m = fd[(size_t)s].m, r.s = s;
+                lf.push_back(r);
+                r.off = fd[(size_t)s].epoff >= 0 ? fd[(size_t)s].epoff : fd[(size_t)s].off; // (the rows of U: p x f, stride p; m = 0: the block itself)
+                lb.push_back(r);
+            }
+            leaf_cnt = (int32_t)lf.size();
+            if (leaf_cnt > 0) {
+                lf.insert(lf.end(), lb.begin(), lb.end());
+                HIPC(dev_upload(&d_leaf, lf), ERROR_HIP_MALLOC);
+            }
+        }
+        if (blocked_slabs || leaf_cnt > 0) {
+            // the same levels once more for the blocked instances: without the leaves (kernels_solve_leaf.hpp) and -- HIPMF_BLOCKED_SLABS=1 --
+            // with wider slabs (the other small fronts' tasks are the same)
             std::vector<SfTask> keep;
             keep.swap(sf);
             std::vector<int32_t> need_keep = need;
             std::fill(need.begin(), need.end(), 1);
-            blocked = true;
+            blocked = blocked_slabs;
+            skip_leaves = leaf_cnt > 0;
             sfk_fwd_band = 0;
             for (int32_t l = 0; l < S.nlevels; l++) {
                 emit_level(l, true);
@@ -1098,6 +1127,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             if (band == 0) sfk_bwd_top = (int32_t)sf.size() - sfk_fwd_cnt;
             sfk_bwd_cnt = (int32_t)sf.size() - sfk_fwd_cnt;
             blocked = false;
+            skip_leaves = false;
             HIPC(dev_upload(&d_sfk, sf), ERROR_HIP_MALLOC);
             HIPC(dev_upload(&d_needk, need), ERROR_HIP_MALLOC);
             sf.swap(keep);
@@ -2342,7 +2372,11 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             if (timed) tri_pending = true;
             return SUCCESSFUL_EXIT;
         }
-        const bool use_k = nk > 1 && d_sfk != nullptr; // the blocked instances have their own slab shapes
+        const bool use_k = nk > 1 && d_sfk != nullptr; // the blocked instances have their own task list (no leaves; optionally wider slabs)
+        const bool leaves = use_k && leaf_cnt > 0;
+        const int32_t leaf_wgs = (leaf_cnt + LEAF_WAVES * LEAF_PER_WAVE - 1) / (LEAF_WAVES * LEAF_PER_WAVE);
+        if (leaves) // the leaves first: nothing in them waits for anything (their parents are tasks of the launches below)
+            hipLaunchKernelGGL(k_leaf_fwd, dim3(leaf_wgs), dim3(64 * LEAF_WAVES), 0, LST, d_leaf, leaf_cnt, d_pool, d_lperm, xp, xstr, wrk, wstr, sync_f, nk);
         const SfTask *T = use_k ? d_sfk : d_sf;
         const int32_t *NEED = use_k ? d_needk : d_need;
         const int32_t t_fwd = use_k ? sfk_fwd_cnt : sf_fwd_cnt;
@@ -2384,8 +2418,10 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
 #undef HIPMF_FWD
 #undef HIPMF_BWD
 #undef HIPMF_BWD1
+        if (leaves) // ... and last: every ancestor of a leaf is complete
+            hipLaunchKernelGGL(k_leaf_bwd, dim3(leaf_wgs), dim3(64 * LEAF_WAVES), 0, LST, d_leaf + leaf_cnt, leaf_cnt, d_pool, d_rows, xp, xstr, nk);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[5], LST), ERROR_HIP_SYNCHRONIZE);
-        times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0);
+        times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0) + 2 * (leaves ? 1 : 0);
         if (timed) tri_pending = true;
         return SUCCESSFUL_EXIT;
     }

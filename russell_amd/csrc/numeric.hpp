@@ -18,6 +18,7 @@ struct SolveTask;
 struct SfTask;
 struct WtHdr;
 struct WtWave;
+struct LeafRec;
 struct ZeroTask;
 struct FactorInfo;
 
@@ -161,6 +162,7 @@ class Solver {
     int64_t wave_front_count = 0; // big fronts that are wave-front tasks in the forward pass of this plan (sf_fwd_wave)
     int64_t gate_waits = 0;      // solves that waited for another handle's solve on the same device (device_gate, numeric.cpp)
     bool tagged_solve() const { return tag_active && use_fused; }
+    int64_t leaf_front_count() const { return use_fused ? leaf_cnt : 0; }
     int64_t chain_fallbacks = 0; // factorisations repeated with one launch per tiled step after a hand-off timeout of a chained launch (never expected)
     int64_t persist_bytes() const { return S.persist_doubles * 8; }
     double last_residual_inf = 0.0, last_omega = 0.0;
@@ -213,6 +215,11 @@ class Solver {
     // 64 / 128-row slabs re-read the vector block of a front less often, but lose more in parallelism -- 144^3, 64 right-hand sides:
     // 4.92 -> 7.06 ms per right-hand side; 200^3, 256 right-hand sides: 4.58 -> 6.86 s (profiles/r03_rejected_experiments.txt)
     bool blocked_slabs = false;
+    // round 5: the leaves of the tree leave the task lists of the blocked (many-RHS) solves: one wavefront carries sixteen columns through
+    // LEAF_PER_WAVE leaves (kernels_solve_leaf.hpp).  HIPMF_LEAF_KERNELS=0: every small front stays a task.
+    bool leaf_kernels = true;
+    LeafRec *d_leaf = nullptr;   // records of the leaves: forward part, then backward part (other panel offsets)
+    int32_t leaf_cnt = 0;
     SfTask *d_sfk = nullptr;
     int32_t *d_needk = nullptr;
     int32_t sfk_fwd_cnt = 0, sfk_bwd_cnt = 0, sfk_fwd_band = 0, sfk_bwd_top = 0;

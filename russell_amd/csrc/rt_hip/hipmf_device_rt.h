@@ -28,6 +28,9 @@ __device__ __forceinline__ i32x4 ld_i32x4(const int *p) {
 __device__ __forceinline__ void st_lds_f64x2(double *p, f64x2 v) { *(f64x2 *)p = v; }
 __device__ __forceinline__ void st_lds_i32x4(int *p, i32x4 v) { *(i32x4 *)p = v; }
 
+// nothing is scheduled across this point (keeps the loads of an unrolled loop's later iterations from being hoisted above the earlier
+// ones: register pressure)
+#define HIPMF_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // the value is needed (in a scalar register) at this point of the program: its load cannot sink below
 #define HIPMF_KEEP_SCALAR(x) asm volatile("" ::"s"(x))
 #define HIPMF_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]

@@ -181,6 +181,43 @@ def test_blocked_many_rhs_instances_agree_with_single_solves(emu_lib, grid, nrhs
     s.close()
 
 
+@pytest.mark.parametrize("nrhs", [3, 16, 21])
+def test_leaf_kernels_of_the_blocked_solves_agree_with_the_task_form(emu_lib, nrhs, monkeypatch):
+    # round 5: in the blocked (many-RHS) solves the leaves of the tree run in kernels of their own, one wavefront carrying sixteen columns
+    # through eight leaves (kernels_solve_leaf.hpp); the other fronts stay tasks.  Forward: the sums of sf_fwd_small; backward: plain
+    # column order -- equal to rounding, every column independent of what shares its block.
+    for n, rp, ci, v, kw in ((*P.poisson2d(60, 50), {}), (*P.convection_diffusion2d(40, peclet=30.0, scale_decades=0.0), {}), (*P.poisson3d(10), {}),
+                             (*_lower(P.poisson2d(48, 44)), {"general_symmetric": True})):
+        rng = np.random.default_rng(nrhs)
+        XS = rng.standard_normal((nrhs, n))
+        if kw:
+            full = P.poisson2d(48, 44)
+            B = np.array([P.csr_matvec(full[0], full[1], full[2], full[3], XS[j]) for j in range(nrhs)])
+        else:
+            B = np.array([P.csr_matvec(n, rp, ci, v, XS[j]) for j in range(nrhs)])
+        got = {}
+        for leaf in ("1", "0"):
+            monkeypatch.setenv("HIPMF_LEAF_KERNELS", leaf)
+            s = Hipmf(emu_lib)
+            assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+            assert s.factorize(v) == 0
+            got[leaf] = (s.solve_many(B), s.counter("leaf_fronts"), s.counter("fused_fallbacks"))
+            if leaf == "1":  # a column's result does not depend on what shares its block
+                alone = s.solve_many(B[:2])
+                assert np.array_equal(alone[1], got[leaf][0][1])
+            s.close()
+        monkeypatch.delenv("HIPMF_LEAF_KERNELS")
+        assert got["1"][1] > 0 and got["0"][1] == 0 and got["1"][2] == 0
+        assert np.max(np.abs(got["1"][0] - got["0"][0])) <= 1e-12 * np.max(np.abs(got["0"][0]))
+        assert np.max(np.abs(got["1"][0] - XS)) <= 1e-11 * np.max(np.abs(XS))
+
+
+def _lower(mat):
+    n, rp, ci, v = mat
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    return n, lrp, lci, lv
+
+
 GOLDEN_ORDERING = {
     # grid: (sha256 of the int32 permutation, first 16 hex digits; nnz(L); nnz(U); supernodes; levels; largest front)
     (48, 40): ("29d941a96643a52a", 43832, 45752, 205, 9, 67),

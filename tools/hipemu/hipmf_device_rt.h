@@ -37,6 +37,7 @@ inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
     return c;
 }
 
+#define HIPMF_SCHED_BARRIER() ((void)0)
 #define HIPMF_KEEP_SCALAR(x) ((void)(x))
 #define HIPMF_ALLOW_LDS(kernel, bytes) ((void)0)
 #define HIPMF_DYN_SHARED(T, name) T *name = (T *)(((uintptr_t)hipemu::g_dynshared.data() + 15) & ~(uintptr_t)15)
