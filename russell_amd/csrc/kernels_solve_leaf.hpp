@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_fwd(const LeafRec *__r
     __shared__ __attribute__((aligned(16))) double lds[LEAF_WAVES][LEAF_LDS_FWD];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     double *L = lds[wave];
-    int *done = sync + 16; // (SF_SYNC_HEADER of kernels_solve_fused.hpp)
+    (void)sync;
     const int i0 = (blockIdx.x * LEAF_WAVES + wave) * LEAF_PER_WAVE;
     if (i0 >= nleaf) return;
     const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;
@@ -135,10 +135,9 @@ __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_fwd(const LeafRec *__r
         if (lane < p) reinterpret_cast<int32_t *>(L + LEAF_OFF_I)[lane] = lp;
         wave_sync();
         leaf_fwd_body(L, lane, f, p, first, woff, xp, xstr, work, wstr, nk);
-        // the leaf's parent is a task of a later launch on the same stream; the counter is what that task looks at
-        drain_stores();
-        if (lane == 0) flag_add(done + s, 1);
-        (void)rowptr;
+        // (the leaf's parent is a task of a LATER launch on the same stream: it finds the update vector complete, and the task list of
+        //  the blocked instances expects no completion count from a leaf -- no drain, no counter)
+        (void)rowptr, (void)s;
     }
 }
 

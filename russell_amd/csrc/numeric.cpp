@@ -1008,7 +1008,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                 int32_t s = S.level_sn[k];
                 if (tree && in_w[(size_t)s]) continue;
-                if (skip_leaves && is_leaf_front(s)) continue;
+                if (skip_leaves && is_leaf_front(s)) {
+                    need[(size_t)(forward ? 0 : ns) + s] = 0; // (done by a launch of its own before / after the tasks': nobody counts it)
+                    continue;
+                }
                 if (S.fsize(s) <= SMALL_F) {
                     small.push_back(s);
                     continue;

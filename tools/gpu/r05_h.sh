@@ -1,0 +1,9 @@
+# round 5: kernel stats of blocked solves (64 right-hand sides at C2, refinement off)
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_many
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_many -o run -- python $GRAFT_REPO_ROOT/tools/many_rhs.py 2d 1000 64 0 > /tmp/prof_many.log 2>&1
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05h
+python tools/rocpd_summary.py $(find /tmp/prof_many -name '*.db' | head -1) > gpurun_out/r05h/many_rhs_kernel_stats.txt 2>&1
+head -16 gpurun_out/r05h/many_rhs_kernel_stats.txt
+tail -2 /tmp/prof_many.log
