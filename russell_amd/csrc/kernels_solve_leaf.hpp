@@ -42,6 +42,11 @@ constexpr int LEAF_OFF_XB = LEAF_PANEL, LEAF_XB_LD = 17, LEAF_OFF_Z = LEAF_OFF_X
 constexpr int LEAF_OFF_I = LEAF_OFF_INV + 16, LEAF_OFF_T = LEAF_OFF_I + 32, LEAF_OFF_X2 = LEAF_OFF_T + 16 * 16, LEAF_LDS = LEAF_OFF_X2 + LEAF_MMAX * 16;
 constexpr int LEAF_LDS_FWD = LEAF_OFF_X2; // the forward kernel has no update block: 10.8 KB per wave (backward: 16.9 KB)
 
+// entry (row r, column c) of the block of vectors (column-major, column stride xstr).  A row-major block -- the sixteen columns of a row in
+// one 128-byte line, for the gathers of the backward pass -- was measured and lost: with lane = row elsewhere in the blocked kernels every
+// load / store instruction then touches 64 lines instead of 4 (0.304 against 0.272 ms per right-hand side, profiles/r05_rejected_experiments.txt)
+__device__ __forceinline__ int64_t leaf_x(int64_t xstr, int64_t r, int c) { return (int64_t)c * xstr + r; }
+
 __device__ __forceinline__ void leaf_rec(const LeafRec *__restrict__ recs, int i, int lane, int64_t &off, int64_t &woff, int64_t &rowptr, int &first, int &p,
                                          int &m, int &s) {
     const long long w = reinterpret_cast<const long long *>(recs + i)[lane < 6 ? lane : 0];
@@ -83,20 +88,57 @@ __device__ __forceinline__ void leaf_fwd_body(double *L, int lane, int f, int p,
         }
     }
     const bool live = c < nk;
-    double *xc = xp + (int64_t)(live ? c : 0) * xstr + first;
+    // (plain stores: whoever reads these entries is a task of a LATER launch)
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        if (live && rs + 4 * q < p) st_agent(xc + rs + 4 * q, y[q]);
+        if (live && rs + 4 * q < p) xp[leaf_x(xstr, first + rs + 4 * q, c)] = y[q];
     double *wc = work + (int64_t)(live ? c : 0) * wstr + woff;
 #pragma unroll 1
     for (int r = p + rs; r < f; r += 4) { // the lane's off-diagonal rows: u_r = 0 - sum_j l_rj y_j, j ascending (sf_fwd_small's order)
         double u = 0.0;
 #pragma unroll 4
         for (int j = 0; j < p; j++) u -= L[r + j * f] * Yb[j * 16 + c];
-        if (live) st_agent(wc + r, u);
+        if (live) wc[r] = u;
     }
 }
 
+// What a wavefront fetches for one leaf (everything requested at once; clamped addresses: unconditional loads)
+struct LeafLoads {
+    double pc[LEAF_PANEL / 64]; // the panel as flat pieces of 64 doubles
+    double xb[4];               // rows rs, rs + 4, ... of the pivot block of column c
+    int32_t lp;                 // forward: the interchange of pivot row `lane`
+};
+struct LeafInfo {
+    int64_t off, woff, rowptr;
+    int first, p, m, s;
+};
+__device__ __forceinline__ void leaf_issue(LeafLoads &D, const LeafInfo &R, int lane, const double *__restrict__ pool, const int32_t *__restrict__ lperm,
+                                           const double *xp, int64_t xstr, int nk) {
+    const int c = lane & 15, rs = lane >> 4;
+    const int np = ((R.p + R.m) * R.p + 63) >> 6;
+    const double *src = pool + R.off;
+#pragma unroll
+    for (int q = 0; q < LEAF_PANEL / 64; q++) D.pc[q] = src[(q < np ? 64 * q : 0) + lane];
+    const int cc = c < nk ? c : 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) D.xb[q] = xp[leaf_x(xstr, R.first + (rs + 4 * q < R.p ? rs + 4 * q : 0), cc)];
+    D.lp = lperm ? lperm[R.first + (lane < R.p ? lane : 0)] : 0;
+}
+__device__ __forceinline__ void leaf_park(double *L, const LeafLoads &D, const LeafInfo &R, int lane) {
+    const int c = lane & 15, rs = lane >> 4;
+    const int np = ((R.p + R.m) * R.p + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < LEAF_PANEL / 64; q++)
+        if (q < np) L[64 * q + lane] = D.pc[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (rs + 4 * q < R.p) L[LEAF_OFF_XB + (rs + 4 * q) * LEAF_XB_LD + c] = D.xb[q];
+    if (lane < R.p) reinterpret_cast<int32_t *>(L + LEAF_OFF_I)[lane] = D.lp;
+}
+
+// The leaves of a wavefront as a software pipeline: while leaf i is computed out of LDS, the record of leaf i + 1 has arrived and its
+// panel, pivot block and interchanges are in flight in registers (a leaf is a chain record -> loads -> LDS -> substitution -> stores of
+// ~9 us end to end, of which the substitution is a third: unpipelined, the kernel was bound by that chain, profiles/r05_rejected_experiments.txt).
 __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_fwd(const LeafRec *__restrict__ recs, int nleaf, const double *__restrict__ pool,
                                                               const int32_t *__restrict__ lperm, double *xp, int64_t xstr, double *work, int64_t wstr,
                                                               int *sync, int nk) {
@@ -107,37 +149,24 @@ __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_fwd(const LeafRec *__r
     const int i0 = (blockIdx.x * LEAF_WAVES + wave) * LEAF_PER_WAVE;
     if (i0 >= nleaf) return;
     const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;
-    const int c = lane & 15, rs = lane >> 4;
     L[LEAF_OFF_Z + (lane & 1)] = 0.0;
+    LeafInfo R, Rn;
+    LeafLoads D, Dn;
+    leaf_rec(recs, i0, lane, R.off, R.woff, R.rowptr, R.first, R.p, R.m, R.s);
+    leaf_issue(D, R, lane, pool, lperm, xp, xstr, nk);
 #pragma unroll 1
     for (int i = i0; i < i1; i++) {
-        int64_t off, woff, rowptr;
-        int first, p, m, s;
-        leaf_rec(recs, i, lane, off, woff, rowptr, first, p, m, s);
-        const int f = p + m, np = (f * p + 63) >> 6;
-        // everything the leaf needs, requested at once: the panel as flat pieces, the pivot rows of the block, the interchanges
-        double pc[LEAF_PANEL / 64];
-        const double *src = pool + off;
-#pragma unroll
-        for (int q = 0; q < LEAF_PANEL / 64; q++) pc[q] = src[(q < np ? 64 * q : 0) + lane];
-        double xb[4];
-        const double *xc = xp + (int64_t)(c < nk ? c : 0) * xstr + first;
-#pragma unroll
-        for (int q = 0; q < 4; q++) xb[q] = xc[rs + 4 * q < p ? rs + 4 * q : 0];
-        const int lp = lperm[first + (lane < p ? lane : 0)];
+        const int in = i + 1 < i1 ? i + 1 : i; // (the last leaf fetches itself once more: unconditional loads, results dropped)
+        leaf_rec(recs, in, lane, Rn.off, Rn.woff, Rn.rowptr, Rn.first, Rn.p, Rn.m, Rn.s);
         wave_sync(); // (the previous leaf's LDS reads are over)
-#pragma unroll
-        for (int q = 0; q < LEAF_PANEL / 64; q++)
-            if (q < np) L[64 * q + lane] = pc[q];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (rs + 4 * q < p) L[LEAF_OFF_XB + (rs + 4 * q) * LEAF_XB_LD + c] = xb[q];
-        if (lane < p) reinterpret_cast<int32_t *>(L + LEAF_OFF_I)[lane] = lp;
+        leaf_park(L, D, R, lane);
+        leaf_issue(Dn, Rn, lane, pool, lperm, xp, xstr, nk); // in flight while this leaf is computed
         wave_sync();
-        leaf_fwd_body(L, lane, f, p, first, woff, xp, xstr, work, wstr, nk);
+        leaf_fwd_body(L, lane, R.p + R.m, R.p, R.first, R.woff, xp, xstr, work, wstr, nk);
         // (the leaf's parent is a task of a LATER launch on the same stream: it finds the update vector complete, and the task list of
         //  the blocked instances expects no completion count from a leaf -- no drain, no counter)
-        (void)rowptr, (void)s;
+        R = Rn;
+        D = Dn;
     }
 }
 
@@ -182,12 +211,13 @@ __device__ __forceinline__ void leaf_bwd_body(double *L, int lane, int p, int m,
         }
     }
     const bool live = c < nk;
-    double *xc = xp + (int64_t)(live ? c : 0) * xstr + first;
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        if (live && rs + 4 * q < p) xc[rs + 4 * q] = v[q];
+        if (live && rs + 4 * q < p) xp[leaf_x(xstr, first + rs + 4 * q, c)] = v[q];
 }
 
+// Backward: the same pipeline; the solved entries of the ancestors (x2) are a gather through the row numbers, i.e. one more dependent
+// round trip: the row numbers of leaf i + 1 travel with its panel, the gather of leaf i is requested at the head of its iteration.
 __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_bwd(const LeafRec *__restrict__ recs, int nleaf, const double *__restrict__ pool,
                                                               const int32_t *__restrict__ rows, double *xp, int64_t xstr, int nk) {
     __shared__ __attribute__((aligned(16))) double lds[LEAF_WAVES][LEAF_LDS];
@@ -198,43 +228,38 @@ __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_bwd(const LeafRec *__r
     const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;
     const int c = lane & 15, rs = lane >> 4;
     L[LEAF_OFF_Z + (lane & 1)] = 0.0;
+    const int cc = c < nk ? c : 0;
+    LeafInfo R, Rn;
+    LeafLoads D, Dn;
+    int32_t ridx[LEAF_MMAX / 4], ridxn[LEAF_MMAX / 4]; // global row numbers of the lane's off-diagonal rows rs, rs + 4, ...
+    leaf_rec(recs, i0, lane, R.off, R.woff, R.rowptr, R.first, R.p, R.m, R.s);
+    leaf_issue(D, R, lane, pool, nullptr, xp, xstr, nk);
+#pragma unroll
+    for (int q = 0; q < LEAF_MMAX / 4; q++) ridx[q] = rows[R.rowptr + (rs + 4 * q < R.m ? rs + 4 * q : 0)];
 #pragma unroll 1
     for (int i = i0; i < i1; i++) {
-        int64_t off, woff, rowptr;
-        int first, p, m, s;
-        leaf_rec(recs, i, lane, off, woff, rowptr, first, p, m, s);
-        const int f = p + m, np = (f * p + 63) >> 6;
-        double pc[LEAF_PANEL / 64];
-        const double *src = pool + off;
-#pragma unroll
-        for (int q = 0; q < LEAF_PANEL / 64; q++) pc[q] = src[(q < np ? 64 * q : 0) + lane];
-        const double *xcol = xp + (int64_t)(c < nk ? c : 0) * xstr;
-        double xb[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) xb[q] = xcol[first + (rs + 4 * q < p ? rs + 4 * q : 0)];
-        // x2: the solved entries of the ancestors, by global row number (every ancestor is complete: earlier launches of the pass)
-        const int32_t *rw = rows + rowptr;
+        const int in = i + 1 < i1 ? i + 1 : i;
+        leaf_rec(recs, in, lane, Rn.off, Rn.woff, Rn.rowptr, Rn.first, Rn.p, Rn.m, Rn.s);
+        // x2 of this leaf: every ancestor is complete (earlier launches of the pass)
         double x2[LEAF_MMAX / 4];
 #pragma unroll
-        for (int q = 0; q < LEAF_MMAX / 4; q++) {
-            const int r = rs + 4 * q;
-            x2[q] = xcol[rw[r < m ? r : 0]];
-        }
+        for (int q = 0; q < LEAF_MMAX / 4; q++) x2[q] = xp[leaf_x(xstr, ridx[q], cc)];
         wave_sync();
+        leaf_park(L, D, R, lane);
+        leaf_issue(Dn, Rn, lane, pool, nullptr, xp, xstr, nk);
 #pragma unroll
-        for (int q = 0; q < LEAF_PANEL / 64; q++)
-            if (q < np) L[64 * q + lane] = pc[q];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (rs + 4 * q < p) L[LEAF_OFF_XB + (rs + 4 * q) * LEAF_XB_LD + c] = xb[q];
+        for (int q = 0; q < LEAF_MMAX / 4; q++) ridxn[q] = rows[Rn.rowptr + (rs + 4 * q < Rn.m ? rs + 4 * q : 0)];
 #pragma unroll
         for (int q = 0; q < LEAF_MMAX / 4; q++)
-            if (rs + 4 * q < m) L[LEAF_OFF_X2 + (rs + 4 * q) * 16 + c] = x2[q];
+            if (rs + 4 * q < R.m) L[LEAF_OFF_X2 + (rs + 4 * q) * 16 + c] = x2[q];
         wave_sync();
-        if (lane < p) L[LEAF_OFF_INV + lane] = 1.0 / L[lane + lane * p];
+        if (lane < R.p) L[LEAF_OFF_INV + lane] = 1.0 / L[lane + lane * R.p];
         wave_sync();
-        leaf_bwd_body(L, lane, p, m, first, xp, xstr, nk);
-        (void)woff, (void)s;
+        leaf_bwd_body(L, lane, R.p, R.m, R.first, xp, xstr, nk);
+        R = Rn;
+        D = Dn;
+#pragma unroll
+        for (int q = 0; q < LEAF_MMAX / 4; q++) ridx[q] = ridxn[q];
     }
 }
 
