@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_bwd(const LeafRec *__r
     leaf_rec(recs, i0, lane, R.off, R.woff, R.rowptr, R.first, R.p, R.m, R.s);
     leaf_issue(D, R, lane, pool, nullptr, xp, xstr, nk);
 #pragma unroll
-    for (int q = 0; q < LEAF_MMAX / 4; q++) ridx[q] = rows[R.rowptr + (rs + 4 * q < R.m ? rs + 4 * q : 0)];
+    for (int q = 0; q < LEAF_MMAX / 4; q++) ridx[q] = rs + 4 * q < R.m ? rows[R.rowptr + rs + 4 * q] : 0; // (m = 0: nothing to read at rowptr -- it may be the END of `rows`; row 0 of x is always there)
 #pragma unroll 1
     for (int i = i0; i < i1; i++) {
         const int in = i + 1 < i1 ? i + 1 : i;
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_bwd(const LeafRec *__r
         leaf_park(L, D, R, lane);
         leaf_issue(Dn, Rn, lane, pool, nullptr, xp, xstr, nk);
 #pragma unroll
-        for (int q = 0; q < LEAF_MMAX / 4; q++) ridxn[q] = rows[Rn.rowptr + (rs + 4 * q < Rn.m ? rs + 4 * q : 0)];
+        for (int q = 0; q < LEAF_MMAX / 4; q++) ridxn[q] = rs + 4 * q < Rn.m ? rows[Rn.rowptr + rs + 4 * q] : 0;
 #pragma unroll
         for (int q = 0; q < LEAF_MMAX / 4; q++)
             if (rs + 4 * q < R.m) L[LEAF_OFF_X2 + (rs + 4 * q) * 16 + c] = x2[q];

@@ -147,3 +147,30 @@ def test_stream_events_with_and_without_system_fences_give_the_same_factor(monke
     for a, bb in zip(got[0][0], got[1][0]):
         assert np.array_equal(a, bb)
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2] == 0
+
+
+def test_blocked_solves_of_tiny_and_disconnected_matrices():
+    # found by tools/fuzz.py on the device (round 5): a leaf WITHOUT off-diagonal rows (a front that is root and leaf at once: matrices of
+    # <= 16 unknowns, disconnected blocks) made the backward leaf kernel read the row structure past its end -- a memory fault on the GPU,
+    # invisible on the CPU emulator.  Blocks of 2 ... 20 right-hand sides on such matrices, against dense LAPACK.
+    import scipy.sparse as sp
+    rng = np.random.default_rng(77)
+    for n, blocks in ((1, 1), (2, 1), (5, 1), (16, 1), (12, 3), (40, 8), (96, 6), (300, 30)):
+        A = sp.lil_matrix((n, n))
+        size = n // blocks
+        for bidx in range(blocks):
+            lo, hi = bidx * size, (n if bidx == blocks - 1 else (bidx + 1) * size)
+            A[lo:hi, lo:hi] = rng.uniform(-1, 1, (hi - lo, hi - lo)) + 4.0 * np.eye(hi - lo)
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        s = Hipmf()
+        assert s.initialize(n, rp, ci) == 0
+        assert s.factorize(v) == 0
+        for nrhs in (2, 9, 20):
+            XS = rng.standard_normal((nrhs, n))
+            B = np.array([A @ XS[j] for j in range(nrhs)])
+            X = s.solve_many(B)
+            assert np.max(np.abs(X - XS)) <= 1e-10 * max(1.0, np.max(np.abs(XS))), (n, blocks, nrhs)
+        assert s.counter("fused_fallbacks") == 0
+        s.close()
