@@ -12,5 +12,6 @@ export TMPDIR=/tmp
   echo "HIPMF_LEAF_KERNELS=0 tools/fuzz.py 100 7000:"; HIPMF_LEAF_KERNELS=0 timeout 600 python tools/fuzz.py 100 7000 2>&1 | tail -1
 ) > $OUT/fuzz.txt 2>&1
 cat $OUT/fuzz.txt
+( time timeout 600 python -m pytest tests/test_round5_gpu.py tests/test_random_patterns_gpu.py tests/test_matrix_zoo_gpu.py -m gpu -q ) > $OUT/pytest_extra.txt 2>&1; tail -3 $OUT/pytest_extra.txt
 ( time timeout 600 ./russell_amd/lib/brusselator_pde --npoint 513 -g hipmf ) > $OUT/config5_radau5_brusselator_513.txt 2>&1
 tail -8 $OUT/config5_radau5_brusselator_513.txt
