@@ -131,7 +131,7 @@ __device__ __forceinline__ double wt_fwd_steps(const double *L, int pslot, int l
     return v;
 }
 
-__device__ __forceinline__ void wt_fwd_front(double *L, int q, int lane, double *x, double *work, int *done) {
+__device__ __forceinline__ void wt_fwd_front(double *L, int q, int lane, double *x, double *work, int *done, bool publish) {
     const int32_t *Mi = reinterpret_cast<const int32_t *>(L + WT_OFF_M);
     const int32_t *LPi = reinterpret_cast<const int32_t *>(L + WT_OFF_LP);
     const double *X = L + WT_OFF_X;
@@ -182,15 +182,20 @@ __device__ __forceinline__ void wt_fwd_front(double *L, int q, int lane, double 
     } else {
         const int s = wave_bcast_i32(ri, 9);
         const int64_t woff = (int64_t)(((unsigned long long)(unsigned)wave_bcast_i32(ri, 11) << 32) | (unsigned)wave_bcast_i32(ri, 10));
-        if (lane >= p && lane < f) st_agent(work + woff + lane, v);
-        drain_stores();
-        if (lane == 0) flag_add(done + s, 1);
+        // (publish = false: the fronts above poll the words themselves -- tagged hand-offs, kernels_solve_fused.hpp -- and run in a LATER
+        //  launch: plain stores, no drain, no counter)
+        if (publish) {
+            if (lane >= p && lane < f) st_agent(work + woff + lane, v);
+            drain_stores();
+            if (lane == 0) flag_add(done + s, 1);
+        } else if (lane >= p && lane < f)
+            work[woff + lane] = v;
     }
 }
 
 __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restrict__ waves, const WtHdr *__restrict__ hdrs,
                                                         const int32_t *__restrict__ meta, const double *__restrict__ pool,
-                                                        const int32_t *__restrict__ lperm, int *sync, double *work, double *x) {
+                                                        const int32_t *__restrict__ lperm, int *sync, double *work, double *x, int publish) {
     __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     // the wave's record: lanes 0 .. 15 hold the 16 words of its first batch's header, lanes 16 / 17 its four integers
@@ -235,7 +240,7 @@ __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_fwd(const WtWave *__restri
         wave_sync();
         if (j == b0 + 1) HIPMF_STAMP((int)blockIdx.x / 6, 7);
         if (j == b0 + 1) HIPMF_STAMP_VAL((int)blockIdx.x / 6, 9, nrec);
-        for (int q = 0; q < nrec; q++) wt_fwd_front(L, q, lane, x, work, done);
+        for (int q = 0; q < nrec; q++) wt_fwd_front(L, q, lane, x, work, done, publish != 0);
         if (j == b0 + 1) HIPMF_STAMP((int)blockIdx.x / 6, 8);
         h0 = h1;
         h1 = h2;

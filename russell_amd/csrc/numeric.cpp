@@ -2321,7 +2321,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             const int32_t *const no_rep_idx = nullptr;
             int *const no_rep = nullptr;
             if (wg > 0)
-                hipLaunchKernelGGL(k_wt_fwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave, d_wt_hdr, d_wt_meta, d_pool, d_lperm, sync_f, wrk, xp);
+                hipLaunchKernelGGL(k_wt_fwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave, d_wt_hdr, d_wt_meta, d_pool, d_lperm, sync_f, wrk, xp, tag ? 0 : 1);
             // the fronts above the wave-subtrees: the many mid-level tasks at full occupancy, then the top levels (a chain of
             // hand-offs between few, large fronts) with their shares of E / E' parked in LDS before the wait
             const int32_t f_mid = sf2_fwd_mid, f_top = sf2_fwd_cnt - sf2_fwd_mid, b_top = sf2_bwd_top, b_mid = sf2_bwd_cnt - sf2_bwd_top;
