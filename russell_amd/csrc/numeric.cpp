@@ -1131,6 +1131,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             sfk_bwd_cnt = (int32_t)sf.size() - sfk_fwd_cnt;
             blocked = false;
             skip_leaves = false;
+            sfk_host.clear();
+            if (getenv("HIPMF_SF_TRACE"))
+                for (const SfTask &t : sf) sfk_host.push_back(t.kind), sfk_host.push_back(t.a);
             HIPC(dev_upload(&d_sfk, sf), ERROR_HIP_MALLOC);
             HIPC(dev_upload(&d_needk, need), ERROR_HIP_MALLOC);
             sf.swap(keep);
@@ -1308,8 +1311,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                 if (d_trace) { // (profiling aid: the stamps of THIS list's tasks)
                     (void)hipFree(d_trace);
                     d_trace = nullptr;
-                    HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 8 * std::max<size_t>(sf.size(), 1)), ERROR_HIP_MALLOC);
-                    HIPC(hipMemset(d_trace, 0, sizeof(unsigned long long) * 8 * std::max<size_t>(sf.size(), 1)), ERROR_HIP_MALLOC);
+                    // (room for the stamps of the blocked instances' upper launches too: a blocked solve writes into the same buffer)
+                    const size_t ntr2 = std::max<size_t>(std::max<size_t>(sf.size(), (size_t)(sfk_fwd_cnt - sfk_fwd_band) + (size_t)sfk_bwd_top), 1);
+                    HIPC(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 8 * ntr2), ERROR_HIP_MALLOC);
+                    HIPC(hipMemset(d_trace, 0, sizeof(unsigned long long) * 8 * ntr2), ERROR_HIP_MALLOC);
                     sf_host.clear();
                     for (const SfTask &t : sf) sf_host.push_back(t.kind), sf_host.push_back(t.a);
                 }
@@ -2828,17 +2833,21 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
     HIPC(hipGetLastError(), ERROR_HIP_LAUNCH);
     harvest_tri();
-    if (use_fused && d_trace) {
+    if (use_fused && d_trace && (nrhs == 1 || !sfk_host.empty())) {
         // dump: one line per task of the two upper launches: direction, level, front, kind, p, f, four stamps (10 ns units)
-        const bool tr_tree = tree_active;
-        const size_t nf = tr_tree ? (size_t)sf2_fwd_cnt : (size_t)(sf_fwd_launch - std::min(sf_fwd_band, sf_fwd_launch));
-        const size_t nb = tr_tree ? (size_t)sf2_bwd_cnt : (size_t)sf_bwd_top;
+        // (a blocked solve: the stamps of its last block, against the task list of the blocked instances)
+        const bool tr_k = nrhs > 1, tr_tree = !tr_k && tree_active;
+        const std::vector<int32_t> &host = tr_k ? sfk_host : sf_host;
+        const int32_t band0 = tr_k ? sfk_fwd_band : sf_fwd_band, fwd_all = tr_k ? sfk_fwd_cnt : sf_fwd_cnt;
+        const size_t nf = tr_tree ? (size_t)sf2_fwd_cnt : (size_t)((tr_k ? sfk_fwd_cnt : sf_fwd_launch) - std::min(band0, tr_k ? sfk_fwd_cnt : sf_fwd_launch));
+        const size_t nb = tr_tree ? (size_t)sf2_bwd_cnt : (size_t)(tr_k ? sfk_bwd_top : sf_bwd_top);
         std::vector<unsigned long long> tr(8 * (nf + nb));
         (void)hipMemcpy(tr.data(), d_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost);
         if (FILE *fp = fopen(getenv("HIPMF_SF_TRACE"), "w")) {
             for (size_t k = 0; k < nf + nb; k++) {
-                const size_t ti = tr_tree ? k : (k < nf ? (size_t)sf_fwd_band + k : (size_t)sf_fwd_cnt + (k - nf));
-                const int32_t kind = sf_host[2 * ti], a = sf_host[2 * ti + 1];
+                const size_t ti = tr_tree ? k : (k < nf ? (size_t)band0 + k : (size_t)fwd_all + (k - nf));
+                if (2 * ti + 1 >= host.size()) break;
+                const int32_t kind = host[2 * ti], a = host[2 * ti + 1];
                 fprintf(fp, "%c %d %d %d %d %d %llu %llu %llu %llu %llu %llu\n", k < nf ? 'F' : 'B', S.sn_level[a], a, kind, S.npiv(a), S.fsize(a),
                         tr[8 * k], tr[8 * k + 1], tr[8 * k + 2], tr[8 * k + 3], tr[8 * k + 4], tr[8 * k + 5]);
             }

@@ -351,7 +351,7 @@ class Solver {
     bool solve_lanes_auto = true; // no HIPMF_SOLVE_LANES given: one lane when the factor exceeds 64 GB (solve())
     int32_t block_cols = 0;    // columns per block of the many-RHS driver once its buffers exist (8 or 16; HIPMF_BLOCK_COLS forces one)
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
-    std::vector<int32_t> sf_host;           // (kind, front) per task, kept only when tracing
+    std::vector<int32_t> sf_host, sfk_host; // (kind, front) per task (single-column lists / blocked list), kept only when tracing
     FactorInfo *d_info = nullptr;
     unsigned long long *d_scalar = nullptr; // [0] anorm bits, [4 ...] the norm slots of k_residual (lane 0)
     double *d_work = nullptr, *d_vals = nullptr, *d_xp = nullptr, *d_r = nullptr, *d_den = nullptr, *d_b = nullptr, *d_x = nullptr,
