@@ -196,6 +196,7 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
                                              launches of two handles are never resident together) */
 #define HIPMF_COUNTER_WAVE_FRONTS 12      /* big fronts (f > 64) whose forward solve step is the work of one wavefront (at most 128 rows, 32 pivots) */
 #define HIPMF_COUNTER_LEAF_FRONTS 13      /* leaves of the tree that the blocked (many-RHS) solves run in kernels of their own, sixteen columns per wavefront */
+#define HIPMF_COUNTER_SPLIT_SLABS 14      /* backward slabs of the blocked solves whose dot products are split over several tasks (levels of few slabs near the root of a large factor) */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

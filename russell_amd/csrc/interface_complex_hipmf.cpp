@@ -322,6 +322,7 @@ int64_t complex_solver_hipmf_get_counter(struct InterfaceComplexHIPMF *h, int32_
     case HIPMF_COUNTER_GATE_WAITS: return s.gate_waits;
     case HIPMF_COUNTER_WAVE_FRONTS: return s.wave_front_count;
     case HIPMF_COUNTER_LEAF_FRONTS: return s.leaf_front_count();
+    case HIPMF_COUNTER_SPLIT_SLABS: return s.split_slab_count();
     default: return -1;
     }
 }

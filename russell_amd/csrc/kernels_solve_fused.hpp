@@ -46,7 +46,9 @@ struct SfTask {
                         // 2:    forward pass, single right-hand side: group of WAVE FRONTS (a, b, c, d; -1 = none) -- big fronts (stored as
                         //       E) of at most SF_WF_ROWS rows and SF_WF_PIV pivots, one per wavefront (sf_fwd_wave)
     int32_t a, b, c, d;
-    int32_t pad;
+    int32_t part;       // backward slabs of the blocked instances, levels of few tasks: 0 = the slab's whole dot product; otherwise
+                        // q | Q << 8: this task forms part q of Q of it (a contiguous range of positions; the Q parts are consecutive tasks),
+                        // d = the group's first 256-double unit in the scratch of partial sums (see k_bwd_fused)
 };
 
 // wait until *cnt >= need (relaxed agent-scope polls); false on timeout or when another waiter timed out
@@ -1054,7 +1056,8 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag,
-                                                   int stage, const int32_t *__restrict__ rep_idx, int *rep, double *xt) {
+                                                   int stage, const int32_t *__restrict__ rep_idx, int *rep, double *xt, double *split_scr,
+                                                   int *split_cnt) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
     static_assert(!TAG || (K == 1 && !SMALL_ONLY), "the tagged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles (see k_fwd_fused)
@@ -1089,9 +1092,22 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     const int rr = tid & ((1 << sh) - 1), g = tid >> sh, G = 256 >> sh;
     const int i = r0 + rr;
     // columns of inv(U11) left of the slab's first 32-column block are zero
-    const int jmin = (r0 / NB) * NB;
+    const int jmin0 = (r0 / NB) * NB;
+    // SPLIT dot products (blocked instances, levels of few tasks: numeric.cpp).  The top levels of a 3D factor hold a few hundred slabs
+    // of 16 rows whose dot products run over tens of thousands of positions: one workgroup per compute unit, each with ~32 KB in flight,
+    // leaves most of the memory system idle (144^3, 16 columns: the top eleven levels were half of the backward pass).  A slab's
+    // positions [jmin0, f) are dealt to Q consecutive tasks in contiguous ranges (multiples of the chunk); each leaves its partial tile
+    // sums in a scratch, the LAST one to arrive (a counter per slab; it resets the counter for the next pass) adds the Q partial sums
+    // in the order of the parts -- the result does not depend on who arrives last -- and finishes the slab like an unsplit task.
+    const int Q = K > 1 ? ((t.part >> 8) & 0xff) : 0, qpart = t.part & 0xff;
+    int jmin = jmin0, jend = f;
+    if (K > 1 && Q > 1) {
+        const int len = (((f - jmin0 + Q - 1) / Q + CHK - 1) / CHK) * CHK;
+        jmin = jmin0 + qpart * len < f ? jmin0 + qpart * len : f;
+        jend = jmin + len < f ? jmin + len : f;
+    }
     // ---- before the wait: y1 (forward launch) and the row numbers of x2 for the first chunk ----
-    const int e1 = jmin + CHK < f ? jmin + CHK : f;
+    const int e1 = jmin + CHK < jend ? jmin + CHK : jend;
     int xrow[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1175,8 +1191,8 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     for (int q = 0; q < ((SYM && K == 1) ? SF_SYMC : 1); q++) sacc[q][0] = 0.0;
     f64x4 macc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     const int nsub = (1 << sh) >> 4; // 16-output tiles of the slab
-    for (int c0 = jmin; c0 < f; c0 += CHK) {
-        const int c1 = c0 + CHK < f ? c0 + CHK : f;
+    for (int c0 = jmin; c0 < jend; c0 += CHK) {
+        const int c1 = c0 + CHK < jend ? c0 + CHK : jend;
         if (c0 > jmin) {
             for (int j = c0 + tid; j < c1; j += 256) {
                 const int row = (j < p) ? 0 : rws[j - p];
@@ -1249,13 +1265,36 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
         __syncthreads();
     }
     if (trace && tid == 0) tr_d = dev_clock();
+    bool finish = true; // (workgroup-uniform) this task completes the slab
     if (K > 1) {
         sf_mma_store(macc, mt, nsub, wave, lane);
         __syncthreads();
-        if (tid < (1 << sh) && r0 + tid < r1) {
+        if (Q > 1) {
+            // part qpart of the slab: nsub units of 16 rows x 16 columns
+            double *mine = split_scr + ((int64_t)t.d + (int64_t)qpart * nsub) * 256;
+            if (tid < (1 << sh)) {
+#pragma unroll
+                for (int c = 0; c < K; c++) st_agent(mine + tid * 16 + c, sf_mma_sum(mt, nsub, tid, c));
+            }
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) red[0] = (double)flag_add(split_cnt + t.d, 1);
+            __syncthreads();
+            finish = (int)red[0] == Q - 1;
+            if (finish && tid == 0) flag_store(split_cnt + t.d, 0);
+        }
+        if (finish && tid < (1 << sh) && r0 + tid < r1) {
 #pragma unroll
             for (int c = 0; c < K; c++)
-                if (c < nk) st_agent(x + c * xstr + fd.first + r0 + tid, sf_mma_sum(mt, nsub, tid, c));
+                if (c < nk) {
+                    double tot;
+                    if (Q > 1) {
+                        tot = 0.0;
+                        for (int qq = 0; qq < Q; qq++) tot += ld_agent(split_scr + ((int64_t)t.d + (int64_t)qq * nsub) * 256 + tid * 16 + c);
+                    } else
+                        tot = sf_mma_sum(mt, nsub, tid, c);
+                    st_agent(x + c * xstr + fd.first + r0 + tid, tot);
+                }
         }
     } else if (sym) {
         // the 64 partial sums of a column are added in a fixed (butterfly) order
@@ -1280,9 +1319,11 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     }
     if (trace && tid == 0) tr2 = dev_clock();
     if constexpr (!TAG) {
-        drain_stores();
-        __syncthreads();
-        if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
+        if (finish) { // (a part that is not the last one of its slab has nothing to publish)
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
+        }
     }
     if (trace && tid == 0) {
         unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;

@@ -88,9 +88,10 @@ void Solver::release() {
     if (d_chain_cnt) (void)hipFree(d_chain_cnt);
     d_chain = nullptr, d_chain_cnt = nullptr, chain_words = 0;
     for (void *p : {(void *)d_wt_hdr, (void *)d_wt_meta, (void *)d_wt_wave, (void *)d_sf2, (void *)d_need2, (void *)d_rep_idx, (void *)d_rep, (void *)d_sf3,
-                    (void *)d_need3, (void *)d_sfk, (void *)d_needk, (void *)d_leaf})
+                    (void *)d_need3, (void *)d_sfk, (void *)d_needk, (void *)d_leaf, (void *)d_split_scr, (void *)d_split_cnt})
         if (p) (void)hipFree(p);
     d_leaf = nullptr, leaf_cnt = 0;
+    d_split_scr = nullptr, d_split_cnt = nullptr, split_units = 0, split_slabs = 0;
     d_wt_hdr = nullptr, d_wt_meta = nullptr, d_wt_wave = nullptr, d_sf2 = nullptr, d_need2 = nullptr, d_rep_idx = nullptr, d_rep = nullptr;
     rep_words = 0;
     d_sf3 = nullptr, d_need3 = nullptr;
@@ -362,6 +363,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_TREE_SOLVE")) use_tree = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_TAG_SOLVE")) use_tag = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_LEAF_KERNELS")) leaf_kernels = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_SPLIT_TASKS")) split_tasks = std::max(0, atoi(e));
+    if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
     if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
@@ -973,6 +976,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         std::vector<char> in_w((size_t)ns, 0); // fronts that belong to a wave-subtree (kernels_solve_tree.hpp)
         bool tree = false;                     // the task list being built is the one above the wave-subtrees
         bool blocked = false;                  // ... the one of the blocked (many-RHS) instances
+        bool klist = false;                    // ... the blocked instances' own list (d_sfk)
+        int32_t k_fwd_rows = 0;                // klist, per level: log2 of the forward slab rows of the largest fronts (0: sf_big_rows)
+        int32_t k_bwd_groups = 0;              // klist, per level: backward slabs of the big fronts of the level
         int32_t top_level = S.nlevels;         // ... its levels >= top_level run in a launch of their own (LDS-staged slabs)
         auto kind_of = [&](int32_t s, bool forward) {
             const int32_t len = forward ? S.npiv(s) : S.fsize(s);
@@ -985,6 +991,7 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             // fronts of thousands of rows: every slab workgroup gathers ALL children's update vectors, so 16-row slabs (625 of them
             // for 10 000 rows) re-read them hundreds of times; 64-row slabs still give >= 32 workgroups per front
             // (3D 100^3: pass pair 3.44 -> 3.33 ms, 64 right-hand sides 182 -> 160 ms)
+            if (forward && klist && k_fwd_rows > 0 && S.fsize(s) >= sf_big_front) return k_fwd_rows;
             if (forward && sf_big_rows > 0 && S.fsize(s) >= sf_big_front) return sf_big_rows;
             // above the wave-subtrees: a thread's share of its row of E / E' (len / G entries, G = 256 / rows column groups) is parked
             // in LDS / registers BEFORE the wait, so the slabs are cut for <= ~40 entries per thread
@@ -1005,6 +1012,27 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
         };
         auto emit_level = [&](int32_t l, bool forward) {
             std::vector<int32_t> small, wavef;
+            if (klist) {
+                // Levels of FEW tasks near the root of a large (3D) factor: one workgroup per compute unit streams its slab with ~32 KB in
+                // flight and the memory system idles.  Forward: narrower slabs for the largest fronts (their vector block is assembled
+                // once: a narrow slab re-reads it from L2, nothing else); backward: the slabs' dot products are split (k_bwd_fused).
+                k_fwd_rows = 0, k_bwd_groups = 0;
+                if (forward && sf_big_rows > 0 && split_tasks > 0) {
+                    for (int32_t rows_log = sf_big_rows; rows_log >= 4; rows_log--) {
+                        int64_t cnt = 0;
+                        for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++)
+                            if (S.fsize(S.level_sn[k]) >= sf_big_front) cnt += (S.fsize(S.level_sn[k]) + (1 << rows_log) - 1) >> rows_log;
+                        k_fwd_rows = rows_log;
+                        if (cnt == 0 || cnt >= split_tasks) break;
+                    }
+                    if (k_fwd_rows == sf_big_rows) k_fwd_rows = 0;
+                }
+                if (!forward)
+                    for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
+                        const int32_t s = S.level_sn[k];
+                        if (S.fsize(s) > SMALL_F && !(skip_leaves && is_leaf_front(s))) k_bwd_groups += (S.npiv(s) + (1 << kind_of(s, false)) - 1) >> kind_of(s, false);
+                    }
+            }
             for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) {
                 int32_t s = S.level_sn[k];
                 if (tree && in_w[(size_t)s]) continue;
@@ -1035,7 +1063,23 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                 }
                 need[(size_t)(forward ? 0 : ns) + s] = (ext + rows - 1) / rows + nasm;
                 const size_t first_slab = sf.size();
-                for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), nasm, 0});
+                // (klist, backward, a level of few slabs, long dot products: Q parts per slab -- only the last one to arrive publishes)
+                int32_t Q = 1;
+                if (klist && !forward && split_tasks > 0 && k_bwd_groups < 8 * split_tasks && S.fsize(s) >= split_minlen && kind >= 4) {
+                    // enough parts to fill the device when the level has few slabs; parts of ~2 split_minlen positions when the dot products
+                    // are long (a level of 840 slabs of 450 us each runs as one full round of workgroups and one nearly empty one)
+                    const int64_t q_cnt = k_bwd_groups < split_tasks ? (3 * (int64_t)split_tasks / 2 + k_bwd_groups - 1) / std::max(1, k_bwd_groups) : 1;
+                    const int64_t q_len = S.fsize(s) / (2 * (int64_t)split_minlen);
+                    Q = (int32_t)std::min<int64_t>(std::min<int64_t>(8, std::max(q_cnt, q_len)), S.fsize(s) / std::max(1, split_minlen / 4));
+                }
+                if (Q >= 2) {
+                    for (int32_t r0 = 0; r0 < ext; r0 += rows) {
+                        for (int32_t q = 0; q < Q; q++) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), (int32_t)split_units, q | (Q << 8)});
+                        split_units += (int64_t)Q * (rows / 16);
+                        split_slabs++;
+                    }
+                } else
+                    for (int32_t r0 = 0; r0 < ext; r0 += rows) sf.push_back({kind, s, r0, std::min(ext, r0 + rows), nasm, 0});
                 // 8-row slabs read 64-byte segments of E / E': two neighbouring slabs share every 128-byte line, and a line is fetched once per
                 // XCD that asks for it (tools/microbench/fetch_calib.hip: 64-byte segments move twice their bytes).  Workgroup b runs on XCD
                 // b mod 8 (observed, MI355X_MICROARCH.md), so the slabs 2j and 2j + 1 are placed eight tasks apart: the second one finds
@@ -1116,6 +1160,8 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             std::fill(need.begin(), need.end(), 1);
             blocked = blocked_slabs;
             skip_leaves = leaf_cnt > 0;
+            klist = true;
+            split_units = 0, split_slabs = 0;
             sfk_fwd_band = 0;
             for (int32_t l = 0; l < S.nlevels; l++) {
                 emit_level(l, true);
@@ -1131,6 +1177,13 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             sfk_bwd_cnt = (int32_t)sf.size() - sfk_fwd_cnt;
             blocked = false;
             skip_leaves = false;
+            klist = false;
+            if (split_units > 0) {
+                if (split_units >= (int64_t)0x7fffffff) return ERROR_HIPMF_SYMBOLIC;
+                HIPC(hipMalloc((void **)&d_split_scr, sizeof(double) * 256 * (size_t)split_units), ERROR_HIP_MALLOC);
+                HIPC(hipMalloc((void **)&d_split_cnt, sizeof(int32_t) * (size_t)split_units), ERROR_HIP_MALLOC);
+                HIPC(hipMemset(d_split_cnt, 0, sizeof(int32_t) * (size_t)split_units), ERROR_HIP_MALLOC);
+            }
             sfk_host.clear();
             if (getenv("HIPMF_SF_TRACE"))
                 for (const SfTask &t : sf) sfk_host.push_back(t.kind), sfk_host.push_back(t.a);
@@ -2335,7 +2388,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
                        sync_f, sync_err, wrk, xp, 1, xstr, wstr, TRACE, STAGE, RIDX, REP)
 #define HIPMF_TREE_BWD(SYMV, STGV, TAGV, CNT, DYN, TASKS, TRACE, STAGE, RIDX, REP)                                                            \
     hipLaunchKernelGGL((k_bwd_fused<false, 1, SYMV, STGV, TAGV>), dim3(CNT), dim3(256), DYN, LST, TASKS, d_fd, d_pool, d_rows, d_need2 + ns,   \
-                       sync_b, sync_err, wrk, xp, 1, xstr, wstr, TRACE, d_diag, STAGE, RIDX, REP, TAGV ? xt : (double *)nullptr)
+                       sync_b, sync_err, wrk, xp, 1, xstr, wstr, TRACE, d_diag, STAGE, RIDX, REP, TAGV ? xt : (double *)nullptr, (double *)nullptr, (int *)nullptr)
             unsigned long long *tr_top = no_tr ? no_tr + 8 * (size_t)f_mid : no_tr;
             if (f_mid > 0) {
                 if (tag) HIPMF_TREE_FWD(false, true, f_mid, 0, d_sf2, no_tr, 0, no_rep_idx, no_rep);
@@ -2396,7 +2449,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
                        sync_err, wrk, xp, nk, xstr, wstr, TRACE, 0, (const int32_t *)nullptr, (int *)nullptr)
 #define HIPMF_BWD1(SMALL, KK, SYMM, CNT, TASKS, TRACE)                                                                                     \
     hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, NEED + ns, sync_b,        \
-                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr)
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, d_split_scr, d_split_cnt)
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     do {                                                                                                                                  \
         if (!SMALL && S.sym_mode) HIPMF_BWD1(false, KK, true, CNT, TASKS, TRACE);                                                          \
@@ -2459,10 +2512,10 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             if (cnt <= 0) continue;
             if (S.sym_mode)
                 hipLaunchKernelGGL((k_bwd_fused<false, 1, true, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
-                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr);
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr);
             else
                 hipLaunchKernelGGL((k_bwd_fused<false, 1, false, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
-                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr);
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr);
             launches++;
         }
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);

@@ -163,6 +163,7 @@ class Solver {
     int64_t gate_waits = 0;      // solves that waited for another handle's solve on the same device (device_gate, numeric.cpp)
     bool tagged_solve() const { return tag_active && use_fused; }
     int64_t leaf_front_count() const { return use_fused ? leaf_cnt : 0; }
+    int64_t split_slab_count() const { return use_fused ? split_slabs : 0; }
     int64_t chain_fallbacks = 0; // factorisations repeated with one launch per tiled step after a hand-off timeout of a chained launch (never expected)
     int64_t persist_bytes() const { return S.persist_doubles * 8; }
     double last_residual_inf = 0.0, last_omega = 0.0;
@@ -220,6 +221,14 @@ class Solver {
     bool leaf_kernels = true;
     LeafRec *d_leaf = nullptr;   // records of the leaves: forward part, then backward part (other panel offsets)
     int32_t leaf_cnt = 0;
+    // blocked instances, backward pass, levels of few slabs with long dot products (the top of a 3D factor): a slab's dot products are
+    // split over Q consecutive tasks (k_bwd_fused); forward, the largest fronts of such levels get narrower slabs.  A level qualifies
+    // below split_tasks slabs (HIPMF_SPLIT_TASKS, 0: never), a front from split_minlen rows on (HIPMF_SPLIT_MINLEN).
+    int32_t split_tasks = 512, split_minlen = 2048;
+    int64_t split_units = 0;       // 256-double units of the scratch of partial sums
+    int64_t split_slabs = 0;
+    double *d_split_scr = nullptr;
+    int32_t *d_split_cnt = nullptr; // one arrival counter per unit (the first unit of a slab's group is used; reset by the last arriver)
     SfTask *d_sfk = nullptr;
     int32_t *d_needk = nullptr;
     int32_t sfk_fwd_cnt = 0, sfk_bwd_cnt = 0, sfk_fwd_band = 0, sfk_bwd_top = 0;

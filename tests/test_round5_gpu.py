@@ -174,3 +174,35 @@ def test_blocked_solves_of_tiny_and_disconnected_matrices():
             assert np.max(np.abs(X - XS)) <= 1e-10 * max(1.0, np.max(np.abs(XS))), (n, blocks, nrhs)
         assert s.counter("fused_fallbacks") == 0
         s.close()
+
+
+def test_split_dot_products_of_blocked_backward_slabs_on_the_device(monkeypatch):
+    # levels of few slabs with long dot products (the top of a 3D factor): a backward slab of the blocked instances is dealt to Q tasks, the
+    # last one to arrive adds the partial sums in the order of the parts (k_bwd_fused).  60^3 with the default thresholds (the top levels
+    # qualify) and with every level forced: equal to rounding with the unsplit tasks, the same bits from solve to solve (whoever arrives
+    # last), no fallback; L D L^T fronts too.
+    n, rp, ci, v = P.poisson3d(60)
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    rng = np.random.default_rng(60)
+    XS = rng.standard_normal((32, n))
+    B = np.array([P.csr_matvec(n, rp, ci, v, XS[j]) for j in range(32)])
+    for arrays, kw in (((rp, ci, v), {}), ((lrp, lci, lv), {"general_symmetric": True})):
+        got = {}
+        for tag, env in (("off", {"HIPMF_SPLIT_TASKS": "0"}), ("default", {}), ("forced", {"HIPMF_SPLIT_TASKS": "1000000", "HIPMF_SPLIT_MINLEN": "256"})):
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
+            s = Hipmf()
+            assert s.initialize(n, arrays[0], arrays[1], refinement_nstep=0, **kw) == 0
+            assert s.factorize(arrays[2]) == 0
+            X = s.solve_many(B)
+            for _ in range(3):
+                assert np.array_equal(X, s.solve_many(B))
+            got[tag] = (X, s.counter("split_slabs"), s.counter("fused_fallbacks"))
+            s.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        assert got["off"][1] == 0 and got["default"][1] > 0 and got["forced"][1] > got["default"][1]
+        for tag in ("off", "default", "forced"):
+            assert got[tag][2] == 0
+            assert np.max(np.abs(got[tag][0] - XS)) <= 1e-10 * np.max(np.abs(XS))
+            assert np.max(np.abs(got[tag][0] - got["off"][0])) <= 1e-12 * np.max(np.abs(got["off"][0]))

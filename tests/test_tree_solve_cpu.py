@@ -212,6 +212,36 @@ def test_leaf_kernels_of_the_blocked_solves_agree_with_the_task_form(emu_lib, nr
         assert np.max(np.abs(got["1"][0] - XS)) <= 1e-11 * np.max(np.abs(XS))
 
 
+def test_split_dot_products_of_the_blocked_backward_slabs(emu_lib, monkeypatch):
+    # round 5: on levels of few slabs with long dot products (the top of a 3D factor) a backward slab of the blocked instances is dealt to
+    # Q consecutive tasks, each with a contiguous range of positions; the last one to arrive adds the partial sums in the order of the
+    # parts (k_bwd_fused).  Forced here on small matrices (every level qualifies, fronts from 64 rows on): equal to rounding with the
+    # unsplit tasks, the same bits from solve to solve whoever arrives last, LU and L D L^T fronts, blocks of 16 and of 8 columns.
+    full = P.poisson3d(16)
+    for (n, rp, ci, v), kw, blocks in ((full, {}, (16,)), (_lower(full), {"general_symmetric": True}, (16, 7))):
+        ref = full
+        for nrhs in blocks:
+            rng = np.random.default_rng(nrhs)
+            XS = rng.standard_normal((nrhs, n))
+            B = np.array([P.csr_matvec(ref[0], ref[1], ref[2], ref[3], XS[j]) for j in range(nrhs)])
+            got = {}
+            for split in ("0", "1000000"):
+                monkeypatch.setenv("HIPMF_SPLIT_TASKS", split)
+                monkeypatch.setenv("HIPMF_SPLIT_MINLEN", "64")
+                s = Hipmf(emu_lib)
+                assert s.initialize(n, rp, ci, refinement_nstep=0, **kw) == 0
+                assert s.factorize(v) == 0
+                X = s.solve_many(B)
+                assert np.array_equal(X, s.solve_many(B))
+                got[split] = (X, s.counter("split_slabs"), s.counter("fused_fallbacks"))
+                s.close()
+            monkeypatch.delenv("HIPMF_SPLIT_TASKS")
+            monkeypatch.delenv("HIPMF_SPLIT_MINLEN")
+            assert got["0"][1] == 0 and got["1000000"][1] > 0 and got["1000000"][2] == 0
+            assert np.max(np.abs(got["1000000"][0] - got["0"][0])) <= 1e-12 * np.max(np.abs(got["0"][0]))
+            assert np.max(np.abs(got["1000000"][0] - XS)) <= 1e-11 * np.max(np.abs(XS))
+
+
 def _lower(mat):
     n, rp, ci, v = mat
     lrp, lci, lv = P.lower_triangle(n, rp, ci, v)

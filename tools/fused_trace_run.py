@@ -10,8 +10,13 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 n, rp, ci, v = P.poisson3d(N) if os.environ.get("TRACE_3D") else P.poisson2d(N)  # (TRACE_3D=1: the N^3 7-point matrix)
 b = P.csr_matvec(n, rp, ci, v, P.manufactured_solution(n))
 s = Hipmf()
-assert s.initialize(n, rp, ci, refinement_nstep=0) == 0
-assert s.factorize(v) == 0
+if os.environ.get("TRACE_SYM"):  # (TRACE_SYM=1: handed over as its lower triangle -> L D L^T fronts)
+    lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
+    assert s.initialize(n, lrp, lci, refinement_nstep=0, general_symmetric=True) == 0
+    assert s.factorize(lv) == 0
+else:
+    assert s.initialize(n, rp, ci, refinement_nstep=0) == 0
+    assert s.factorize(v) == 0
 nrhs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 import numpy as np
 for _ in range(3):
