@@ -652,6 +652,49 @@ __device__ __forceinline__ void sf_children(int tid, int nch, int ncd, const int
     }
 }
 
+// The same sums for the blocked instances (K > 1) when the children are many and short -- the lower levels of a 3D factor: six to ten
+// children of 30 - 100 rows each, where sf_children's two children per round trip leave most of the 256 threads without an entry and
+// the rounds (10 - 17 us of a ~27 us task, profiles/r05_solve_trace_200cube_sym_16col.txt) are what the task spends its time on.  Here a
+// round takes as many consecutive children as fit on the 256 threads (at most eight), one row of one child per thread, everything
+// fetched in one round trip; the adds then run child by child in ascending order as before: the same bits as sf_children.
+// Requires the children's descriptors in LDS (nch <= 64) and no child of more than 256 rows.
+template <int K>
+__device__ __forceinline__ void sf_children_packed(int tid, int nch, const int64_t *cd_woff, const int64_t *cd_rel, const int32_t *cd_m,
+                                                   const int32_t *__restrict__ rel, const double *work, double *wc, int wld, double *wsl, int c0,
+                                                   int c1, int p, int r0, int r1, int nk, int64_t wstr) {
+    int cb = 0;
+    while (cb < nch) { // (workgroup-uniform)
+        int ce = cb, tot = 0, mine = -1, myi = 0;
+        while (ce < nch && ce - cb < 8 && tot + cd_m[ce] <= 256) {
+            const int m = cd_m[ce];
+            if (mine < 0 && tid < tot + m) mine = ce, myi = tid - tot;
+            tot += m;
+            ce++;
+        }
+        // (clamped addresses: the loads are unconditional -- see ld_cols; a thread without an entry re-reads entry 0 of the round's first child)
+        const int ch = mine >= 0 ? mine : cb;
+        const int qq = rel[cd_rel[ch] + myi];
+        const int q = mine >= 0 ? qq : -1;
+        double uv[K];
+        ld_cols<K>(uv, work, wstr, cd_woff[ch] + myi, nk);
+        for (int k = cb; k < ce; k++) {
+            if (mine == k) {
+                if (q >= c0 && q < c1) {
+#pragma unroll
+                    for (int cc = 0; cc < K; cc++)
+                        if (cc < nk) wc[cc * wld + q - c0] += uv[cc];
+                } else if (c0 == 0 && q >= p && q >= r0 && q < r1) {
+#pragma unroll
+                    for (int cc = 0; cc < K; cc++)
+                        if (cc < nk) wsl[cc * 128 + q - r0] += uv[cc];
+                }
+            }
+            __syncthreads();
+        }
+        cb = ce;
+    }
+}
+
 // pairwise sum over the G <= 32 column groups of row rr in a fixed order
 __device__ __forceinline__ double sf_group_sum(const double *red, int rows, int rr, int G) {
     double tsum[32];
@@ -747,6 +790,9 @@ __device__ __forceinline__ double sf_mma_sum(const double *mt, int nsub, int rr,
 // kernel also runs thousands of small fronts, whose occupancy pays for every VGPR (measured in round 2: 108 -> 152 VGPRs, slower).
 // TAG (K = 1 only): data-tagged hand-offs (see sf_tag_wait) -- no completion counters, no drains; the task list then holds no
 // ASSEMBLE tasks (their intermediate result would sit where the parent looks for the final one).
+#ifndef HIPMF_PACKED_GATHER
+#define HIPMF_PACKED_GATHER 1 // (0: A/B builds without sf_children_packed)
+#endif
 #ifndef HIPMF_SF_FWD_WGS
 #define HIPMF_SF_FWD_WGS 3 // workgroups per compute unit the single-column forward instances above the wave-subtrees are compiled for (A/B builds)
 #endif
@@ -970,7 +1016,9 @@ __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WG
             }
             __syncthreads();
         }
-        if (cm_max <= 256)
+        if (K > 1 && HIPMF_PACKED_GATHER && nch > (K <= 8 ? 4 : 2) && nch <= 64 && cm_max <= 256) {
+            if constexpr (K > 1) sf_children_packed<K>(tid, nch, cd_woff, cd_rel, cd_m, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr);
+        } else if (cm_max <= 256)
             sf_children<(K == 1 ? 8 : (K <= 8 ? 4 : 2)), 1, K, TAG>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr, err);
         else // (top-level instance: six entries per thread and child in one round trip -- 1 536 rows)
             sf_children<2, (STG ? 6 : (K == 1 ? 4 : (K <= 8 ? 2 : 1))), K, TAG>(tid, nch, ncd, cd_woff, cd_rel, cd_m, fd, FD, child_idx, rel, work, wc, CHK, wsl, c0, c1, p, r0, r1, nk, wstr, err);
