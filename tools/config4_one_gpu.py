@@ -68,5 +68,5 @@ print(json.dumps({"workload": "3D 7-point Poisson %d^3 (n = %d), lower triangle 
                   "ms_per_rhs": round(t_solve * 1e3 / NRHS, 2), "rhs_per_s": round(NRHS / t_solve, 1), "h2d_rhs_s": round(t_h2d, 2),
                   "pool_gb": round(st["pool_bytes"] / 1e9, 1), "nnz_l": st["nnz_l"], "flops": st["flops"],
                   "lu_equivalent_tflops": round(st["flops"] / t_fac / 1e12, 1), "max_relative_error_3_columns": err,
-                  "fused_fallbacks": s.stats().get("fused_fallbacks", -1), "refinement_steps_last_block": st["refinement_steps"]}))
+                  "fused_fallbacks": s.stats().get("fused_fallbacks", -1), "refinement_steps_first_column": st["refinement_steps"]}))
 s.close()
