@@ -1095,6 +1095,83 @@ __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WG
     }
 }
 
+// ---- backward step of one WAVE FRONT by one wavefront (round 5) ----
+// The mirror image of sf_fwd_wave for the LU fronts:  x1 = E' [y1; x2]  with p <= SF_WF_PIV outputs and f <= SF_WF_ROWS positions.  Lane
+// (i = lane mod 32, h = lane / 32) owns output i and the positions h, h + 2, ...; the first SF_WB_PRE of its entries of row i of E' are
+// requested before anything is waited for; y1 (forward launch) and the ancestors' entries x2 (the tagged shadow xt under TAG, else x after
+// the parent's completion count) go to the wave's LDS copy of the front's vector; two accumulators per lane, the halves added by one
+// shuffle.  Same result as the slab tasks to rounding (another summation order).
+constexpr int SF_WB_PRE = 16;
+template <bool TAG>
+__device__ __forceinline__ void sf_bwd_wave(int s, int lane, double *w, const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
+                                            const int32_t *__restrict__ rows, const int32_t *__restrict__ need, int *done, int *err,
+                                            const double *work, double *x, double *xt) {
+    const FrontDesc fd = FD[s];
+    const int p = fd.p, f = fd.p + fd.m;
+    const int64_t ld = fd.ldp;
+    const double *Ep = pool + fd.epoff;
+    const double *W = work + fd.woff; // y1: written by the forward launch
+    const int32_t *rws = rows + fd.rowptr;
+    const int i = lane & 31, h = lane >> 5;
+    const double *Ei = Ep + (i < p ? i : p - 1);
+    double e[SF_WB_PRE];
+#pragma unroll
+    for (int c = 0; c < SF_WB_PRE; c++) {
+        const int j = h + 2 * c;
+        e[c] = Ei[(int64_t)(j < f ? j : f - 1) * ld];
+    }
+    // the front's vector: y1 on the pivot positions, x2 (row numbers first) below; positions lane and lane + 64
+    const int j0 = lane, j1 = lane + 64;
+    const double y0 = W[j0 < p ? j0 : 0];
+    const int row0 = (j0 >= p && j0 < f) ? rws[j0 - p] : -1, row1 = (j1 < f) ? rws[j1 - p] : -1; // (p <= 32 < 64 <= j1)
+    if constexpr (!TAG) {
+        if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
+        wave_sync();
+    }
+    double v0, v1;
+    if constexpr (TAG) {
+        v0 = ld_agent(xt + (row0 >= 0 ? row0 : 0)), v1 = ld_agent(xt + (row1 >= 0 ? row1 : 0));
+        if (row0 >= 0) v0 = sf_tag_wait(xt + row0, v0, err);
+        if (row1 >= 0) v1 = sf_tag_wait(xt + row1, v1, err);
+    } else {
+        v0 = ld_agent(x + (row0 >= 0 ? row0 : 0)), v1 = ld_agent(x + (row1 >= 0 ? row1 : 0));
+    }
+    w[j0] = j0 < p ? y0 : (row0 >= 0 ? v0 : 0.0);
+    w[j1] = row1 >= 0 ? v1 : 0.0;
+    wave_sync();
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int c = 0; c < SF_WB_PRE; c += 2) {
+        if (2 * c < f) { // (wave-uniform bound; positions past f multiply a clamped entry by the zero the vector holds there)
+            a += e[c] * w[h + 2 * c];
+            b += e[c + 1] * w[h + 2 * c + 2];
+        }
+    }
+    for (int c0 = SF_WB_PRE; 2 * c0 < f; c0 += SF_WB_PRE) { // (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < SF_WB_PRE; c++) {
+            const int j = h + 2 * (c0 + c);
+            e[c] = Ei[(int64_t)(j < f ? j : f - 1) * ld];
+        }
+#pragma unroll
+        for (int c = 0; c < SF_WB_PRE; c += 2) {
+            const int ja = h + 2 * (c0 + c), jb = ja + 2;
+            a += e[c] * (ja < SF_WF_ROWS ? w[ja] : 0.0);
+            b += e[c + 1] * (jb < SF_WF_ROWS ? w[jb] : 0.0);
+        }
+    }
+    double tot = a + b;
+    tot += __shfl_xor(tot, 32);
+    if (lane < p) { // (h = 0: lanes 0 .. p - 1)
+        st_agent(x + fd.first + lane, tot);
+        if constexpr (TAG) st_agent(xt + fd.first + lane, tot);
+    }
+    if constexpr (!TAG) {
+        drain_stores();
+        if (lane == 0) flag_add(done + s, 1);
+    }
+}
+
 // Backward pass, one launch per band of levels (tasks ordered root first).
 // SYM: instance for factors whose big fronts are L D L^T (x1 = E^T [D^{-1} y1; x2], transposed GEMV); the LU instance carries none of it.
 // TAG (K = 1 only): data-tagged hand-offs -- a front's solved pivot entries also go to the tagged shadow `xt` of x (all tag words before
@@ -1126,6 +1203,13 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
         return;
     }
     if (SMALL_ONLY) return;
+    if constexpr (K == 1 && !SMALL_ONLY && !SYM) {
+        if (t.kind == 2) { // wave fronts: one big front of few rows and pivots per wavefront
+            const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
+            if (s >= 0) sf_bwd_wave<TAG>(s, lane, lds + SF_WF_ROWS * wave, FD, pool, rows, need, done, err, work, x, xt);
+            return;
+        }
+    }
     // ---- pivot rows [r0, r1) of the big front t.a:  x1 = E' [y1; x2] ----
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr_g = 0, tr_d = 0;
     if (trace && tid == 0) tr0 = dev_clock();

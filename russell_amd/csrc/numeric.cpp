@@ -366,6 +366,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SPLIT_TASKS")) split_tasks = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
     if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_WAVE_FRONTS_BWD")) wave_fronts_bwd = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_UP_STAGE")) up_stage = std::max(0, std::min(64, atoi(e) / 8 * 8));
@@ -1052,6 +1053,13 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                     wavef.push_back(s);
                     need[(size_t)s] = 1;
                     wave_front_count++;
+                    continue;
+                }
+                // ... and in the backward pass (LU fronts: x1 = E' [y1; x2], sf_bwd_wave)
+                if (tree && !forward && wave_fronts && wave_fronts_bwd && !slab64 && !S.sym_mode && S.sn_level[s] < top_level && S.fsize(s) <= SF_WF_ROWS &&
+                    S.npiv(s) <= SF_WF_PIV) {
+                    wavef.push_back(s);
+                    need[(size_t)ns + s] = 1;
                     continue;
                 }
                 const int32_t kind = kind_of(s, forward), rows = 1 << kind, ext = forward ? S.fsize(s) : S.npiv(s);

@@ -27,6 +27,7 @@ else:
 
 VARIANTS = [
     ("defaults (tagged hand-offs, wave fronts)", {}),
+    ("wave fronts in the forward pass only", {"HIPMF_WAVE_FRONTS_BWD": "0"}),
     ("slab tasks instead of wave fronts", {"HIPMF_WAVE_FRONTS": "0"}),
     ("completion counters (HIPMF_TAG_SOLVE=0)", {"HIPMF_TAG_SOLVE": "0"}),
     ("counters, no wave fronts (round 4)", {"HIPMF_TAG_SOLVE": "0", "HIPMF_WAVE_FRONTS": "0"}),
@@ -36,7 +37,7 @@ VARIANTS = [
     ("caps 40 fronts / 128 KB per wave-subtree", {"HIPMF_WT_FRONTS": "40", "HIPMF_WT_KB": "128"}),
 ]
 if os.environ.get("SOLVE_VARIANTS_SHORT"):
-    VARIANTS = VARIANTS[:2]
+    VARIANTS = VARIANTS[:3]
 LIB = next((a[4:] for a in sys.argv[2:] if a.startswith("lib=")), None)
 ONLY = next((a[5:] for a in sys.argv[2:] if a.startswith("only=")), None)
 extra = [a for a in sys.argv[2:] if "=" in a and not a.startswith("lib=") and not a.startswith("only=")]
