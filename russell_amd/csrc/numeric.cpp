@@ -367,6 +367,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
     if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WAVE_FRONTS_BWD")) wave_fronts_bwd = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_MID_BWD_LEN4")) mid_bwd_len4 = std::max(1, atoi(e));
+    if (const char *e = getenv("HIPMF_MID_BWD_LEN5")) mid_bwd_len5 = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_FRONTS")) wt_max_fronts = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_WT_KB")) wt_max_kb = std::max(1, atoi(e));
     if (const char *e = getenv("HIPMF_UP_STAGE")) up_stage = std::max(0, std::min(64, atoi(e) / 8 * 8));
@@ -922,7 +924,8 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     // (kernels_solve_fused.hpp, sf_tag_wait) arm the first two parts with ONE memset before a pass pair.
     // Tagged hand-offs need a task list without ASSEMBLE tasks: matrices with fronts of sf_asm_front rows or more (3D: bound by
     // bandwidth, not by the hand-offs) keep the completion counters.
-    const bool tag_plan = use_tag && WP.ok_tree && !WP.roots.empty() && (sf_asm_front <= 0 || S.max_front < sf_asm_front);
+    const bool tag_shape = WP.ok_tree && !WP.roots.empty() && (sf_asm_front <= 0 || S.max_front < sf_asm_front); // (what the tagged hand-offs need; HIPMF_TAG_SOLVE=0 keeps the task shapes)
+    const bool tag_plan = use_tag && tag_shape;
     std::vector<char> interior((size_t)ns, 0);
     if (tag_plan)
         for (int32_t R : WP.roots)
@@ -1004,6 +1007,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
                 while (G < up_max_groups && len > 32 * G) G *= 2;
                 return G == 32 ? 3 : (G == 16 ? 4 : (G == 8 ? 5 : (G == 4 ? 6 : 7)));
             }
+            // backward slabs of the factors that qualify for the tagged hand-offs (a level is a hop of poll + dot products + store: shorter dot products per thread
+            // are worth the extra tasks): 16 rows from 256 positions on, 32 rows from 64 on (C2: backward 210.6 -> 207.0 us)
+            if (tree && tag_shape && !forward && !slab64) return len >= mid_bwd_len4 ? 4 : (len >= mid_bwd_len5 ? 5 : (len > 32 ? 6 : 7));
             return slab64 ? 6 : (len >= 512 ? 4 : (len >= 128 ? 5 : (len > 32 ? 6 : 7)));
         };
         bool skip_leaves = false;              // ... the one of the blocked instances when the leaves have kernels of their own
