@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <sstream>
 
 #include "../../../include/russell_hipmf.h"
@@ -879,11 +880,8 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
         // (csr_matrix.rs:359-480), so the triplet order may change between calls: the map is only used while the indices are
         // the ones it was built from (O(nnz) compare); otherwise the values go through the host conversion, and a changed
         // pattern is refused.
-        if (value_map_set && (std::memcmp(map_i.data(), mat.indices_i.data(), sizeof(int32_t) * mat.nnz) != 0 ||
-                              std::memcmp(map_j.data(), mat.indices_j.data(), sizeof(int32_t) * mat.nnz) != 0)) {
-            value_map_set = false;
-            map_i.clear(), map_j.clear();
-        }
+        // (that compare reads 16 bytes per triplet -- 1.5 - 2 ms of a 8.6 ms repeat call at 5 M triplets -- and its answer is almost always
+        //  "same": it runs on a host thread of its own BESIDE the mapped factorisation below, which is thrown away if the answer is "changed")
         if (!value_map_set) { // (the device refreshes the values through the map otherwise: no host conversion per call)
             const std::vector<int32_t> rp0 = csr.row_pointers, ci0 = csr.col_indices;
             StrError e = csr.update_from_coo(mat);
@@ -948,11 +946,29 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
     }
     uint64_t t0 = now_ns();
     int32_t status;
-    if (value_map_set && !first_call)
+    if (value_map_set && !first_call) {
+        std::future<bool> same = std::async(std::launch::async, [&]() {
+            return std::memcmp(map_i.data(), mat.indices_i.data(), sizeof(int32_t) * mat.nnz) == 0 &&
+                   std::memcmp(map_j.data(), mat.indices_j.data(), sizeof(int32_t) * mat.nnz) == 0;
+        });
         status = g_backend.factorize_mapped((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
                                             &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose,
                                             mat.values.data());
-    else
+        if (!same.get()) {
+            // the triplets came in another order than the map was built from: the factorisation just made used the wrong values.
+            // Host conversion (which also refuses a changed pattern), then the plain factorisation; the map is not used again.
+            value_map_set = false;
+            map_i.clear(), map_j.clear();
+            const std::vector<int32_t> rp0 = csr.row_pointers, ci0 = csr.col_indices;
+            StrError e = csr.update_from_coo(mat);
+            if (e) return e;
+            const size_t nz0 = (size_t)rp0[csr.nrow];
+            if (csr.row_pointers != rp0 || std::memcmp(ci0.data(), csr.col_indices.data(), sizeof(int32_t) * nz0) != 0)
+                return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
+            status = g_backend.factorize((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
+                                         &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose, csr.values.data());
+        }
+    } else
         status = g_backend.factorize((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
                                          &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose, csr.values.data());
     first_call = false;

@@ -280,6 +280,10 @@ class Solver {
     bool use_tag = true;                    // HIPMF_TAG_SOLVE=0: completion counters instead of data-tagged hand-offs above the wave-subtrees
     bool wave_fronts = true;                // HIPMF_WAVE_FRONTS=0: the big fronts of few rows / pivots right above the wave-subtrees stay 256-thread slab tasks in the forward pass
     int32_t mid_bwd_len4 = 256, mid_bwd_len5 = 64; // backward slabs below the top levels, tagged hand-offs: 16 / 32 rows from these dot lengths on (HIPMF_MID_BWD_LEN4 / _LEN5)
+    // host-pointer solves: buffers seen in the previous call are copied without the pinned staging buffer (HIPMF_HOST_DIRECT=0: always staged)
+    bool host_direct = true;
+    const double *last_host_rhs = nullptr;
+    double *last_host_x = nullptr;
     bool wave_fronts_bwd = true; // ... and of the backward pass (HIPMF_WAVE_FRONTS_BWD=0: slab tasks there)
     bool tag_active = false;                // the launches above the wave-subtrees run their TAG instances (kernels_solve_fused.hpp, sf_tag_wait)
     int64_t work_arm0 = 0;                  // ... of which the first work_arm0 doubles (the roots of the wave-subtrees) are not armed: k_wt_fwd writes them in a launch of its own

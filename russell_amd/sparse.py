@@ -467,9 +467,13 @@ class _Actual:
 
     def solve(self, rhs, x=None, verbose=False):
         rhs = _vec(rhs)
-        out = np.zeros(self._ndim if (x is None and self._ndim is not None) else (len(x) if x is not None else rhs.size))
+        # (the reference's signature is solve(&mut x, &rhs): a caller's float64 vector is written in place, like the Rust caller's)
+        if isinstance(x, np.ndarray) and x.dtype == np.float64 and x.ndim == 1 and x.flags.c_contiguous and x.flags.writeable:
+            out = x
+        else:
+            out = np.zeros(self._ndim if (x is None and self._ndim is not None) else (len(x) if x is not None else rhs.size))
         _check(_L().rh_linsolver_solve(self._h, _ptr(out), out.size, _ptr(rhs), rhs.size, int(verbose)))
-        if x is not None:
+        if x is not None and out is not x:
             x[:] = out
         return out
 

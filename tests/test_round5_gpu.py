@@ -206,3 +206,26 @@ def test_split_dot_products_of_blocked_backward_slabs_on_the_device(monkeypatch)
             assert got[tag][2] == 0
             assert np.max(np.abs(got[tag][0] - XS)) <= 1e-10 * np.max(np.abs(XS))
             assert np.max(np.abs(got[tag][0] - got["off"][0])) <= 1e-12 * np.max(np.abs(got["off"][0]))
+
+
+def test_host_solves_with_the_same_buffers_skip_the_staging_copy():
+    # a caller that comes back with the SAME (x, rhs) host buffers as in its last call is copied directly, any other call goes through
+    # the pinned staging buffer (numeric.cpp, Solver::solve): the same bits either way, and a change of buffers in between is harmless
+    n, rp, ci, v = P.poisson2d(300, 280)
+    rng = np.random.default_rng(9)
+    b1, b2 = rng.standard_normal(n), rng.standard_normal(n)
+    s = Hipmf()
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    lib = s.lib
+    x1, x2 = np.zeros(n), np.zeros(n)
+    ref1, ref2 = s.solve(b1), s.solve(b2)  # (fresh buffers: staged)
+    for rep in range(3):  # first call of a pair staged, the following ones direct
+        assert lib.solver_hipmf_solve(s.h, x1, b1, 0) == 0
+        assert np.array_equal(x1, ref1)
+    assert lib.solver_hipmf_solve(s.h, x2, b2, 0) == 0 and np.array_equal(x2, ref2)
+    b1[:] = b2  # same buffers, new contents
+    assert lib.solver_hipmf_solve(s.h, x1, b1, 0) == 0 and np.array_equal(x1, ref2)
+    assert lib.solver_hipmf_solve(s.h, x1, b1, 0) == 0 and np.array_equal(x1, ref2)
+    assert _metric(n, rp, ci, v, x1, b2) <= 1e-10
+    s.close()

@@ -242,6 +242,28 @@ def test_split_dot_products_of_the_blocked_backward_slabs(emu_lib, monkeypatch):
             assert np.max(np.abs(got["1000000"][0] - XS)) <= 1e-11 * np.max(np.abs(XS))
 
 
+def test_host_solves_with_the_same_buffers_take_the_direct_copies(emu_lib):
+    # Solver::solve copies a single right-hand side directly when the caller comes back with the (x, rhs) buffers of its last call, through
+    # the pinned staging buffer otherwise: same results, and new contents in the same buffers are what gets solved (the GPU twin:
+    # tests/test_round5_gpu.py)
+    n, rp, ci, v = P.poisson2d(40, 36)
+    rng = np.random.default_rng(9)
+    b1, b2 = rng.standard_normal(n), rng.standard_normal(n)
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci) == 0
+    assert s.factorize(v) == 0
+    x1, x2 = np.zeros(n), np.zeros(n)
+    ref1, ref2 = s.solve(b1), s.solve(b2)
+    for rep in range(3):
+        assert s.lib.solver_hipmf_solve(s.h, x1, b1, 0) == 0
+        assert np.array_equal(x1, ref1)
+    assert s.lib.solver_hipmf_solve(s.h, x2, b2, 0) == 0 and np.array_equal(x2, ref2)
+    b1[:] = b2
+    assert s.lib.solver_hipmf_solve(s.h, x1, b1, 0) == 0 and np.array_equal(x1, ref2)
+    assert s.lib.solver_hipmf_solve(s.h, x1, b1, 0) == 0 and np.array_equal(x1, ref2)
+    s.close()
+
+
 def _lower(mat):
     n, rp, ci, v = mat
     lrp, lci, lv = P.lower_triangle(n, rp, ci, v)
