@@ -985,11 +985,16 @@ int64_t SolverHIPMF::get_counter(int32_t which) const { return solver ? g_backen
 int64_t ComplexSolverHIPMF::get_counter(int32_t which) const { return solver ? g_backend.zget_counter((InterfaceComplexHIPMF *)solver, which) : -1; }
 
 StrError SolverHIPMF::solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) {
+    return solve_slices(x.data(), x.size(), rhs.data(), rhs.size(), verbose);
+}
+
+// the same on borrowed slices (&mut [f64], &[f64] in the reference): what the C glue of the Python driver calls, without copies
+StrError SolverHIPMF::solve_slices(double *x, size_t nx, const double *rhs, size_t nr, bool verbose) {
     if (!factorized) return "the function factorize must be called before solve";
-    if (x.size() != initialized_ndim) return "the dimension of the vector of unknown values x is incorrect";
-    if (rhs.size() != initialized_ndim) return "the dimension of the right-hand side vector is incorrect";
+    if (nx != initialized_ndim) return "the dimension of the vector of unknown values x is incorrect";
+    if (nr != initialized_ndim) return "the dimension of the right-hand side vector is incorrect";
     uint64_t t0 = now_ns();
-    int32_t status = g_backend.solve((InterfaceHIPMF *)solver, x.data(), rhs.data(), verbose ? 1 : 0);
+    int32_t status = g_backend.solve((InterfaceHIPMF *)solver, x, rhs, verbose ? 1 : 0);
     if (status != SUCCESSFUL_EXIT) return handle_hipmf_error_code(status);
     time_solve_ns = now_ns() - t0;
     return nullptr;
@@ -1701,6 +1706,7 @@ const char *rh_linsolver_factorize(void *h, void *coo, const RhParams *params) {
 }
 const char *rh_linsolver_solve(void *h, double *x, int64_t nx, const double *rhs, int64_t nr, int32_t verbose) {
     RhSolver *s = (RhSolver *)h;
+    if (SolverHIPMF *a = dynamic_cast<SolverHIPMF *>(s->ls.actual.get())) return a->solve_slices(x, (size_t)nx, rhs, (size_t)nr, verbose != 0);
     std::vector<double> xx((size_t)nx), rr(rhs, rhs + nr);
     StrError e = s->ls.actual->solve(xx, rr, verbose != 0);
     if (!e) std::copy(xx.begin(), xx.end(), x);

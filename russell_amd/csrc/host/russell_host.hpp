@@ -192,6 +192,7 @@ class SolverHIPMF : public LinSolTrait {
     ~SolverHIPMF() override;
     StrError factorize(const CooMatrix &mat, const LinSolParams *params) override;
     StrError solve(std::vector<double> &x, const std::vector<double> &rhs, bool verbose) override;
+    StrError solve_slices(double *x, size_t nx, const double *rhs, size_t nr, bool verbose); // (borrowed slices: no copies)
     void update_stats(StatsLinSol &stats) const override;
     uint64_t get_ns_init() const override { return time_initialize_ns; }
     uint64_t get_ns_fact() const override { return time_factorize_ns; }
