@@ -300,6 +300,10 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             std::lock_guard<std::mutex> lock(err_mutex);
             last_error = "Not enough memory: a host allocation failed";
             prep_code = ERROR_MALLOC;
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            last_error = "initialize: the device set-up failed with an exception";
+            prep_code = ERROR_HIPMF_INVALID_VALUE;
         }
     });
     struct PrepJoiner { // (every early return below waits for the thread)
