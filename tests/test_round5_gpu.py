@@ -197,6 +197,9 @@ def test_split_dot_products_of_blocked_backward_slabs_on_the_device(monkeypatch)
             X = s.solve_many(B)
             for _ in range(3):
                 assert np.array_equal(X, s.solve_many(B))
+            X7 = s.solve_many(B[:7])  # (the 8-column instance: chunks of 512 positions)
+            assert np.array_equal(X7, s.solve_many(B[:7]))
+            assert np.max(np.abs(X7 - XS[:7])) <= 1e-10 * np.max(np.abs(XS))
             got[tag] = (X, s.counter("split_slabs"), s.counter("fused_fallbacks"))
             s.close()
             for k in env:
