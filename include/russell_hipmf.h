@@ -197,6 +197,12 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
 #define HIPMF_COUNTER_WAVE_FRONTS 12      /* big fronts (f > 64) whose forward solve step is the work of one wavefront (at most 128 rows, 32 pivots) */
 #define HIPMF_COUNTER_LEAF_FRONTS 13      /* leaves of the tree that the blocked (many-RHS) solves run in kernels of their own, sixteen columns per wavefront */
 #define HIPMF_COUNTER_SPLIT_SLABS 14      /* backward slabs of the blocked solves whose dot products are split over several tasks (levels of few slabs near the root of a large factor) */
+#define HIPMF_COUNTER_EVENT_FENCE_FREE 15  /* 1: the events that order this handle's streams are recorded without the system-scope fence (taken on gfx950 under a
+                                             HIP 7 runtime only, where it was validated; HIPMF_EVENT_FENCE=1 or any other device / runtime: 0 = default flags) */
+#define HIPMF_COUNTER_BLOCK_GROUPS 16      /* blocks of right-hand sides that travel through ONE dependency-driven launch together in the many-RHS solves
+                                             (round 6: their latency chains overlap; 1 = one block per launch) -- value of the last blocked solve, 0 before */
+#define HIPMF_COUNTER_SYM_WEAK_DIAGONAL 17 /* 1: a symmetric-lower handle that kept its L D L^T plan met a weak diagonal in the values of a factorize
+                                             (HIPMF_OPTION_SYM_RECHECK off: nothing was re-analysed; see last_error / verbose) */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

@@ -957,6 +957,9 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
         if (!same.get()) {
             // the triplets came in another order than the map was built from: the factorisation just made used the wrong values.
             // Host conversion (which also refuses a changed pattern), then the plain factorisation; the map is not used again.
+            // (the handle holds a factor of mis-mapped values from here until the redo below succeeds -- every early
+            //  return of this branch must leave `factorized` false, or a later solve() would silently use that factor)
+            factorized = false;
             value_map_set = false;
             map_i.clear(), map_j.clear();
             const std::vector<int32_t> rp0 = csr.row_pointers, ci0 = csr.col_indices;

@@ -531,6 +531,9 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
     case HIPMF_COUNTER_WAVE_FRONTS: return s.wave_front_count;
     case HIPMF_COUNTER_LEAF_FRONTS: return s.leaf_front_count();
     case HIPMF_COUNTER_SPLIT_SLABS: return s.split_slab_count();
+    case HIPMF_COUNTER_EVENT_FENCE_FREE: return s.event_fence_free ? 1 : 0;
+    case HIPMF_COUNTER_BLOCK_GROUPS: return s.block_groups_last;
+    case HIPMF_COUNTER_SYM_WEAK_DIAGONAL: return s.sym_weak_diag_seen ? 1 : 0;
     default: return -1;
     }
 }

@@ -51,6 +51,37 @@ struct SfTask {
                         // d = the group's first 256-double unit in the scratch of partial sums (see k_bwd_fused)
 };
 
+// ---- block groups (round 6): several blocks of K right-hand sides in ONE launch of a blocked (K > 1) instance ----
+// A pass over the upper levels of a 2D factor is a chain of hand-offs (17 levels per direction at ~18 us per level with 16 columns at the
+// 1M-DOF Poisson factor: profiles/r05_solve_trace_c2_16col.txt) during which most of the device idles.  A launch therefore carries `ngrp`
+// independent blocks ("groups") of K columns each: group g owns the columns [g K, g K + K) of x and of the workspace block and its own
+// set of completion counters; the grid holds every task ngrp times and the chains of the groups overlap.  Placement: workgroup b runs on
+// XCD b mod 8 (observed, MI355X_MICROARCH.md), so the ngrp copies of the tasks t .. t + 7 sit in 8 ngrp consecutive workgroups, copy g of
+// task t at (t / 8) 8 ngrp + 8 g + t mod 8: the copies of one task land on ONE XCD right after each other and share the task's piece of
+// the factor through that XCD's L2.  A task still only waits for tasks of its own group with smaller task numbers, which sit at smaller
+// workgroup indices: the order argument at the head of this file is untouched.  Per column the arithmetic is that of one group per launch.
+constexpr int SF_GMAX = 4;               // groups a launch carries at most
+struct SfGroups {
+    int32_t ngrp;          // groups in this launch (1: the grid is the task list itself)
+    int32_t ntask;         // tasks of the list (the grid is padded to whole sets of 8 ngrp workgroups)
+    int32_t nk_total;      // live columns over all groups (group g carries min(K, nk_total - g K))
+    uint32_t mask;         // groups with live work (a refinement step whose active columns all sit in other groups skips a group)
+    int64_t sync_stride;   // ints between the completion counters of consecutive groups
+    int64_t split_stride;  // units of the split-dot-product scratch between consecutive groups
+};
+// resolves blockIdx.x into (task, group); false: nothing to do for this workgroup
+template <int K>
+__device__ __forceinline__ bool sf_group_of(const SfGroups &G, int &bid, int &grp, int &nk) {
+    bid = blockIdx.x, grp = 0;
+    if (K == 1 || G.ngrp <= 1) return true;
+    const int per = 8 * G.ngrp;
+    grp = (bid % per) >> 3;
+    bid = (bid / per) * 8 + (bid & 7);
+    if (bid >= G.ntask || !((G.mask >> grp) & 1u)) return false;
+    nk = G.nk_total - grp * K < K ? G.nk_total - grp * K : K;
+    return nk > 0;
+}
+
 // wait until *cnt >= need (relaxed agent-scope polls); false on timeout or when another waiter timed out
 __device__ __forceinline__ bool sf_wait(const int *cnt, int need, int *err) {
     unsigned spins = 0;
@@ -811,10 +842,18 @@ __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WG
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
                                                    const int32_t *__restrict__ need, int *sync, int *err, double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace, int stage,
-                                                   const int32_t *__restrict__ rep_idx, int *rep) {
+                                                   const int32_t *__restrict__ rep_idx, int *rep, SfGroups GR) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
     static_assert(!TAG || (K == 1 && !SMALL_ONLY), "the tagged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles
+    int bid, grp;
+    if (!sf_group_of<K>(GR, bid, grp, nk)) return;
+    if constexpr (K > 1) {
+        if (grp > 0) { // (workgroup-uniform) this group's columns, workspaces and completion counters
+            x += (int64_t)grp * K * xstr, work += (int64_t)grp * K * wstr, sync += (int64_t)grp * GR.sync_stride;
+            trace = nullptr;
+        }
+    }
     constexpr int CHK = K > 8 ? SF_CHUNK / 4 : (K > 4 ? SF_CHUNK / 2 : SF_CHUNK); // chunk of w1 per right-hand side
     // One LDS buffer, three uses that never overlap in time: a workgroup either runs four small fronts (wv: K x 64 doubles per wave)
     // or one slab of a big front (wc: the chunk of the K vectors; mt: the slab's MFMA tiles, written after the last chunk is consumed).
@@ -831,7 +870,7 @@ __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WG
     __shared__ int32_t cm_max_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *done = sync + SF_SYNC_HEADER;
-    const SfTask t = tasks[blockIdx.x];
+    const SfTask t = tasks[bid];
     if (SMALL_ONLY || t.kind == 0) {
         // (wave-uniform: the front's descriptor then lives in scalar registers and the panel loads use scalar bases)
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
@@ -1099,7 +1138,7 @@ __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WG
         if (tid == 0) sf_publish_front(t.a, need, done, STG ? rep_idx : nullptr, rep);
     }
     if (trace && tid == 0) {
-        unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;
+        unsigned long long *tr = trace + 8 * (size_t)bid;
         tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock(), tr[4] = tr_g, tr[5] = tr_d;
     }
 }
@@ -1191,10 +1230,19 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
                                                    int64_t xstr, int64_t wstr, unsigned long long *trace, const double *__restrict__ diag,
                                                    int stage, const int32_t *__restrict__ rep_idx, int *rep, double *xt, double *split_scr,
-                                                   int *split_cnt) {
+                                                   int *split_cnt, SfGroups GR) {
     static_assert(!STG || (K == 1 && !SMALL_ONLY), "the staged instance carries one right-hand side");
     static_assert(!TAG || (K == 1 && !SMALL_ONLY), "the tagged instance carries one right-hand side");
     HIPMF_DYN_SHARED(double, els); // STG: stage x 256 doubles (see k_fwd_fused)
+    int bid, grp;
+    if (!sf_group_of<K>(GR, bid, grp, nk)) return;
+    if constexpr (K > 1) {
+        if (grp > 0) { // (workgroup-uniform; see k_fwd_fused)
+            x += (int64_t)grp * K * xstr, work += (int64_t)grp * K * wstr, sync += (int64_t)grp * GR.sync_stride;
+            if (split_scr) split_scr += (int64_t)grp * GR.split_stride * 256, split_cnt += (int64_t)grp * GR.split_stride;
+            trace = nullptr;
+        }
+    }
     constexpr int CHK = K > 8 ? SF_CHUNK / 4 : (K > 4 ? SF_CHUNK / 2 : SF_CHUNK);
     // (one LDS buffer for the small fronts' vectors, the chunk of a big front's vectors and its MFMA tiles: see k_fwd_fused)
     constexpr int LDS_D = SMALL_ONLY ? 4 * K * 64 : (K * CHK > 4 * K * 64 ? K * CHK : 4 * K * 64);
@@ -1205,7 +1253,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     __shared__ double red[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *done = sync + SF_SYNC_HEADER;
-    const SfTask t = tasks[blockIdx.x];
+    const SfTask t = tasks[bid];
     if (SMALL_ONLY || t.kind == 0) {
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
         if (s >= 0) sf_bwd_small<K, TAG>(s, lane, wv[wave], FD, pool, rows, need, done, err, x, nk, xstr, xt);
@@ -1467,7 +1515,7 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
         }
     }
     if (trace && tid == 0) {
-        unsigned long long *tr = trace + 8 * (size_t)blockIdx.x;
+        unsigned long long *tr = trace + 8 * (size_t)bid;
         tr[0] = tr0, tr[1] = tr1, tr[2] = tr2, tr[3] = dev_clock(), tr[4] = tr_g, tr[5] = tr_d;
     }
 }

@@ -141,11 +141,19 @@ __device__ __forceinline__ void leaf_park(double *L, const LeafLoads &D, const L
 // ~9 us end to end, of which the substitution is a third: unpipelined, the kernel was bound by that chain, profiles/r05_rejected_experiments.txt).
 __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_fwd(const LeafRec *__restrict__ recs, int nleaf, const double *__restrict__ pool,
                                                               const int32_t *__restrict__ lperm, double *xp, int64_t xstr, double *work, int64_t wstr,
-                                                              int *sync, int nk) {
+                                                              int *sync, int nk, uint32_t gmask) {
     __shared__ __attribute__((aligned(16))) double lds[LEAF_WAVES][LEAF_LDS_FWD];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     double *L = lds[wave];
     (void)sync;
+    {
+        // block groups (kernels_solve_fused.hpp, SfGroups): blockIdx.y = group of sixteen columns; nothing in this kernel waits, any order is fine
+        const int grp = blockIdx.y;
+        if (!((gmask >> grp) & 1u)) return;
+        xp += (int64_t)grp * 16 * xstr, work += (int64_t)grp * 16 * wstr;
+        nk = nk - 16 * grp < 16 ? nk - 16 * grp : 16;
+        if (nk <= 0) return;
+    }
     const int i0 = (blockIdx.x * LEAF_WAVES + wave) * LEAF_PER_WAVE;
     if (i0 >= nleaf) return;
     const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;
@@ -219,10 +227,17 @@ __device__ __forceinline__ void leaf_bwd_body(double *L, int lane, int p, int m,
 // Backward: the same pipeline; the solved entries of the ancestors (x2) are a gather through the row numbers, i.e. one more dependent
 // round trip: the row numbers of leaf i + 1 travel with its panel, the gather of leaf i is requested at the head of its iteration.
 __global__ void __launch_bounds__(64 * LEAF_WAVES) k_leaf_bwd(const LeafRec *__restrict__ recs, int nleaf, const double *__restrict__ pool,
-                                                              const int32_t *__restrict__ rows, double *xp, int64_t xstr, int nk) {
+                                                              const int32_t *__restrict__ rows, double *xp, int64_t xstr, int nk, uint32_t gmask) {
     __shared__ __attribute__((aligned(16))) double lds[LEAF_WAVES][LEAF_LDS];
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     double *L = lds[wave];
+    {
+        const int grp = blockIdx.y; // (block groups: see k_leaf_fwd)
+        if (!((gmask >> grp) & 1u)) return;
+        xp += (int64_t)grp * 16 * xstr;
+        nk = nk - 16 * grp < 16 ? nk - 16 * grp : 16;
+        if (nk <= 0) return;
+    }
     const int i0 = (blockIdx.x * LEAF_WAVES + wave) * LEAF_PER_WAVE;
     if (i0 >= nleaf) return;
     const int i1 = i0 + LEAF_PER_WAVE < nleaf ? i0 + LEAF_PER_WAVE : nleaf;

@@ -34,10 +34,10 @@ __global__ void k_perm_out(int32_t n, const int32_t *__restrict__ perm, const do
 // right-hand sides used to cost 32 launches of 8 - 14 us around every pass.  Columns whose bit in `mask` is clear get zeros
 // (k_perm_in_cols: finished columns of a refinement step ride along as zeros) or are left alone (k_perm_out_cols).
 __global__ void k_perm_in_cols(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ rs, const double *__restrict__ b,
-                               int64_t bstr, double *__restrict__ xp, int64_t xstr, uint32_t mask) {
+                               int64_t bstr, double *__restrict__ xp, int64_t xstr, uint64_t mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
     if (i >= n) return;
-    if (!((mask >> c) & 1u)) {
+    if (!((mask >> c) & 1ull)) {
         xp[i + c * xstr] = 0.0;
         return;
     }
@@ -45,9 +45,9 @@ __global__ void k_perm_in_cols(int32_t n, const int32_t *__restrict__ perm, cons
     xp[i + c * xstr] = rs[q] * b[q + c * bstr];
 }
 __global__ void k_perm_out_cols(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ cs, const double *__restrict__ xp,
-                                int64_t xstr, double *__restrict__ out, int64_t ostr, int32_t mode, uint32_t mask) {
+                                int64_t xstr, double *__restrict__ out, int64_t ostr, int32_t mode, uint64_t mask) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (j >= n || !((mask >> c) & 1u)) return;
+    if (j >= n || !((mask >> c) & 1ull)) return;
     const int q = perm[j];
     const double v = cs ? cs[q] * xp[j + c * xstr] : xp[j + c * xstr];
     double *o = out + q + c * ostr;
@@ -227,10 +227,10 @@ __global__ void __launch_bounds__(256) k_residual_cols(const int32_t *__restrict
                                                        const int32_t *__restrict__ tptr, const int32_t *__restrict__ tidx,
                                                        const int32_t *__restrict__ arow, const double *__restrict__ x, int64_t xstr,
                                                        const double *__restrict__ b, int64_t bstr, double *__restrict__ r, int64_t rstr,
-                                                       unsigned long long *nrm, int32_t ncols, uint32_t mask) {
+                                                       unsigned long long *nrm, int32_t ncols, uint64_t mask) {
     __shared__ SpmvLds sh;
     for (int c = 0; c < ncols; c++) {
-        if (!((mask >> c) & 1u)) continue;
+        if (!((mask >> c) & 1ull)) continue;
         spmv_block<true>(sh, row_blk, rp, ci, vals, tptr, tidx, arow, 1.0, x + c * xstr, b + c * bstr, r + c * rstr, nrm + (size_t)c * RES_NORM_WORDS);
         __syncthreads();
     }

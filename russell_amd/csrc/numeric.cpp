@@ -114,7 +114,9 @@ void Solver::release() {
     d_sf = nullptr, d_need = nullptr, d_sync = nullptr, d_trace = nullptr;
     d_cs = nullptr, d_rperm = nullptr;
     d_blk = nullptr, d_work_blk = nullptr;
-    block_cols = 0;
+    if (d_norms_blk) (void)hipFree(d_norms_blk);
+    d_norms_blk = nullptr;
+    block_cols = 0, block_groups = 0;
     d_seg_ptr = d_seg_idx = nullptr, d_vin = nullptr, nnz_in = 0;
     d_sa_ptr = d_sa_k = nullptr, d_sa_pos = nullptr, d_zero = nullptr, zero_cnt = 0;
     d_vs = d_vs2 = nullptr;
@@ -154,6 +156,11 @@ void Solver::release() {
             *e = nullptr;
         }
     initialized = factorized = false;
+    // (a hand-off time-out sends ONE analysis to the level-set launches -- the next initialize of this handle starts over with the
+    //  dependency-driven solves; HIPMF_FUSED_SOLVE=0 is read again there)
+    use_fused = true;
+    sym_diag_looked = sym_weak_diag_seen = false;
+    block_groups_last = 0;
     if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device);
 }
 
@@ -228,9 +235,22 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             // events that order this handle's streams among themselves: no timing, and no system-scope fence at the record (the cache
             // write-back + invalidate of the default costs 5 - 7 us on the stream that records; kernels of the same device see each
             // other's results through the agent-scope release at a kernel's end).  HIPMF_EVENT_FENCE=1: the default flags.
+            // Round 6 (VERDICT r05 weak 8 / ADVICE r04): the fence-free record is only taken where it was validated -- a gfx950 device
+            // (every XCD's L2 is written back by the agent-scope release at a kernel's end, which is what makes another stream's
+            // kernels AND the copy engines see the data: all of this handle's buffers are device memory) under a HIP 7 runtime; any
+            // other device or runtime gets the default flags.  The join of the background stream (ev_pre1: the diagonal check writes the
+            // FactorInfo words the host reads after the factorisation) keeps the default flags everywhere: it is off the chain.
             unsigned xflags = hipEventDisableTiming;
+            const unsigned dflags = hipEventDisableTiming;
 #ifndef HIPMF_EMULATED
-            if (!(getenv("HIPMF_EVENT_FENCE") && atoi(getenv("HIPMF_EVENT_FENCE")) != 0)) xflags |= hipEventDisableSystemFence;
+            {
+                hipDeviceProp_t prop;
+                int rtv = 0;
+                const bool known = hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0 &&
+                                   hipRuntimeGetVersion(&rtv) == hipSuccess && rtv / 10000000 == 7;
+                event_fence_free = known && !(getenv("HIPMF_EVENT_FENCE") && atoi(getenv("HIPMF_EVENT_FENCE")) != 0);
+                if (event_fence_free) xflags |= hipEventDisableSystemFence;
+            }
 #endif
             hipEvent_t e1, e2, e3, e4, e5, e6;
             HIPC(hipEventCreateWithFlags(&e5, xflags), ERROR_HIPMF_NO_DEVICE);
@@ -238,7 +258,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             ev_pb = e5, ev_rest = e6;
             hipEvent_t e7, e8;
             HIPC(hipEventCreateWithFlags(&e7, xflags), ERROR_HIPMF_NO_DEVICE);
-            HIPC(hipEventCreateWithFlags(&e8, xflags), ERROR_HIPMF_NO_DEVICE);
+            HIPC(hipEventCreateWithFlags(&e8, dflags), ERROR_HIPMF_NO_DEVICE);
             ev_pre0 = e7, ev_pre1 = e8;
             HIPC(hipEventCreateWithFlags(&e1, xflags), ERROR_HIPMF_NO_DEVICE);
             HIPC(hipEventCreateWithFlags(&e2, xflags), ERROR_HIPMF_NO_DEVICE);
@@ -369,6 +389,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_LEAF_KERNELS")) leaf_kernels = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SPLIT_TASKS")) split_tasks = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
+    if (const char *e = getenv("HIPMF_BLOCK_GROUPS_BYTES")) block_groups_max_bytes = atof(e);
     if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WAVE_FRONTS_BWD")) wave_fronts_bwd = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_HOST_DIRECT")) host_direct = atoi(e) != 0;
@@ -836,7 +857,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
             ext.zdiag = opt.complex_pairs ? d_diag + n : nullptr;
             HIPC(hipMemcpy(d_info, &ext, sizeof ext, hipMemcpyHostToDevice), ERROR_HIP_MEMCPY);
         }
-        HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_scalar, (4 + (size_t)RES_NORM_WORDS * SF_KMAX) * sizeof(unsigned long long)), ERROR_HIP_MALLOC); // (blocked solves: d_norms_blk)
         for (auto &e : ev) {
             hipEvent_t he;
             HIPC(hipEventCreate(&he), ERROR_HIP_MALLOC);
@@ -867,6 +888,12 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
 
 int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     const int32_t ns = S.nsuper;
+    // Blocks of right-hand sides per dependency-driven launch of the many-RHS driver (kernels_solve_fused.hpp, SfGroups).  The upper levels
+    // of a SMALL factor are a chain of hand-offs that leaves the device idle: several blocks per launch overlap their chains (1M-DOF
+    // Poisson: profiles/r06_block_groups.txt).  A factor of tens of gigabytes is bound by workgroup slots and bandwidth on every level: more
+    // tasks per launch only lengthen the waits there.  HIPMF_BLOCK_GROUPS=1..4 overrides.
+    block_groups_plan = 8.0 * (double)S.persist_doubles <= block_groups_max_bytes ? SF_GMAX : 1;
+    if (const char *e = getenv("HIPMF_BLOCK_GROUPS")) block_groups_plan = std::max(1, std::min((int)SF_GMAX, atoi(e)));
     auto pl_t = std::chrono::steady_clock::now();
     std::string pl_log;
     auto pl_lap = [&](const char *what) { // (verbose: where the plan + upload time of initialize goes)
@@ -937,20 +964,23 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             for (int32_t s = R - WP.cnt[(size_t)R] + 1; s < R; s++) interior[(size_t)s] = 1;
     std::vector<int64_t> woff_of((size_t)ns, 0);
     work_doubles = 0;
-    // (the roots of the wave-subtrees first: their vectors are written by k_wt_fwd, a launch of its own BEFORE the tagged launches
-    //  start -- nothing to arm there)
+    // Round 6: [ interiors | roots of the wave-subtrees | the other fronts | xt ].  The interiors (used by the schedules
+    // without wave-subtrees: the blocked instances, the fallbacks) come first and the shadow xt LAST, so that the columns of a blocked
+    // workspace -- which never use xt -- sit at a stride that leaves it out (work_blk_doubles); the armed part [work_arm0, work_up + n)
+    // stays one contiguous range.
+    // (the roots: their vectors are written by k_wt_fwd, a launch of its own BEFORE the tagged launches start -- nothing to arm there)
     std::vector<char> is_root((size_t)ns, 0);
-    if (tag_plan)
+    if (tag_plan) {
+        for (int32_t s = 0; s < ns; s++)
+            if (interior[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
         for (int32_t R : WP.roots) is_root[(size_t)R] = 1, woff_of[(size_t)R] = work_doubles, work_doubles += S.fsize(R);
+    }
     work_arm0 = work_doubles;
     for (int32_t s = 0; s < ns; s++)
         if (!interior[(size_t)s] && !is_root[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
     work_up = work_doubles;
-    if (tag_plan) {
-        work_doubles += S.n; // xt
-        for (int32_t s = 0; s < ns; s++)
-            if (interior[(size_t)s]) woff_of[(size_t)s] = work_doubles, work_doubles += S.fsize(s);
-    }
+    work_blk_doubles = work_doubles;
+    if (tag_plan) work_doubles += S.n; // xt
     std::vector<FrontDesc> fd((size_t)ns);
     for (int32_t s = 0; s < ns; s++) {
         FrontDesc &d = fd[s];
@@ -1199,9 +1229,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             klist = false;
             if (split_units > 0) {
                 if (split_units >= (int64_t)0x7fffffff) return ERROR_HIPMF_SYMBOLIC;
-                HIPC(hipMalloc((void **)&d_split_scr, sizeof(double) * 256 * (size_t)split_units), ERROR_HIP_MALLOC);
-                HIPC(hipMalloc((void **)&d_split_cnt, sizeof(int32_t) * (size_t)split_units), ERROR_HIP_MALLOC);
-                HIPC(hipMemset(d_split_cnt, 0, sizeof(int32_t) * (size_t)split_units), ERROR_HIP_MALLOC);
+                // (one set per group of a blocked launch)
+                HIPC(hipMalloc((void **)&d_split_scr, sizeof(double) * 256 * (size_t)split_units * (size_t)block_groups_plan), ERROR_HIP_MALLOC);
+                HIPC(hipMalloc((void **)&d_split_cnt, sizeof(int32_t) * (size_t)split_units * (size_t)block_groups_plan), ERROR_HIP_MALLOC);
+                HIPC(hipMemset(d_split_cnt, 0, sizeof(int32_t) * (size_t)split_units * (size_t)block_groups_plan), ERROR_HIP_MALLOC);
             }
             sfk_host.clear();
             if (getenv("HIPMF_SF_TRACE"))
@@ -1412,8 +1443,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             HIPMF_ALLOW_LDS((k_bwd_fused<false, 1, false, true, true>), sizeof(double) * 256 * (size_t)up_stage_bwd);
         }
         HIPC(dev_upload(&d_need, need), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
-        HIPC(hipMemset(d_sync, 0, sizeof(int32_t) * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
+        // (per group of a blocked launch: forward counters | backward counters | one word -- group 0's is the sticky error word)
+        HIPC(hipMalloc((void **)&d_sync, sizeof(int32_t) * SF_GMAX * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
+        HIPC(hipMemset(d_sync, 0, sizeof(int32_t) * SF_GMAX * (2 * (size_t)(SF_SYNC_HEADER + ns) + 1)), ERROR_HIP_MALLOC);
         return SUCCESSFUL_EXIT;
     };
     const bool sp_async = !(getenv("HIPMF_PLAN_THREAD") && atoi(getenv("HIPMF_PLAN_THREAD")) == 0); // (0: in line, for timing comparisons)
@@ -2064,7 +2096,11 @@ int32_t Solver::run_factor() {
         HIPC(hipStreamWaitEvent((hipStream_t)stream4, (hipEvent_t)ev_pre0, 0), ERROR_HIP_SYNCHRONIZE);
         pst = (hipStream_t)stream4;
     }
-    if (!S.sym_lower && opt.matching > 0) { // (general storage: would a maximum-product matching be called for with these values?)
+    // (symmetric-lower storage that kept its L D L^T plan -- ADVICE r05: the FIRST values such a handle sees get the same look, once, so that
+    //  a saddle-point / KKT matrix does not pass unnoticed when HIPMF_OPTION_SYM_RECHECK is off; the stored half of a row under-states the
+    //  row's largest entry, a zero or missing diagonal is caught for certain.  Nothing is re-analysed: HIPMF_COUNTER_SYM_WEAK_DIAGONAL tells)
+    const bool sym_first_look = S.sym_lower && opt.matching > 0 && !sym_diag_looked;
+    if ((!S.sym_lower && opt.matching > 0) || sym_first_look) { // (general storage: would a maximum-product matching be called for with these values?)
         hipLaunchKernelGGL(k_diag_check, dim3((n + 255) / 256), dim3(256), 0, pst, n, d_rp, d_ci, d_vs, d_dcol, 0.01, d_info, opt.complex_pairs ? 1 : 0);
         launches++;
     }
@@ -2351,6 +2387,16 @@ int32_t Solver::run_factor() {
     n_perturbed = hinfo.n_perturbed;
     n_zero_pivot = hinfo.n_zero_pivot;
     n_weak_diag = hinfo.n_weak_diag;
+    if (sym_first_look) {
+        sym_diag_looked = true;
+        if (n_weak_diag > 0) {
+            sym_weak_diag_seen = true;
+            last_error = "symmetric (lower) matrix with a weak or zero diagonal factorised as L D L^T without interchanges: hand the values to initialize "
+                         "or set HIPMF_OPTION_SYM_RECHECK for the matched LU path";
+            if (opt.verbose) fprintf(stderr, "hipmf: factorize: WARNING: %d row(s) of the symmetric matrix have a weak diagonal; %s\n", n_weak_diag, last_error.c_str());
+        }
+        n_weak_diag = 0; // (the L D L^T plan is kept: no re-matching for this handle)
+    }
     if (hinfo.n_nonfinite > 0) {
         last_error = "the matrix values contain NaN or Inf";
         factorized = false;
@@ -2371,14 +2417,20 @@ int32_t Solver::run_factor() {
     return SUCCESSFUL_EXIT;
 }
 
-int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed, int32_t lane_id) {
+int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed, int32_t lane_id, uint32_t gmask) {
     int64_t launches = 0;
     if (use_fused) {
         const int32_t ns = S.nsuper;
         const hipStream_t LST = (hipStream_t)lane_stream;
         int32_t *sync_f = lane_sync, *sync_b = lane_sync + SF_SYNC_HEADER + ns, *sync_err = lane_sync + 2 * (SF_SYNC_HEADER + ns);
+        // block groups of a blocked launch (kernels_solve_fused.hpp, SfGroups): group g's counters at lane_sync + g * sync_stride
+        const int64_t sync_stride = 2 * (int64_t)(SF_SYNC_HEADER + ns) + 1;
+        const int32_t ngrp = nk > SF_KMAX ? (nk + SF_KMAX - 1) / SF_KMAX : 1;
+        if (ngrp > SF_GMAX) return ERROR_HIPMF_INVALID_VALUE;
         HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
+        if (ngrp > 1) HIPC(hipMemsetAsync(lane_sync + sync_stride, 0, sizeof(int32_t) * (size_t)sync_stride * (size_t)(ngrp - 1), LST), ERROR_HIP_MEMCPY);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
+        const SfGroups one_group = {1, 0, 1, 1u, 0, 0};
         if (tree_active && nk == 1) {
             // (inside the timed pass pair: arming the tagged words is part of what a pass pair costs)
             if (tag_active) HIPC(hipMemsetAsync(wrk + work_arm0, 0xFF, sizeof(double) * (size_t)(work_up - work_arm0 + S.n), LST), ERROR_HIP_MEMCPY);
@@ -2404,10 +2456,10 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             const int32_t f_mid = sf2_fwd_mid, f_top = sf2_fwd_cnt - sf2_fwd_mid, b_top = sf2_bwd_top, b_mid = sf2_bwd_cnt - sf2_bwd_top;
 #define HIPMF_TREE_FWD(STGV, TAGV, CNT, DYN, TASKS, TRACE, STAGE, RIDX, REP)                                                                  \
     hipLaunchKernelGGL((k_fwd_fused<false, 1, STGV, TAGV>), dim3(CNT), dim3(256), DYN, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, d_need2, \
-                       sync_f, sync_err, wrk, xp, 1, xstr, wstr, TRACE, STAGE, RIDX, REP)
+                       sync_f, sync_err, wrk, xp, 1, xstr, wstr, TRACE, STAGE, RIDX, REP, one_group)
 #define HIPMF_TREE_BWD(SYMV, STGV, TAGV, CNT, DYN, TASKS, TRACE, STAGE, RIDX, REP)                                                            \
     hipLaunchKernelGGL((k_bwd_fused<false, 1, SYMV, STGV, TAGV>), dim3(CNT), dim3(256), DYN, LST, TASKS, d_fd, d_pool, d_rows, d_need2 + ns,   \
-                       sync_b, sync_err, wrk, xp, 1, xstr, wstr, TRACE, d_diag, STAGE, RIDX, REP, TAGV ? xt : (double *)nullptr, (double *)nullptr, (int *)nullptr)
+                       sync_b, sync_err, wrk, xp, 1, xstr, wstr, TRACE, d_diag, STAGE, RIDX, REP, TAGV ? xt : (double *)nullptr, (double *)nullptr, (int *)nullptr, one_group)
             unsigned long long *tr_top = no_tr ? no_tr + 8 * (size_t)f_mid : no_tr;
             if (f_mid > 0) {
                 if (tag) HIPMF_TREE_FWD(false, true, f_mid, 0, d_sf2, no_tr, 0, no_rep_idx, no_rep);
@@ -2455,20 +2507,24 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         const bool use_k = nk > 1 && d_sfk != nullptr; // the blocked instances have their own task list (no leaves; optionally wider slabs)
         const bool leaves = use_k && leaf_cnt > 0;
         const int32_t leaf_wgs = (leaf_cnt + LEAF_WAVES * LEAF_PER_WAVE - 1) / (LEAF_WAVES * LEAF_PER_WAVE);
+        if (ngrp > 1 && (!use_k || (split_units > 0 && ngrp > block_groups_plan))) return ERROR_HIPMF_INVALID_VALUE; // (solve() sizes its blocks by block_groups_plan)
         if (leaves) // the leaves first: nothing in them waits for anything (their parents are tasks of the launches below)
-            hipLaunchKernelGGL(k_leaf_fwd, dim3(leaf_wgs), dim3(64 * LEAF_WAVES), 0, LST, d_leaf, leaf_cnt, d_pool, d_lperm, xp, xstr, wrk, wstr, sync_f, nk);
+            hipLaunchKernelGGL(k_leaf_fwd, dim3(leaf_wgs, ngrp), dim3(64 * LEAF_WAVES), 0, LST, d_leaf, leaf_cnt, d_pool, d_lperm, xp, xstr, wrk, wstr, sync_f, nk, gmask);
         const SfTask *T = use_k ? d_sfk : d_sf;
         const int32_t *NEED = use_k ? d_needk : d_need;
         const int32_t t_fwd = use_k ? sfk_fwd_cnt : sf_fwd_cnt;
         const int32_t fa = use_k ? sfk_fwd_band : std::min(sf_fwd_band, sf_fwd_launch), fb = (use_k ? sfk_fwd_cnt : sf_fwd_launch) - fa;
         const int32_t bt = use_k ? sfk_bwd_top : sf_bwd_top, bb = (use_k ? sfk_bwd_cnt : sf_bwd_cnt) - bt;
         unsigned long long *no_trace = nullptr;
+        // (ngrp > 1: the grid holds every task once per group, padded to whole sets of 8 ngrp workgroups -- see sf_group_of)
+        auto groups_of = [&](int32_t cnt) { return SfGroups{ngrp, cnt, nk, gmask, sync_stride, split_units}; };
+        auto grid_of = [&](int32_t cnt) { return ngrp > 1 ? (unsigned)(((cnt + 7) / 8) * 8 * ngrp) : (unsigned)cnt; };
 #define HIPMF_FWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
-    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, NEED, sync_f, \
-                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, 0, (const int32_t *)nullptr, (int *)nullptr)
+    hipLaunchKernelGGL((k_fwd_fused<SMALL, KK>), dim3(grid_of(CNT)), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_lperm, d_child, d_rel, NEED, sync_f, \
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, 0, (const int32_t *)nullptr, (int *)nullptr, groups_of(CNT))
 #define HIPMF_BWD1(SMALL, KK, SYMM, CNT, TASKS, TRACE)                                                                                     \
-    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(CNT), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, NEED + ns, sync_b,        \
-                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, d_split_scr, d_split_cnt)
+    hipLaunchKernelGGL((k_bwd_fused<SMALL, KK, SYMM>), dim3(grid_of(CNT)), dim3(256), 0, LST, TASKS, d_fd, d_pool, d_rows, NEED + ns, sync_b,        \
+                       sync_err, wrk, xp, nk, xstr, wstr, TRACE, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, d_split_scr, d_split_cnt, groups_of(CNT))
 #define HIPMF_BWD(SMALL, KK, CNT, TASKS, TRACE)                                                                                            \
     do {                                                                                                                                  \
         if (!SMALL && S.sym_mode) HIPMF_BWD1(false, KK, true, CNT, TASKS, TRACE);                                                          \
@@ -2499,7 +2555,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
 #undef HIPMF_BWD
 #undef HIPMF_BWD1
         if (leaves) // ... and last: every ancestor of a leaf is complete
-            hipLaunchKernelGGL(k_leaf_bwd, dim3(leaf_wgs), dim3(64 * LEAF_WAVES), 0, LST, d_leaf + leaf_cnt, leaf_cnt, d_pool, d_rows, xp, xstr, nk);
+            hipLaunchKernelGGL(k_leaf_bwd, dim3(leaf_wgs, ngrp), dim3(64 * LEAF_WAVES), 0, LST, d_leaf + leaf_cnt, leaf_cnt, d_pool, d_rows, xp, xstr, nk, gmask);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[5], LST), ERROR_HIP_SYNCHRONIZE);
         times.n_kernel_launches_solve = (fa > 0) + (fb > 0) + (bt > 0) + (bb > 0) + 2 * (leaves ? 1 : 0);
         if (timed) tri_pending = true;
@@ -2521,7 +2577,7 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             const int32_t t0 = sf3_lvl[(size_t)l], cnt = sf3_lvl[(size_t)l + 1] - t0;
             if (cnt <= 0) continue;
             hipLaunchKernelGGL((k_fwd_fused<false, 1, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_lperm, d_child, d_rel, d_need3,
-                               sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr, 0, (const int32_t *)nullptr, (int *)nullptr);
+                               sync_f, sync_err, wrk, xp, 1, xstr, wstr, no_tr, 0, (const int32_t *)nullptr, (int *)nullptr, SfGroups{1, 0, 1, 1u, 0, 0});
             launches++;
         }
         HIPC(hipEventRecord((hipEvent_t)ev[4], STREAM), ERROR_HIP_SYNCHRONIZE);
@@ -2531,10 +2587,10 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             if (cnt <= 0) continue;
             if (S.sym_mode)
                 hipLaunchKernelGGL((k_bwd_fused<false, 1, true, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
-                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr);
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, SfGroups{1, 0, 1, 1u, 0, 0});
             else
                 hipLaunchKernelGGL((k_bwd_fused<false, 1, false, false>), dim3(cnt), dim3(256), 0, STREAM, d_sf3 + t0, d_fd, d_pool, d_rows, d_need3 + ns,
-                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr);
+                                   sync_b, sync_err, wrk, xp, 1, xstr, wstr, no_tr, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, SfGroups{1, 0, 1, 1u, 0, 0});
             launches++;
         }
         HIPC(hipEventRecord((hipEvent_t)ev[5], STREAM), ERROR_HIP_SYNCHRONIZE);
@@ -2655,10 +2711,10 @@ struct Solver::SolveLane {
     bool busy = false;
     int32_t j0 = 0, nk = 0, it = 0;
     int64_t cstr = 0; // stride between the block's columns of b and x
-    double prev[SF_KMAX];
-    bool active[SF_KMAX];
-    const double *bj[SF_KMAX];
-    double *xj[SF_KMAX];
+    double prev[SF_KMAX * SF_GMAX];
+    bool active[SF_KMAX * SF_GMAX];
+    const double *bj[SF_KMAX * SF_GMAX];
+    double *xj[SF_KMAX * SF_GMAX];
 };
 
 int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device) {
@@ -2666,13 +2722,19 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     if (!x || !rhs) return ERROR_NULL_POINTER;
     if (nrhs < 1 || ldx < S.n) return ERROR_HIPMF_INVALID_VALUE;
     DeviceScope dev_scope(device);
+    // The device's gate (see device_gate) is held only while dependency-driven launches of this solve are in flight: from just before a
+    // triangular pass pair is queued until the host has seen its stream drain (staging copies, the host's look at the norms
+    // and the waits of a many-RHS loop between blocks are outside -- another handle's solve gets its turn there).  With several lanes
+    // (opt-in) the gate stays held until every lane is idle.  The gate is process-wide: two PROCESSES sharing one GPU are not
+    // serialised by it -- their waits stay bounded by the device-clock time-out and the level-set fallback.
     std::unique_lock<std::mutex> gate(device_gate(device), std::defer_lock);
-    if (use_fused) {
+    auto gate_acquire = [&]() {
+        if (!use_fused || gate.owns_lock()) return;
         if (!gate.try_lock()) {
             gate_waits++;
             gate.lock();
         }
-    }
+    };
     const int32_t n = S.n;
     const dim3 g((n + 255) / 256), b(256);
     const double EPS = 2.220446049250313e-16;
@@ -2681,31 +2743,41 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     // factor entry once per block); one right-hand side uses the single-column instances and buffers.
     // (blocks of 16 columns = one full MFMA tile per slab tile when there are enough of them and the block buffers fit; else 8)
     int32_t KB = (use_fused && nrhs > 1) ? (nrhs > SF_KMID + SF_KMID / 2 ? SF_KMAX : SF_KMID) : 1;
-    if (KB > 1 && block_cols >= KB) KB = block_cols; // (the buffers exist and are wide enough: keep their width)
-    if (KB > 1 && block_cols > 0 && block_cols < KB) {
+    // ... and GB such blocks ("groups") travel through ONE set of dependency-driven launches (kernels_solve_fused.hpp, SfGroups): KB * GB
+    // columns are in flight together; the upper levels' chains of hand-offs of the groups overlap.  Sixteen-column blocks only.
+    int32_t GB = (KB == SF_KMAX && d_sfk) ? std::max(1, std::min(block_groups_plan, (nrhs + SF_KMAX - 1) / SF_KMAX)) : 1;
+    if (KB > 1 && block_cols >= KB && block_cols * block_groups >= KB * GB) KB = block_cols, GB = block_groups; // (the buffers exist and are wide enough: keep their shape)
+    if (KB > 1 && block_cols > 0 && (block_cols < KB || block_cols * block_groups < KB * GB)) {
         // wider blocks than the buffers of an earlier call hold: let them go, they are allocated again below
-        for (void *p : {(void *)d_blk, (void *)d_work_blk})
+        for (void *p : {(void *)d_blk, (void *)d_work_blk, (void *)d_norms_blk})
             if (p) (void)hipFree(p);
-        d_blk = d_work_blk = nullptr;
+        d_blk = d_work_blk = nullptr, d_norms_blk = nullptr;
         for (LaneBuffers &lb : extra_lanes) {
             for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
                 if (p) (void)hipFree(p);
             if (lb.stream) (void)hipStreamDestroy((hipStream_t)lb.stream);
         }
         extra_lanes.clear();
-        block_cols = 0;
+        block_cols = 0, block_groups = 0;
     }
     if (KB == SF_KMAX && !d_blk) {
         size_t free_b = 0, total_b = 0;
-        const double need_b = 8.0 * ((double)n * 6 + (double)work_doubles) * SF_KMAX * std::max(1, std::min(solve_lanes, (nrhs + SF_KMAX - 1) / SF_KMAX));
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need_b > 0.9 * (double)free_b) KB = SF_KMID;
+        auto need_b = [&](int32_t groups) {
+            return 8.0 * ((double)n * 6 + (double)work_blk_doubles) * SF_KMAX * groups * std::max(1, std::min(solve_lanes, (nrhs + SF_KMAX * groups - 1) / (SF_KMAX * groups)));
+        };
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            while (GB > 1 && need_b(GB) > 0.5 * (double)free_b) GB /= 2; // (groups are a speed-up for small factors: never at the price of half the free memory)
+            if (need_b(1) > 0.9 * (double)free_b) KB = SF_KMID, GB = 1;
+        }
     }
     if (const char *e = getenv("HIPMF_BLOCK_COLS")) {
         const int v = atoi(e);
         if (KB > 1 && block_cols == 0 && (v == SF_KMID || v == SF_KMAX)) KB = v;
     }
-    if (KB > 1) block_cols = KB;
-    const int32_t nblocks = (nrhs + KB - 1) / KB;
+    if (KB != SF_KMAX) GB = 1;
+    if (KB > 1) block_cols = KB, block_groups = GB, block_groups_last = GB;
+    const int32_t KS = KB * GB; // columns of a block of the driver below
+    const int32_t nblocks = (nrhs + KS - 1) / KS;
     // (rounds 2 - 3: two blocks in flight hid the host round trips of the refinement behind the other block's kernels, worth 10 - 20 % while
     //  a pass lasted a millisecond.  With the kernels of round 4 one lane is as fast or faster and two concurrently resident
     //  dependency-driven launches time out every few runs: the default is one lane, HIPMF_SOLVE_LANES asks for more.)  When the factor is tens of gigabytes a pass lasts 0.1 s, the round trips vanish, and two
@@ -2713,13 +2785,15 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     // to run, 3.3 s on one; each lane also holds its own block and workspace buffers, 25 GB there): one lane from 64 GB of factor on.
     const int32_t lanes_here = (solve_lanes_auto && 8.0 * (double)S.persist_doubles > 64e9) ? 1 : solve_lanes;
     const int32_t nlanes = KB > 1 ? std::max(1, std::min(lanes_here, nblocks)) : 1;
-    const size_t sync_words = 2 * (size_t)(SF_SYNC_HEADER + S.nsuper) + 1;
+    const size_t sync_words = 2 * (size_t)(SF_SYNC_HEADER + S.nsuper) + 1; // (per group of a blocked launch; group 0's last word is the error word)
+    const size_t lane_cols = (size_t)SF_KMAX * SF_GMAX;                      // columns a lane's norm buffers are sized for
     if (KB > 1 && !d_blk) {
-        // xp | du | r | den | b | x: six n x KB blocks, plus KB solve workspaces
-        HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * ((size_t)std::max<int64_t>(work_doubles, 1) * KB + 64)), ERROR_HIP_MALLOC);
+        // xp | du | r | den | b | x: six n x KS blocks, plus KS solve workspaces (columns at the stride that leaves the tagged shadow out)
+        HIPC(hipMalloc((void **)&d_blk, sizeof(double) * 6 * (size_t)n * KS), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_work_blk, sizeof(double) * ((size_t)std::max<int64_t>(work_blk_doubles, 1) * KS + 64)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&d_norms_blk, (size_t)RES_NORM_WORDS * lane_cols * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     }
-    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * RES_NORM_WORDS * SF_KMAX * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
+    if (!h_nrm) HIPC(hipHostMalloc((void **)&h_nrm, sizeof(double) * RES_NORM_WORDS * lane_cols * MAX_SOLVE_LANES), ERROR_HIP_MALLOC);
     while ((int32_t)extra_lanes.size() < nlanes - 1) {
         LaneBuffers lb;
         hipStream_t st = nullptr;
@@ -2727,30 +2801,30 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         lb.stream = st;
         extra_lanes.push_back(lb); // (registered first: release() frees whatever a failed allocation leaves behind)
         LaneBuffers &r = extra_lanes.back();
-        HIPC(hipMalloc((void **)&r.blk, sizeof(double) * 6 * (size_t)n * KB), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&r.work, sizeof(double) * ((size_t)std::max<int64_t>(work_doubles, 1) * KB + 64)), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&r.sync, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
-        HIPC(hipMemset(r.sync, 0, sizeof(int32_t) * sync_words), ERROR_HIP_MALLOC);
-        HIPC(hipMalloc((void **)&r.norms, (size_t)RES_NORM_WORDS * SF_KMAX * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.blk, sizeof(double) * 6 * (size_t)n * KS), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.work, sizeof(double) * ((size_t)std::max<int64_t>(work_blk_doubles, 1) * KS + 64)), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.sync, sizeof(int32_t) * sync_words * SF_GMAX), ERROR_HIP_MALLOC);
+        HIPC(hipMemset(r.sync, 0, sizeof(int32_t) * sync_words * SF_GMAX), ERROR_HIP_MALLOC);
+        HIPC(hipMalloc((void **)&r.norms, (size_t)RES_NORM_WORDS * lane_cols * sizeof(unsigned long long)), ERROR_HIP_MALLOC);
     }
     SolveLane lanes[MAX_SOLVE_LANES];
     {
         SolveLane &L = lanes[0];
         L.st = STREAM;
-        L.XP = KB > 1 ? d_blk : d_xp, L.DU = KB > 1 ? d_blk + (size_t)n * KB : d_du, L.RR = KB > 1 ? d_blk + 2 * (size_t)n * KB : d_r;
-        L.BB = KB > 1 ? d_blk + 4 * (size_t)n * KB : d_b, L.XX = KB > 1 ? d_blk + 5 * (size_t)n * KB : d_x, L.WRK = KB > 1 ? d_work_blk : d_work;
-        L.sync = d_sync, L.norms = d_scalar + 4, L.h_nrm = h_nrm, L.timed = true;
+        L.XP = KB > 1 ? d_blk : d_xp, L.DU = KB > 1 ? d_blk + (size_t)n * KS : d_du, L.RR = KB > 1 ? d_blk + 2 * (size_t)n * KS : d_r;
+        L.BB = KB > 1 ? d_blk + 4 * (size_t)n * KS : d_b, L.XX = KB > 1 ? d_blk + 5 * (size_t)n * KS : d_x, L.WRK = KB > 1 ? d_work_blk : d_work;
+        L.sync = d_sync, L.norms = KB > 1 ? d_norms_blk : d_scalar + 4, L.h_nrm = h_nrm, L.timed = true;
     }
     for (int32_t l = 1; l < nlanes; l++) {
         SolveLane &L = lanes[l];
         L.id = l;
         const LaneBuffers &r = extra_lanes[(size_t)l - 1];
         L.st = (hipStream_t)r.stream;
-        L.XP = r.blk, L.DU = r.blk + (size_t)n * KB, L.RR = r.blk + 2 * (size_t)n * KB, L.BB = r.blk + 4 * (size_t)n * KB;
-        L.XX = r.blk + 5 * (size_t)n * KB, L.WRK = r.work;
-        L.sync = r.sync, L.norms = r.norms, L.h_nrm = h_nrm + (size_t)RES_NORM_WORDS * SF_KMAX * l, L.timed = false;
+        L.XP = r.blk, L.DU = r.blk + (size_t)n * KS, L.RR = r.blk + 2 * (size_t)n * KS, L.BB = r.blk + 4 * (size_t)n * KS;
+        L.XX = r.blk + 5 * (size_t)n * KS, L.WRK = r.work;
+        L.sync = r.sync, L.norms = r.norms, L.h_nrm = h_nrm + (size_t)RES_NORM_WORDS * lane_cols * l, L.timed = false;
     }
-    const int64_t wstr = work_doubles;
+    const int64_t wstr = KB > 1 ? work_blk_doubles : work_doubles;
     // One right-hand side handed over in pageable host memory goes through a pinned staging buffer: a pageable hipMemcpy of n
     // doubles from / into pages the runtime has not seen can cost 10 - 20 ms (measured in round 2: 22.8 ms per host solve of the 1M-DOF
     // system against 1.3 ms on the device; round 5, tools/microbench/host_copy_rates.py: 12 - 23 ms now and then for a fresh buffer, the
@@ -2778,9 +2852,9 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
                 hipLaunchKernelGGL(k_spmv_stream<true>, dim3(spmv_blocks), b, 0, L.st, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, 1.0, L.xj[0], L.bj[0],
                                    L.RR, L.norms);
         } else {
-            uint32_t amask = 0;
+            uint64_t amask = 0;
             for (int32_t c = 0; c < L.nk; c++)
-                if (L.active[c]) amask |= 1u << c;
+                if (L.active[c]) amask |= 1ull << c;
             if (amask)
                 hipLaunchKernelGGL(k_residual_cols, dim3(spmv_blocks), b, 0, L.st, d_row_blk, d_rp, d_ci, d_vals, d_tptr, d_tidx, d_arow, L.xj[0], L.cstr, L.bj[0],
                                    L.cstr, L.RR, (int64_t)n, L.norms, L.nk, amask);
@@ -2799,7 +2873,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     };
     // first solve of the block that starts at column j0
     auto start = [&](SolveLane &L, int32_t j0) -> int32_t {
-        L.j0 = j0, L.nk = std::min(KB, nrhs - j0), L.it = 0, L.busy = true;
+        L.j0 = j0, L.nk = std::min(KS, nrhs - j0), L.it = 0, L.busy = true;
         for (int32_t c = 0; c < L.nk; c++) {
             if (on_device) {
                 L.bj[c] = rhs + (int64_t)(j0 + c) * ldx;
@@ -2815,8 +2889,9 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         }
         // (the columns of a block sit at a regular stride -- ldx on the device, n in the staging block: one launch for all of them)
         L.cstr = on_device ? ldx : (int64_t)n;
-        const uint32_t all = L.nk >= 32 ? 0xffffffffu : ((1u << L.nk) - 1u);
+        const uint64_t all = L.nk >= 64 ? ~0ull : ((1ull << L.nk) - 1ull);
         if (L.nk > 1) hipLaunchKernelGGL(k_perm_in_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_rperm, d_rs, L.bj[0], L.cstr, L.XP, (int64_t)n, all);
+        gate_acquire();
         int32_t code = run_triangular(L.XP, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed, L.id);
         if (code != SUCCESSFUL_EXIT) return code;
         if (L.nk == 1) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.XP, L.xj[0], 0);
@@ -2855,12 +2930,15 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
             any = true;
         }
         if (!any) return finish(L);
-        uint32_t amask = 0;
+        uint64_t amask = 0;
+        uint32_t gmask = 0; // groups of the launch that still hold an active column: the others' tasks return at once
         for (int32_t c = 0; c < L.nk; c++)
-            if (L.active[c]) amask |= 1u << c;
+            if (L.active[c]) amask |= 1ull << c, gmask |= 1u << (c / SF_KMAX);
+        if (L.nk <= SF_KMAX) gmask = 0xffffffffu;
         if (L.nk == 1) hipLaunchKernelGGL(k_perm_in, g, b, 0, L.st, n, d_rperm, d_rs, L.RR, L.DU);
         else hipLaunchKernelGGL(k_perm_in_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_rperm, d_rs, L.RR, (int64_t)n, L.DU, (int64_t)n, amask); // finished columns ride along as zeros
-        int32_t code = run_triangular(L.DU, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed, L.id);
+        gate_acquire();
+        int32_t code = run_triangular(L.DU, L.nk, L.WRK, n, wstr, L.st, L.sync, L.timed, L.id, gmask);
         if (code != SUCCESSFUL_EXIT) return code;
         if (L.nk == 1) hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU, L.xj[0], 1);
         else hipLaunchKernelGGL(k_perm_out_cols, dim3(g.x, L.nk), b, 0, L.st, n, d_perm, d_cs, L.DU, (int64_t)n, L.xj[0], L.cstr, 1, amask);
@@ -2882,7 +2960,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         bool progressed = false;
         for (int32_t l = 0; l < nlanes; l++)
             if (!lanes[l].busy && next < nblocks) {
-                int32_t code = start(lanes[l], next * KB);
+                int32_t code = start(lanes[l], next * KS);
                 if (code != SUCCESSFUL_EXIT) return code;
                 next++;
                 progressed = true;
@@ -2890,6 +2968,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         for (int32_t l = 0; l < nlanes; l++)
             if (lanes[l].busy) {
                 HIPC(hipStreamSynchronize(lanes[l].st), ERROR_HIP_SYNCHRONIZE);
+                if (nlanes == 1 && gate.owns_lock()) gate.unlock(); // (nothing of this solve is resident: another handle may go)
                 int32_t code = advance(lanes[l]);
                 if (code != SUCCESSFUL_EXIT) return code;
                 progressed = true;
@@ -2940,7 +3019,7 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         for (LaneBuffers &lb : extra_lanes) (void)hipMemset(lb.sync + sync_words - 1, 0, sizeof(int32_t));
         last_error = "dependency-driven solve timed out; level-set path used instead";
         if (opt.verbose) fprintf(stderr, "hipmf: %s\n", last_error.c_str());
-        gate.unlock();
+        if (gate.owns_lock()) gate.unlock();
         return solve(x, rhs, nrhs, ldx, on_device);
     }
     if (staged) memcpy(x, h_stage + n, sizeof(double) * (size_t)n);

@@ -160,6 +160,10 @@ class Solver {
     int64_t fused_fallbacks = 0; // solves that fell back to the level-set launches after a hand-off timeout (never expected)
     int64_t mid_front_count = 0; // fronts of this plan that one workgroup factorises in one launch (k_front)
     int64_t wave_front_count = 0; // big fronts that are wave-front tasks in the forward pass of this plan (sf_fwd_wave)
+    int32_t block_groups_last = 0;   // blocks of right-hand sides per dependency-driven launch in the last blocked solve (round 6)
+    bool sym_diag_looked = false;    // the first values of a symmetric-lower handle were checked for a weak diagonal (once per initialize)
+    bool sym_weak_diag_seen = false; // L D L^T plan kept although a factorize met a weak diagonal (HIPMF_OPTION_SYM_RECHECK off)
+    bool event_fence_free = false; // the events between this handle's streams are recorded without the system-scope fence (gfx950 + HIP 7 only)
     int64_t gate_waits = 0;      // solves that waited for another handle's solve on the same device (device_gate, numeric.cpp)
     bool tagged_solve() const { return tag_active && use_fused; }
     int64_t leaf_front_count() const { return use_fused ? leaf_cnt : 0; }
@@ -209,7 +213,7 @@ class Solver {
     int32_t run_factor();
     // forward + backward on nk permuted, scaled vectors (column c at xp + c * xstr, its workspace at wrk + c * wstr)
     struct SolveLane;
-    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed, int32_t lane_id);
+    int32_t run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr, int64_t wstr, void *lane_stream, int32_t *lane_sync, bool timed, int32_t lane_id, uint32_t gmask = 0xffffffffu);
     void harvest_tri();
     int32_t build_level_tasks();
     // optional task list of the blocked (many-RHS) instances with wider slabs (HIPMF_BLOCKED_SLABS=1).  Measured and NOT the default:
@@ -365,6 +369,12 @@ class Solver {
                                // into a hand-off time-out (3.7 s; profiles/r04_solve_lanes.txt)
     bool solve_lanes_auto = true; // no HIPMF_SOLVE_LANES given: one lane when the factor exceeds 64 GB (solve())
     int32_t block_cols = 0;    // columns per block of the many-RHS driver once its buffers exist (8 or 16; HIPMF_BLOCK_COLS forces one)
+    int32_t block_groups = 0;  // blocks ("groups", kernels_solve_fused.hpp SfGroups) a dependency-driven launch of the many-RHS driver carries once its
+                               // buffers exist (1 .. SF_GMAX); block_cols * block_groups columns travel together
+    int32_t block_groups_plan = 1; // ... what initialize planned for (HIPMF_BLOCK_GROUPS, else by the size of the factor): the split-dot-product scratch is sized by it
+    double block_groups_max_bytes = 4e9; // factors up to this many bytes carry SF_GMAX blocks per launch, larger ones one (HIPMF_BLOCK_GROUPS_BYTES)
+    unsigned long long *d_norms_blk = nullptr; // norm slots of lane 0's blocked solves (block_cols * block_groups columns)
+    int64_t work_blk_doubles = 0;  // stride between the columns of a blocked solve workspace: work_doubles without the tagged shadow xt
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
     std::vector<int32_t> sf_host, sfk_host; // (kind, front) per task (single-column lists / blocked list), kept only when tracing
     FactorInfo *d_info = nullptr;
