@@ -809,6 +809,7 @@ def main():
                                     "physical_factor_bytes_per_pass_pair": int(fbytes), "achieved": round(moved / (many["solve_ms"] * 1e-3) / 1e9, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(moved / (many["solve_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "ms_per_rhs": round(many["solve_ms"] / max(count, 1), 4),
+                                    "blocks_per_launch": int(s.counter("block_groups")),
                                     "fused_solve_fallbacks": int(stm.get("fused_fallbacks", 0))}
             except Exception as exc:
                 many["roofline"] = {"error": repr(exc)}

@@ -128,6 +128,11 @@ int32_t solver_hipmf_solve(struct InterfaceHIPMF *solver, double *x, const doubl
 int32_t solver_hipmf_solve_many(struct InterfaceHIPMF *solver, double *x, const double *rhs, int32_t nrhs, int32_t ld,
                                 C_BOOL verbose);
 
+/* Optional, any time after initialize: allocates and touches the block buffers of a later solve_many / solve_device / solve_many_sharded with
+ * up to `nrhs` right-hand sides (a few GB at config 4's size; the FIRST blocked solve of a handle otherwise pays for them: 0.4 s there).
+ * A rank that waits for the factor of another rank (solver_hipmf_broadcast_factor) calls it while the root factorises.  nrhs < 2: no-op. */
+int32_t solver_hipmf_prepare_solve_many(struct InterfaceHIPMF *solver, int32_t nrhs);
+
 /* the same two phases with operands already resident in HBM (device pointers) */
 int32_t solver_hipmf_factorize_device(struct InterfaceHIPMF *solver, const double *d_values);
 int32_t solver_hipmf_solve_device(struct InterfaceHIPMF *solver, double *d_x, const double *d_rhs, int32_t nrhs, int32_t ld);
@@ -203,6 +208,8 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
                                              (round 6: their latency chains overlap; 1 = one block per launch) -- value of the last blocked solve, 0 before */
 #define HIPMF_COUNTER_SYM_WEAK_DIAGONAL 17 /* 1: a symmetric-lower handle that kept its L D L^T plan met a weak diagonal in the values of a factorize
                                              (HIPMF_OPTION_SYM_RECHECK off: nothing was re-analysed; see last_error / verbose) */
+#define HIPMF_COUNTER_BCAST_SLICED_BYTES 18 /* bytes of factor that solver_hipmf_broadcast_factor moved as slices over all xGMI links (two point-to-point
+                                             steps; three or more ranks, parts of >= 64 MB) instead of through ncclBroadcast, summed over the calls */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only

@@ -27,6 +27,7 @@ SYMBOLS = {
                                            C.c_int32, f64p]),
     "solver_hipmf_solve": (C.c_int32, [C.c_void_p, f64p, f64p, C.c_int32]),
     "solver_hipmf_solve_many": (C.c_int32, [C.c_void_p, f64p, f64p, C.c_int32, C.c_int32, C.c_int32]),
+    "solver_hipmf_prepare_solve_many": (C.c_int32, [C.c_void_p, C.c_int32]),
     "solver_hipmf_factorize_device": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "solver_hipmf_solve_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "solver_hipmf_mat_vec_mul": (C.c_int32, [C.c_void_p, f64p, C.c_double, f64p]),

@@ -887,8 +887,10 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
             StrError e = csr.update_from_coo(mat);
             if (e) return e;
             const size_t nz0 = (size_t)rp0[csr.nrow];
-            if (csr.row_pointers != rp0 || std::memcmp(ci0.data(), csr.col_indices.data(), sizeof(int32_t) * nz0) != 0)
+            if (csr.row_pointers != rp0 || std::memcmp(ci0.data(), csr.col_indices.data(), sizeof(int32_t) * nz0) != 0) {
+                csr.row_pointers = rp0, csr.col_indices = ci0; // (the handle keeps the pattern it was initialised with: a later valid call is compared with THAT)
                 return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
+            }
         }
     } else {
         if (mat.nrow != mat.ncol) return "the matrix must be square";
@@ -966,8 +968,10 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
             StrError e = csr.update_from_coo(mat);
             if (e) return e;
             const size_t nz0 = (size_t)rp0[csr.nrow];
-            if (csr.row_pointers != rp0 || std::memcmp(ci0.data(), csr.col_indices.data(), sizeof(int32_t) * nz0) != 0)
+            if (csr.row_pointers != rp0 || std::memcmp(ci0.data(), csr.col_indices.data(), sizeof(int32_t) * nz0) != 0) {
+                csr.row_pointers = rp0, csr.col_indices = ci0; // (the handle keeps the pattern it was initialised with: a later valid call is compared with THAT)
                 return "subsequent factorizations must use the same matrix (sparsity pattern differs)";
+            }
             status = g_backend.factorize((InterfaceHIPMF *)solver, &effective_ordering, &effective_scaling, &perturbed_pivots, &rcond_estimate,
                                          &determinant_coefficient, &determinant_exponent, compute_determinant ? 1 : 0, verbose, csr.values.data());
         }

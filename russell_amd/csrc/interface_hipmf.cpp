@@ -29,6 +29,7 @@ struct InterfaceHIPMF {
     int32_t effective_ordering = 0;
     // solver_hipmf_set_option (before initialize)
     int32_t opt_matching = 1, opt_pivoting = 1, opt_sym_recheck = 0;
+    int64_t bcast_sliced_bytes = 0; // bytes of factor that travelled as slices over all links (solver_hipmf_broadcast_factor, round 6)
     double opt_hybrid = 0.0;
     // a symmetric-lower matrix with a weak diagonal is analysed and factorised as the mirrored GENERAL matrix (with the matching):
     // the caller keeps handing over lower-triangle values, entry k of the handle's CSR is entry emap[k] of the caller's
@@ -534,6 +535,7 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
     case HIPMF_COUNTER_EVENT_FENCE_FREE: return s.event_fence_free ? 1 : 0;
     case HIPMF_COUNTER_BLOCK_GROUPS: return s.block_groups_last;
     case HIPMF_COUNTER_SYM_WEAK_DIAGONAL: return s.sym_weak_diag_seen ? 1 : 0;
+    case HIPMF_COUNTER_BCAST_SLICED_BYTES: return h->bcast_sliced_bytes;
     default: return -1;
     }
 }
@@ -577,7 +579,14 @@ struct Rccl {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclBroadcast) broadcast = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    // (round 6: the factor travels as slices over all links -- point-to-point sends in groups; optional: without them the broadcast stays)
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
     bool tried = false, ok = false;
+    bool p2p() const { return send && recv && group_start && group_end && comm_count; }
 };
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
@@ -595,6 +604,11 @@ bool rccl_load() {
     g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(g_rccl.dl, "ncclCommDestroy");
     g_rccl.broadcast = (decltype(g_rccl.broadcast))dlsym(g_rccl.dl, "ncclBroadcast");
     g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(g_rccl.dl, "ncclAllReduce");
+    g_rccl.send = (decltype(g_rccl.send))dlsym(g_rccl.dl, "ncclSend");
+    g_rccl.recv = (decltype(g_rccl.recv))dlsym(g_rccl.dl, "ncclRecv");
+    g_rccl.group_start = (decltype(g_rccl.group_start))dlsym(g_rccl.dl, "ncclGroupStart");
+    g_rccl.group_end = (decltype(g_rccl.group_end))dlsym(g_rccl.dl, "ncclGroupEnd");
+    g_rccl.comm_count = (decltype(g_rccl.comm_count))dlsym(g_rccl.dl, "ncclCommCount");
     g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.broadcast && g_rccl.all_reduce;
     return g_rccl.ok;
 }
@@ -674,16 +688,55 @@ static int32_t broadcast_factor_body(struct InterfaceHIPMF *h, void *comm, int32
     if (solver_hipmf_factor_parts(h, 4, ptrs, nb) != 4) return ERROR_HIPMF_INVALID_VALUE;
     ptrs[4] = s.d_vals_ptr(), nb[4] = s.S.nnz_a * 8;
     ptrs[5] = (s.matched && s.d_cs) ? (void *)s.d_cs : nullptr, nb[5] = ptrs[5] ? (int64_t)s.S.n * 8 : 0;
-    // ring / tree collectives over xGMI are per-link bound: large messages (256 MB) keep every link busy
-    const int64_t chunk = 256ll << 20;
+    // xGMI is point-to-point: every GPU has ONE link to each peer (~153 GB/s).  A broadcast that leaves the root over one link -- a ring --
+    // is bound by that link: F / 153 GB/s (config 4's 84 GB: 0.55 s, more than the sharded solves it feeds).  Round 6: a part of at least
+    // HIPMF_BCAST_SLICE_MIN bytes travels as N slices over ALL links, in two steps of point-to-point transfers (N ranks):
+    //   A. the root sends slice r to rank r (N - 1 links of the root busy at once);
+    //   B. every rank sends ITS slice to every other rank but the root (the root: its own slice to everybody) -- all links busy;
+    // per link and step F / N bytes: 2 F / (N 153 GB/s), a quarter of the ring's time at N = 8.  The ranks hold the same plan (checked
+    // above), so every rank computes the same slices; the bytes past the last whole slice and the small parts use ncclBroadcast.
+    // HIPMF_BCAST_SLICES=0 keeps the plain broadcast.
+    int nranks = 1;
+    const bool want_slices = !(getenv("HIPMF_BCAST_SLICES") && atoi(getenv("HIPMF_BCAST_SLICES")) == 0);
+    if (g_rccl.p2p() && g_rccl.comm_count((ncclComm_t)comm, &nranks) != ncclSuccess) nranks = 1;
+    int64_t slice_min = 64ll << 20;
+    if (const char *e = getenv("HIPMF_BCAST_SLICE_MIN")) slice_min = std::max<int64_t>(4096, atoll(e));
+    const int64_t chunk = 256ll << 20; // (plain broadcast: large messages keep the links of a ring busy)
     int64_t total = 0;
-    for (int i = 0; i < 6; i++)
-        for (int64_t off = 0; off < nb[i]; off += chunk) {
+    for (int i = 0; i < 6; i++) {
+        int64_t done = 0;
+        if (want_slices && g_rccl.p2p() && nranks >= 3 && nb[i] >= slice_min) {
+            const int64_t sl = (nb[i] / nranks) & ~(int64_t)511; // whole 512-byte units per slice
+            char *base = (char *)ptrs[i];
+            if (sl > 0) {
+                // A: root -> r
+                if (g_rccl.group_start() != ncclSuccess) return ERROR_HIPMF_COMM;
+                bool bad = false;
+                if (rank == root) {
+                    for (int r = 0; r < nranks; r++)
+                        if (r != root) bad = bad || g_rccl.send(base + (int64_t)r * sl, (size_t)sl, ncclChar, r, (ncclComm_t)comm, st) != ncclSuccess;
+                } else
+                    bad = g_rccl.recv(base + (int64_t)rank * sl, (size_t)sl, ncclChar, root, (ncclComm_t)comm, st) != ncclSuccess;
+                if (g_rccl.group_end() != ncclSuccess || bad) return ERROR_HIPMF_COMM;
+                // B: r -> q for every pair r != q, q != root (slice r)
+                if (g_rccl.group_start() != ncclSuccess) return ERROR_HIPMF_COMM;
+                for (int q = 0; q < nranks; q++) {
+                    if (q == rank) continue;
+                    if (q != root) bad = bad || g_rccl.send(base + (int64_t)rank * sl, (size_t)sl, ncclChar, q, (ncclComm_t)comm, st) != ncclSuccess;
+                    if (rank != root) bad = bad || g_rccl.recv(base + (int64_t)q * sl, (size_t)sl, ncclChar, q, (ncclComm_t)comm, st) != ncclSuccess;
+                }
+                if (g_rccl.group_end() != ncclSuccess || bad) return ERROR_HIPMF_COMM;
+                done = sl * nranks;
+                h->bcast_sliced_bytes += done;
+            }
+        }
+        for (int64_t off = done; off < nb[i]; off += chunk) {
             const int64_t len = std::min(chunk, nb[i] - off);
             char *p = (char *)ptrs[i] + off;
             if (g_rccl.broadcast(p, p, (size_t)len, ncclChar, root, (ncclComm_t)comm, st) != ncclSuccess) return ERROR_HIPMF_COMM;
-            total += len;
         }
+        total += nb[i];
+    }
     if (hipStreamSynchronize(st) != hipSuccess) return ERROR_HIP_SYNCHRONIZE;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (bytes_sent) *bytes_sent = total;
@@ -714,6 +767,13 @@ int32_t solver_hipmf_solve_many_sharded(struct InterfaceHIPMF *h, double *d_x, c
     if (num_columns) *num_columns = count;
     if (count == 0) return SUCCESSFUL_EXIT;
     return h->solver.solve(d_x + (int64_t)first * ld, d_rhs + (int64_t)first * ld, count, ld, true);
+}
+
+int32_t solver_hipmf_prepare_solve_many(struct InterfaceHIPMF *h, int32_t nrhs) {
+    if (!h) return ERROR_NULL_POINTER;
+    if (!h->solver.initialized) return ERROR_NEED_INITIALIZATION;
+    if (nrhs < 0) return ERROR_HIPMF_INVALID_VALUE;
+    return guarded(h, [&]() { return h->solver.prepare_many(nrhs); });
 }
 
 const char *solver_hipmf_last_error(struct InterfaceHIPMF *h) { return h ? h->solver.last_error.c_str() : "null solver"; }

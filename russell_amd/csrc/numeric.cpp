@@ -2717,8 +2717,21 @@ struct Solver::SolveLane {
     double *xj[SF_KMAX * SF_GMAX];
 };
 
+// The buffers of a blocked solve of `nrhs` right-hand sides (six n x KS blocks, KS workspaces, norm slots, the pinned norm mirror) cost
+// the FIRST solve_many of a handle a few tenths of a second at config 4's size (0.735 s against 0.34 s): this call allocates
+// and touches them ahead of time -- any time after initialize, e.g. while another rank still factorises.  Same decisions as solve().
+int32_t Solver::prepare_many(int32_t nrhs) {
+    if (!initialized) return ERROR_NEED_INITIALIZATION;
+    if (nrhs < 2) return SUCCESSFUL_EXIT;
+    static double dummy = 0.0;
+    prepare_only = true;
+    const int32_t code = solve(&dummy, &dummy, nrhs, S.n, true);
+    prepare_only = false;
+    return code;
+}
+
 int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device) {
-    if (!factorized) return ERROR_NEED_FACTORIZATION;
+    if (!factorized && !prepare_only) return ERROR_NEED_FACTORIZATION;
     if (!x || !rhs) return ERROR_NULL_POINTER;
     if (nrhs < 1 || ldx < S.n) return ERROR_HIPMF_INVALID_VALUE;
     DeviceScope dev_scope(device);
@@ -2825,6 +2838,16 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
         L.sync = r.sync, L.norms = r.norms, L.h_nrm = h_nrm + (size_t)RES_NORM_WORDS * lane_cols * l, L.timed = false;
     }
     const int64_t wstr = KB > 1 ? work_blk_doubles : work_doubles;
+    if (prepare_only) { // (prepare_many: the buffers exist now; first touch, then back)
+        if (KB > 1) {
+            HIPC(hipMemsetAsync(d_blk, 0, sizeof(double) * 6 * (size_t)n * KS, STREAM), ERROR_HIP_MEMCPY);
+            HIPC(hipMemsetAsync(d_work_blk, 0, sizeof(double) * ((size_t)std::max<int64_t>(work_blk_doubles, 1) * KS + 64), STREAM), ERROR_HIP_MEMCPY);
+            HIPC(hipMemsetAsync(d_norms_blk, 0, (size_t)RES_NORM_WORDS * lane_cols * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
+            HIPC(hipMemcpyAsync(h_nrm, d_norms_blk, (size_t)RES_NORM_WORDS * std::min<size_t>(lane_cols, (size_t)KS) * sizeof(double), hipMemcpyDeviceToHost, STREAM), ERROR_HIP_MEMCPY);
+        }
+        HIPC(hipStreamSynchronize(STREAM), ERROR_HIP_SYNCHRONIZE);
+        return SUCCESSFUL_EXIT;
+    }
     // One right-hand side handed over in pageable host memory goes through a pinned staging buffer: a pageable hipMemcpy of n
     // doubles from / into pages the runtime has not seen can cost 10 - 20 ms (measured in round 2: 22.8 ms per host solve of the 1M-DOF
     // system against 1.3 ms on the device; round 5, tools/microbench/host_copy_rates.py: 12 - 23 ms now and then for a fresh buffer, the

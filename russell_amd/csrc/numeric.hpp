@@ -125,6 +125,7 @@ class Solver {
     int32_t set_value_map(int64_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx, bool signed_map = false);
     int32_t factorize_mapped(const double *input, bool on_device);
     int32_t solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device);
+    int32_t prepare_many(int32_t nrhs); // the block buffers of a later many-RHS solve, ahead of time
     int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
     int32_t determinant(double *mantissa, double *exponent, double *rcond);
     int32_t rcond_estimate(double *rcond); // min |u_ii| / max |u_ii| by a device reduction
@@ -371,6 +372,7 @@ class Solver {
     int32_t block_cols = 0;    // columns per block of the many-RHS driver once its buffers exist (8 or 16; HIPMF_BLOCK_COLS forces one)
     int32_t block_groups = 0;  // blocks ("groups", kernels_solve_fused.hpp SfGroups) a dependency-driven launch of the many-RHS driver carries once its
                                // buffers exist (1 .. SF_GMAX); block_cols * block_groups columns travel together
+    bool prepare_only = false;     // solve() stops after its buffers exist (prepare_many)
     int32_t block_groups_plan = 1; // ... what initialize planned for (HIPMF_BLOCK_GROUPS, else by the size of the factor): the split-dot-product scratch is sized by it
     double block_groups_max_bytes = 4e9; // factors up to this many bytes carry SF_GMAX blocks per launch, larger ones one (HIPMF_BLOCK_GROUPS_BYTES)
     unsigned long long *d_norms_blk = nullptr; // norm slots of lane 0's blocked solves (block_cols * block_groups columns)

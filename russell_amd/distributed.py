@@ -22,19 +22,52 @@ def _as_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
 
 
-def broadcast_factor(solver, d_values, dist, src=0, device=None, chunk_bytes=256 << 20):
+def _spread_slices(ptr, nbytes, dist, src, device, rank, world):
+    """The two point-to-point steps of solver_hipmf_broadcast_factor (interface_hipmf.cpp, round 6) on a torch.distributed group: the part
+    [ptr, ptr + nbytes) is cut into `world` slices of whole 512-byte units; A: the source sends slice r to rank r; B: every rank sends ITS
+    slice to every other rank but the source (the source: its own slice to everybody).  On xGMI every transfer of a step has a link of its
+    own: 2 F / (N x link rate) instead of the F / link rate of a ring.  Returns the bytes covered (the tail goes by broadcast)."""
+    sl = (nbytes // world) & ~511
+    if sl <= 0:
+        return 0
+    ops = []
+    if rank == src:
+        ops = [dist.P2POp(dist.isend, _as_tensor(ptr + r * sl, sl, device), r) for r in range(world) if r != src]
+    else:
+        ops = [dist.P2POp(dist.irecv, _as_tensor(ptr + rank * sl, sl, device), src)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    ops = []
+    for q in range(world):
+        if q == rank:
+            continue
+        if q != src:
+            ops.append(dist.P2POp(dist.isend, _as_tensor(ptr + rank * sl, sl, device), q))
+        if rank != src:
+            ops.append(dist.P2POp(dist.irecv, _as_tensor(ptr + q * sl, sl, device), q))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return sl * world
+
+
+def broadcast_factor(solver, d_values, dist, src=0, device=None, chunk_bytes=256 << 20, slices=True, slice_min_bytes=64 << 20):
     """Numeric factor of `solver` (rank `src` has factorised; every rank has run `initialize` on the same structure, which
     is deterministic) -> all ranks, in place, straight between the solvers' own device buffers -- the FOUR parts of
     solver_hipmf_factor_parts: persistent part of the front pool, local row interchanges, row scaling, pivots (the D of the
     L D L^T fronts, the determinant and rcond come from them) -- in chunks of `chunk_bytes` (ring collectives over xGMI are per-link bound, large
-    messages keep the links busy).  Afterwards the other ranks adopt the factor; `d_values` = device pointer of the matrix
+    messages keep the links busy); with three or more ranks a part of at least `slice_min_bytes` travels as slices over all links
+    (_spread_slices).  Afterwards the other ranks adopt the factor; `d_values` = device pointer of the matrix
     values of the calling rank (for the refinement SpMV).  Returns the number of bytes broadcast."""
     total = 0
+    world, rank = dist.get_world_size(), dist.get_rank()
     for ptr, nbytes in solver.factor_buffers():
-        for off in range(0, nbytes, chunk_bytes):
+        done = 0
+        if slices and world >= 3 and nbytes >= slice_min_bytes:
+            done = _spread_slices(ptr, nbytes, dist, src, device, rank, world)
+        for off in range(done, nbytes, chunk_bytes):
             n = min(chunk_bytes, nbytes - off)
             dist.broadcast(_as_tensor(ptr + off, n, device), src=src)
-            total += n
+        total += nbytes
     if device is not None and str(device) != "cpu":
         import torch
         torch.cuda.synchronize(device)

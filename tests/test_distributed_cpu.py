@@ -130,7 +130,9 @@ def _shard8_worker(rank, world, port, out, emu, nrhs_total):
         s.h2d(d_w, 3.0 * v)
         assert s.factorize_device(d_w) == 0
         s.dev_free(d_w)
-    broadcast_factor(s, d_v, dist, src=0, device=None, chunk_bytes=1 << 15)
+    # (round 6: the pool travels as eight slices in two point-to-point steps -- scatter from the root, then everybody's slice to everybody --
+    #  the path solver_hipmf_broadcast_factor takes over xGMI; the small parts and the tail by broadcast)
+    broadcast_factor(s, d_v, dist, src=0, device=None, chunk_bytes=1 << 15, slices=True, slice_min_bytes=1 << 14)
     # this rank's columns, solved in place of the WHOLE n x nrhs arrays through the C-ABI's sharded entry point
     d_b, d_x = s.dev_alloc(B.nbytes), s.dev_alloc(B.nbytes)
     s.h2d(d_b, B)
