@@ -210,6 +210,10 @@ int32_t solver_hipmf_reset_timers(struct InterfaceHIPMF *solver);
                                              (HIPMF_OPTION_SYM_RECHECK off: nothing was re-analysed; see last_error / verbose) */
 #define HIPMF_COUNTER_BCAST_SLICED_BYTES 18 /* bytes of factor that solver_hipmf_broadcast_factor moved as slices over all xGMI links (two point-to-point
                                              steps; three or more ranks, parts of >= 64 MB) instead of through ncclBroadcast, summed over the calls */
+#define HIPMF_COUNTER_KRYLOV_ITERATIONS 19 /* steps of the Krylov rescue in the last solve: after a factorisation that PERTURBED pivots (static pivot order:
+                                             what UMFPACK's dynamic pivoting, interface_umfpack.c:167, would have avoided) a column whose refined solution
+                                             leaves |b - A x|_2 > 1e-13 |b|_2 is finished by flexible GMRES preconditioned with the factorisation
+                                             (rank(E) + 1 steps in exact arithmetic); 0: not needed.  HIPMF_KRYLOV=0 switches it off */
 int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 
 /* Options of LinSolParams that the initialize signature (kept in the shape of interface_cudss.cu:190-203 minus the cuDSS-only
@@ -217,9 +221,15 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
  *   HIPMF_OPTION_MATCHING            lin_sol_params.rs:13 / enums.rs Matching: 0 = None (never), 1 = Auto (default: when values are
  *                                    handed to initialize and the diagonal is weak), 2 = always; every reference variant other than
  *                                    None / Auto selects THE matching this backend has (maximum product + scaling, MC64 job 5)
- *   HIPMF_OPTION_PIVOTING            lin_sol_params.rs:16 / enums.rs Pivoting: 1 = Auto / LocalBlock (partial pivoting inside the pivot
- *                                    block of a small front / the 32-row diagonal tile of a tiled one, tiny pivots perturbed and counted);
- *                                    None / GlobalCol / GlobalRow / Diagonal are not available: ERROR_NOT_AVAILABLE
+ *   HIPMF_OPTION_PIVOTING            lin_sol_params.rs:16 / enums.rs Pivoting as an integer (0 Auto, 1 None, 2 GlobalCol, 3 GlobalRow, 4 Diagonal,
+ *                                    5 LocalBlock): a REQUEST, as in the cuDSS shim, which reads the effective strategy back after
+ *                                    factorize (interface_cudss.cu:485-491).  Every value is accepted (round 6; rounds 1 - 5 refused all but
+ *                                    Auto / LocalBlock); the kernels have ONE strategy, readable as HIPMF_OPTION_EFFECTIVE_PIVOTING = 5
+ *                                    (LocalBlock): partial pivoting inside the pivot block of a small front / the 32-row diagonal tile of a
+ *                                    tiled one; a pivot below pivot_epsilon max|a| is replaced by +-sqrt(machine eps) max|a| and counted;
+ *                                    solves after such a factorisation are finished by a Krylov rescue when refinement is not enough
+ *                                    (HIPMF_COUNTER_KRYLOV_ITERATIONS), and an exactly zero pivot means status 1 ("singular") only when a
+ *                                    probe solve confirms it
  *   HIPMF_OPTION_HYBRID_MEMORY       lin_sol_params.rs:39 (cuDSS hybrid memory, factor 0.01 .. 0.99; interface_cudss.cu:347-380: the factor spills
  *                                    to host memory, factor x total is the device share).  Accepted, range-checked and kept (get_option
  *                                    returns it), and WITHOUT effect on what fits: this backend has no out-of-core path, the factor +
@@ -243,6 +253,7 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *solver, int32_t which);
 #define HIPMF_OPTION_ERROR_ESTIMATES 3
 #define HIPMF_OPTION_CONDITION_NUMBERS 4
 #define HIPMF_OPTION_SYM_RECHECK 5
+#define HIPMF_OPTION_EFFECTIVE_PIVOTING 6 /* get_option only */
 int32_t solver_hipmf_set_option(struct InterfaceHIPMF *solver, int32_t option, double value);
 int32_t solver_hipmf_get_option(struct InterfaceHIPMF *solver, int32_t option, double *value);
 

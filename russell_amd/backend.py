@@ -128,7 +128,7 @@ class Hipmf:
         out.update({k: float(v) for k, v in zip(DSTAT_NAMES, d)})
         return out
 
-    COUNTERS = {"rematch": 0, "weak_diagonal_rows": 1, "fused_fallbacks": 2, "persistent_bytes": 3, "arena_bytes": 4, "symmetric_ldlt": 5, "sym_expanded": 6, "chain_fallbacks": 7, "mid_fronts": 8, "plan_digest": 9, "tagged_solve": 10, "gate_waits": 11, "wave_fronts": 12, "leaf_fronts": 13, "split_slabs": 14, "event_fence_free": 15, "block_groups": 16, "sym_weak_diagonal": 17, "bcast_sliced_bytes": 18}
+    COUNTERS = {"rematch": 0, "weak_diagonal_rows": 1, "fused_fallbacks": 2, "persistent_bytes": 3, "arena_bytes": 4, "symmetric_ldlt": 5, "sym_expanded": 6, "chain_fallbacks": 7, "mid_fronts": 8, "plan_digest": 9, "tagged_solve": 10, "gate_waits": 11, "wave_fronts": 12, "leaf_fronts": 13, "split_slabs": 14, "event_fence_free": 15, "block_groups": 16, "sym_weak_diagonal": 17, "bcast_sliced_bytes": 18, "krylov_iterations": 19}
 
     OPTIONS = {"matching": 0, "pivoting": 1, "hybrid_memory": 2, "error_estimates": 3, "condition_numbers": 4, "sym_recheck": 5}
 

@@ -701,9 +701,13 @@ std::string StatsLinSol::to_json(bool pretty) const {
       << "\"matrix\":{\"name\":" << q(matrix_name) << ",\"nrow\":" << nrow << ",\"ncol\":" << ncol << ",\"nnz\":" << nnz
       << ",\"nnz_actual\":" << nnz_actual << ",\"complex\":" << (complex ? "true" : "false") << ",\"symmetric\":" << q(symmetric) << "},"
       << "\"requests\":{\"ordering\":" << q(ordering) << ",\"scaling\":" << q(scaling) << ",\"matching\":" << q(matching)
-      << ",\"positive_definite\":" << (positive_definite ? "true" : "false") << "},"
+      << ",\"pivoting\":" << q(pivoting) << ",\"mumps_num_threads\":0"
+      << ",\"positive_definite\":" << (positive_definite ? "true" : "false")
+      << ",\"hybrid_memory_factor\":" << (has_hybrid_memory_factor ? f(hybrid_memory_factor) : std::string("null")) << "},"
       << "\"output\":{\"effective_ordering\":" << q(effective_ordering) << ",\"effective_scaling\":" << q(effective_scaling)
-      << ",\"effective_matching\":" << q(effective_matching) << ",\"rcond_estimate\":" << f(rcond_estimate)
+      << ",\"effective_matching\":" << q(effective_matching) << ",\"effective_pivoting\":" << q(effective_pivoting)
+      << ",\"effective_mumps_num_threads\":0,\"openmp_num_threads\":0,\"umfpack_strategy\":" << q(umfpack_strategy)
+      << ",\"umfpack_rcond_estimate\":" << f(rcond_estimate) << ",\"rcond_estimate\":" << f(rcond_estimate)
       << ",\"perturbed_pivots\":" << perturbed_pivots << "},"
       << "\"determinant\":{\"mantissa_real\":" << f(det_mantissa) << ",\"mantissa_imag\":" << f(det_mantissa_imag) << ",\"base\":" << f(det_base)
       << ",\"exponent\":" << f(det_exponent) << "},"
@@ -717,7 +721,10 @@ std::string StatsLinSol::to_json(bool pretty) const {
       << "\"time_nanoseconds\":{\"read_matrix\":" << read_matrix_ns << ",\"initialize_array\":" << arr(initialize_ns)
       << ",\"initialize\":" << avg(initialize_ns) << ",\"factorize_array\":" << arr(factorize_ns) << ",\"factorize\":" << avg(factorize_ns)
       << ",\"solve_array\":" << arr(solve_ns) << ",\"solve\":" << avg(solve_ns) << ",\"total_ifs_array\":" << arr(total)
-      << ",\"total_ifs\":" << avg(total) << ",\"verify\":" << verify_ns << "}}";
+      << ",\"total_ifs\":" << avg(total) << ",\"verify\":" << verify_ns << "},"
+      // (stats_lin_sol.rs:100-113: MUMPS's own error analysis; zeros for every other solver, as in the reference)
+      << "\"mumps_stats\":{\"inf_norm_a\":0.0,\"inf_norm_x\":0.0,\"scaled_residual\":0.0,\"backward_error_omega1\":0.0,\"backward_error_omega2\":0.0,"
+         "\"normalized_delta_x\":0.0,\"condition_number1\":0.0,\"condition_number2\":0.0}}";
     return pretty ? json_pretty(o.str()) : o.str();
 }
 
@@ -908,8 +915,10 @@ StrError SolverHIPMF::factorize(const CooMatrix &mat, const LinSolParams *params
         compute_determinant = par.compute_determinant;
         uint64_t t0 = now_ns();
         // the parameters the initialize signature does not carry (lin_sol_params.rs:13-16,39)
-        if (par.pivoting != Pivoting::Auto && par.pivoting != Pivoting::LocalBlock)
-            return "HIPMF pivots inside the pivot block only (Pivoting::Auto or Pivoting::LocalBlock)";
+        // (round 6: Pivoting is a request, as for cuDSS -- solver_cudss.rs:233,298 hands it over and reads the EFFECTIVE strategy back.
+        //  Every value is accepted; what runs is partial pivoting inside the pivot block = LocalBlock, with replaced pivots and the
+        //  Krylov rescue for what that cannot fix; update_stats reports it)
+        if (g_backend.set_option((InterfaceHIPMF *)solver, HIPMF_OPTION_PIVOTING, (double)(int32_t)par.pivoting) != SUCCESSFUL_EXIT) return "HIPMF: invalid pivoting option";
         const double mval = par.matching == Matching::None ? 0.0 : (par.matching == Matching::Auto ? 1.0 : 2.0);
         if (g_backend.set_option((InterfaceHIPMF *)solver, HIPMF_OPTION_MATCHING, mval) != SUCCESSFUL_EXIT) return "HIPMF: invalid matching option";
         if (par.has_hybrid_memory_factor) {
@@ -1205,6 +1214,7 @@ void ComplexSolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.det_base = 10.0, stats.det_exponent = determinant_exponent;
     stats.perturbed_pivots = perturbed_pivots;
     stats.effective_matching = effective_matching ? "MaxProdScaled" : "None";
+    stats.effective_pivoting = "LocalBlock";
 }
 
 StrError SolverHIPMF::solve_many(std::vector<double> &x, const std::vector<double> &rhs, size_t nrhs) {
@@ -1231,6 +1241,7 @@ void SolverHIPMF::update_stats(StatsLinSol &stats) const {
     stats.det_exponent = determinant_exponent;
     stats.perturbed_pivots = perturbed_pivots;
     stats.effective_matching = effective_matching ? "MaxProdScaled" : "None";
+    stats.effective_pivoting = "LocalBlock"; // (enums.rs Pivoting::LocalBlock: pivot search inside the diagonal block of the supernode)
 }
 
 StrError LinSolver::create(LinSolver &out, Genie genie) {

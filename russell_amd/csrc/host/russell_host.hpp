@@ -47,7 +47,8 @@ enum class Pivoting : int32_t { Auto = 0, None, GlobalCol, GlobalRow, Diagonal, 
 //              winner) is reported by update_stats
 //   matching   None -> never; Auto -> when the diagonal is weak; any named variant -> always (there is one matching: maximum product
 //              + scaling, what cuDSS calls MaxDiagProduct)
-//   pivoting   Auto / LocalBlock -> partial pivoting inside the pivot block (the only strategy); others: factorize returns an error
+//   pivoting   a REQUEST, as for cuDSS (solver_cudss.rs:233,298: the effective strategy comes back from factorize): every value is accepted,
+//              what runs is partial pivoting inside the pivot block (LocalBlock) + replaced pivots + Krylov rescue; StatsLinSol reports it
 //   hybrid_memory_factor  recorded; a factor that does not fit HBM is refused with the "Not enough memory" string the reference's
 //              harness recognises (stats_lin_sol.rs:334-340)
 //   compute_error_estimates / compute_condition_numbers  always available from the actual solver (get_error_estimate / rcond_estimate)
@@ -158,6 +159,12 @@ bool is_memory_error(const char *message);
 struct StatsLinSol {
     std::string solver = "Unknown", matrix_name = "Unknown", symmetric = "Unknown", ordering = "Unknown", scaling = "Unknown",
                 matching = "Unknown", effective_ordering = "Unknown", effective_scaling = "Unknown", effective_matching = "Unknown";
+    // round 6: the fields of stats_lin_sol.rs:36-60 the mirror used to leave out (requests.pivoting / mumps_num_threads /
+    // hybrid_memory_factor, output.effective_pivoting / effective_mumps_num_threads / openmp_num_threads / umfpack_strategy /
+    // umfpack_rcond_estimate) and the mumps_stats block (:100-113): a consumer of the reference's JSON finds every key
+    std::string pivoting = "Unknown", effective_pivoting = "Unknown", umfpack_strategy = "Unknown";
+    bool has_hybrid_memory_factor = false;
+    double hybrid_memory_factor = 0.0;
     size_t nrow = 0, ncol = 0, nnz = 0, nnz_actual = 0;
     bool complex = false, positive_definite = false, out_of_memory = false;
     double rcond_estimate = 0.0, det_mantissa = 0.0, det_mantissa_imag = 0.0, det_base = 0.0, det_exponent = 0.0;

@@ -29,6 +29,8 @@ struct Options {
     std::string matrix_market_file, genie = "hipmf", ordering = "Auto", scaling = "Auto", matching_sym = "None", matching_gen = "Auto";
     bool positive_definite = false, verbose = false, determinant = false, hide_json = false;
     long nrun = 1;
+    bool has_hybrid = false;
+    double hybrid = 0.0;
 };
 
 // enums.rs:45-66,159-222 (Ordering::from / Scaling::from): case-insensitive names, anything else -> Auto
@@ -104,6 +106,7 @@ int main(int argc, char **argv) {
                     fprintf(stderr, "hybrid memory factor must be in [0.01, 0.99]\n");
                     return 1;
                 }
+                opt.has_hybrid = true, opt.hybrid = v; // (solve_matrix_market.rs:132-138: handed to the solver and recorded in the requests)
             }
         } else if (arg == "-p" || arg == "--positive-definite") opt.positive_definite = true;
         else if (arg == "-v" || arg == "--verbose") opt.verbose = true;
@@ -133,6 +136,11 @@ int main(int argc, char **argv) {
     stats.ordering = ordering_name(params.ordering);
     stats.scaling = scaling_name(params.scaling);
     stats.positive_definite = params.positive_definite;
+    stats.pivoting = "Auto"; // (lin_sol_params.rs:16 default; the reference's harness has no switch for it either)
+    if (opt.has_hybrid) {
+        params.has_hybrid_memory_factor = true, params.hybrid_memory_factor = opt.hybrid;
+        stats.has_hybrid_memory_factor = true, stats.hybrid_memory_factor = opt.hybrid;
+    }
 
     uint64_t t0 = now_ns();
     MatrixMarketData data;

@@ -28,7 +28,7 @@ struct InterfaceHIPMF {
     int32_t ordering_requested = 0;
     int32_t effective_ordering = 0;
     // solver_hipmf_set_option (before initialize)
-    int32_t opt_matching = 1, opt_pivoting = 1, opt_sym_recheck = 0;
+    int32_t opt_matching = 1, opt_pivoting = 0, opt_sym_recheck = 0;
     int64_t bcast_sliced_bytes = 0; // bytes of factor that travelled as slices over all links (solver_hipmf_broadcast_factor, round 6)
     double opt_hybrid = 0.0;
     // a symmetric-lower matrix with a weak diagonal is analysed and factorised as the mirrored GENERAL matrix (with the matching):
@@ -232,8 +232,10 @@ int32_t solver_hipmf_set_option(struct InterfaceHIPMF *h, int32_t option, double
         h->opt_matching = (int32_t)value;
         return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_PIVOTING:
-        if (value != 1.0) return ERROR_NOT_AVAILABLE; // (the only strategy of the kernels: partial pivoting inside the pivot block)
-        h->opt_pivoting = 1;
+        // enums.rs Pivoting as an integer: 0 Auto, 1 None, 2 GlobalCol, 3 GlobalRow, 4 Diagonal, 5 LocalBlock -- a REQUEST (cuDSS reports the
+        // effective strategy back from factorize, interface_cudss.cu:485-491): recorded; the kernels' one strategy runs whatever is asked
+        if (!(value >= 0.0 && value <= 5.0) || value != (double)(int32_t)value) return ERROR_HIPMF_INVALID_VALUE;
+        h->opt_pivoting = (int32_t)value;
         return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_HYBRID_MEMORY:
         if (!(value > 0.0 && value < 1.0)) return ERROR_HIPMF_INVALID_VALUE;
@@ -254,6 +256,7 @@ int32_t solver_hipmf_get_option(struct InterfaceHIPMF *h, int32_t option, double
     switch (option) {
     case HIPMF_OPTION_MATCHING: *value = h->solver.initialized ? h->solver.opt.matching : h->opt_matching; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_PIVOTING: *value = h->opt_pivoting; return SUCCESSFUL_EXIT;
+    case HIPMF_OPTION_EFFECTIVE_PIVOTING: *value = 5.0; return SUCCESSFUL_EXIT; // LocalBlock
     case HIPMF_OPTION_HYBRID_MEMORY: *value = h->opt_hybrid; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_SYM_RECHECK: *value = h->opt_sym_recheck; return SUCCESSFUL_EXIT;
     case HIPMF_OPTION_ERROR_ESTIMATES: *value = h->solver.last_omega; return SUCCESSFUL_EXIT;
@@ -536,6 +539,7 @@ int64_t solver_hipmf_get_counter(struct InterfaceHIPMF *h, int32_t which) {
     case HIPMF_COUNTER_BLOCK_GROUPS: return s.block_groups_last;
     case HIPMF_COUNTER_SYM_WEAK_DIAGONAL: return s.sym_weak_diag_seen ? 1 : 0;
     case HIPMF_COUNTER_BCAST_SLICED_BYTES: return h->bcast_sliced_bytes;
+    case HIPMF_COUNTER_KRYLOV_ITERATIONS: return s.krylov_iterations;
     default: return -1;
     }
 }

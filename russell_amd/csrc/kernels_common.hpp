@@ -151,6 +151,18 @@ struct FactorInfo {
     int32_t n_nonfinite;  // NaN / Inf among the scaled input values (the factorisation is refused)
     int32_t n_weak_diag;  // rows whose (matched, scaled) diagonal is below 1 % of the row's largest entry (k_diag_check)
 };
+// Static pivoting (round 6): a pivot is REPLACED when it is below the threshold pivot_eps max|a| (cuDSS's pivot_epsilon, 1e-13 by
+// default: what is smaller than that is rounding noise) -- but by +-sqrt(machine eps) max|a|, not by the threshold itself (unless the
+// caller's threshold is larger).  A replacement of 1e-13 max|a| makes the trailing matrix receive updates of 1e13 times its own size: every
+// digit of it is lost, the factors are no longer the LU of a matrix NEAR A and neither refinement nor the Krylov rescue (numeric.cpp)
+// recovers the solution (tests/test_matrix_zoo_gpu.py, the +-1 family: forward error 1e-4 ... 1e2).  With sqrt(eps) half of the digits
+// survive: the factors are the LU of A + E, |E| ~ 1e-8 |A|, rank(E) = number of replaced pivots -- the choice of SuperLU_DIST's static
+// pivoting (Li & Demmel) and of PARDISO for symmetric indefinite matrices.  Pivots at or above the threshold are never touched.
+__device__ __forceinline__ double pivot_replacement(double pivot_eps, double anorm) {
+    const double r = 1.4901161193847656e-08; // sqrt(2^-52)
+    return (pivot_eps > r ? pivot_eps : (pivot_eps > 0.0 ? r : 0.0)) * anorm; // (pivot_eps == 0: the caller asked for no replacement value)
+}
+
 // What the device allocation behind a FactorInfo pointer really holds.  zdiag (PAIRED instances of the factorisation kernels only: the
 // real-equivalent form of a complex matrix, interface_complex_hipmf.cpp): the COMPLEX pivots, zdiag[2 k], zdiag[2 k + 1] = Re, Im of the
 // pivot of the complex elimination step k (permuted numbering: k = first / 2 + step / 2 of the front) -- what the determinant of the

@@ -103,9 +103,10 @@ __global__ void __launch_bounds__(256) k_extend_add_lds(const EaTask *__restrict
             a[c] = (tid < nb && c < nb) ? T[cc * EA_TILE_R + rr] : (tid == c ? 1.0 : 0.0);
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
         int step, npert, nzero;
         double zr = 0.0, zi = 0.0;
-        tile_lu32_z<!SYM, PAIRED>(a, tid, eps, step, npert, nzero, zr, zi);
+        tile_lu32_z<!SYM, PAIRED>(a, tid, eps, rep, step, npert, nzero, zr, zi);
         if (tid < nb) {
             double *dw = dws + (int64_t)t.lu_slot * NB * NB;
             double dg = 1.0;

@@ -35,7 +35,7 @@ constexpr int LU_KB = 8;
 // is the real row is the parity of its original position, lp.  zd: where the complex pivots of this front go (2 doubles per pair).
 template <int NW, bool PIVOT, bool PAIRED = false>
 __device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int ld, const int f, const int p, int32_t *lp, int32_t *pivpos,
-                                               const double eps, FactorInfo *info, double *zd = nullptr) {
+                                               const double eps, const double rep, FactorInfo *info, double *zd = nullptr) {
     constexpr int KB = LU_KB, T = 64 * NW;
     const int lin = threadIdx.x, lane = lin & 63, wave = lin >> 6;
     for (int c0 = 0; c0 < p; c0 += KB) {
@@ -72,11 +72,15 @@ __device__ __forceinline__ void lds_lu_blocked(double *__restrict__ S, const int
                     double d = wave_bcast(a[st], pv);
                     double inv = wave_bcast(myinv, pv);
                     if (fabs(d) < eps || d == 0.0) {
-                        double dn = (d < 0.0) ? -eps : eps;
+                        double dn = (d < 0.0) ? -rep : rep;
                         if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
                         if (lane == pv) a[st] = dn;
                         npert++;
-                        if (d == 0.0) nzero++;
+                        // An exactly zero pivot is what UMFPACK reports as a singular matrix (status 1, solver_umfpack.rs:492) -- when the
+                        // whole column is zero.  Here the column goes on below the pivot block (rows that belong to the ancestors: a solver
+                        // with dynamic pivoting would take one of them, interface_umfpack.c:167): a non-zero entry there means the
+                        // matrix need not be singular -- the pivot counts as perturbed only (round 6: the +-1 family of the matrix zoo).
+                        if (d == 0.0 && __ballot(active && r >= p && a[st] != 0.0) == 0ull) nzero++;
                         d = dn;
                         inv = 1.0 / dn;
                     }
@@ -246,6 +250,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const
     const int p = fd.p, f = fd.p + fd.m;
     double *F = pool + fd.off;
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
     // descriptors of up to 64 children, one lane each (on their way while the front is zeroed and A's entries come in)
     const int nch = fd.child_end - fd.child_begin;
     int64_t d_cb = 0, d_ldc = 0, d_rel = 0;
@@ -326,8 +331,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const
         if (tid < p) lp[tid] = tid;
     }
     __syncthreads();
-    if constexpr (PAIRED) lds_lu_blocked<NW, true, true>(sm, ld, f, p, lp, pivpos, eps, info, reinterpret_cast<const FactorInfoExt *>(info)->zdiag + fd.first);
-    else lds_lu_blocked<NW, true>(sm, ld, f, p, lp, pivpos, eps, info);
+    if constexpr (PAIRED) lds_lu_blocked<NW, true, true>(sm, ld, f, p, lp, pivpos, eps, rep, info, reinterpret_cast<const FactorInfoExt *>(info)->zdiag + fd.first);
+    else lds_lu_blocked<NW, true>(sm, ld, f, p, lp, pivpos, eps, rep, info);
     // A front with a packed copy of its rows of U keeps L alone in its pivot block (zeros on and above the diagonal) and U alone in the
     // copy (zeros below the diagonal of U11): the wave-subtree solves (kernels_solve_tree.hpp) then need no per-lane tests in their
     // substitution steps; every other reader masks those entries anyway.
@@ -366,7 +371,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 6 : 2) k_small_factor(const
 // largest of the column: its modulus is within sqrt 2 of the largest), and the 2 x 2 blocks [a -b; b a] keep their shape in the
 // Schur complement (to rounding).  zr + i zi: the complex pivot, valid in the lane that was chosen at an even step.
 template <bool PIVOT = true, bool PAIRED = false>
-__device__ __forceinline__ void tile_lu32_z(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero, double &zr, double &zi) {
+__device__ __forceinline__ void tile_lu32_z(double (&a)[NB], int lane, double eps, double rep, int &step, int &npert, int &nzero, double &zr, double &zi) {
     step = -1;
     npert = 0;
     nzero = 0;
@@ -390,7 +395,7 @@ __device__ __forceinline__ void tile_lu32_z(double (&a)[NB], int lane, double ep
         double d = wave_bcast(a[c], pv);
         double inv = wave_bcast(myinv, pv);
         if (fabs(d) < eps || d == 0.0) {
-            double dn = (d < 0.0) ? -eps : eps;
+            double dn = (d < 0.0) ? -rep : rep;
             if (dn == 0.0) dn = 1.0;
             if (lane == pv) a[c] = dn;
             npert++;
@@ -414,9 +419,9 @@ __device__ __forceinline__ void tile_lu32_z(double (&a)[NB], int lane, double ep
         for (int cc = c + 1; cc < NB; cc++) a[cc] -= lmul * wave_bcast(a[cc], pv);
     }
 }
-template <bool PIVOT = true> __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps, int &step, int &npert, int &nzero) {
+template <bool PIVOT = true> __device__ __forceinline__ void tile_lu32(double (&a)[NB], int lane, double eps, double rep, int &step, int &npert, int &nzero) {
     double zr, zi;
-    tile_lu32_z<PIVOT, false>(a, lane, eps, step, npert, nzero, zr, zi);
+    tile_lu32_z<PIVOT, false>(a, lane, eps, rep, step, npert, nzero, zr, zi);
 }
 
 // Tiled path, step 0 of the levels with MANY tiled fronts: one wavefront per front factorises the first diagonal tile and parks it
@@ -439,9 +444,10 @@ __global__ void __launch_bounds__(64) k_diag0(const FrontDesc *__restrict__ LFD,
         a[c] = (tid < nb && c < nb) ? F[rr + (int64_t)cc * ld] : (tid == c ? 1.0 : 0.0);
     }
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
     int step, npert, nzero;
     double zr = 0.0, zi = 0.0;
-    tile_lu32_z<!SYM, PAIRED>(a, tid, eps, step, npert, nzero, zr, zi);
+    tile_lu32_z<!SYM, PAIRED>(a, tid, eps, rep, step, npert, nzero, zr, zi);
     if (tid < nb) {
         double *dw = dws + (int64_t)slot * NB * NB; // step 0 uses buffer 0
         double dg = 1.0;
@@ -638,9 +644,10 @@ __device__ __forceinline__ void panel_body(PanelLds &sh, const int slot, const i
             a[c] = in ? fv : (tid == c ? 1.0 : 0.0);
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
         int step, npert, nzero;
         double zr = 0.0, zi = 0.0;
-        tile_lu32_z<!SYM, PAIRED>(a, tid, eps, step, npert, nzero, zr, zi);
+        tile_lu32_z<!SYM, PAIRED>(a, tid, eps, rep, step, npert, nzero, zr, zi);
         if (tid < NB) {
             // rows go to LDS in pivot order: row `step` of the interchanged tile is this lane's row
             double dg = 1.0;
@@ -948,9 +955,10 @@ __device__ __forceinline__ void update_body(UpdateLdsT<TS> &sh, const int slot, 
             a2[16 + c] = half == 0 ? other : acc[c];
         }
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
         int step, npert, nzero;
         double zr = 0.0, zi = 0.0;
-        tile_lu32_z<!SYM, PAIRED>(a2, tid, eps, step, npert, nzero, zr, zi); // lanes >= 32 are not candidates and take no part
+        tile_lu32_z<!SYM, PAIRED>(a2, tid, eps, rep, step, npert, nzero, zr, zi); // lanes >= 32 are not candidates and take no part
         if (tid < nb2) {
             double *dwo = dws + ((int64_t)(((k0 / NB) + 1) & 1) * dws_stride + slot) * NB * NB;
             double dgv = 1.0;

@@ -48,7 +48,7 @@ template <int TS> struct BstepLdsT {
 // moves one register down as it is updated, the column of the inverse that replaces the pivot column enters at register 31; after 32
 // steps every column is back in its place.  The body (~110 instructions) is fetched once.  Always 32 steps: the caller pads a smaller
 // block with identity rows / columns (their pivots are 1, chosen at their own steps).  Results as tile_inv32.
-__device__ __forceinline__ void tile_inv32_rot(double (&a)[NB], int lane, double eps, int &step, double &dval, int32_t *rk, int &npert, int &nzero) {
+__device__ __forceinline__ void tile_inv32_rot(double (&a)[NB], int lane, double eps, double rep, int &step, double &dval, int32_t *rk, int &npert, int &nzero) {
     step = -1;
     dval = 1.0;
     npert = 0;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void tile_inv32_rot(double (&a)[NB], int lane, double
         double d = wave_bcast(a[0], pv);
         double inv = wave_bcast(myinv, pv);
         if (fabs(d) < eps || d == 0.0) {
-            double dn = (d < 0.0) ? -eps : eps;
+            double dn = (d < 0.0) ? -rep : rep;
             if (dn == 0.0) dn = 1.0;
             npert++;
             if (d == 0.0) nzero++;
@@ -99,9 +99,10 @@ __global__ void __launch_bounds__(64) k_dinv0(const FrontDesc *__restrict__ LFD,
         a[c] = in ? v : (tid == c ? 1.0 : 0.0);
     }
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
     int step, npert, nzero;
     double dval;
-    tile_inv32_rot(a, tid, eps, step, dval, rk, npert, nzero);
+    tile_inv32_rot(a, tid, eps, rep, step, dval, rk, npert, nzero);
     wave_sync();
     if (tid < nb) {
         double *Ep = pool + fd.epoff;
@@ -262,9 +263,10 @@ __device__ __forceinline__ void bstep_body(BstepLdsT<TS> &sh, const int t, const
 #pragma unroll
         for (int c = 0; c < NB; c++) a2[c] = Us[c * US_LD + (tid & 31)];
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
         int step, npert, nzero;
         double dval;
-        tile_inv32_rot(a2, tid, eps, step, dval, sh.rk, npert, nzero); // lanes >= 32 are not candidates and take no part
+        tile_inv32_rot(a2, tid, eps, rep, step, dval, sh.rk, npert, nzero); // lanes >= 32 are not candidates and take no part
         wave_sync();
         if (tid < nb2) {
             double *Dn = Ep + base + (int64_t)base * pstr;

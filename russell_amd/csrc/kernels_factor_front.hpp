@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
         }
     }
     const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+    const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
     HIPMF_STAMP(blockIdx.x, 1);
     // ---- Gauss-Jordan over the pivot block ----
     int step = -1;     // the elimination step at which this lane's row was chosen
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(64 * MID_NW) k_front(const FrontDesc *__restri
             double d = wave_bcast(col, pv);
             double inv = wave_bcast(myinv, pv);
             if (fabs(d) < eps || d == 0.0) {
-                double dn = (d < 0.0) ? -eps : eps;
+                double dn = (d < 0.0) ? -rep : rep;
                 if (dn == 0.0) dn = 1.0; // eps == 0 requested and an exact zero: keep the factors finite
                 npert++;
                 if (d == 0.0) nzero++;
@@ -349,7 +350,7 @@ struct MidlLds {
 // this lane, column position k belonging to the row chosen at step k (rk, written by the caller's lane).  np: steps to run (<= 32).
 // PAIRED: as tile_lu32_z (np even) -- the odd step takes the partner row of the even step's pivot; zr + i zi: the pair's complex pivot.
 template <bool PAIRED = false>
-__device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np, double eps, int &step, double &dval, int32_t *rk, int &npert, int &nzero,
+__device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np, double eps, double rep, int &step, double &dval, int32_t *rk, int &npert, int &nzero,
                                            double &zr, double &zi) {
     step = -1;
     dval = 1.0;
@@ -370,7 +371,7 @@ __device__ __forceinline__ void tile_inv32(double (&a)[MIDL_P], int lane, int np
             double d = wave_bcast(a[c], pv);
             double inv = wave_bcast(myinv, pv);
             if (fabs(d) < eps || d == 0.0) {
-                double dn = (d < 0.0) ? -eps : eps;
+                double dn = (d < 0.0) ? -rep : rep;
                 if (dn == 0.0) dn = 1.0;
                 npert++;
                 if (d == 0.0) nzero++;
@@ -461,9 +462,10 @@ __global__ void __launch_bounds__(64 * MIDL_NW) k_front_lu(const FrontDesc *__re
     // ---- G = inv(F11) in the registers of wavefront 0; out: Gs / GsT (LDS), E_top, the identity part of E', pivots, interchanges ----
     if (wave == 0) {
         const double eps = pivot_eps * __longlong_as_double((long long)*anorm_bits);
+        const double rep = pivot_replacement(pivot_eps, __longlong_as_double((long long)*anorm_bits));
         int step, npert, nzero;
         double dval, zr = 0.0, zi = 0.0;
-        tile_inv32<PAIRED>(a, lane, p, eps, step, dval, sh.rk, npert, nzero, zr, zi);
+        tile_inv32<PAIRED>(a, lane, p, eps, rep, step, dval, sh.rk, npert, nzero, zr, zi);
         wave_sync(); // (sh.rk of every step visible to the lanes of this wavefront)
         if (lane < p) { // (the rows of the block are the lanes 0 .. p-1: each was chosen at some step < p)
 #pragma unroll

@@ -33,27 +33,49 @@ __global__ void k_perm_out(int32_t n, const int32_t *__restrict__ perm, const do
 // The same for a block of columns in ONE launch (blockIdx.y = column; column c of b / xp / out at base + c * stride): a block of 16
 // right-hand sides used to cost 32 launches of 8 - 14 us around every pass.  Columns whose bit in `mask` is clear get zeros
 // (k_perm_in_cols: finished columns of a refinement step ride along as zeros) or are left alone (k_perm_out_cols).
-__global__ void k_perm_in_cols(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ rs, const double *__restrict__ b,
-                               int64_t bstr, double *__restrict__ xp, int64_t xstr, uint64_t mask) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+// Round 6: a thread carries PERM_CW columns of its row -- the permutation entry and the scaling factor are fetched once per row and
+// chunk of columns instead of once per column (they were 12 of the 28 bytes a column entry moved: 64 columns of the 1M-DOF system
+// 542 + 486 us per pass, profiles/r06_many_rhs_kernel_stats.txt), and the PERM_CW gathers of a thread are in flight together.
+// blockIdx.y = chunk of PERM_CW columns.
+constexpr int PERM_CW = 8;
+__global__ void __launch_bounds__(256) k_perm_in_cols(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ rs, const double *__restrict__ b,
+                                                      int64_t bstr, double *__restrict__ xp, int64_t xstr, uint64_t mask, int32_t ncols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, c0 = blockIdx.y * PERM_CW;
     if (i >= n) return;
-    if (!((mask >> c) & 1ull)) {
-        xp[i + c * xstr] = 0.0;
-        return;
-    }
+    const uint32_t m = (uint32_t)((mask >> c0) & ((1u << PERM_CW) - 1u));
     const int q = perm[i];
-    xp[i + c * xstr] = rs[q] * b[q + c * bstr];
+    const double r = rs[q];
+    double v[PERM_CW];
+#pragma unroll
+    for (int k = 0; k < PERM_CW; k++) v[k] = b[q + (int64_t)(c0 + k < ncols ? c0 + k : c0) * bstr]; // (clamped column: unconditional loads)
+#pragma unroll
+    for (int k = 0; k < PERM_CW; k++)
+        if (c0 + k < ncols) xp[i + (int64_t)(c0 + k) * xstr] = ((m >> k) & 1u) ? r * v[k] : 0.0;
 }
-__global__ void k_perm_out_cols(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ cs, const double *__restrict__ xp,
-                                int64_t xstr, double *__restrict__ out, int64_t ostr, int32_t mode, uint64_t mask) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (j >= n || !((mask >> c) & 1ull)) return;
+__global__ void __launch_bounds__(256) k_perm_out_cols(int32_t n, const int32_t *__restrict__ perm, const double *__restrict__ cs, const double *__restrict__ xp,
+                                                       int64_t xstr, double *__restrict__ out, int64_t ostr, int32_t mode, uint64_t mask, int32_t ncols) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, c0 = blockIdx.y * PERM_CW;
+    if (j >= n) return;
+    const uint32_t m = (uint32_t)((mask >> c0) & ((1u << PERM_CW) - 1u));
+    if (m == 0) return;
     const int q = perm[j];
-    const double v = cs ? cs[q] * xp[j + c * xstr] : xp[j + c * xstr];
-    double *o = out + q + c * ostr;
-    if (mode == 1) *o += v;
-    else if (mode == 2) *o -= v;
-    else *o = v;
+    const double sc = cs ? cs[q] : 1.0;
+    double v[PERM_CW], o[PERM_CW];
+#pragma unroll
+    for (int k = 0; k < PERM_CW; k++) v[k] = xp[j + (int64_t)(c0 + k < ncols ? c0 + k : c0) * xstr];
+    if (mode != 0) {
+#pragma unroll
+        for (int k = 0; k < PERM_CW; k++) o[k] = out[q + (int64_t)(c0 + k < ncols ? c0 + k : c0) * ostr];
+    }
+#pragma unroll
+    for (int k = 0; k < PERM_CW; k++)
+        if (c0 + k < ncols && ((m >> k) & 1u)) {
+            const double t = cs ? sc * v[k] : v[k];
+            double *dst = out + q + (int64_t)(c0 + k) * ostr;
+            if (mode == 1) *dst = o[k] + t;
+            else if (mode == 2) *dst = o[k] - t;
+            else *dst = t;
+        }
 }
 
 // CSR SpMV in "stream" form, shared by y = alpha A x (mat_vec_mul, csr_matrix.rs:709-729) and by the residual of the iterative

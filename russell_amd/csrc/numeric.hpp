@@ -125,6 +125,17 @@ class Solver {
     int32_t set_value_map(int64_t nnz_in, const int32_t *seg_ptr, const int32_t *seg_idx, bool signed_map = false);
     int32_t factorize_mapped(const double *input, bool on_device);
     int32_t solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device);
+    int32_t solve_core(double *x, const double *rhs, int32_t nrhs, int64_t ldx, bool on_device); // the driver of solve(): triangular passes + refinement
+    int32_t krylov_rescue(double *x, const double *rhs, bool on_device);                          // see numeric.cpp
+    int32_t singular_verdict();      // exactly zero pivots were met: singular (status 1), or only an unlucky static order (0)?  One probe solve decides
+    int64_t zero_pivots_absorbed = 0; // exactly zero pivots of factorisations that the probe solve found NOT singular (summed)
+    bool krylov_enabled = true;      // HIPMF_KRYLOV=0: no rescue (the refined solution is returned as it is)
+    bool in_rescue = false;
+    int32_t krylov_restart = 40;     // directions per cycle (HIPMF_KRYLOV_RESTART)
+    int32_t krylov_cycles = 4;       // restarts at most
+    double krylov_tol = 1e-13;       // |b - A x|_2 <= tol |b|_2 ends the rescue (and is what triggers it)
+    int64_t krylov_iterations = 0;   // FGMRES steps of the last solve (0: no rescue ran or was needed)
+    double krylov_last_relres = 0.0; // |b - A x|_2 / |b|_2 after the last rescue
     int32_t prepare_many(int32_t nrhs); // the block buffers of a later many-RHS solve, ahead of time
     int32_t spmv(double *y, const double *x, double alpha, bool on_device); // y = alpha A x with the factorize()d values
     int32_t determinant(double *mantissa, double *exponent, double *rcond);

@@ -68,10 +68,13 @@ def test_lin_sol_params_matching_pivoting_hybrid(host_on_emu):
     solver2.actual.factorize(_coo(n, r, c, A[r, c]), par2)  # static pivoting alone: still a solution after refinement, or perturbed pivots
     x2 = solver2.actual.solve(b)
     assert np.all(np.isfinite(x2))
+    # round 6: Pivoting is a request (as for cuDSS, which reports the effective strategy back: solver_cudss.rs:298,381-390) -- every
+    # value is accepted, the one strategy of the kernels runs, StatsLinSol says which
     par3 = RS.LinSolParams()
     par3.pivoting = 2  # Pivoting::GlobalCol
-    with pytest.raises(Exception, match="pivots inside the pivot block"):
-        RS.LinSolver(RS.Genie.Hipmf).actual.factorize(_coo(n, r, c, A[r, c]), par3)
+    solver3 = RS.LinSolver(RS.Genie.Hipmf)
+    solver3.actual.factorize(_coo(n, r, c, A[r, c]), par3)
+    assert np.max(np.abs(solver3.actual.solve(b) - xs)) < 1e-10
     par4 = RS.LinSolParams()
     par4.hybrid_memory_factor = 1.5
     with pytest.raises(Exception, match="hybrid_memory_factor"):
@@ -87,7 +90,10 @@ def test_set_option_before_and_after_initialize(emu_lib):
     lib = s.lib
     val = C.c_double(0.0)
     assert lib.solver_hipmf_set_option(s.h, 0, 0.0) == 0          # matching off
-    assert lib.solver_hipmf_set_option(s.h, 1, 2.0) == 400000     # Pivoting::GlobalCol: ERROR_NOT_AVAILABLE
+    assert lib.solver_hipmf_set_option(s.h, 1, 2.0) == 0          # Pivoting::GlobalCol: a request, recorded (round 6)
+    assert lib.solver_hipmf_set_option(s.h, 1, 7.0) == 803        # not a value of enums.rs Pivoting
+    assert lib.solver_hipmf_get_option(s.h, 1, C.byref(val)) == 0 and val.value == 2.0
+    assert lib.solver_hipmf_get_option(s.h, 6, C.byref(val)) == 0 and val.value == 5.0  # effective: LocalBlock
     assert lib.solver_hipmf_set_option(s.h, 2, 1.5) == 803        # hybrid factor out of range: invalid value
     assert lib.solver_hipmf_set_option(s.h, 2, 0.25) == 0
     assert lib.solver_hipmf_get_option(s.h, 4, C.byref(val)) == 600000  # condition number: needs a factorisation

@@ -135,3 +135,67 @@ def test_refused_repeat_factorize_leaves_no_usable_factor(host_on_emu):
     # the handle recovers with a valid call
     solver.actual.factorize(coo(rows, ci, v))
     assert np.max(np.abs(solver.actual.solve(b) - 1.0)) < 1e-12
+
+
+def _pm1(n, k, rng):
+    # random +-1 entries, k per row plus a permutation: every transversal has the same product -- the maximum-product matching has nothing
+    # to prefer, and elimination in exact +-1 arithmetic runs into EXACTLY zero pivots inside the pivot blocks of the static order
+    import scipy.sparse as sp
+    rows = np.repeat(np.arange(n), k)
+    A = sp.csr_matrix((rng.choice([-1.0, 1.0], n * k), (rows, rng.integers(0, n, n * k))), shape=(n, n))
+    A = A + sp.csr_matrix((rng.choice([-1.0, 1.0], n), (np.arange(n), rng.permutation(n))), shape=(n, n))
+    A.sum_duplicates()
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A.tocsr()
+
+
+@pytest.mark.parametrize("seed", [100, 101, 104])
+def test_static_pivot_failures_are_rescued_not_reported_as_singular(emu_lib, monkeypatch, seed):
+    # what the matching cannot fix.  UMFPACK pivots dynamically (interface_umfpack.c:167) and solves these; here the
+    # zero pivots are replaced by sqrt(eps) max|a| (kernels_common.hpp, pivot_replacement), refinement + the Krylov rescue finish the solve,
+    # and the probe solve of factorize tells "unlucky order" from "singular" (status 0, not UMFPACK's 1)
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(seed)
+    A = _pm1(700 + 100 * (seed % 7), 4 + seed % 3, rng)
+    n = A.shape[0]
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    xs = rng.standard_normal(n)
+    b = A @ xs
+    e_ref = np.max(np.abs(spla.splu(A.tocsc()).solve(b) - xs)) / np.max(np.abs(xs))
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci, values=v) == 0
+    assert s.factorize(v) == 0
+    assert s.num_perturbed > 0  # (the family does need replaced pivots: that is what the test is about)
+    x = s.solve(b)
+    assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) <= 10.0 * e_ref + 1e-12
+    assert np.max(np.abs(A @ x - b)) / (np.max(np.abs(v)) + 1.0) <= 1e-10  # VerifyLinSys relative_error
+    s.close()
+    # without the rescue: the old verdict (status 1 for an exactly zero pivot)
+    monkeypatch.setenv("HIPMF_KRYLOV", "0")
+    s = Hipmf(emu_lib)
+    assert s.initialize(n, rp, ci, values=v) == 0
+    assert s.factorize(v) in (0, 1)
+    s.close()
+
+
+def test_singular_matrix_is_still_singular(emu_lib):
+    # solver_umfpack.rs:624-630: Error(1) "Matrix is singular" -- the probe solve must not talk a singular matrix into status 0
+    import scipy.sparse as sp
+    for dense in (np.array([[1.0, 2.0], [2.0, 4.0]]), np.array([[1.0, 0.0, 2.0], [0.0, 0.0, 0.0], [3.0, 0.0, 1.0]])):
+        A = sp.csr_matrix(dense)
+        A = sp.csr_matrix((np.where(dense[dense != 0] != 0, dense[dense != 0], 0.0), A.indices, A.indptr), shape=A.shape) if False else A
+        # (keep explicit zeros of the middle row out: give the row its diagonal entry with value 0)
+        M = sp.lil_matrix(dense)
+        r, c = np.nonzero(dense)
+        rows, cols, vals = list(r), list(c), list(dense[r, c])
+        for i in range(dense.shape[0]):
+            if not np.any(dense[i]):
+                rows.append(i), cols.append(i), vals.append(0.0)
+        order = np.lexsort((cols, rows))
+        rows, cols, vals = np.array(rows)[order], np.array(cols)[order], np.array(vals)[order]
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=dense.shape[0]))]).astype(np.int32)
+        s = Hipmf(emu_lib)
+        assert s.initialize(dense.shape[0], rp, cols.astype(np.int32)) == 0
+        assert s.factorize(vals.astype(np.float64)) == 1
+        s.close()

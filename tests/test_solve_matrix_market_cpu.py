@@ -18,14 +18,17 @@ HARNESS = os.path.join(ROOT, "russell_amd", "lib", "solve_matrix_market")
 SCHEMA = {
     "main": {"platform", "blas_lib", "solver", "local_sparse", "out_of_memory"},
     "matrix": {"name", "nrow", "ncol", "nnz", "nnz_actual", "complex", "symmetric"},
-    "requests": {"ordering", "scaling", "matching", "positive_definite"},
-    "output": {"effective_ordering", "effective_scaling", "effective_matching", "rcond_estimate", "perturbed_pivots"},
+    "requests": {"ordering", "scaling", "matching", "pivoting", "mumps_num_threads", "positive_definite", "hybrid_memory_factor"},
+    "output": {"effective_ordering", "effective_scaling", "effective_matching", "effective_pivoting", "effective_mumps_num_threads",
+               "openmp_num_threads", "umfpack_strategy", "umfpack_rcond_estimate", "rcond_estimate", "perturbed_pivots"},
     "determinant": {"mantissa_real", "mantissa_imag", "base", "exponent"},
     "verify": {"max_abs_a", "max_abs_ax", "max_abs_diff", "relative_error"},
     "time_human": {"read_matrix", "initialize_array", "initialize", "factorize_array", "factorize", "solve_array", "solve", "total_ifs_array",
                    "total_ifs", "verify"},
     "time_nanoseconds": {"read_matrix", "initialize_array", "initialize", "factorize_array", "factorize", "solve_array", "solve",
                          "total_ifs_array", "total_ifs", "verify"},
+    "mumps_stats": {"inf_norm_a", "inf_norm_x", "scaled_residual", "backward_error_omega1", "backward_error_omega2", "normalized_delta_x",
+                    "condition_number1", "condition_number2"},
 }
 
 

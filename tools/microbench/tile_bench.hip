@@ -39,7 +39,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k_tile(const double *_
     int step = 0, npert = 0, nzero = 0;
     double dval = 1.0;
     // (the clock is read after the last loaded value was used: a[31] feeds the first instruction below)
-    if (MODE == 0) tile_lu32<true>(a, tid, 1e-13, step, npert, nzero);
+    if (MODE == 0) tile_lu32<true>(a, tid, 1e-13, 1e-13, step, npert, nzero);
     else if (MODE == 1) {
         double zr, zi;
         tile_inv32(a, tid, NB, 1e-13, step, dval, rk, npert, nzero, zr, zi);
