@@ -165,6 +165,23 @@ template <int K> __device__ __forceinline__ void ld_cols(double (&v)[K], const d
     for (int c = 0; c < K; c++) v[c] = ld_agent(base + (int64_t)(c < nk ? c : 0) * cstr + off);
 }
 
+// PLAIN instances (round 6, blocked solves: the all-small band at the bottom of the tree as ONE LAUNCH PER LEVEL): everything a front reads was
+// written by an EARLIER launch of the stream, so ordinary loads and stores do -- which the compiler batches (sixteen columns in one
+// round trip without the clamping tricks), which need no drain before a counter, and which are not one fabric transaction per lane and
+// column like the write-through stores (measured on the blocked small-front step: stores + drain 7 - 9 us of a 16 - 23 us front,
+// profiles/r03_rejected_experiments.txt).
+template <int K, bool PLAIN> __device__ __forceinline__ void ld_cols_p(double (&v)[K], const double *base, int64_t cstr, int64_t off, int nk) {
+    if constexpr (PLAIN) {
+#pragma unroll
+        for (int c = 0; c < K; c++) v[c] = base[(int64_t)(c < nk ? c : 0) * cstr + off];
+    } else
+        ld_cols<K>(v, base, cstr, off, nk);
+}
+template <bool PLAIN> __device__ __forceinline__ void st_p(double *p, double v) {
+    if constexpr (PLAIN) *p = v;
+    else st_agent(p, v);
+}
+
 // All kernels are templates on K = the number of right-hand sides a launch carries (1: the instances the
 // benchmark path uses; SF_KMAX: the many-RHS instances, which read every factor entry ONCE for K columns -- the
 // solves are HBM-bound, so K columns cost little more than one).  Column c of x lives at x + c * xstr, its solve
@@ -172,7 +189,7 @@ template <int K> __device__ __forceinline__ void ld_cols(double (&v)[K], const d
 // big-front slabs of the blocked instances run on MFMA tiles (sf_mma_chunk): another summation order, equal to rounding.
 
 // ---- forward step of one small front by one wavefront; w = K x 64 doubles of LDS owned by this wave ----
-template <int K, bool TAG = false>
+template <int K, bool TAG = false, bool PLAIN = false>
 __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
                                              const int32_t *__restrict__ lperm, const int32_t *__restrict__ child_idx,
                                              const int32_t *__restrict__ rel, const int32_t *__restrict__ need, int *done, int *err,
@@ -184,7 +201,7 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
     double *xs = x + fd.first;
     {
         double xv[K];
-        ld_cols<K>(xv, xs, xstr, lane < p ? lane : 0, nk);
+        ld_cols_p<K, PLAIN>(xv, xs, xstr, lane < p ? lane : 0, nk);
 #pragma unroll
         for (int c = 0; c < K; c++)
             if (c < nk) w[c][lane] = (lane < p) ? xv[c] : 0.0;
@@ -205,7 +222,7 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             const int ch = child_idx[fd.child_begin + c0 + lane];
             const FrontDesc cd = FD[ch];
             c_woff = cd.woff, c_rowptr = cd.rowptr, c_p = cd.p, c_m = cd.m;
-            if constexpr (!TAG) sf_wait(done + ch, need[ch], err); // (TAG: the gathered words themselves say when they are there)
+            if constexpr (!TAG && !PLAIN) sf_wait(done + ch, need[ch], err); // (TAG: the gathered words themselves say when they are there)
         }
         wave_sync();
         const int nbatch = nch - c0 < 64 ? nch - c0 : 64;
@@ -214,7 +231,7 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
             // them in child order (fixed order: reproducible sums)
             const int myr = (lane < nbatch && c_m == 1) ? rel[c_rowptr] : -1;
             double myv[K];
-            ld_cols<K>(myv, work, wstr, myr >= 0 ? c_woff + c_p : 0, nk);
+            ld_cols_p<K, PLAIN>(myv, work, wstr, myr >= 0 ? c_woff + c_p : 0, nk);
             if constexpr (TAG) {
                 if (myr >= 0) myv[0] = sf_tag_wait(work + c_woff + c_p, myv[0], err);
             }
@@ -249,7 +266,7 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
                 const int gl = lane < cm ? lane : 0;
                 const int r = rel[rowptr + gl];
                 double gv[K];
-                ld_cols<K>(gv, work, wstr, woff + cp + gl, nk);
+                ld_cols_p<K, PLAIN>(gv, work, wstr, woff + cp + gl, nk);
                 if (lane < cm) {
 #pragma unroll
                     for (int c = 0; c < K; c++)
@@ -286,10 +303,10 @@ __device__ __forceinline__ void sf_fwd_small(int s, int lane, double (*w)[64], c
 #pragma unroll
     for (int c = 0; c < K; c++)
         if (c < nk) {
-            if (lane < p) st_agent(xs + c * xstr + lane, v[c]);
-            else if (lane < f) st_agent(W + c * wstr + lane, v[c]);
+            if (lane < p) st_p<PLAIN>(xs + c * xstr + lane, v[c]);
+            else if (lane < f) st_p<PLAIN>(W + c * wstr + lane, v[c]);
         }
-    if constexpr (!TAG) {
+    if constexpr (!TAG && !PLAIN) {
         drain_stores();
         if (lane == 0) flag_add(done + s, 1);
     }
@@ -416,7 +433,7 @@ __device__ __forceinline__ void sf_fwd_wave(int s, int lane, double *w, const Fr
 }
 
 // ---- backward step of one small front by one wavefront; xg = K x 64 doubles of LDS owned by this wave ----
-template <int K, bool TAG = false>
+template <int K, bool TAG = false, bool PLAIN = false>
 __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], const FrontDesc *__restrict__ FD, const double *__restrict__ pool,
                                              const int32_t *__restrict__ rows, const int32_t *__restrict__ need, int *done, int *err,
                                              double *x, int nk, int64_t xstr, double *xt = nullptr) {
@@ -427,7 +444,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     const int32_t *rws = rows + fd.rowptr;
     const int myrow = (lane < m) ? rws[lane] : 0;
     double y1[K]; // from the forward launch
-    ld_cols<K>(y1, xs, xstr, lane < p ? lane : 0, nk);
+    ld_cols_p<K, PLAIN>(y1, xs, xstr, lane < p ? lane : 0, nk);
 #pragma unroll
     for (int c = 0; c < K; c++) y1[c] = (c < nk && lane < p) ? y1[c] : 0.0;
     const int sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
@@ -449,7 +466,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     // the reciprocal of the lane's own pivot, once (a division per pivot step was the larger part of the substitution's instructions);
     // requested and formed before the wait
     const double inv_d = (lane < p) ? 1.0 / Ub[lane + (int64_t)lane * us] : 1.0;
-    if constexpr (!TAG) {
+    if constexpr (!TAG && !PLAIN) {
         if (fd.parent >= 0 && lane == 0) sf_wait(done + fd.parent, need[fd.parent], err);
     }
     wave_sync();
@@ -459,7 +476,7 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
             xv[0] = ld_agent(xt + myrow);
             if (lane < m) xv[0] = sf_tag_wait(xt + myrow, xv[0], err);
         } else
-            ld_cols<K>(xv, x, xstr, myrow, nk); // (myrow = 0 for the lanes past the front's rows: a valid address, the value is dropped)
+            ld_cols_p<K, PLAIN>(xv, x, xstr, myrow, nk); // (myrow = 0 for the lanes past the front's rows: a valid address, the value is dropped)
         if (lane < m) {
 #pragma unroll
             for (int c = 0; c < K; c++)
@@ -516,10 +533,10 @@ __device__ __forceinline__ void sf_bwd_small(int s, int lane, double (*xg)[64], 
     if (lane < p) {
 #pragma unroll
         for (int c = 0; c < K; c++)
-            if (c < nk) st_agent(xs + c * xstr + lane, v[c]);
+            if (c < nk) st_p<PLAIN>(xs + c * xstr + lane, v[c]);
         if constexpr (TAG) st_agent(xt + fd.first + lane, v[0]);
     }
-    if constexpr (!TAG) {
+    if constexpr (!TAG && !PLAIN) {
         drain_stores();
         if (lane == 0) flag_add(done + s, 1);
     }
@@ -836,7 +853,7 @@ __device__ __forceinline__ double sf_mma_sum(const double *mt, int nsub, int rr,
 #ifndef HIPMF_SF_FWD_WGS
 #define HIPMF_SF_FWD_WGS 3 // workgroups per compute unit the single-column forward instances above the wave-subtrees are compiled for (A/B builds)
 #endif
-template <bool SMALL_ONLY, int K, bool STG = false, bool TAG = false>
+template <bool SMALL_ONLY, int K, bool STG = false, bool TAG = false, bool PLAIN = false>
 __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WGS : 3) k_fwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ lperm,
                                                    const int32_t *__restrict__ child_idx, const int32_t *__restrict__ rel,
@@ -874,7 +891,8 @@ __global__ void __launch_bounds__(256, (K == 1 && !SMALL_ONLY) ? HIPMF_SF_FWD_WG
     if (SMALL_ONLY || t.kind == 0) {
         // (wave-uniform: the front's descriptor then lives in scalar registers and the panel loads use scalar bases)
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
-        if (s >= 0) sf_fwd_small<K, TAG>(s, lane, wv[wave], FD, pool, lperm, child_idx, rel, need, done, err, work, x, nk, xstr, wstr);
+        static_assert(!PLAIN || SMALL_ONLY, "plain loads / stores: the per-level launches of the all-small band only");
+        if (s >= 0) sf_fwd_small<K, TAG, PLAIN>(s, lane, wv[wave], FD, pool, lperm, child_idx, rel, need, done, err, work, x, nk, xstr, wstr);
         return;
     }
     if (SMALL_ONLY) return; // (never reached: the small-only instance is launched on all-small bands)
@@ -1224,7 +1242,7 @@ __device__ __forceinline__ void sf_bwd_wave(int s, int lane, double *w, const Fr
 // SYM: instance for factors whose big fronts are L D L^T (x1 = E^T [D^{-1} y1; x2], transposed GEMV); the LU instance carries none of it.
 // TAG (K = 1 only): data-tagged hand-offs -- a front's solved pivot entries also go to the tagged shadow `xt` of x (all tag words before
 // the launch), and that is where the fronts below read their x2 from, re-loading what is not there yet (see sf_tag_wait).
-template <bool SMALL_ONLY, int K, bool SYM, bool STG = false, bool TAG = false>
+template <bool SMALL_ONLY, int K, bool SYM, bool STG = false, bool TAG = false, bool PLAIN = false>
 __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__ tasks, const FrontDesc *__restrict__ FD,
                                                    const double *__restrict__ pool, const int32_t *__restrict__ rows,
                                                    const int32_t *__restrict__ need, int *sync, int *err, const double *work, double *x, int nk,
@@ -1256,7 +1274,8 @@ __global__ void __launch_bounds__(256, 3) k_bwd_fused(const SfTask *__restrict__
     const SfTask t = tasks[bid];
     if (SMALL_ONLY || t.kind == 0) {
         const int s = wave_uniform(wave == 0 ? t.a : (wave == 1 ? t.b : (wave == 2 ? t.c : t.d)));
-        if (s >= 0) sf_bwd_small<K, TAG>(s, lane, wv[wave], FD, pool, rows, need, done, err, x, nk, xstr, xt);
+        static_assert(!PLAIN || SMALL_ONLY, "plain loads / stores: the per-level launches of the all-small band only");
+        if (s >= 0) sf_bwd_small<K, TAG, PLAIN>(s, lane, wv[wave], FD, pool, rows, need, done, err, x, nk, xstr, xt);
         return;
     }
     if (SMALL_ONLY) return;

@@ -390,6 +390,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SPLIT_TASKS")) split_tasks = std::max(0, atoi(e));
     if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
     if (const char *e = getenv("HIPMF_BLOCK_GROUPS_BYTES")) block_groups_max_bytes = atof(e);
+    if (const char *e = getenv("HIPMF_PLAIN_BAND")) plain_band = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_KRYLOV")) krylov_enabled = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_KRYLOV_RESTART")) krylov_restart = std::max(4, atoi(e));
     if (const char *e = getenv("HIPMF_KRYLOV_TOL")) krylov_tol = atof(e);
@@ -893,8 +894,9 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     const int32_t ns = S.nsuper;
     // Blocks of right-hand sides per dependency-driven launch of the many-RHS driver (kernels_solve_fused.hpp, SfGroups).  The upper levels
     // of a SMALL factor are a chain of hand-offs that leaves the device idle: several blocks per launch overlap their chains (1M-DOF
-    // Poisson: profiles/r06_block_groups.txt).  A factor of tens of gigabytes is bound by workgroup slots and bandwidth on every level: more
-    // tasks per launch only lengthen the waits there.  HIPMF_BLOCK_GROUPS=1..4 overrides.
+    // Poisson: 0.281 -> 0.221 ms per right-hand side, profiles/r06_block_groups.txt).  Large 3D factors gain less (144^3: 3.28 -> 2.97 ms per
+    // right-hand side; config 4's 84 GB with its 32-column shard: 398 -> 381 ms) but still gain: no size limit by default; the block
+    // buffers never take more than half of the free device memory (solve()).  HIPMF_BLOCK_GROUPS=1..4 overrides.
     block_groups_plan = 8.0 * (double)S.persist_doubles <= block_groups_max_bytes ? SF_GMAX : 1;
     if (const char *e = getenv("HIPMF_BLOCK_GROUPS")) block_groups_plan = std::max(1, std::min((int)SF_GMAX, atoi(e)));
     auto pl_t = std::chrono::steady_clock::now();
@@ -1215,18 +1217,27 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
             klist = true;
             split_units = 0, split_slabs = 0;
             sfk_fwd_band = 0;
+            sfk_band_f.assign(1, 0), sfk_band_b.clear();
             for (int32_t l = 0; l < S.nlevels; l++) {
                 emit_level(l, true);
+                if (l < band) sfk_band_f.push_back((int32_t)sf.size()); // (round 6: the all-small band runs one PLAIN launch per level)
                 if (l + 1 == band) sfk_fwd_band = (int32_t)sf.size();
             }
             sfk_fwd_cnt = (int32_t)sf.size();
             sfk_bwd_top = 0;
             for (int32_t l = S.nlevels - 1; l >= 0; l--) {
                 if (l + 1 == band) sfk_bwd_top = (int32_t)sf.size() - sfk_fwd_cnt;
+                if (l < band) sfk_band_b.push_back((int32_t)sf.size() - sfk_fwd_cnt);
                 emit_level(l, false);
             }
             if (band == 0) sfk_bwd_top = (int32_t)sf.size() - sfk_fwd_cnt;
             sfk_bwd_cnt = (int32_t)sf.size() - sfk_fwd_cnt;
+            sfk_band_b.push_back(sfk_bwd_cnt);
+            if (plain_band)
+                // the fronts of the band complete in launches of their own before (forward) / after (backward) the dependency-driven
+                // launch of the levels above: nobody counts them, like the leaves
+                for (int32_t l = 0; l < band; l++)
+                    for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; k++) need[(size_t)S.level_sn[k]] = 0, need[(size_t)ns + S.level_sn[k]] = 0;
             blocked = false;
             skip_leaves = false;
             klist = false;
@@ -2533,27 +2544,58 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         if (!SMALL && S.sym_mode) HIPMF_BWD1(false, KK, true, CNT, TASKS, TRACE);                                                          \
         else HIPMF_BWD1(SMALL, KK, false, CNT, TASKS, TRACE);                                                                              \
     } while (0)
+        // (round 6, blocked instances: the all-small band as one PLAIN launch per level -- ordinary loads and stores, no counters)
+        const bool band_plain = use_k && plain_band && (int32_t)sfk_band_f.size() >= 2 && sfk_band_f.back() == fa;
+#define HIPMF_FWD_PLAIN(KK)                                                                                                                \
+    for (size_t li = 0; li + 1 < sfk_band_f.size(); li++) {                                                                               \
+        const int32_t c0 = sfk_band_f[li], cn = sfk_band_f[li + 1] - c0;                                                                  \
+        if (cn > 0)                                                                                                                       \
+            hipLaunchKernelGGL((k_fwd_fused<true, KK, false, false, true>), dim3(grid_of(cn)), dim3(256), 0, LST, T + c0, d_fd, d_pool, d_lperm, d_child, \
+                               d_rel, NEED, sync_f, sync_err, wrk, xp, nk, xstr, wstr, no_trace, 0, (const int32_t *)nullptr, (int *)nullptr, groups_of(cn)); \
+    }
         if (nk == 1) {
             if (fa > 0) HIPMF_FWD(true, 1, fa, T, no_trace);
             if (fb > 0) HIPMF_FWD(false, 1, fb, T + fa, timed ? d_trace : no_trace);
         } else if (nk <= SF_KMID) {
-            if (fa > 0) HIPMF_FWD(true, SF_KMID, fa, T, no_trace);
+            if (band_plain) {
+                HIPMF_FWD_PLAIN(SF_KMID)
+            } else if (fa > 0)
+                HIPMF_FWD(true, SF_KMID, fa, T, no_trace);
             if (fb > 0) HIPMF_FWD(false, SF_KMID, fb, T + fa, timed ? d_trace : no_trace);
         } else {
-            if (fa > 0) HIPMF_FWD(true, SF_KMAX, fa, T, no_trace);
+            if (band_plain) {
+                HIPMF_FWD_PLAIN(SF_KMAX)
+            } else if (fa > 0)
+                HIPMF_FWD(true, SF_KMAX, fa, T, no_trace);
             if (fb > 0) HIPMF_FWD(false, SF_KMAX, fb, T + fa, timed ? d_trace : no_trace);
         }
+#undef HIPMF_FWD_PLAIN
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[4], LST), ERROR_HIP_SYNCHRONIZE);
+#define HIPMF_BWD_PLAIN(KK)                                                                                                                \
+    for (size_t li = 0; li + 1 < sfk_band_b.size(); li++) {                                                                               \
+        const int32_t c0 = sfk_band_b[li], cn = sfk_band_b[li + 1] - c0;                                                                  \
+        if (cn > 0)                                                                                                                       \
+            hipLaunchKernelGGL((k_bwd_fused<true, KK, false, false, false, true>), dim3(grid_of(cn)), dim3(256), 0, LST, T + t_fwd + c0, d_fd, d_pool, \
+                               d_rows, NEED + ns, sync_b, sync_err, wrk, xp, nk, xstr, wstr, no_trace, d_diag, 0, (const int32_t *)nullptr, (int *)nullptr, \
+                               (double *)nullptr, (double *)nullptr, (int *)nullptr, groups_of(cn));                                       \
+    }
         if (nk == 1) {
             if (bt > 0) HIPMF_BWD(false, 1, bt, T + t_fwd, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
             if (bb > 0) HIPMF_BWD(true, 1, bb, T + t_fwd + bt, no_trace);
         } else if (nk <= SF_KMID) {
             if (bt > 0) HIPMF_BWD(false, SF_KMID, bt, T + t_fwd, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
-            if (bb > 0) HIPMF_BWD(true, SF_KMID, bb, T + t_fwd + bt, no_trace);
+            if (band_plain) {
+                HIPMF_BWD_PLAIN(SF_KMID)
+            } else if (bb > 0)
+                HIPMF_BWD(true, SF_KMID, bb, T + t_fwd + bt, no_trace);
         } else {
             if (bt > 0) HIPMF_BWD(false, SF_KMAX, bt, T + t_fwd, (timed && d_trace) ? d_trace + 8 * (size_t)fb : nullptr);
-            if (bb > 0) HIPMF_BWD(true, SF_KMAX, bb, T + t_fwd + bt, no_trace);
+            if (band_plain) {
+                HIPMF_BWD_PLAIN(SF_KMAX)
+            } else if (bb > 0)
+                HIPMF_BWD(true, SF_KMAX, bb, T + t_fwd + bt, no_trace);
         }
+#undef HIPMF_BWD_PLAIN
 #undef HIPMF_FWD
 #undef HIPMF_BWD
 #undef HIPMF_BWD1

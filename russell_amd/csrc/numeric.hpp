@@ -248,6 +248,9 @@ class Solver {
     SfTask *d_sfk = nullptr;
     int32_t *d_needk = nullptr;
     int32_t sfk_fwd_cnt = 0, sfk_bwd_cnt = 0, sfk_fwd_band = 0, sfk_bwd_top = 0;
+    bool plain_band = true;                    // HIPMF_PLAIN_BAND=0: the all-small band of the blocked solves stays ONE dependency-driven launch per direction
+    std::vector<int32_t> sfk_band_f, sfk_band_b; // task offsets of the band's levels in d_sfk (forward: levels ascending from task 0; backward: relative to
+                                               // the first backward task, the band's levels descending) -- one PLAIN launch per level (round 6)
     SfTask *d_sf3 = nullptr;   // tasks of the level-by-level launches of the dependency-driven kernels (fallback of L D L^T / very large fronts)
     int32_t *d_need3 = nullptr;
     std::vector<int32_t> sf3_lvl, sf3_lvl_b; // task offsets per level: forward (leaves first), backward (root first)
@@ -385,7 +388,7 @@ class Solver {
                                // buffers exist (1 .. SF_GMAX); block_cols * block_groups columns travel together
     bool prepare_only = false;     // solve() stops after its buffers exist (prepare_many)
     int32_t block_groups_plan = 1; // ... what initialize planned for (HIPMF_BLOCK_GROUPS, else by the size of the factor): the split-dot-product scratch is sized by it
-    double block_groups_max_bytes = 4e9; // factors up to this many bytes carry SF_GMAX blocks per launch, larger ones one (HIPMF_BLOCK_GROUPS_BYTES)
+    double block_groups_max_bytes = 1e18; // factors up to this many bytes carry SF_GMAX blocks per launch, larger ones one (HIPMF_BLOCK_GROUPS_BYTES; no limit by default: measured to pay up to config 4's 84 GB, profiles/r06_block_groups.txt)
     unsigned long long *d_norms_blk = nullptr; // norm slots of lane 0's blocked solves (block_cols * block_groups columns)
     int64_t work_blk_doubles = 0;  // stride between the columns of a blocked solve workspace: work_doubles without the tagged shadow xt
     unsigned long long *d_trace = nullptr;  // HIPMF_SF_TRACE=<file>: device-clock stamps of the upper tasks (profiling aid)
