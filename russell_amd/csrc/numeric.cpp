@@ -16,6 +16,13 @@
 #include <mutex>
 
 #include "kernels.hpp"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <pthread.h>
+#include <atomic>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
 #include "matching.hpp"
 
 namespace hipmf {
@@ -2075,10 +2082,134 @@ int32_t Solver::factorize_mapped(const double *input, bool on_device) {
 // One gate per device, process-wide: a solve holds it from its first launch to its last synchronisation, so at most one handle's
 // dependency-driven launches are in flight on a device; the other handle's solve waits (a solve takes a millisecond).  Launches that wait
 // for nothing inside themselves (factorisations, products, the level-set solves) are not gated: they cannot hold anything up.
-static std::mutex &device_gate(int device) {
-    static std::mutex gates[64];
+// Round 6: the gate also orders PROCESSES that share a GPU (two ranks on one device, a notebook beside a job): behind the in-process
+// mutex sits a process-shared ROBUST pthread mutex in a page of /dev/shm/russell_hipmf_gate_<PCI bus id of the device> -- uncontended, a
+// lock / unlock pair is two atomic operations in user space (a first version used flock(): two system calls per pass pair cost 0.9 % of
+// the headline on the sandboxed GPU boxes, profiles/r06_two_processes.txt); a process that dies with the lock held leaves it
+// recoverable (EOWNERDEAD -> pthread_mutex_consistent).  The process that creates the file initialises the mutex and then publishes a
+// magic word; one that finds the file waits for the word (a creator that died in between: no process gate for the late-comers).  Where
+// the file cannot be opened or mapped the gate stays in-process; HIPMF_PROCESS_GATE=0 switches the shared part off.
+struct SharedGatePage {
+    std::atomic<uint32_t> magic;
+    pthread_mutex_t mu;
+};
+struct DeviceGate {
+    std::mutex mu;
+    int state = -2; // -2: not tried yet, -1: no shared part, 0: shared page mapped
+    SharedGatePage *page = nullptr;
+    void open_shared(int device) {
+        state = -1;
+#ifndef HIPMF_EMULATED
+        if (const char *e = getenv("HIPMF_PROCESS_GATE"))
+            if (atoi(e) == 0) return;
+        constexpr uint32_t MAGIC = 0x48504d47u; // "HPMG"
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return;
+        for (char *c = bus; *c; c++)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        char path[160];
+        snprintf(path, sizeof path, "/dev/shm/russell_hipmf_gate_%s", bus);
+        const mode_t old = umask(0);
+        bool creator = true;
+        int fd = ::open(path, O_CREAT | O_EXCL | O_RDWR | O_CLOEXEC, 0666);
+        if (fd < 0 && errno == EEXIST) creator = false, fd = ::open(path, O_RDWR | O_CLOEXEC);
+        umask(old);
+        if (fd < 0) return;
+        if (creator && ftruncate(fd, (off_t)sizeof(SharedGatePage)) != 0) {
+            ::close(fd);
+            return;
+        }
+        if (!creator) { // (the creator may not have sized the file yet)
+            struct stat st;
+            for (int spin = 0; spin < 2000; spin++) {
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(SharedGatePage)) break;
+                usleep(500);
+            }
+            if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(SharedGatePage)) {
+                ::close(fd);
+                return;
+            }
+        }
+        void *m = mmap(nullptr, sizeof(SharedGatePage), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return;
+        SharedGatePage *pg = (SharedGatePage *)m;
+        if (creator) {
+            pthread_mutexattr_t at;
+            bool ok = pthread_mutexattr_init(&at) == 0;
+            ok = ok && pthread_mutexattr_setpshared(&at, PTHREAD_PROCESS_SHARED) == 0;
+            ok = ok && pthread_mutexattr_setrobust(&at, PTHREAD_MUTEX_ROBUST) == 0;
+            ok = ok && pthread_mutex_init(&pg->mu, &at) == 0;
+            (void)pthread_mutexattr_destroy(&at);
+            if (!ok) {
+                munmap(m, sizeof(SharedGatePage));
+                return;
+            }
+            pg->magic.store(MAGIC, std::memory_order_release);
+        } else {
+            bool ready = false;
+            for (int spin = 0; spin < 2000 && !ready; spin++) { // <= 1 s
+                ready = pg->magic.load(std::memory_order_acquire) == MAGIC;
+                if (!ready) usleep(500);
+            }
+            if (!ready) {
+                munmap(m, sizeof(SharedGatePage));
+                return;
+            }
+        }
+        page = pg;
+        state = 0;
+#else
+        (void)device;
+#endif
+    }
+    // (call with mu held) true: the shared lock was free
+    bool file_lock(int device) {
+        if (state == -2) open_shared(device);
+        if (state != 0) return true;
+        int r = pthread_mutex_trylock(&page->mu);
+        bool free_ = r == 0 || r == EOWNERDEAD;
+        if (r == EBUSY) r = pthread_mutex_lock(&page->mu);
+        if (r == EOWNERDEAD) (void)pthread_mutex_consistent(&page->mu); // (the owner died inside a solve: the lock is ours now)
+        if (r != 0 && r != EOWNERDEAD) state = -1;                      // (unusable: in-process only from now on)
+        shared_held = state == 0;
+        return free_;
+    }
+    void file_unlock() {
+        if (shared_held) (void)pthread_mutex_unlock(&page->mu);
+        shared_held = false;
+    }
+    bool shared_held = false;
+};
+static DeviceGate &device_gate(int device) {
+    static DeviceGate gates[64];
     return gates[device >= 0 && device < 64 ? device : 0];
 }
+// what std::unique_lock<std::mutex> was to the in-process gate
+struct GateLock {
+    DeviceGate &g;
+    int device;
+    bool owned = false;
+    GateLock(DeviceGate &gate, int dev) : g(gate), device(dev) {}
+    ~GateLock() {
+        if (owned) unlock();
+    }
+    bool owns_lock() const { return owned; }
+    // true: nobody held the gate (neither another handle of this process nor another process)
+    bool lock_counting() {
+        bool free_ = g.mu.try_lock();
+        if (!free_) g.mu.lock();
+        if (!g.file_lock(device)) free_ = false;
+        owned = true;
+        return free_;
+    }
+    void lock() { (void)lock_counting(); }
+    void unlock() {
+        g.file_unlock();
+        g.mu.unlock();
+        owned = false;
+    }
+};
 
 int32_t Solver::run_factor() {
     const int32_t n = S.n;
@@ -2091,7 +2222,7 @@ int32_t Solver::run_factor() {
     HIPC(hipMemsetAsync(d_scalar, 0, 4 * sizeof(unsigned long long), STREAM), ERROR_HIP_MEMCPY);
     HIPC(hipMemsetAsync(d_info, 0, sizeof(FactorInfo), STREAM), ERROR_HIP_MEMCPY);
     const bool chained = use_chain && d_chain_cnt != nullptr;
-    std::unique_lock<std::mutex> gate(device_gate(device), std::defer_lock); // (the chained tiled steps wait inside their launch: see device_gate)
+    GateLock gate(device_gate(device), device); // (the chained tiled steps wait inside their launch: see device_gate)
     if (chained) gate.lock();
     const bool PZ = opt.complex_pairs; // the pivot searches keep the (real, imaginary) rows of a complex row together (tile_lu32_z)
     if (chained) HIPC(hipMemsetAsync(d_chain_cnt, 0, sizeof(int32_t) * (size_t)chain_words, STREAM), ERROR_HIP_MEMCPY);
@@ -2956,13 +3087,10 @@ int32_t Solver::solve_core(double *x, const double *rhs, int32_t nrhs, int64_t l
     // and the waits of a many-RHS loop between blocks are outside -- another handle's solve gets its turn there).  With several lanes
     // (opt-in) the gate stays held until every lane is idle.  The gate is process-wide: two PROCESSES sharing one GPU are not
     // serialised by it -- their waits stay bounded by the device-clock time-out and the level-set fallback.
-    std::unique_lock<std::mutex> gate(device_gate(device), std::defer_lock);
+    GateLock gate(device_gate(device), device);
     auto gate_acquire = [&]() {
         if (!use_fused || gate.owns_lock()) return;
-        if (!gate.try_lock()) {
-            gate_waits++;
-            gate.lock();
-        }
+        if (!gate.lock_counting()) gate_waits++;
     };
     const int32_t n = S.n;
     const dim3 g((n + 255) / 256), b(256);
