@@ -741,10 +741,17 @@ static int32_t broadcast_factor_body(struct InterfaceHIPMF *h, void *comm, int32
         }
         total += nb[i];
     }
+    // 3. what the root's factorisation knows about itself and the solves of every rank need: how many pivots were replaced (round 6: a rank
+    //    that adopts a factor with replaced pivots runs the Krylov rescue like the root, numeric.cpp)
+    int64_t tail[2] = {s.n_perturbed, 0}, got_tail[2] = {0, 0};
+    bool tail_fail = hipMemcpyAsync(h->d_hdr, tail, sizeof(tail), hipMemcpyHostToDevice, st) != hipSuccess;
+    tail_fail = g_rccl.broadcast(h->d_hdr, h->d_hdr, sizeof(tail), ncclChar, root, (ncclComm_t)comm, st) != ncclSuccess || tail_fail;
+    tail_fail = hipMemcpyAsync(got_tail, h->d_hdr, sizeof(got_tail), hipMemcpyDeviceToHost, st) != hipSuccess || tail_fail;
     if (hipStreamSynchronize(st) != hipSuccess) return ERROR_HIP_SYNCHRONIZE;
+    if (tail_fail) return ERROR_HIPMF_COMM;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (bytes_sent) *bytes_sent = total;
-    if (rank != root) s.mark_factor_adopted();
+    if (rank != root) s.mark_factor_adopted((int32_t)std::min<int64_t>(got_tail[0], 0x7fffffff));
     return SUCCESSFUL_EXIT;
 }
 

@@ -2986,6 +2986,7 @@ int32_t Solver::krylov_rescue(double *x, const double *rhs, bool on_device) {
     int32_t code = residual();
     if (code != SUCCESSFUL_EXIT) return code;
     double rnorm = nrm2(r);
+    krylov_last_relres = rnorm / bnorm;
     if (!(rnorm > krylov_tol * bnorm)) return SUCCESSFUL_EXIT; // the refined solution is fine
     const int32_t m = std::max(4, std::min(krylov_restart, n));
     const int32_t saved_nstep = opt.refinement_nstep;
@@ -3073,6 +3074,9 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     for (int32_t j = 0; j < nrhs; j++) {
         const int32_t c = krylov_rescue(x + (int64_t)j * ldx, rhs + (int64_t)j * ldx, on_device);
         if (c != SUCCESSFUL_EXIT) return c;
+        // (a factorisation the rescue cannot repair -- e.g. a kept L D L^T plan on a saddle-point matrix, dozens of replaced pivots AND
+        //  growth -- fails for every column alike: the other columns keep their refined solutions instead of paying 160 solves each)
+        if (krylov_last_relres > 1e-6) break;
     }
     return SUCCESSFUL_EXIT;
 }

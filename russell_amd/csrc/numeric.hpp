@@ -148,7 +148,7 @@ class Solver {
     int32_t set_expansion(int64_t nnz_lower, const std::vector<int32_t> &emap);
     int64_t expansion_inputs() const { return nnz_low; }
     const std::vector<int32_t> &expansion_map() const { return h_emap; }
-    void mark_factor_adopted() { n_perturbed = n_zero_pivot = 0, factorized = true; } // ... including the matrix values
+    void mark_factor_adopted(int32_t root_perturbed = 0) { n_perturbed = root_perturbed, n_zero_pivot = 0, factorized = true; } // ... including the matrix values; the root's count of replaced pivots decides about the Krylov rescue here too
     void *d_diag_ptr() const { return d_diag; }
     // FNV-1a over what two handles must share to exchange a factor: the fill-reducing permutation, the matching's row permutation, the
     // layout of the pool (computed at initialize / after a re-matching factorize)
