@@ -157,6 +157,12 @@ struct NDRegion {
     int32_t begin, end, pos, id;
     bool connected;
     int32_t parent_size; // vertices of the region this one was cut out of (the whole graph: INT32_MAX)
+    // Round 6: side A of a split is the head of the parent's level structure (levels below the separator + the thinned separator
+    // vertices), and its first vertex is the parent's root: the breadth-first search from that vertex inside A would visit exactly that
+    // head again, in the same order.  The split therefore hands A what that search would have produced -- its eccentricity and the
+    // candidate of the pseudo-peripheral iteration (the minimum-degree vertex of its last level) -- and A starts with its SECOND search.
+    // Same permutation bit for bit (tests/test_tree_solve_cpu.py's golden hash), one search of three less on every A side.
+    int32_t first_ecc = -1, first_cand = -1;
 };
 
 // BFS inside region `id` from `root`; fills t.queue[0..count) in visit order, w.lev, t.lvl_ptr.
@@ -253,6 +259,8 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
     // When it reaches every vertex the region is connected and the sweep -- one more pass over the region's adjacency -- is skipped.
     bool have_bfs = false;
     int32_t count0 = 0, ecc0 = 0;
+    const bool known_first = R.first_cand >= 0 && size > leaf; // (side A of a split: connected, first search known -- see NDRegion)
+    if (known_first) R.connected = true;
     if (!R.connected && size > leaf) {
         ecc0 = bfs_region(w, t, w.verts[R.begin], R.id, count0);
         if (count0 == size) R.connected = true, have_bfs = true;
@@ -302,17 +310,22 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
     }
     // pseudo-peripheral vertex: repeat BFS from a minimum-degree vertex of the last level
     int32_t root = w.verts[R.begin], count = count0;
-    int32_t ecc = have_bfs ? ecc0 : bfs_region(w, t, root, R.id, count);
+    int32_t ecc = known_first ? R.first_ecc : (have_bfs ? ecc0 : bfs_region(w, t, root, R.id, count));
     for (int32_t it = 0; it < 4; it++) {
-        int32_t lb = t.lvl_ptr[t.lvl_ptr.size() - 2], le = t.lvl_ptr.back();
-        int32_t cand = t.queue[lb];
-        int64_t cdeg = g.ptr[cand + 1] - g.ptr[cand];
-        for (int32_t k = lb + 1; k < le; k++) {
-            int32_t v = t.queue[k];
-            int64_t d = g.ptr[v + 1] - g.ptr[v];
-            if (d < cdeg || (d == cdeg && v < cand)) {
-                cand = v;
-                cdeg = d;
+        int32_t cand;
+        if (known_first && it == 0) {
+            cand = R.first_cand; // (what the loop below would pick from the last level of the search from `root`)
+        } else {
+            int32_t lb = t.lvl_ptr[t.lvl_ptr.size() - 2], le = t.lvl_ptr.back();
+            cand = t.queue[lb];
+            int64_t cdeg = g.ptr[cand + 1] - g.ptr[cand];
+            for (int32_t k = lb + 1; k < le; k++) {
+                int32_t v = t.queue[k];
+                int64_t d = g.ptr[v + 1] - g.ptr[v];
+                if (d < cdeg || (d == cdeg && v < cand)) {
+                    cand = v;
+                    cdeg = d;
+                }
             }
         }
         if (cand == root) break;
@@ -385,7 +398,23 @@ static void nd_process(NDShared &w, NDScratch &t, const SymbolicOptions &opt, in
     }
     std::copy(t.tmp.begin(), t.tmp.begin() + nA + nB, w.verts.begin() + R.begin);
     out.push_back({R.begin + nA, R.begin + nA + nB, R.pos + nA, idB, false, size});
-    out.push_back({R.begin, R.begin + nA, R.pos, idA, false, size});
+    NDRegion RA = {R.begin, R.begin + nA, R.pos, idA, false, size};
+    if (t.tmp[0] == root && lb > 0) {
+        // A's own search from `root`: levels 0 .. best - 1 as here, then the thinned separator vertices (level `best`, if any) -- its last
+        // level is t.tmp[lb, nA) when that is not empty, else this structure's level best - 1
+        const int32_t l0 = nA > lb ? lb : t.lvl_ptr[best - 1], l1 = nA > lb ? nA : lb;
+        const int32_t *src = nA > lb ? t.tmp.data() : t.queue.data();
+        int32_t cand = src[l0];
+        int64_t cdeg = g.ptr[cand + 1] - g.ptr[cand];
+        for (int32_t k = l0 + 1; k < l1; k++) {
+            const int32_t v = src[k];
+            const int64_t d = g.ptr[v + 1] - g.ptr[v];
+            if (d < cdeg || (d == cdeg && v < cand)) cand = v, cdeg = d;
+        }
+        RA.first_ecc = nA > lb ? best : best - 1;
+        RA.first_cand = cand;
+    }
+    out.push_back(RA);
 }
 
 static void nested_dissection(const Graph &g, const SymbolicOptions &opt, std::vector<int32_t> &perm, std::vector<int32_t> &leaf_of,
