@@ -401,6 +401,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_KRYLOV")) krylov_enabled = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_KRYLOV_RESTART")) krylov_restart = std::max(4, atoi(e));
     if (const char *e = getenv("HIPMF_KRYLOV_TOL")) krylov_tol = atof(e);
+    if (const char *e = getenv("HIPMF_KRYLOV_OMEGA")) krylov_omega_ok = atof(e);
     if (const char *e = getenv("HIPMF_WAVE_FRONTS")) wave_fronts = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_WAVE_FRONTS_BWD")) wave_fronts_bwd = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_HOST_DIRECT")) host_direct = atoi(e) != 0;
@@ -3072,6 +3073,10 @@ int32_t Solver::solve(double *x, const double *rhs, int32_t nrhs, int64_t ldx, b
     DeviceScope dev_scope(device);
     krylov_iterations = 0;
     for (int32_t j = 0; j < nrhs; j++) {
+        // A column whose componentwise backward error the refinement brought to rounding level is DONE, whatever its residual is relative
+        // to |b| (an ill-conditioned system: |A||x| >> |b|): a backward-stable solution is all a direct solver owes, and the rescue's
+        // residual test would otherwise cost such columns dozens of extra solves after every factorisation that replaced a pivot.
+        if ((size_t)j < col_omega.size() && col_omega[(size_t)j] <= krylov_omega_ok) continue;
         const int32_t c = krylov_rescue(x + (int64_t)j * ldx, rhs + (int64_t)j * ldx, on_device);
         if (c != SUCCESSFUL_EXIT) return c;
         // (a factorisation the rescue cannot repair -- e.g. a kept L D L^T plan on a saddle-point matrix, dozens of replaced pivots AND
@@ -3100,6 +3105,9 @@ int32_t Solver::solve_core(double *x, const double *rhs, int32_t nrhs, int64_t l
     const dim3 g((n + 255) / 256), b(256);
     const double EPS = 2.220446049250313e-16;
     refinement_steps_done = 0;
+    // (componentwise backward error of every column's final solution where the refinement measured it; infinity: not measured -- refinement
+    //  switched off, or more steps asked for than a measurement follows)
+    col_omega.assign((size_t)nrhs, opt.refinement_nstep > 0 ? 0.0 : INFINITY);
     // Blocks of KB right-hand sides go through the triangular solves together (the dependency-driven kernels read each
     // factor entry once per block); one right-hand side uses the single-column instances and buffers.
     // (blocks of 16 columns = one full MFMA tile per slab tile when there are enough of them and the block buffers fit; else 8)
@@ -3289,8 +3297,10 @@ int32_t Solver::solve_core(double *x, const double *rhs, int32_t nrhs, int64_t l
             if (L.it > 0 && !(omega < L.prev[c])) {
                 hipLaunchKernelGGL(k_perm_out, g, b, 0, L.st, n, d_perm, d_cs, L.DU + (size_t)c * n, L.xj[c], 2); // take the last correction back (rare: one launch per such column)
                 L.active[c] = false;
+                col_omega[(size_t)(L.j0 + c)] = L.prev[c]; // (the solution it goes back to)
                 continue;
             }
+            col_omega[(size_t)(L.j0 + c)] = omega; // backward error of the column's current solution (what the Krylov rescue looks at)
             if (L.j0 + c == 0) last_residual_inf = rn, last_omega = omega;
             if (opt.verbose && L.j0 + c == 0) fprintf(stderr, "hipmf: refinement step %d: |r|_inf = %.3e, omega = %.3e\n", L.it, rn, omega);
             if (omega <= EPS || L.it == opt.refinement_nstep || (L.it > 0 && omega > 0.5 * L.prev[c])) {

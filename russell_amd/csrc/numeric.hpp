@@ -133,6 +133,8 @@ class Solver {
     bool in_rescue = false;
     int32_t krylov_restart = 40;     // directions per cycle (HIPMF_KRYLOV_RESTART)
     int32_t krylov_cycles = 4;       // restarts at most
+    double krylov_omega_ok = 1e-13;  // a column whose refined solution has a componentwise backward error up to this is not looked at by the rescue (HIPMF_KRYLOV_OMEGA)
+    std::vector<double> col_omega;   // per column of the last solve: omega of its final solution as the refinement measured it
     double krylov_tol = 1e-13;       // |b - A x|_2 <= tol |b|_2 ends the rescue (and is what triggers it)
     int64_t krylov_iterations = 0;   // FGMRES steps of the last solve (0: no rescue ran or was needed)
     double krylov_last_relres = 0.0; // |b - A x|_2 / |b|_2 after the last rescue

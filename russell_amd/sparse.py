@@ -104,7 +104,7 @@ class LinSolParams:
         self.compute_determinant = False
         self.verbose = False
         self.matching = 1                 # enums.rs Matching: 0 None, 1 Auto, 2.. the named variants (all select the maximum-product matching)
-        self.pivoting = 0                 # enums.rs Pivoting: 0 Auto, 5 LocalBlock; the others are refused
+        self.pivoting = 0                 # enums.rs Pivoting: 0 Auto .. 5 LocalBlock: a request (round 6); effective: LocalBlock
         self.hybrid_memory_factor = None  # lin_sol_params.rs:39 (recorded; no out-of-core path)
         self.compute_error_estimates = False
         self.compute_condition_numbers = False

@@ -43,7 +43,7 @@ for env in ({}, {"HIPMF_TAG_SOLVE": "0"}, {"HIPMF_UP_TOP_FRONTS": "1"}):
         s = Hipmf(lib)
         assert s.initialize(n, rp, ci, **kw) == 0
         assert s.factorize(v) == 0
-        for nrhs in (1, 2, 18):
+        for nrhs in (1, 2, 18, 40):  # (18, 40: two and three block groups per launch, the last group partly filled)
             XS = rng.standard_normal((nrhs, n))
             B = np.array([A @ XS[j] for j in range(nrhs)])
             X = s.solve_many(B) if nrhs > 1 else s.solve(B[0])[None, :]
