@@ -41,7 +41,7 @@ static void run(int p, int m, int nf, bool check) {
         FrontDesc &d = fd[(size_t)s];
         d.off = (int64_t)s * per, d.eoff = d.off + (int64_t)f * f, d.epoff = d.eoff + (int64_t)f * p;
         d.p = p, d.m = m, d.first = s * p, d.ld = ld, d.flags = FD_BIG | FD_DENSE_TOP, d.ugroup = 2;
-        d.rowptr = 0, d.woff = 0, d.child_begin = d.child_end = 0, d.parent = -1, d.pad = 0;
+        d.rowptr = 0, d.woff = 0, d.child_begin = d.child_end = 0, d.parent = -1, d.ldp = p;
     }
     double *pool, *diag;
     int32_t *lperm;
@@ -73,8 +73,8 @@ static void run(int p, int m, int nf, bool check) {
         CK(hipMemcpy(pool, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, 0));
         if (lu) {
-            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_lu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * MIDL_LDS_DOUBLES)));
-            hipLaunchKernelGGL(k_front_lu, dim3(nf), dim3(64 * MIDL_NW), dyn, 0, dfd, pool, lperm, an, 1e-13, info, diag);
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_lu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * MIDL_LDS_DOUBLES)));
+            hipLaunchKernelGGL(k_front_lu<false>, dim3(nf), dim3(64 * MIDL_NW), dyn, 0, dfd, pool, lperm, an, 1e-13, info, diag);
         } else if (cls == 0) launch<10>(nf, dyn, dfd, pool, lperm, an, info, diag);
         else if (cls == 1) launch<16>(nf, dyn, dfd, pool, lperm, an, info, diag);
         else launch<24>(nf, dyn, dfd, pool, lperm, an, info, diag);

@@ -23,7 +23,7 @@ __global__ void bench_lu(const double *in, double *out, long long *cycles, int r
         for (int c = 0; c < NB; c++) a[c] = (tid < NB) ? T[tid][c] + 1e-9 * it : 0.0;
         long long t0 = clock64();
         int step, npert, nzero;
-        tile_lu32(a, tid, 1e-300, step, npert, nzero);
+        tile_lu32(a, tid, 1e-300, 1e-300, step, npert, nzero);
         long long t1 = clock64();
         if (tid == 0) cycles[it] = t1 - t0;
 #pragma unroll

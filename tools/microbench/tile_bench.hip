@@ -42,9 +42,9 @@ template <int MODE> __global__ void __launch_bounds__(64) k_tile(const double *_
     if (MODE == 0) tile_lu32<true>(a, tid, 1e-13, 1e-13, step, npert, nzero);
     else if (MODE == 1) {
         double zr, zi;
-        tile_inv32(a, tid, NB, 1e-13, step, dval, rk, npert, nzero, zr, zi);
+        tile_inv32(a, tid, NB, 1e-13, 1e-13, step, dval, rk, npert, nzero, zr, zi);
     }
-    else tile_inv32_rot(a, tid, 1e-13, step, dval, rk, npert, nzero);
+    else tile_inv32_rot(a, tid, 1e-13, 1e-13, step, dval, rk, npert, nzero);
     unsigned long long t2 = dev_clock();
     if (tid < NB) {
         double *o = out + (size_t)blockIdx.x * NB * NB;
