@@ -331,9 +331,21 @@ __device__ __forceinline__ void wt_bwd_front(double *L, int q, int lane, double 
     wave_sync();
 }
 
+// `arm` (round 6; tagged hand-offs, kernels_solve_fused.hpp): this is the LAST kernel of a pass pair, and by the time it starts nothing
+// reads the words the tasks above the wave-subtrees handed to each other any more (their vectors in `work`, the shadow xt: the backward
+// launches above are complete, this kernel reads x).  Every workgroup therefore re-arms its slice of those arm_words words with the tag
+// pattern for the NEXT pass pair: the 16 MB hipMemsetAsync in front of every pass pair (5 - 6 us plus a launch gap inside the timed pair)
+// is only needed before the first one.
 __global__ void __launch_bounds__(64 * WT_WAVES) k_wt_bwd(const WtWave *__restrict__ waves, const WtHdr *__restrict__ hdrs,
-                                                        const int32_t *__restrict__ meta, const double *__restrict__ pool, double *x) {
+                                                        const int32_t *__restrict__ meta, const double *__restrict__ pool, double *x,
+                                                        double *arm, long long arm_words) {
     __shared__ __attribute__((aligned(16))) double lds[WT_WAVES][WT_LDS];
+    if (arm) {
+        const long long per = (arm_words + gridDim.x - 1) / gridDim.x, a0 = per * blockIdx.x;
+        const long long a1 = a0 + per < arm_words ? a0 + per : arm_words;
+        const double tagv = __longlong_as_double(-1LL); // (SF_TAG_BITS)
+        for (long long i = a0 + threadIdx.x; i < a1; i += 64 * WT_WAVES) arm[i] = tagv;
+    }
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const long long *WV = reinterpret_cast<const long long *>(waves + (blockIdx.x * WT_WAVES + wave));
     const long long wrec = WV[lane & 31]; // (see k_wt_fwd)

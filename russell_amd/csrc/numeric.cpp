@@ -107,6 +107,7 @@ void Solver::release() {
         if (p) (void)hipFree(p);
     d_emap = nullptr, d_vlow = nullptr, nnz_low = 0;
     wt_waves = wt_recs = sf2_fwd_cnt = sf2_bwd_cnt = 0, tree_active = false, tag_active = false, work_up = work_arm0 = 0;
+    tags_armed = false;
     for (LaneBuffers &lb : extra_lanes) {
         for (void *p : {(void *)lb.blk, (void *)lb.work, (void *)lb.sync, (void *)lb.norms})
             if (p) (void)hipFree(p);
@@ -398,6 +399,7 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
     if (const char *e = getenv("HIPMF_BLOCK_GROUPS_BYTES")) block_groups_max_bytes = atof(e);
     if (const char *e = getenv("HIPMF_PLAIN_BAND")) plain_band = atoi(e) != 0;
+    if (const char *e = getenv("HIPMF_REARM_TAGS")) rearm_tags = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_KRYLOV")) krylov_enabled = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_KRYLOV_RESTART")) krylov_restart = std::max(4, atoi(e));
     if (const char *e = getenv("HIPMF_KRYLOV_TOL")) krylov_tol = atof(e);
@@ -2573,13 +2575,18 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
         const int64_t sync_stride = 2 * (int64_t)(SF_SYNC_HEADER + ns) + 1;
         const int32_t ngrp = nk > SF_KMAX ? (nk + SF_KMAX - 1) / SF_KMAX : 1;
         if (ngrp > SF_GMAX) return ERROR_HIPMF_INVALID_VALUE;
-        HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
+        // (the tagged single-column pass pair touches no completion counter: the wave-subtrees publish nothing, the tasks above poll data)
+        const bool counters_unused = tree_active && nk == 1 && tag_active;
+        if (!counters_unused) HIPC(hipMemsetAsync(lane_sync, 0, sizeof(int32_t) * 2 * (size_t)(SF_SYNC_HEADER + ns), LST), ERROR_HIP_MEMCPY);
         if (ngrp > 1) HIPC(hipMemsetAsync(lane_sync + sync_stride, 0, sizeof(int32_t) * (size_t)sync_stride * (size_t)(ngrp - 1), LST), ERROR_HIP_MEMCPY);
         if (timed) HIPC(hipEventRecord((hipEvent_t)ev[3], LST), ERROR_HIP_SYNCHRONIZE);
         const SfGroups one_group = {1, 0, 1, 1u, 0, 0};
         if (tree_active && nk == 1) {
             // (inside the timed pass pair: arming the tagged words is part of what a pass pair costs)
-            if (tag_active) HIPC(hipMemsetAsync(wrk + work_arm0, 0xFF, sizeof(double) * (size_t)(work_up - work_arm0 + S.n), LST), ERROR_HIP_MEMCPY);
+            // (round 6: k_wt_bwd, the last kernel of a pass pair, re-arms the words for the next one -- the memset is for the first pass
+            //  pair of a workspace, and for whatever follows a pass that did not end with k_wt_bwd)
+            if (tag_active && !(rearm_tags && tags_armed && wrk == d_work))
+                HIPC(hipMemsetAsync(wrk + work_arm0, 0xFF, sizeof(double) * (size_t)(work_up - work_arm0 + S.n), LST), ERROR_HIP_MEMCPY);
             else if (d_rep)
                 HIPC(hipMemsetAsync(d_rep + 2 * (size_t)rep_words * (size_t)lane_id, 0, sizeof(int32_t) * 2 * (size_t)rep_words, LST), ERROR_HIP_MEMCPY);
         }
@@ -2642,9 +2649,12 @@ int32_t Solver::run_triangular(double *xp, int32_t nk, double *wrk, int64_t xstr
             }
 #undef HIPMF_TREE_FWD
 #undef HIPMF_TREE_BWD
+            const bool rearm = tag && rearm_tags && wg > 0 && wrk == d_work;
             if (wg > 0)
                 hipLaunchKernelGGL(k_wt_bwd, dim3(wg), dim3(64 * WT_WAVES), 0, LST, d_wt_wave + (size_t)wg * WT_WAVES, d_wt_hdr + wt_hdr_fwd,
-                                   d_wt_meta + wt_meta_fwd, d_pool, xp);
+                                   d_wt_meta + wt_meta_fwd, d_pool, xp, rearm ? wrk + work_arm0 : (double *)nullptr,
+                                   (long long)(work_up - work_arm0 + S.n));
+            tags_armed = rearm;
             if (timed) HIPC(hipEventRecord((hipEvent_t)ev[5], LST), ERROR_HIP_SYNCHRONIZE);
             times.n_kernel_launches_solve = 2 * (wg > 0) + (f_mid > 0) + (f_top > 0) + (S.sym_mode ? (sf2_bwd_cnt > 0) : (b_top > 0) + (b_mid > 0));
             if (timed) tri_pending = true;

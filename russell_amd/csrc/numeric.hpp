@@ -250,6 +250,10 @@ class Solver {
     SfTask *d_sfk = nullptr;
     int32_t *d_needk = nullptr;
     int32_t sfk_fwd_cnt = 0, sfk_bwd_cnt = 0, sfk_fwd_band = 0, sfk_bwd_top = 0;
+    bool rearm_tags = false;                   // HIPMF_REARM_TAGS=1: k_wt_bwd re-arms the tagged words for the next pass pair instead of a memset before every pass pair
+                                               // (built and measured in round 6: same bits, NOT faster -- pass pair 0.4037 - 0.4076 against 0.4012 - 0.4058 ms, solve
+                                               // 0.94 - 0.95 against 0.91 ms, profiles/r06_rejected_experiments.txt; default off)
+    bool tags_armed = false;                   // the tagged words of d_work hold the tag pattern (left by the last pass pair's k_wt_bwd)
     bool plain_band = true;                    // HIPMF_PLAIN_BAND=0: the all-small band of the blocked solves stays ONE dependency-driven launch per direction
     std::vector<int32_t> sfk_band_f, sfk_band_b; // task offsets of the band's levels in d_sfk (forward: levels ascending from task 0; backward: relative to
                                                // the first backward task, the band's levels descending) -- one PLAIN launch per level (round 6)
