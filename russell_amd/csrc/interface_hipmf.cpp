@@ -716,18 +716,28 @@ static int32_t broadcast_factor_body(struct InterfaceHIPMF *h, void *comm, int32
                 // A: root -> r
                 if (g_rccl.group_start() != ncclSuccess) return ERROR_HIPMF_COMM;
                 bool bad = false;
+                // (a slice travels in pieces of at most 1 GiB: every piece one send / recv pair of the group, the same pieces on both ends)
+                const int64_t piece = 1ll << 30;
+                auto send_slice = [&](int64_t slice, int peer) {
+                    for (int64_t o = 0; o < sl; o += piece)
+                        bad = bad || g_rccl.send(base + slice * sl + o, (size_t)std::min(piece, sl - o), ncclChar, peer, (ncclComm_t)comm, st) != ncclSuccess;
+                };
+                auto recv_slice = [&](int64_t slice, int peer) {
+                    for (int64_t o = 0; o < sl; o += piece)
+                        bad = bad || g_rccl.recv(base + slice * sl + o, (size_t)std::min(piece, sl - o), ncclChar, peer, (ncclComm_t)comm, st) != ncclSuccess;
+                };
                 if (rank == root) {
                     for (int r = 0; r < nranks; r++)
-                        if (r != root) bad = bad || g_rccl.send(base + (int64_t)r * sl, (size_t)sl, ncclChar, r, (ncclComm_t)comm, st) != ncclSuccess;
+                        if (r != root) send_slice(r, r);
                 } else
-                    bad = g_rccl.recv(base + (int64_t)rank * sl, (size_t)sl, ncclChar, root, (ncclComm_t)comm, st) != ncclSuccess;
+                    recv_slice(rank, root);
                 if (g_rccl.group_end() != ncclSuccess || bad) return ERROR_HIPMF_COMM;
                 // B: r -> q for every pair r != q, q != root (slice r)
                 if (g_rccl.group_start() != ncclSuccess) return ERROR_HIPMF_COMM;
                 for (int q = 0; q < nranks; q++) {
                     if (q == rank) continue;
-                    if (q != root) bad = bad || g_rccl.send(base + (int64_t)rank * sl, (size_t)sl, ncclChar, q, (ncclComm_t)comm, st) != ncclSuccess;
-                    if (rank != root) bad = bad || g_rccl.recv(base + (int64_t)q * sl, (size_t)sl, ncclChar, q, (ncclComm_t)comm, st) != ncclSuccess;
+                    if (q != root) send_slice(rank, q);
+                    if (rank != root) recv_slice(q, q);
                 }
                 if (g_rccl.group_end() != ncclSuccess || bad) return ERROR_HIPMF_COMM;
                 done = sl * nranks;
