@@ -396,7 +396,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_TAG_SOLVE")) use_tag = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_LEAF_KERNELS")) leaf_kernels = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_SPLIT_TASKS")) split_tasks = std::max(0, atoi(e));
-    if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)); // (small values: tests)
+    split_minlen_env = false;
+    if (const char *e = getenv("HIPMF_SPLIT_MINLEN")) split_minlen = std::max(64, atoi(e)), split_minlen_env = true; // (small values: tests)
     if (const char *e = getenv("HIPMF_BLOCK_GROUPS_BYTES")) block_groups_max_bytes = atof(e);
     if (const char *e = getenv("HIPMF_PLAIN_BAND")) plain_band = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_REARM_TAGS")) rearm_tags = atoi(e) != 0;
@@ -909,6 +910,10 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     // buffers never take more than half of the free device memory (solve()).  HIPMF_BLOCK_GROUPS=1..4 overrides.
     block_groups_plan = 8.0 * (double)S.persist_doubles <= block_groups_max_bytes ? SF_GMAX : 1;
     if (const char *e = getenv("HIPMF_BLOCK_GROUPS")) block_groups_plan = std::max(1, std::min((int)SF_GMAX, atoi(e)));
+    // (the split dot products of the blocked backward slabs were tuned with ONE block per launch; several groups per launch fill the levels
+    //  of few slabs by themselves, and every split costs a scratch round trip: with four groups, fronts from 8 192 rows on instead of 2 048 --
+    //  config 4's shard 0.318 -> 0.303 s, 144^3 2.97 -> 2.91, 100^3 0.80 -> 0.78 ms per right-hand side, profiles/r06_block_groups.txt)
+    if (!split_minlen_env) split_minlen = 2048 * block_groups_plan;
     auto pl_t = std::chrono::steady_clock::now();
     std::string pl_log;
     auto pl_lap = [&](const char *what) { // (verbose: where the plan + upload time of initialize goes)

@@ -242,7 +242,8 @@ class Solver {
     // blocked instances, backward pass, levels of few slabs with long dot products (the top of a 3D factor): a slab's dot products are
     // split over Q consecutive tasks (k_bwd_fused); forward, the largest fronts of such levels get narrower slabs.  A level qualifies
     // below split_tasks slabs (HIPMF_SPLIT_TASKS, 0: never), a front from split_minlen rows on (HIPMF_SPLIT_MINLEN).
-    int32_t split_tasks = 512, split_minlen = 2048;
+    int32_t split_tasks = 512, split_minlen = 2048; // (split_minlen: 2 048 x the planned block groups unless HIPMF_SPLIT_MINLEN says otherwise)
+    bool split_minlen_env = false;
     int64_t split_units = 0;       // 256-double units of the scratch of partial sums
     int64_t split_slabs = 0;
     double *d_split_scr = nullptr;
