@@ -418,7 +418,8 @@ int32_t Solver::initialize_impl(int32_t n, const int32_t *rp, const int32_t *ci,
     if (const char *e = getenv("HIPMF_UP_REPLICAS")) use_rep = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_UP_PAIR_XCD")) up_pair_xcd = atoi(e) != 0;
     if (const char *e = getenv("HIPMF_UP_MAX_GROUPS")) up_max_groups = std::max(2, std::min(32, atoi(e)));
-    if (const char *e = getenv("HIPMF_BLOCKED_SLABS")) blocked_slabs = atoi(e) != 0;
+    blocked_slabs_env = false;
+    if (const char *e = getenv("HIPMF_BLOCKED_SLABS")) blocked_slabs = atoi(e) != 0, blocked_slabs_env = true;
     if (const char *e = getenv("HIPMF_UP_STAGE_MID")) up_stage_mid = std::max(0, std::min(32, atoi(e) / 8 * 8));
     if (const char *e = getenv("HIPMF_SF_BIG_ROWS")) sf_big_rows = std::max(0, std::min(7, atoi(e))); // log2 of the forward slab rows of the largest fronts (0: by dot length only)
     if (const char *e = getenv("HIPMF_SF_BIG_FRONT")) sf_big_front = std::max(65, atoi(e));
@@ -914,6 +915,12 @@ int32_t Solver::upload_plan(const std::function<int32_t()> &tail) {
     //  of few slabs by themselves, and every split costs a scratch round trip: with four groups, fronts from 8 192 rows on instead of 2 048 --
     //  config 4's shard 0.318 -> 0.303 s, 144^3 2.97 -> 2.91, 100^3 0.80 -> 0.78 ms per right-hand side, profiles/r06_block_groups.txt)
     if (!split_minlen_env) split_minlen = 2048 * block_groups_plan;
+    // Wider slabs for the blocked instances (64 rows, 128 forward for long dot products: every slab stages the whole vector block of its
+    // front, so wide slabs re-read it less often) lost with one block per launch (round 3: 144^3 4.92 -> 7.06 ms per right-hand side) and
+    // win on the LARGE 3D factors once several groups share a launch -- config 4's shard 0.304 -> 0.290 s, 144^3 2.91 -> 2.79 ms per
+    // right-hand side -- while the smaller ones lose (100^3 0.788 -> 0.822, the 1M-DOF 2D factor 0.217 -> 0.284): on from a largest front
+    // of 16 384 rows (144^3: 20 736, 100^3: 10 000); HIPMF_BLOCKED_SLABS=0 / 1 overrides.  (profiles/r06_block_groups.txt)
+    if (!blocked_slabs_env) blocked_slabs = block_groups_plan > 1 && S.max_front >= 16384;
     auto pl_t = std::chrono::steady_clock::now();
     std::string pl_log;
     auto pl_lap = [&](const char *what) { // (verbose: where the plan + upload time of initialize goes)

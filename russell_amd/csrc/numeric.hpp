@@ -234,6 +234,7 @@ class Solver {
     // 64 / 128-row slabs re-read the vector block of a front less often, but lose more in parallelism -- 144^3, 64 right-hand sides:
     // 4.92 -> 7.06 ms per right-hand side; 200^3, 256 right-hand sides: 4.58 -> 6.86 s (profiles/r03_rejected_experiments.txt)
     bool blocked_slabs = false;
+    bool blocked_slabs_env = false; // HIPMF_BLOCKED_SLABS was given (else: on for factors whose largest front has >= 16 384 rows when several groups share a launch)
     // round 5: the leaves of the tree leave the task lists of the blocked (many-RHS) solves: one wavefront carries sixteen columns through
     // LEAF_PER_WAVE leaves (kernels_solve_leaf.hpp).  HIPMF_LEAF_KERNELS=0: every small front stays a task.
     bool leaf_kernels = true;
