@@ -34,14 +34,16 @@ namespace hipmf {
 #define HIPMF_WT_STACK 320
 #endif
 #ifndef HIPMF_WT_WAVES
-#define HIPMF_WT_WAVES 2
+#define HIPMF_WT_WAVES 1 // (round 6: one wave-subtree per workgroup and a 320-word meta block: 14 080 B of LDS per wave, eleven waves per CU
+                         //  instead of ten -- pass pair at C2 400.0 - 400.7 -> 389.5 - 390.1 us, 2000^2 1 456 -> 1 413, 100^3 3 118 -> 3 086;
+                         //  two waves per workgroup with the same footprint: no gain; four: 423 - 426.  profiles/r06_wt_variants.txt)
 #endif
 constexpr int WT_NCH = HIPMF_WT_NCH;    // 512-byte pieces of factor per batch
 constexpr int WT_CHUNK = 64;            // doubles per piece (64 lanes x 8 bytes; with 1 KB pieces the pass fetched 1.25x the algorithmic bytes:
                                         // a piece is read whole, and what follows a front's panel in the pool is its contribution block)
 constexpr int WT_NREC = 8;              // fronts per batch at most
 #ifndef HIPMF_WT_MI
-#define HIPMF_WT_MI 512
+#define HIPMF_WT_MI 320
 #endif
 constexpr int WT_MI = HIPMF_WT_MI;      // 32-bit words of a batch's meta block: WT_NREC records of 16 words, then the index lists
 constexpr int WT_X = HIPMF_WT_X;        // pivots of a wave-subtree at most (multiple of 256)
@@ -108,8 +110,11 @@ __device__ __forceinline__ void wt_park(double *L, int lane, const double (&pc)[
 #pragma unroll
     for (int c = 0; c < WT_NCH; c++) L[WT_CHUNK * c + lane] = pc[c];
     int32_t *Mi = reinterpret_cast<int32_t *>(L + WT_OFF_M);
-#pragma unroll
-    for (int c = 0; c < 2; c++) st_lds_i32x4(Mi + 256 * c + 4 * lane, mc[c]);
+    // (the meta area holds WT_MI words: the second chunk of 256 is stored as far as it fits -- with WT_MI < 512 an unguarded store ran into
+    //  the x area behind it; found in round 6 when the footprint was cut, tools/gpu/r06_z*.sh)
+    static_assert(WT_MI >= 256 && WT_MI % 4 == 0 && WT_MI <= 512, "meta block: one full chunk of 256 words, at most two");
+    st_lds_i32x4(Mi + 4 * lane, mc[0]);
+    if (WT_MI == 512 || 256 + 4 * lane < WT_MI) st_lds_i32x4(Mi + 256 + 4 * lane, mc[1]);
 }
 
 // ------------------------------------------------------------------ forward: one front out of LDS
