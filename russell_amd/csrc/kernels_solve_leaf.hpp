@@ -24,8 +24,14 @@ constexpr int LEAF_KC = 16;         // columns a wavefront carries (blocks of 8 
 constexpr int LEAF_PMAX = 16;       // pivots of a leaf at most
 constexpr int LEAF_MMAX = 48;       // off-diagonal rows at most
 constexpr int LEAF_PANEL = 768;     // doubles of panel at most (12 flat pieces of 64)
-constexpr int LEAF_PER_WAVE = 8;    // consecutive leaves per wavefront
-constexpr int LEAF_WAVES = 4;       // wavefronts per workgroup
+#ifndef HIPMF_LEAF_PER_WAVE
+#define HIPMF_LEAF_PER_WAVE 8
+#endif
+#ifndef HIPMF_LEAF_WAVES
+#define HIPMF_LEAF_WAVES 4
+#endif
+constexpr int LEAF_PER_WAVE = HIPMF_LEAF_PER_WAVE; // consecutive leaves per wavefront
+constexpr int LEAF_WAVES = HIPMF_LEAF_WAVES;       // wavefronts per workgroup
 
 struct LeafRec { // 48 bytes: six 8-byte words, fetched by six lanes
     int64_t off;    // forward: pool offset of the f x f block (its first p columns = [L11; L21], stride f); backward: of the p x f rows of U (stride p)
